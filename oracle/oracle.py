@@ -1,0 +1,385 @@
+"""ctypes loader for the CPU oracle (oracle/rrtx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from rrtqx_3d_amd/ (the product path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "librrtx_oracle.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class Sphere(C.Structure):
+    _fields_ = [("c", C.c_double * 3), ("radius", C.c_double), ("life_span", C.c_double),
+                ("unused", C.c_int32), ("pad", C.c_int32)]
+
+
+class Polygon(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("nverts", C.c_int32), ("verts", c_double_p),
+                ("cx", C.c_double), ("cy", C.c_double), ("radius", C.c_double),
+                ("life_span", C.c_double), ("unused", C.c_int32), ("pad", C.c_int32)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds). Returns the .so path."""
+    src = os.path.join(_HERE, "rrtx_oracle.c")
+    hdr = os.path.join(_HERE, "rrtx_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)
+             or any(os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr)))
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    L.orc_euclid.restype = C.c_double
+    L.orc_euclid.argtypes = [c_double_p, c_double_p, C.c_int]
+    L.orc_ball_radius.restype = C.c_double
+    L.orc_ball_radius.argtypes = [C.c_double, C.c_double, C.c_int64, C.c_int]
+    L.orc_kd_create.restype = C.c_void_p
+    L.orc_kd_create.argtypes = [C.c_int]
+    L.orc_kd_destroy.argtypes = [C.c_void_p]
+    L.orc_kd_set_wraps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), c_double_p]
+    L.orc_kd_insert.restype = C.c_int64
+    L.orc_kd_insert.argtypes = [C.c_void_p, c_double_p]
+    L.orc_kd_size.restype = C.c_int64
+    L.orc_kd_size.argtypes = [C.c_void_p]
+    L.orc_kd_depth.restype = C.c_int64
+    L.orc_kd_depth.argtypes = [C.c_void_p]
+    L.orc_kd_nearest.argtypes = [C.c_void_p, c_double_p, c_int64_p, c_double_p]
+    L.orc_kd_nearest_naive.argtypes = [C.c_void_p, c_double_p, c_int64_p, c_double_p]
+    L.orc_kd_find_within_range.restype = C.c_void_p
+    L.orc_kd_find_within_range.argtypes = [C.c_void_p, C.c_double, c_double_p]
+    L.orc_kd_find_more_within_range.argtypes = [C.c_void_p, C.c_double, c_double_p, C.c_void_p]
+    L.orc_list_length.restype = C.c_int64
+    L.orc_list_length.argtypes = [C.c_void_p]
+    L.orc_list_read.restype = C.c_int64
+    L.orc_list_read.argtypes = [C.c_void_p, C.c_int64, c_int32_p, c_double_p]
+    L.orc_kd_empty_range_list.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_range_naive.restype = C.c_int64
+    L.orc_range_naive.argtypes = [C.c_void_p, C.c_double, c_double_p, C.c_int64, c_int32_p, c_double_p]
+    L.orc_ghost_points.restype = C.c_int
+    L.orc_ghost_points.argtypes = [C.c_void_p, c_double_p, C.c_double, C.c_int, c_double_p]
+    L.orc_distance_point_to_segment3.restype = C.c_double
+    L.orc_distance_point_to_segment3.argtypes = [c_double_p] * 3
+    L.orc_edge_check_sphere.restype = C.c_int
+    L.orc_edge_check_sphere.argtypes = [C.POINTER(Sphere), c_double_p, c_double_p, C.c_double]
+    L.orc_edge_check_spheres.restype = C.c_int
+    L.orc_edge_check_spheres.argtypes = [C.POINTER(Sphere), C.c_int, c_double_p, c_double_p, C.c_double, c_int32_p]
+    L.orc_point_check_spheres.restype = C.c_int
+    L.orc_point_check_spheres.argtypes = [C.POINTER(Sphere), C.c_int, c_double_p, C.c_double, C.c_int, c_double_p]
+    L.orc_polygon_ctor.argtypes = [c_double_p, C.c_int, c_double_p, c_double_p, c_double_p]
+    L.orc_dist_sqrd_point_to_segment.restype = C.c_double
+    L.orc_dist_sqrd_point_to_segment.argtypes = [c_double_p] * 3
+    L.orc_segment_dist_sqrd.restype = C.c_double
+    L.orc_segment_dist_sqrd.argtypes = [c_double_p] * 4
+    L.orc_point_in_polygon.restype = C.c_int
+    L.orc_point_in_polygon.argtypes = [c_double_p, c_double_p, C.c_int]
+    L.orc_dist_to_polygon_sqrd.restype = C.c_double
+    L.orc_dist_to_polygon_sqrd.argtypes = [c_double_p, c_double_p, C.c_int]
+    L.orc_edge_check_polygon.restype = C.c_int
+    L.orc_edge_check_polygon.argtypes = [C.POINTER(Polygon), c_double_p, c_double_p, C.c_double]
+    L.orc_edge_check_polygons.restype = C.c_int
+    L.orc_edge_check_polygons.argtypes = [C.POINTER(Polygon), C.c_int, c_double_p, c_double_p, C.c_double, c_int32_p]
+    L.orc_point_check_polygons.restype = C.c_int
+    L.orc_point_check_polygons.argtypes = [C.POINTER(Polygon), C.c_int, c_double_p, C.c_double, c_double_p]
+    L.orc_dubins_steer.argtypes = [c_double_p, c_double_p, C.c_double, c_double_p, C.c_char_p,
+                                   c_double_p, C.c_int, C.POINTER(C.c_int)]
+    L.orc_dubins_edge_check_polygons.restype = C.c_int
+    L.orc_dubins_edge_check_polygons.argtypes = [C.POINTER(Polygon), C.c_int, c_double_p, c_double_p,
+                                                 c_double_p, C.c_int, C.c_double, C.c_double, c_int32_p]
+    L.orc_julia_range_len.restype = C.c_int64
+    L.orc_julia_range_len.argtypes = [C.c_double] * 3
+    L.orc_extend_batch_spheres.restype = C.c_int64
+    L.orc_extend_batch_spheres.argtypes = [C.c_void_p, C.POINTER(Sphere), C.c_int, c_double_p, C.c_int64,
+                                           C.c_double, C.c_double, c_int64_p, c_int64_p, c_int64_p]
+    _lib = L
+    return L
+
+
+def _dp(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_double_p)
+
+
+def _vec(x) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+
+
+def euclid(x, y) -> float:
+    x, y = _vec(x), _vec(y)
+    return lib().orc_euclid(_dp(x), _dp(y), len(x))
+
+
+def ball_radius(delta: float, ball_constant: float, n: int, d: int) -> float:
+    return lib().orc_ball_radius(delta, ball_constant, n, d)
+
+
+class KDTree:
+    """The reference's incremental kd-tree (R/kdTree_general.jl)."""
+
+    def __init__(self, d: int, wraps=None, wrap_points=None):
+        self.d = d
+        self._h = lib().orc_kd_create(d)
+        if wraps:
+            w = (C.c_int * len(wraps))(*wraps)
+            wp = (C.c_double * len(wraps))(*wrap_points)
+            lib().orc_kd_set_wraps(self._h, len(wraps), w, wp)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_kd_destroy(self._h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def insert(self, pos) -> int:
+        p = _vec(pos)
+        assert len(p) == self.d
+        return lib().orc_kd_insert(self._h, _dp(p))
+
+    def insert_many(self, pts: np.ndarray):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        f = lib().orc_kd_insert
+        base = pts.ctypes.data
+        stride = self.d * 8
+        for i in range(pts.shape[0]):
+            f(self._h, C.cast(base + i * stride, c_double_p))
+
+    @property
+    def size(self) -> int:
+        return lib().orc_kd_size(self._h)
+
+    def depth(self) -> int:
+        return lib().orc_kd_depth(self._h)
+
+    def nearest(self, q, naive: bool = False):
+        q = _vec(q)
+        idx = C.c_int64()
+        dist = C.c_double()
+        f = lib().orc_kd_nearest_naive if naive else lib().orc_kd_nearest
+        f(self._h, _dp(q), C.byref(idx), C.byref(dist))
+        return idx.value, dist.value
+
+    def within_range(self, r: float, q, more=()):
+        """kdFindWithinRange (+ kdFindMoreWithinRange for each extra (r, q) in `more`).
+        Returns (idx, key) in list order (front first)."""
+        q = _vec(q)
+        L = lib()
+        lst = L.orc_kd_find_within_range(self._h, r, _dp(q))
+        for (r2, q2) in more:
+            q2 = _vec(q2)
+            L.orc_kd_find_more_within_range(self._h, r2, _dp(q2), lst)
+        n = L.orc_list_length(lst)
+        idx = np.empty(n, dtype=np.int32)
+        key = np.empty(n, dtype=np.float64)
+        L.orc_list_read(lst, n, idx.ctypes.data_as(c_int32_p), _dp(key))
+        L.orc_kd_empty_range_list(self._h, lst)
+        return idx, key
+
+    def range_naive(self, r: float, q):
+        q = _vec(q)
+        L = lib()
+        n = L.orc_range_naive(self._h, r, _dp(q), 0, None, None)
+        idx = np.empty(n, dtype=np.int32)
+        key = np.empty(n, dtype=np.float64)
+        L.orc_range_naive(self._h, r, _dp(q), n, idx.ctypes.data_as(c_int32_p), _dp(key))
+        return idx, key
+
+    def ghost_points(self, q, best_dist: float):
+        q = _vec(q)
+        out = np.empty((64, self.d), dtype=np.float64)
+        n = lib().orc_ghost_points(self._h, _dp(q), best_dist, 64, _dp(out))
+        return out[:n].copy()
+
+
+def make_spheres(cxyzr: np.ndarray, active=None, life_span=None):
+    cxyzr = np.asarray(cxyzr, dtype=np.float64).reshape(-1, 4)
+    m = cxyzr.shape[0]
+    arr = (Sphere * max(m, 1))()
+    for i in range(m):
+        arr[i].c[0], arr[i].c[1], arr[i].c[2] = cxyzr[i, 0], cxyzr[i, 1], cxyzr[i, 2]
+        arr[i].radius = cxyzr[i, 3]
+        arr[i].life_span = float("inf") if life_span is None else float(life_span[i])
+        arr[i].unused = 0 if (active is None or active[i]) else 1
+    return arr, m
+
+
+def distance_point_to_segment3(c, p0, p1) -> float:
+    c, p0, p1 = _vec(c), _vec(p0), _vec(p1)
+    return lib().orc_distance_point_to_segment3(_dp(c), _dp(p0), _dp(p1))
+
+
+def edge_check_spheres(spheres, m, p0, p1, robot_radius):
+    p0, p1 = _vec(p0), _vec(p1)
+    fh = C.c_int32()
+    hit = lib().orc_edge_check_spheres(spheres, m, _dp(p0), _dp(p1), robot_radius, C.byref(fh))
+    return bool(hit), fh.value
+
+
+def edges_check_spheres(spheres, m, P0: np.ndarray, P1: np.ndarray, robot_radius: float):
+    P0 = np.ascontiguousarray(P0, dtype=np.float64)
+    P1 = np.ascontiguousarray(P1, dtype=np.float64)
+    n, d = P0.shape
+    hit = np.zeros(n, dtype=np.uint8)
+    first = np.full(n, -1, dtype=np.int32)
+    f = lib().orc_edge_check_spheres
+    fh = C.c_int32()
+    b0, b1, st = P0.ctypes.data, P1.ctypes.data, d * 8
+    for i in range(n):
+        hit[i] = f(spheres, m, C.cast(b0 + i * st, c_double_p), C.cast(b1 + i * st, c_double_p),
+                   robot_radius, C.byref(fh))
+        first[i] = fh.value
+    return hit, first
+
+
+def point_check_spheres(spheres, m, p, robot_radius, quick=True):
+    p = _vec(p)
+    cl = C.c_double()
+    r = lib().orc_point_check_spheres(spheres, m, _dp(p), robot_radius, 1 if quick else 0, C.byref(cl))
+    return bool(r), cl.value
+
+
+def points_check_spheres(spheres, m, P: np.ndarray, robot_radius, quick=True):
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    n, d = P.shape
+    unsafe = np.zeros(n, dtype=np.uint8)
+    clr = np.zeros(n, dtype=np.float64)
+    cl = C.c_double()
+    f = lib().orc_point_check_spheres
+    for i in range(n):
+        unsafe[i] = f(spheres, m, C.cast(P.ctypes.data + i * d * 8, c_double_p), robot_radius,
+                      1 if quick else 0, C.byref(cl))
+        clr[i] = cl.value
+    return unsafe, clr
+
+
+def polygon_ctor(verts):
+    v = np.ascontiguousarray(np.asarray(verts, dtype=np.float64).reshape(-1, 2))
+    cx, cy, r = C.c_double(), C.c_double(), C.c_double()
+    lib().orc_polygon_ctor(_dp(v), v.shape[0], C.byref(cx), C.byref(cy), C.byref(r))
+    return cx.value, cy.value, r.value
+
+
+class PolygonSet:
+    """A list of kind-3 polygon obstacles (plus optional kind-1 balls) in list order."""
+
+    def __init__(self, polys, kinds=None, active=None):
+        self.verts = [np.ascontiguousarray(np.asarray(p, dtype=np.float64).reshape(-1, 2)) for p in polys]
+        self.m = len(self.verts)
+        self.arr = (Polygon * max(self.m, 1))()
+        for i, v in enumerate(self.verts):
+            cx, cy, r = polygon_ctor(v)
+            a = self.arr[i]
+            a.kind = 3 if kinds is None else int(kinds[i])
+            a.nverts = v.shape[0]
+            a.verts = _dp(v)
+            a.cx, a.cy, a.radius = cx, cy, r
+            a.life_span = float("inf")
+            a.unused = 0 if (active is None or active[i]) else 1
+
+    def centre_radius(self) -> np.ndarray:
+        return np.array([[self.arr[i].cx, self.arr[i].cy, self.arr[i].radius] for i in range(self.m)],
+                        dtype=np.float64).reshape(-1, 3)
+
+
+def dist_sqrd_point_to_segment(pt, a, b) -> float:
+    pt, a, b = _vec(pt), _vec(a), _vec(b)
+    return lib().orc_dist_sqrd_point_to_segment(_dp(pt), _dp(a), _dp(b))
+
+
+def segment_dist_sqrd(pa, pb, qa, qb) -> float:
+    pa, pb, qa, qb = _vec(pa), _vec(pb), _vec(qa), _vec(qb)
+    return lib().orc_segment_dist_sqrd(_dp(pa), _dp(pb), _dp(qa), _dp(qb))
+
+
+def point_in_polygon(pt, verts) -> bool:
+    pt = _vec(pt)
+    v = np.ascontiguousarray(np.asarray(verts, dtype=np.float64).reshape(-1, 2))
+    return bool(lib().orc_point_in_polygon(_dp(pt), _dp(v), v.shape[0]))
+
+
+def edge_check_polygons(ps: PolygonSet, p0, p1, robot_radius):
+    p0, p1 = _vec(p0), _vec(p1)
+    fh = C.c_int32()
+    hit = lib().orc_edge_check_polygons(ps.arr, ps.m, _dp(p0), _dp(p1), robot_radius, C.byref(fh))
+    return bool(hit), fh.value
+
+
+def edges_check_polygons(ps: PolygonSet, P0, P1, robot_radius):
+    P0 = np.ascontiguousarray(P0, dtype=np.float64)
+    P1 = np.ascontiguousarray(P1, dtype=np.float64)
+    n, d = P0.shape
+    hit = np.zeros(n, dtype=np.uint8)
+    first = np.full(n, -1, dtype=np.int32)
+    fh = C.c_int32()
+    f = lib().orc_edge_check_polygons
+    for i in range(n):
+        hit[i] = f(ps.arr, ps.m, C.cast(P0.ctypes.data + i * d * 8, c_double_p),
+                   C.cast(P1.ctypes.data + i * d * 8, c_double_p), robot_radius, C.byref(fh))
+        first[i] = fh.value
+    return hit, first
+
+
+def point_check_polygons(ps: PolygonSet, p, robot_radius):
+    p = _vec(p)
+    cl = C.c_double()
+    r = lib().orc_point_check_polygons(ps.arr, ps.m, _dp(p), robot_radius, C.byref(cl))
+    return bool(r), cl.value
+
+
+def dubins_steer(s, g, r_min: float, want_traj: bool = True):
+    """Returns (cost, word, traj[P,2])."""
+    s, g = _vec(s), _vec(g)
+    cost = C.c_double()
+    word = C.create_string_buffer(4)
+    cap = 1024
+    traj = np.zeros((cap, 2), dtype=np.float64)
+    n = C.c_int()
+    lib().orc_dubins_steer(_dp(s), _dp(g), r_min, C.byref(cost), word, _dp(traj) if want_traj else None,
+                           cap, C.byref(n))
+    return cost.value, word.value.decode(), traj[: n.value].copy()
+
+
+def dubins_edge_check_polygons(ps: PolygonSet, s, g, traj, robot_radius, r_min):
+    s, g = _vec(s), _vec(g)
+    traj = np.ascontiguousarray(traj, dtype=np.float64).reshape(-1, 2)
+    fh = C.c_int32()
+    hit = lib().orc_dubins_edge_check_polygons(ps.arr, ps.m, _dp(s), _dp(g), _dp(traj), traj.shape[0],
+                                               robot_radius, r_min, C.byref(fh))
+    return bool(hit), fh.value
+
+
+def julia_range_len(start, step, stop) -> int:
+    return lib().orc_julia_range_len(start, step, stop)
+
+
+def extend_batch_spheres(tree: KDTree, spheres, m, queries: np.ndarray, r: float, robot_radius: float):
+    """CPU-baseline loop. Returns (edges_checked, neighbours, hits, nearest_idx)."""
+    q = np.ascontiguousarray(queries, dtype=np.float64)
+    nq = q.shape[0]
+    nearest = np.empty(nq, dtype=np.int64)
+    nn, nh = C.c_int64(), C.c_int64()
+    e = lib().orc_extend_batch_spheres(tree.handle, spheres, m, _dp(q), nq, r, robot_radius,
+                                       nearest.ctypes.data_as(c_int64_p), C.byref(nn), C.byref(nh))
+    return e, nn.value, nh.value, nearest

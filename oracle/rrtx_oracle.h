@@ -1,0 +1,140 @@
+/*
+ * rrtx_oracle.h -- CPU restatement of the RRT^X extend/rewire hot path of
+ * jnetter6/RRTQX_3D (R/ = code_RRTQx_3D/).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product path (rrtqx_3d_amd/, librrtx_hip.so) never links or calls it.
+ *
+ * Parity status: the reference is Julia and cannot be executed in the build
+ * container (no julia binary, no network); the reference holds no golden
+ * vectors or asserting tests for this path.  The oracle is therefore pinned by
+ * (1) the hand-derived known-answer tests K1-K10 of SURVEY.md section 8(c) and
+ * (2) the reference's own differential design (kd-tree vs naive scan,
+ * R/kdTree_general.jl:1039-1148).  LinearAlgebra.dot (OpenBLAS ddot) and
+ * Julia's libm are third-party code outside R/: results that depend on their
+ * last-bit behaviour are "parity unpinned" (see DESIGN.md).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (no FMA contraction: Julia
+ * never contracts a*b+c on its own).
+ */
+#ifndef RRTX_ORACLE_H
+#define RRTX_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- A1: metric (R/DRRT_distance_functions.jl:37) ---------------------- */
+double orc_euclid(const double *x, const double *y, int d);
+/* hyper-ball radius, R/rrtqx.jl:382 */
+double orc_ball_radius(double delta, double ball_constant, int64_t n, int d);
+
+/* ---- A2-A5: kd-tree (R/kdTree_general.jl, R/ghostPoint.jl) ------------- */
+typedef struct orc_kd orc_kd;
+typedef struct orc_list orc_list;
+
+orc_kd *orc_kd_create(int d);
+void orc_kd_destroy(orc_kd *t);
+/* wraps are 0-based dimension indices; wrap_points[i] is the period */
+void orc_kd_set_wraps(orc_kd *t, int nwraps, const int *wraps, const double *wrap_points);
+int64_t orc_kd_insert(orc_kd *t, const double *pos);  /* returns node index (insertion order) */
+int64_t orc_kd_size(const orc_kd *t);
+int64_t orc_kd_depth(const orc_kd *t);
+const double *orc_kd_position(const orc_kd *t, int64_t idx);
+void orc_kd_nearest(orc_kd *t, const double *q, int64_t *idx, double *dist);
+void orc_kd_nearest_naive(orc_kd *t, const double *q, int64_t *idx, double *dist);
+
+/* kdFindWithinRange returns a JList; list order is front -> back, i.e. the
+ * reverse of discovery order (JlistPush inserts at the front). */
+orc_list *orc_kd_find_within_range(orc_kd *t, double r, const double *q);
+void orc_kd_find_more_within_range(orc_kd *t, double r, const double *q, orc_list *l);
+int64_t orc_list_length(const orc_list *l);
+/* copy list front->back into idx/key (cap entries at most); returns length */
+int64_t orc_list_read(const orc_list *l, int64_t cap, int32_t *idx, double *key);
+/* emptyRangeList: clears the inHeap flags and frees the list */
+void orc_kd_empty_range_list(orc_kd *t, orc_list *l);
+/* naive scan with the same inclusivity rule (root <=, others <); ascending idx.
+ * With wraps, ghosts are applied the same way as the tree search. */
+int64_t orc_range_naive(orc_kd *t, double r, const double *q, int64_t cap,
+                        int32_t *idx, double *key);
+
+/* ghost iterator exposed for tests (R/ghostPoint.jl:60-111).  Writes up to cap
+ * ghosts (each d doubles) and returns how many were produced for bestDist. */
+int orc_ghost_points(const orc_kd *t, const double *q, double best_dist, int cap, double *out);
+
+/* ---- A9/A12: sphere obstacles (R/DRRT_Q.jl:1205-1210,1402-1595,1775-1826) */
+typedef struct {
+  double c[3];
+  double radius;
+  double life_span;    /* lifeSpan <= 0 => inactive */
+  int32_t unused;      /* obstacleUnused */
+  int32_t pad;
+} orc_sphere;
+
+double orc_distance_point_to_segment3(const double *c, const double *p0, const double *p1);
+int orc_edge_check_sphere(const orc_sphere *ob, const double *p0, const double *p1, double robot_radius);
+/* explicitEdgeCheck(C, edge): list order, early-out; returns 1 on hit and the
+ * list position of the first hit (or -1) */
+int orc_edge_check_spheres(const orc_sphere *obs, int m, const double *p0, const double *p1,
+                           double robot_radius, int32_t *first_hit);
+/* explicitPointCheck (quick=1: with quickCheck first pass, R/DRRT_Q.jl:1520;
+ * quick=0: explicitPointCheck3D, :1558). wdims = 3 (SimpleEdge Wdist). */
+int orc_point_check_spheres(const orc_sphere *obs, int m, const double *p, double robot_radius,
+                            int quick, double *clearance);
+
+/* ---- A10: polygon obstacles (R/DRRT.jl:1009-1106,1144-1202,1258-1470,1523-1578) */
+typedef struct {
+  int32_t kind;        /* 1 ball, 3 polygon */
+  int32_t nverts;
+  const double *verts; /* nverts x 2 row-major */
+  double cx, cy;       /* Obstacle(3, polygon) ctor centre */
+  double radius;
+  double life_span;
+  int32_t unused;
+  int32_t pad;
+} orc_polygon;
+
+/* Obstacle(kind=3, polygon) ctor: bbox centre + max vertex distance
+ * (R/DRRT_data_structures.jl:229-241) */
+void orc_polygon_ctor(const double *verts, int nverts, double *cx, double *cy, double *radius);
+double orc_dist_sqrd_point_to_segment(const double *pt, const double *a, const double *b);
+double orc_segment_dist_sqrd(const double *pa, const double *pb, const double *qa, const double *qb);
+int orc_point_in_polygon(const double *pt, const double *verts, int nverts);
+double orc_dist_to_polygon_sqrd(const double *pt, const double *verts, int nverts);
+int orc_edge_check_polygon(const orc_polygon *ob, const double *p0, const double *p1, double robot_radius);
+int orc_edge_check_polygons(const orc_polygon *obs, int m, const double *p0, const double *p1,
+                            double robot_radius, int32_t *first_hit);
+int orc_point_check_polygons(const orc_polygon *obs, int m, const double *p, double robot_radius,
+                             double *clearance);
+
+/* ---- A6/A7/A11: steering ------------------------------------------------ */
+/* Dubins calculateTrajectory (R/DRRT_DubinsEdge_functions.jl:329-709), space
+ * without time.  s, g are [x y t theta].  traj (may be NULL) receives up to
+ * traj_cap rows of (x, y); *traj_len receives the number of rows the reference
+ * would produce.  word is 3 chars + NUL. */
+void orc_dubins_steer(const double *s, const double *g, double r_min, double *cost,
+                      char *word, double *traj, int traj_cap, int *traj_len);
+/* explicitEdgeCheck(S, DubinsEdge, obstacle) (:750-774) over a list */
+int orc_dubins_edge_check_polygons(const orc_polygon *obs, int m, const double *s, const double *g,
+                                   const double *traj, int traj_len, double robot_radius,
+                                   double r_min, int32_t *first_hit);
+/* Julia float range length for start:step:stop in the literal fallback branch */
+int64_t orc_julia_range_len(double start, double step, double stop);
+
+/* ---- A13/A8: the per-sample extend inner loop, used as the CPU baseline --
+ * For every query: kdFindNearest, kdFindWithinRange, then for every neighbour
+ * both directed edges: SimpleEdge cost + explicitEdgeCheck over the obstacle
+ * list with first-hit early-out.  Outputs are optional (NULL to skip).
+ * Returns the number of directed edges checked. */
+int64_t orc_extend_batch_spheres(orc_kd *t, const orc_sphere *obs, int m, const double *queries,
+                                 int64_t nq, double r, double robot_radius,
+                                 int64_t *nearest_idx, int64_t *n_neighbors_total,
+                                 int64_t *n_hits_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
