@@ -1,0 +1,190 @@
+/*
+ * rrtx.h -- C ABI of librrtx_hip.so: the MI355X (gfx950) implementation of the
+ * RRT^X extend/rewire hot path of jnetter6/RRTQX_3D.
+ *
+ * The reference (Julia, R/ = code_RRTQx_3D/) has no FFI; the seam is a set of
+ * free functions selected by multiple dispatch (R/README.txt:85-99).  Each entry
+ * point below names the reference function(s) it replaces.  The Julia binding a
+ * maintainer would add is shown in INTEGRATION.md and julia/RRTXHip.jl.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all host buffers are caller-owned and only
+ *     read/written for the duration of the call (GC.@preserve on the Julia side);
+ *   - every function returns RRTX_OK (0) or a negative RRTX_E_* code and never
+ *     throws or aborts; rrtx_last_error(ctx) gives the message;
+ *   - points are passed as n x dim row-major doubles (a Julia dim x n Array);
+ *   - node indices are 0-based insertion order (index 0 is the kd-tree root);
+ *   - a ctx is bound to ONE GPU and is not thread-safe; distinct ctxs are
+ *     independent (one per planner/agent tree, R/rrtqx.jl:29-31);
+ *   - all arithmetic is IEEE fp64 without FMA contraction, so neighbour sets and
+ *     collision booleans are bit-identical to the reference's CPU path; NaN
+ *     inputs are not errors (a zero-length edge is a "hit", R/DRRT_Q.jl:1208);
+ *   - host-pointer calls are synchronous; the *_dev calls take DEVICE pointers,
+ *     enqueue on the ctx stream and return immediately (rrtx_sync to wait).
+ */
+#ifndef RRTX_H
+#define RRTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRTX_OK 0
+#define RRTX_E_INVALID (-1)  /* bad argument */
+#define RRTX_E_CAPACITY (-2) /* caller output buffer too small; see `needed` */
+#define RRTX_E_DEVICE (-3)   /* HIP runtime error */
+#define RRTX_E_NOMEM (-4)
+#define RRTX_E_STATE (-5)    /* call not valid in this state (e.g. empty tree) */
+
+typedef struct rrtx_ctx rrtx_ctx;
+
+typedef struct {
+  int64_t n_nodes;
+  int32_t dim;
+  int32_t n_spheres;         /* as set (active + inactive) */
+  int32_t n_polygons;
+  int32_t n_wraps;
+  /* per-kernel-family device time, accumulated while profiling is enabled
+   * (HIP events on the ctx stream around every launch of that family) */
+  double ms_nn_scan;     int64_t launches_nn_scan;
+  double ms_nn_finish;   int64_t launches_nn_finish;
+  double ms_nn_nearest;  int64_t launches_nn_nearest;
+  double ms_edges;       int64_t launches_edges;
+  double ms_points;      int64_t launches_points;
+  double ms_dubins;      int64_t launches_dubins;
+  /* work counters of the last rrtx_nn_radius* / rrtx_extend_candidates* call */
+  int64_t last_pairs;        /* (query copy, node) visits */
+  int64_t last_neighbors;    /* sum of k */
+} rrtx_stats_t;
+
+/* ---- lifetime ------------------------------------------------------------ */
+/* replaces KDTree{T}(d, KDdist) + CSpace obstacle list construction
+ * (R/kdTree_general.jl:94-112, R/rrtqx.jl:29-31).  dim is 3 (SimpleEdge, 3-D)
+ * or 4 ([x y t theta], Dubins).  device = HIP device ordinal. */
+int rrtx_create(rrtx_ctx **out, int dim, int device, int64_t node_capacity);
+int rrtx_destroy(rrtx_ctx *ctx);
+const char *rrtx_last_error(rrtx_ctx *ctx);
+/* message of the last failing rrtx_create (no ctx exists then) */
+const char *rrtx_create_error(void);
+/* run on a caller-provided hipStream_t (e.g. the stream the caller's framework is using); NULL
+ * restores the ctx-owned stream */
+int rrtx_set_stream(rrtx_ctx *ctx, void *hip_stream);
+void *rrtx_get_stream(rrtx_ctx *ctx);
+int rrtx_sync(rrtx_ctx *ctx);
+int rrtx_profile(rrtx_ctx *ctx, int enable); /* per-kernel HIP-event timing on/off (resets sums) */
+int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
+
+/* ---- tree (A2, A5) --------------------------------------------------------- */
+/* kdInsert (R/kdTree_general.jl:121-170): appends n nodes; *first_index receives
+ * the index of the first one (== treeSize before the call). */
+int rrtx_nodes_append(rrtx_ctx *ctx, const double *pos, int64_t n, int64_t *first_index);
+int64_t rrtx_nodes_count(rrtx_ctx *ctx);
+/* device-to-device variant: pos is a device pointer */
+int rrtx_nodes_append_dev(rrtx_ctx *ctx, const double *pos_dev, int64_t n);
+/* KDTree(d, f, wraps, wrapPoints) (R/kdTree_general.jl:108): dimension
+ * dim_index (0-based) wraps with the given period (Dubins theta: 3, 2*pi;
+ * R/DRRT.jl:3312).  At most 3 wrapped dimensions. */
+int rrtx_set_wrap(rrtx_ctx *ctx, int dim_index, double period);
+
+/* ---- obstacles (A15) ------------------------------------------------------- */
+/* CSpace.obstacles as List{SphereObstacle} in LIST ORDER (front first,
+ * R/list.jl:53-58).  cxyzr is m x 4; active[i] = !(obstacleUnused || lifeSpan<=0)
+ * (R/DRRT_Q.jl:1777); NULL = all active. */
+int rrtx_spheres_set(rrtx_ctx *ctx, const double *cxyzr, const uint8_t *active, int m);
+/* polygon Obstacles (legacy 2-D path, R/DRRT_data_structures.jl:135-265), list
+ * order.  vert_off is m+1 CSR offsets into vxy (2 doubles per vertex);
+ * centre_radius is m x 3 (the Obstacle(3, polygon) ctor values, :229-241, or
+ * NULL to have the library apply that ctor); kind[i] is 1 (ball) or 3
+ * (polygon). */
+int rrtx_polygons_set(rrtx_ctx *ctx, const int32_t *vert_off, const double *vxy,
+                      const double *centre_radius, const uint8_t *kind, const uint8_t *active, int m);
+/* obstacleAugmentation / expiry (R/obstacleAugmentation.jl:106-114,
+ * R/DRRT_Q.jl:3301): change radius and/or active flag of sphere `which`. */
+int rrtx_obstacle_update(rrtx_ctx *ctx, int which, double radius, uint8_t active);
+
+/* ---- nearest neighbours (A3, A4) ------------------------------------------ */
+/* kdFindNearest (R/kdTree_general.jl:357-385), batched.  idx/dist: nq entries.
+ * Ties on distance resolve to the lowest index (the reference's tie order is
+ * its tree-visit order). */
+int rrtx_nn_nearest(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double *dist);
+/* kdFindWithinRange (R/kdTree_general.jl:889-919), batched: for query i the
+ * nodes with KDdist < r[i] (the root, index 0, with <=), wrapped dimensions
+ * handled with the reference's ghost rule; each list sorted by node index,
+ * dist = the key the reference stores.  CSR output; if the total exceeds cap
+ * the call returns RRTX_E_CAPACITY with *needed set (offsets are still valid).
+ * r_stride: 0 = one radius r[0] for all queries, 1 = r[i] per query. */
+int rrtx_nn_radius(rrtx_ctx *ctx, const double *q, const double *r, int r_stride, int nq,
+                   int64_t *offsets /* nq+1 */, int32_t *idx, double *dist, int64_t cap,
+                   int64_t *needed);
+
+/* ---- collision (A8-A12) ----------------------------------------------------- */
+/* explicitEdgeCheck(C, edge) (R/DRRT_Q.jl:1802-1826) for ne straight edges
+ * p0[i] -> p1[i]; obstacle_or_minus1 >= 0 restricts the test to that one
+ * obstacle (explicitEdgeCheck(S, edge, ob), R/DRRT_Q.jl:3248).  kind selects
+ * the obstacle list: 0 = spheres (explicitEdgeCheck3D, :1775-1795, uses the
+ * first 3 coordinates), 1 = polygons (explicitEdgeCheck2D, R/DRRT.jl:1523-1578,
+ * uses the first 2).  hit[i] in {0,1}; first_hit[i] = list position of the
+ * first colliding obstacle or -1 (may be NULL). */
+int rrtx_edges_check(rrtx_ctx *ctx, int kind, const double *p0, const double *p1, int64_t ne,
+                     double robot_radius, int obstacle_or_minus1, uint8_t *hit, int32_t *first_hit);
+/* explicitPointCheck (R/DRRT_Q.jl:1520-1556; quick=0: explicitPointCheck3D,
+ * :1558-1590).  unsafe[i] in {0,1}; clearance[i] = the returned certificate
+ * (0.0 when unsafe). kind as above. */
+int rrtx_points_check(rrtx_ctx *ctx, int kind, const double *p, int64_t np, double robot_radius,
+                      int quick, uint8_t *unsafe, double *clearance);
+
+/* ---- steering (A6, A7, A11) -------------------------------------------------- */
+/* calculateTrajectory(S, ::SimpleEdge) (R/DRRT_SimpleEdge_functions.jl:177-181):
+ * dist over all dim coordinates, wdist over the first 3. */
+int rrtx_simple_steer(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double *dist,
+                      double *wdist);
+/* calculateTrajectory(S, ::DubinsEdge) (R/DRRT_DubinsEdge_functions.jl:329-501),
+ * space without time: cost = edge.dist = edge.Wdist, word = 3 chars per edge
+ * ("rsl","rsr","rlr","lsr","lsl","lrl","xxx").  s, g are ne x 4 [x y t theta]. */
+int rrtx_dubins_steer(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min,
+                      double *cost, uint8_t *word /* ne x 3 */);
+/* Same, plus the discretised trajectory (:506-701) and the two-stage Dubins
+ * collision check against the polygon list (:750-774).  traj_len[i] = number of
+ * polyline rows the reference builds (may be NULL). */
+int rrtx_dubins_edges_check(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne,
+                            double r_min, double robot_radius, double *cost, uint8_t *word,
+                            uint8_t *hit, int32_t *traj_len);
+
+/* ---- fused per-sample preamble of extend() (A13) ----------------------------- */
+/* For each of nq samples: kdFindWithinRange + for every neighbour both directed
+ * SimpleEdges sample->near and near->sample: calculateTrajectory cost and
+ * explicitEdgeCheck over the sphere list (R/DRRT_Q.jl:1927-1979, 2581-2637),
+ * plus kdFindNearest (R/rrtqx.jl:926) and explicitPointCheck of the sample
+ * (R/rrtqx.jl:940).  CSR layout as rrtx_nn_radius; per neighbour entry:
+ * cost (same both ways for SimpleEdge), hit_out (sample->near), hit_in. */
+int rrtx_extend_candidates(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius,
+                           int64_t *offsets, int32_t *idx, double *cost, uint8_t *hit_out,
+                           uint8_t *hit_in, int64_t cap, int64_t *needed, int32_t *nearest_idx,
+                           double *nearest_dist, uint8_t *sample_unsafe);
+
+/* ---- device-resident variants (inputs/outputs are DEVICE pointers) ------------ */
+int rrtx_nn_nearest_dev(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double *dist);
+int rrtx_nn_radius_dev(rrtx_ctx *ctx, const double *q, double r, int nq, int64_t *offsets,
+                       int32_t *idx, double *dist, int64_t cap, int64_t *needed_dev);
+int rrtx_edges_check_dev(rrtx_ctx *ctx, int kind, const double *p0, const double *p1, int64_t ne,
+                         double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
+                         uint8_t *hit, int32_t *first_hit);
+int rrtx_points_check_dev(rrtx_ctx *ctx, int kind, const double *p, int64_t np, double robot_radius,
+                          int quick, uint8_t *unsafe, double *clearance);
+int rrtx_extend_candidates_dev(rrtx_ctx *ctx, const double *q, int nq, double r,
+                               double robot_radius, int64_t *offsets, int32_t *idx, double *cost,
+                               uint8_t *hit_out, uint8_t *hit_in, int64_t cap, int64_t *needed_dev,
+                               int32_t *nearest_idx, double *nearest_dist, uint8_t *sample_unsafe);
+
+/* Per-edge collision bitmask for the multi-GPU exchange (RCCL all-reduce over
+ * xGMI): bit e (e < cap) = hit_out[e], bit cap+e = hit_in[e]; entries at or
+ * beyond *n_valid_dev read as 0.  words has (2*cap+63)/64 uint64 entries. */
+int rrtx_pack_hits_dev(rrtx_ctx *ctx, const uint8_t *hit_out, const uint8_t *hit_in,
+                       const int64_t *n_valid_dev, int64_t cap, uint64_t *words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

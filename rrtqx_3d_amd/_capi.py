@@ -1,0 +1,119 @@
+"""ctypes binding of librrtx_hip.so (include/rrtx.h).
+
+This is the same boundary a Julia `ccall` shim binds (julia/RRTXHip.jl); there is
+no CPU fallback: if the HIP library is missing or no GPU is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librrtx_hip.so")
+
+RRTX_OK = 0
+RRTX_E_INVALID = -1
+RRTX_E_CAPACITY = -2
+RRTX_E_DEVICE = -3
+RRTX_E_NOMEM = -4
+RRTX_E_STATE = -5
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class RrtxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rrtx error {code}: {msg}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int64), ("dim", C.c_int32), ("n_spheres", C.c_int32), ("n_polygons", C.c_int32),
+        ("n_wraps", C.c_int32),
+        ("ms_nn_scan", C.c_double), ("launches_nn_scan", C.c_int64),
+        ("ms_nn_finish", C.c_double), ("launches_nn_finish", C.c_int64),
+        ("ms_nn_nearest", C.c_double), ("launches_nn_nearest", C.c_int64),
+        ("ms_edges", C.c_double), ("launches_edges", C.c_int64),
+        ("ms_points", C.c_double), ("launches_points", C.c_int64),
+        ("ms_dubins", C.c_double), ("launches_dubins", C.c_int64),
+        ("last_pairs", C.c_int64), ("last_neighbors", C.c_int64),
+    ]
+
+
+# every symbol include/rrtx.h declares: (name, restype, argtypes)
+_VP = C.c_void_p
+SYMBOLS = [
+    ("rrtx_create", C.c_int, [C.POINTER(_VP), C.c_int, C.c_int, C.c_int64]),
+    ("rrtx_destroy", C.c_int, [_VP]),
+    ("rrtx_last_error", C.c_char_p, [_VP]),
+    ("rrtx_create_error", C.c_char_p, []),
+    ("rrtx_set_stream", C.c_int, [_VP, _VP]),
+    ("rrtx_get_stream", _VP, [_VP]),
+    ("rrtx_sync", C.c_int, [_VP]),
+    ("rrtx_profile", C.c_int, [_VP, C.c_int]),
+    ("rrtx_stats", C.c_int, [_VP, C.POINTER(Stats)]),
+    ("rrtx_nodes_append", C.c_int, [_VP, _VP, C.c_int64, c_int64_p]),
+    ("rrtx_nodes_count", C.c_int64, [_VP]),
+    ("rrtx_nodes_append_dev", C.c_int, [_VP, _VP, C.c_int64]),
+    ("rrtx_set_wrap", C.c_int, [_VP, C.c_int, C.c_double]),
+    ("rrtx_spheres_set", C.c_int, [_VP, _VP, _VP, C.c_int]),
+    ("rrtx_polygons_set", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int]),
+    ("rrtx_obstacle_update", C.c_int, [_VP, C.c_int, C.c_double, C.c_uint8]),
+    ("rrtx_nn_nearest", C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
+    ("rrtx_nn_radius", C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP, C.c_int64, c_int64_p]),
+    ("rrtx_edges_check", C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP]),
+    ("rrtx_points_check", C.c_int, [_VP, C.c_int, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP]),
+    ("rrtx_simple_steer", C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP]),
+    ("rrtx_dubins_steer", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP]),
+    ("rrtx_dubins_edges_check", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_double, _VP, _VP, _VP, _VP]),
+    ("rrtx_extend_candidates", C.c_int, [_VP, _VP, C.c_int, C.c_double, C.c_double, _VP, _VP, _VP, _VP, _VP,
+                                         C.c_int64, c_int64_p, _VP, _VP, _VP]),
+    ("rrtx_nn_nearest_dev", C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
+    ("rrtx_nn_radius_dev", C.c_int, [_VP, _VP, C.c_double, C.c_int, _VP, _VP, _VP, C.c_int64, _VP]),
+    ("rrtx_edges_check_dev", C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int,
+                                       _VP, _VP]),
+    ("rrtx_points_check_dev", C.c_int, [_VP, C.c_int, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP]),
+    ("rrtx_extend_candidates_dev", C.c_int, [_VP, _VP, C.c_int, C.c_double, C.c_double, _VP, _VP, _VP, _VP, _VP,
+                                             C.c_int64, _VP, _VP, _VP, _VP]),
+    ("rrtx_pack_hits_dev", C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP]),
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load librrtx_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m rrtqx_3d_amd.build` "
+            "(the HIP extension is the only implementation; there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    """numpy array -> void* (None stays NULL)."""
+    if a is None:
+        return None
+    return a.ctypes.data
+
+
+def f64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a

@@ -1,0 +1,258 @@
+"""numpy-facing wrapper of one rrtx_ctx (one tree + obstacle lists on one GPU).
+
+Thin by design: every method is one C-ABI call of include/rrtx.h.  The
+reference-named API (kdInsert, kdFindWithinRange, explicitEdgeCheck, ...) lives in
+rrtqx_3d_amd/drrt.py on top of this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _capi
+from ._capi import RrtxError, Stats, f64
+
+
+class Context:
+    def __init__(self, dim: int = 3, device: int = 0, node_capacity: int = 1024):
+        self._lib = _capi.load()
+        self.dim = dim
+        self.device = device
+        h = C.c_void_p()
+        rc = self._lib.rrtx_create(C.byref(h), dim, device, node_capacity)
+        if rc != _capi.RRTX_OK:
+            raise RrtxError(rc, self._lib.rrtx_create_error().decode())
+        self._h = h
+
+    # ---- lifetime -------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rrtx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != _capi.RRTX_OK:
+            raise RrtxError(rc, self._lib.rrtx_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, stream_ptr: Optional[int]):
+        self._check(self._lib.rrtx_set_stream(self._h, stream_ptr))
+
+    def get_stream(self) -> int:
+        return self._lib.rrtx_get_stream(self._h) or 0
+
+    def sync(self):
+        self._check(self._lib.rrtx_sync(self._h))
+
+    def profile(self, enable: bool):
+        self._check(self._lib.rrtx_profile(self._h, 1 if enable else 0))
+
+    def stats(self) -> Stats:
+        s = Stats()
+        self._check(self._lib.rrtx_stats(self._h, C.byref(s)))
+        return s
+
+    # ---- tree -------------------------------------------------------------------
+    def nodes_append(self, pos) -> int:
+        pos = f64(pos, (-1, self.dim))
+        first = C.c_int64()
+        self._check(self._lib.rrtx_nodes_append(self._h, _capi._ptr(pos), pos.shape[0], C.byref(first)))
+        return first.value
+
+    def nodes_append_dev(self, dev_ptr: int, n: int):
+        self._check(self._lib.rrtx_nodes_append_dev(self._h, dev_ptr, n))
+
+    @property
+    def n_nodes(self) -> int:
+        return self._lib.rrtx_nodes_count(self._h)
+
+    def set_wrap(self, dim_index: int, period: float):
+        self._check(self._lib.rrtx_set_wrap(self._h, dim_index, period))
+
+    # ---- obstacles ----------------------------------------------------------------
+    def spheres_set(self, cxyzr, active=None):
+        cxyzr = f64(cxyzr, (-1, 4))
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        self._check(self._lib.rrtx_spheres_set(self._h, _capi._ptr(cxyzr), _capi._ptr(act), cxyzr.shape[0]))
+
+    def obstacle_update(self, which: int, radius: float, active: bool):
+        self._check(self._lib.rrtx_obstacle_update(self._h, which, radius, 1 if active else 0))
+
+    def polygons_set(self, polys, kinds=None, active=None, centre_radius=None):
+        """polys: list of (P_i x 2) vertex arrays in list order."""
+        polys = [f64(p, (-1, 2)) for p in polys]
+        m = len(polys)
+        off = np.zeros(m + 1, dtype=np.int32)
+        for i, p in enumerate(polys):
+            off[i + 1] = off[i] + p.shape[0]
+        vxy = np.concatenate(polys, axis=0) if m else np.zeros((0, 2))
+        vxy = f64(vxy, (-1, 2))
+        k = None if kinds is None else np.ascontiguousarray(kinds, dtype=np.uint8)
+        a = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        cr = None if centre_radius is None else f64(centre_radius, (-1, 3))
+        self._check(self._lib.rrtx_polygons_set(self._h, _capi._ptr(off), _capi._ptr(vxy), _capi._ptr(cr),
+                                                _capi._ptr(k), _capi._ptr(a), m))
+
+    # ---- nearest neighbours ---------------------------------------------------------
+    def nn_nearest(self, q) -> Tuple[np.ndarray, np.ndarray]:
+        q = f64(q, (-1, self.dim))
+        nq = q.shape[0]
+        idx = np.empty(nq, dtype=np.int32)
+        dist = np.empty(nq, dtype=np.float64)
+        self._check(self._lib.rrtx_nn_nearest(self._h, _capi._ptr(q), nq, _capi._ptr(idx), _capi._ptr(dist)))
+        return idx, dist
+
+    def nn_radius(self, q, r, cap: Optional[int] = None):
+        """Returns CSR (offsets[nq+1], idx, dist). r: scalar or per-query array."""
+        q = f64(q, (-1, self.dim))
+        nq = q.shape[0]
+        r_arr = f64(r, (-1,))
+        stride = 0 if r_arr.shape[0] == 1 else 1
+        if stride == 1 and r_arr.shape[0] != nq:
+            raise ValueError("r must be a scalar or have one entry per query")
+        if cap is None:
+            cap = max(64 * nq, 1024)
+        offsets = np.empty(nq + 1, dtype=np.int64)
+        while True:
+            idx = np.empty(cap, dtype=np.int32)
+            dist = np.empty(cap, dtype=np.float64)
+            needed = C.c_int64()
+            rc = self._lib.rrtx_nn_radius(self._h, _capi._ptr(q), _capi._ptr(r_arr), stride, nq,
+                                          _capi._ptr(offsets), _capi._ptr(idx), _capi._ptr(dist), cap,
+                                          C.byref(needed))
+            if rc == _capi.RRTX_E_CAPACITY:
+                cap = int(needed.value)     # two-call pattern
+                continue
+            self._check(rc)
+            n = int(needed.value)
+            return offsets, idx[:n], dist[:n]
+
+    # ---- collision ---------------------------------------------------------------------
+    def edges_check(self, p0, p1, robot_radius: float, kind: int = 0, obstacle: int = -1,
+                    want_first: bool = True):
+        p0 = f64(p0, (-1, self.dim))
+        p1 = f64(p1, (-1, self.dim))
+        ne = p0.shape[0]
+        hit = np.empty(ne, dtype=np.uint8)
+        first = np.empty(ne, dtype=np.int32) if want_first else None
+        self._check(self._lib.rrtx_edges_check(self._h, kind, _capi._ptr(p0), _capi._ptr(p1), ne, robot_radius,
+                                               obstacle, _capi._ptr(hit), _capi._ptr(first)))
+        return hit, first
+
+    def points_check(self, p, robot_radius: float, kind: int = 0, quick: bool = True):
+        p = f64(p, (-1, self.dim))
+        n = p.shape[0]
+        unsafe = np.empty(n, dtype=np.uint8)
+        clr = np.empty(n, dtype=np.float64)
+        self._check(self._lib.rrtx_points_check(self._h, kind, _capi._ptr(p), n, robot_radius, 1 if quick else 0,
+                                                _capi._ptr(unsafe), _capi._ptr(clr)))
+        return unsafe, clr
+
+    # ---- steering -------------------------------------------------------------------------
+    def simple_steer(self, s, g):
+        s = f64(s, (-1, self.dim))
+        g = f64(g, (-1, self.dim))
+        ne = s.shape[0]
+        dist = np.empty(ne, dtype=np.float64)
+        wdist = np.empty(ne, dtype=np.float64)
+        self._check(self._lib.rrtx_simple_steer(self._h, _capi._ptr(s), _capi._ptr(g), ne, _capi._ptr(dist),
+                                                _capi._ptr(wdist)))
+        return dist, wdist
+
+    def dubins_steer(self, s, g, r_min: float):
+        s = f64(s, (-1, 4))
+        g = f64(g, (-1, 4))
+        ne = s.shape[0]
+        cost = np.empty(ne, dtype=np.float64)
+        word = np.empty((ne, 3), dtype=np.uint8)
+        self._check(self._lib.rrtx_dubins_steer(self._h, _capi._ptr(s), _capi._ptr(g), ne, r_min, _capi._ptr(cost),
+                                                _capi._ptr(word)))
+        return cost, [bytes(w).decode() for w in word]
+
+    def dubins_edges_check(self, s, g, r_min: float, robot_radius: float):
+        s = f64(s, (-1, 4))
+        g = f64(g, (-1, 4))
+        ne = s.shape[0]
+        cost = np.empty(ne, dtype=np.float64)
+        word = np.empty((ne, 3), dtype=np.uint8)
+        hit = np.empty(ne, dtype=np.uint8)
+        tl = np.empty(ne, dtype=np.int32)
+        self._check(self._lib.rrtx_dubins_edges_check(self._h, _capi._ptr(s), _capi._ptr(g), ne, r_min,
+                                                      robot_radius, _capi._ptr(cost), _capi._ptr(word),
+                                                      _capi._ptr(hit), _capi._ptr(tl)))
+        return cost, [bytes(w).decode() for w in word], hit, tl
+
+    # ---- fused extend() preamble --------------------------------------------------------------
+    def extend_candidates(self, q, r: float, robot_radius: float, cap: Optional[int] = None):
+        q = f64(q, (-1, self.dim))
+        nq = q.shape[0]
+        if cap is None:
+            cap = max(64 * nq, 1024)
+        offsets = np.empty(nq + 1, dtype=np.int64)
+        nidx = np.empty(nq, dtype=np.int32)
+        ndist = np.empty(nq, dtype=np.float64)
+        unsafe = np.empty(nq, dtype=np.uint8)
+        while True:
+            idx = np.empty(cap, dtype=np.int32)
+            cost = np.empty(cap, dtype=np.float64)
+            hout = np.empty(cap, dtype=np.uint8)
+            hin = np.empty(cap, dtype=np.uint8)
+            needed = C.c_int64()
+            rc = self._lib.rrtx_extend_candidates(self._h, _capi._ptr(q), nq, r, robot_radius, _capi._ptr(offsets),
+                                                  _capi._ptr(idx), _capi._ptr(cost), _capi._ptr(hout),
+                                                  _capi._ptr(hin), cap, C.byref(needed), _capi._ptr(nidx),
+                                                  _capi._ptr(ndist), _capi._ptr(unsafe))
+            if rc == _capi.RRTX_E_CAPACITY:
+                cap = int(needed.value)
+                continue
+            self._check(rc)
+            n = int(needed.value)
+            return dict(offsets=offsets, idx=idx[:n], cost=cost[:n], hit_out=hout[:n], hit_in=hin[:n],
+                        nearest_idx=nidx, nearest_dist=ndist, sample_unsafe=unsafe)
+
+    # ---- device-pointer variants (pointers are ints, e.g. torch.Tensor.data_ptr()) ----------------
+    def nn_nearest_dev(self, q_ptr: int, nq: int, idx_ptr: int, dist_ptr: int):
+        self._check(self._lib.rrtx_nn_nearest_dev(self._h, q_ptr, nq, idx_ptr, dist_ptr))
+
+    def nn_radius_dev(self, q_ptr: int, r: float, nq: int, offsets_ptr: int, idx_ptr: int, dist_ptr: int, cap: int,
+                      needed_ptr: int):
+        self._check(self._lib.rrtx_nn_radius_dev(self._h, q_ptr, r, nq, offsets_ptr, idx_ptr, dist_ptr, cap,
+                                                 needed_ptr))
+
+    def edges_check_dev(self, kind: int, p0_ptr: int, p1_ptr: int, ne: int, robot_radius: float, obstacle: int,
+                        obs_begin: int, obs_end: int, hit_ptr: int, first_ptr: Optional[int]):
+        self._check(self._lib.rrtx_edges_check_dev(self._h, kind, p0_ptr, p1_ptr, ne, robot_radius, obstacle,
+                                                   obs_begin, obs_end, hit_ptr, first_ptr))
+
+    def points_check_dev(self, kind: int, p_ptr: int, n: int, robot_radius: float, quick: bool, unsafe_ptr: int,
+                         clr_ptr: Optional[int]):
+        self._check(self._lib.rrtx_points_check_dev(self._h, kind, p_ptr, n, robot_radius, 1 if quick else 0,
+                                                    unsafe_ptr, clr_ptr))
+
+    def extend_candidates_dev(self, q_ptr: int, nq: int, r: float, robot_radius: float, offsets_ptr: int,
+                              idx_ptr: int, cost_ptr: int, hit_out_ptr: int, hit_in_ptr: int, cap: int,
+                              needed_ptr: int, nearest_idx_ptr: Optional[int] = None,
+                              nearest_dist_ptr: Optional[int] = None, unsafe_ptr: Optional[int] = None):
+        self._check(self._lib.rrtx_extend_candidates_dev(self._h, q_ptr, nq, r, robot_radius, offsets_ptr, idx_ptr,
+                                                         cost_ptr, hit_out_ptr, hit_in_ptr, cap, needed_ptr,
+                                                         nearest_idx_ptr, nearest_dist_ptr, unsafe_ptr))
+
+    def pack_hits_dev(self, hit_out_ptr: int, hit_in_ptr: int, n_valid_ptr: int, cap: int, words_ptr: int):
+        self._check(self._lib.rrtx_pack_hits_dev(self._h, hit_out_ptr, hit_in_ptr, n_valid_ptr, cap, words_ptr))

@@ -1,0 +1,591 @@
+// kernels_collide.hip -- per-edge and per-point collision checks against the
+// obstacle lists.  Replaces explicitEdgeCheck / explicitPointCheck and their
+// geometry helpers (sphere: R/DRRT_Q.jl:1205-1210, 1402-1595, 1775-1826;
+// polygon: R/DRRT.jl:1009-1106, 1144-1202, 1258-1470, 1523-1578, 1660-1678).
+// gfx950 only.  Lane = edge (or point); the obstacle loop is wave-uniform so
+// obstacle records arrive through scalar loads; a wave leaves the loop as soon
+// as every lane has its answer (ballot early-out).
+#include "exact_math.hpp"
+#include "rrtx_internal.hpp"
+
+namespace rrtx {
+
+namespace {
+
+// ------------------------------------------------------------ spheres -------
+// distancePointToSegment + explicitEdgeCheck3D for one (edge, sphere) pair.
+// Returns true on collision.  t = dot/edgeLen (NOT edgeLen^2) is the
+// reference's formula (R/DRRT_Q.jl:1208) and is reproduced on purpose.
+__device__ __forceinline__ bool edge_hits_sphere(double p0x, double p0y, double p0z, double bx, double by,
+                                                 double bz, double edge_len, const SphRec &ob) {
+  double a0 = ob.cx - p0x, a1 = ob.cy - p0y, a2 = ob.cz - p0z;
+  double dot = (a0 * bx + a1 * by) + a2 * bz;
+  double t = jl_clamp01(dot / edge_len);
+  double qx = p0x + t * bx, qy = p0y + t * by, qz = p0z + t * bz;
+  double s = sq3(ob.cx, ob.cy, ob.cz, qx, qy, qz);
+  // distS > robotRadius + radius  <=>  s >= thr ; collision unless that holds
+  return !(s >= ob.thr);
+}
+
+__global__ __launch_bounds__(256) void edges_spheres_kernel(const double *__restrict__ p0,
+                                                            const double *__restrict__ p1, int stride,
+                                                            long long ne, const SphRec *__restrict__ sph,
+                                                            const int32_t *__restrict__ orig, int m_begin,
+                                                            int m_end, uint8_t *__restrict__ hit,
+                                                            int32_t *__restrict__ first_hit) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = i < ne;
+  double ax = 0, ay = 0, az = 0, ex = 0, ey = 0, ez = 0;
+  if (act) {
+    ax = p0[i * stride + 0]; ay = p0[i * stride + 1]; az = p0[i * stride + 2];
+    ex = p1[i * stride + 0]; ey = p1[i * stride + 1]; ez = p1[i * stride + 2];
+  }
+  const double bx = ex - ax, by = ey - ay, bz = ez - az;
+  const double edge_len = sqrt_rn(sq3(ax, ay, az, ex, ey, ez));
+  bool done = !act;
+  int first = -1;
+  for (int j = m_begin; j < m_end; ++j) {
+    const SphRec ob = sph[j];   // wave-uniform -> scalar load
+    bool h = edge_hits_sphere(ax, ay, az, bx, by, bz, edge_len, ob);
+    if (!done && h) { done = true; first = orig[j]; }
+    if (__ballot(!done) == 0ull) break;   // every edge of this wave already collides
+  }
+  if (act) {
+    hit[i] = first >= 0 ? 1 : 0;
+    if (first_hit) first_hit[i] = first;
+  }
+}
+
+// Candidate edges of extend(): CSR entry e = (query qi, node idx[e]); checks
+// sample->near and near->sample (R/DRRT_Q.jl:1951-1963, 2600-2602).
+__global__ __launch_bounds__(256) void candidate_edges_kernel(
+    const double *__restrict__ q, int stride, const int64_t *__restrict__ offsets, int nq,
+    const int32_t *__restrict__ idx, const double *__restrict__ nx, const double *__restrict__ ny,
+    const double *__restrict__ nz, long long cap, const SphRec *__restrict__ sph, int m,
+    uint8_t *__restrict__ hit_out, uint8_t *__restrict__ hit_in) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = offsets[nq];
+  if (total > cap) total = cap;
+  const bool act = e < total;
+  double sx = 0, sy = 0, sz = 0, tx = 0, ty = 0, tz = 0;
+  if (act) {
+    // owning query: binary search over the offsets
+    int lo = 0, hi = nq;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (offsets[mid] <= e) lo = mid; else hi = mid;
+    }
+    sx = q[(size_t)lo * stride + 0]; sy = q[(size_t)lo * stride + 1]; sz = q[(size_t)lo * stride + 2];
+    const int n = idx[e];
+    tx = nx[n]; ty = ny[n]; tz = nz[n];
+  }
+  // out: sample -> near ; in: near -> sample.  edgeLen is the same expression
+  // either way (squares of negated differences), the direction vector flips.
+  const double bx = tx - sx, by = ty - sy, bz = tz - sz;
+  const double cx = sx - tx, cy = sy - ty, cz = sz - tz;
+  const double len_out = sqrt_rn(sq3(sx, sy, sz, tx, ty, tz));
+  const double len_in = sqrt_rn(sq3(tx, ty, tz, sx, sy, sz));
+  bool out_hit = false, in_hit = false;
+  for (int j = 0; j < m; ++j) {
+    const SphRec ob = sph[j];
+    if (!out_hit) out_hit = edge_hits_sphere(sx, sy, sz, bx, by, bz, len_out, ob);
+    if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len_in, ob);
+    if (__ballot(act && !(out_hit && in_hit)) == 0ull) break;
+  }
+  if (act) {
+    hit_out[e] = out_hit ? 1 : 0;
+    hit_in[e] = in_hit ? 1 : 0;
+  }
+}
+
+// explicitPointCheck over spheres (R/DRRT_Q.jl:1520-1590).  aux holds, per
+// active sphere, radius and thr_in = first s with sqrt(s) > radius.
+__global__ __launch_bounds__(256) void points_spheres_kernel(const double *__restrict__ p, int stride,
+                                                             long long np, const SphRec *__restrict__ sph,
+                                                             const double *__restrict__ radius,
+                                                             const double *__restrict__ thr_in, int m,
+                                                             double robot_radius, int quick,
+                                                             uint8_t *__restrict__ unsafe,
+                                                             double *__restrict__ clearance) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  const double px = p[i * stride + 0], py = p[i * stride + 1], pz = p[i * stride + 2];
+  if (quick) {
+    // quickCheck: inside any sphere  (Wdist > radius => outside, :1410)
+    for (int j = 0; j < m; ++j) {
+      double s = sq3(sph[j].cx, sph[j].cy, sph[j].cz, px, py, pz);
+      if (!(s >= thr_in[j])) {
+        unsafe[i] = 1;
+        if (clearance) clearance[i] = 0.0;
+        return;
+      }
+    }
+  }
+  double ret_cert = __builtin_inf();
+  for (int j = 0; j < m; ++j) {
+    double this_dist = sqrt_rn(sq3(sph[j].cx, sph[j].cy, sph[j].cz, px, py, pz)) - robot_radius;
+    double this_cert = ret_cert;
+    if (!(this_dist - radius[j] > ret_cert)) {
+      this_dist = this_dist - radius[j];
+      if (this_dist < 0.0) {
+        unsafe[i] = 1;
+        if (clearance) clearance[i] = 0.0;
+        return;
+      }
+      this_cert = jl_min(ret_cert, this_dist);
+    }
+    if (this_cert < ret_cert) ret_cert = this_cert;
+  }
+  unsafe[i] = 0;
+  if (clearance) clearance[i] = ret_cert;
+}
+
+// ------------------------------------------------------------ polygons ------
+// distanceSqrdPointToSegment, R/DRRT.jl:1060-1083
+__device__ __forceinline__ double dist_sqrd_point_to_segment(double px, double py, double ax, double ay,
+                                                             double bx, double by) {
+  double vx = px - ax, vy = py - ay;
+  double ux = bx - ax, uy = by - ay;
+  double det = vx * ux + vy * uy;
+  if (det <= 0) {
+    return vx * vx + vy * vy;
+  } else {
+    double len = ux * ux + uy * uy;
+    if (det >= len) {
+      double ex = bx - px, ey = by - py;
+      return ex * ex + ey * ey;
+    } else {
+      double cr = ux * vy - uy * vx;
+      return (cr * cr) / len;
+    }
+  }
+}
+
+// segmentDistSqrd, R/DRRT.jl:1144-1202
+__device__ double segment_dist_sqrd(double pax, double pay, double pbx, double pby, double qax, double qay,
+                                    double qbx, double qby) {
+  bool possible = true;
+  if (fabs(pbx - pax) < .000001) {
+    if ((qax >= pax && qbx >= pax) || (qax <= pax && qbx <= pax)) possible = false;
+  } else {
+    double m = (pby - pay) / (pbx - pax);
+    double diffA = (m * (qax - pax) + pay) - qay;
+    double diffB = (m * (qbx - pax) + pay) - qby;
+    if ((diffA > 0.0 && diffB > 0.0) || (diffA < 0.0 && diffB < 0.0)) possible = false;
+  }
+  if (possible) {
+    if (fabs(qbx - qax) < .000001) {
+      if ((pax >= qax && pbx >= qax) || (pax <= qax && pbx <= qax)) possible = false;
+    } else {
+      double m = (qby - qay) / (qbx - qax);
+      double diffA = (m * (pax - qax) + qay) - pay;
+      double diffB = (m * (pbx - qax) + qay) - pby;
+      if ((diffA > 0.0 && diffB > 0.0) || (diffA < 0.0 && diffB < 0.0)) possible = false;
+    }
+  }
+  if (possible) return 0.0;
+  double r = dist_sqrd_point_to_segment(pax, pay, qax, qay, qbx, qby);
+  r = jl_min(r, dist_sqrd_point_to_segment(pbx, pby, qax, qay, qbx, qby));
+  r = jl_min(r, dist_sqrd_point_to_segment(qax, qay, pax, pay, pbx, pby));
+  r = jl_min(r, dist_sqrd_point_to_segment(qbx, qby, pax, pay, pbx, pby));
+  return r;
+}
+
+// explicitEdgeCheck2D for kinds 1 and 3, R/DRRT.jl:1523-1578
+__device__ bool edge_hits_polygon(double ax, double ay, double bx, double by, double robot_radius,
+                                  const double *__restrict__ meta, const int32_t *__restrict__ off,
+                                  const double *__restrict__ vxy, int j) {
+  const double cx = meta[4 * j + 0], cy = meta[4 * j + 1], rad = meta[4 * j + 2];
+  const int kind = (int)meta[4 * j + 3];
+  double dsq = dist_sqrd_point_to_segment(cx, cy, ax, ay, bx, by);
+  double rr = robot_radius + rad;
+  if (dsq > rr * rr) return false;
+  if (kind == 1) return true;
+  if (kind == 3) {
+    const int b = off[j], e = off[j + 1];
+    const int P = e - b;
+    if (P < 2) return false;
+    double Ax = vxy[2 * (e - 1)], Ay = vxy[2 * (e - 1) + 1];
+    const double rr2 = robot_radius * robot_radius;
+    for (int v = b; v < e; ++v) {
+      double Bx = vxy[2 * v], By = vxy[2 * v + 1];
+      if (segment_dist_sqrd(ax, ay, bx, by, Ax, Ay, Bx, By) < rr2) return true;
+      Ax = Bx; Ay = By;
+    }
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__restrict__ p0,
+                                                             const double *__restrict__ p1, int stride,
+                                                             long long ne, const double *__restrict__ meta,
+                                                             const int32_t *__restrict__ off,
+                                                             const double *__restrict__ vxy,
+                                                             const int32_t *__restrict__ orig, int m_begin,
+                                                             int m_end, double robot_radius,
+                                                             uint8_t *__restrict__ hit,
+                                                             int32_t *__restrict__ first_hit) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = i < ne;
+  double ax = 0, ay = 0, bx = 0, by = 0;
+  if (act) {
+    ax = p0[i * stride + 0]; ay = p0[i * stride + 1];
+    bx = p1[i * stride + 0]; by = p1[i * stride + 1];
+  }
+  bool done = !act;
+  int first = -1;
+  for (int j = m_begin; j < m_end; ++j) {
+    if (!done && edge_hits_polygon(ax, ay, bx, by, robot_radius, meta, off, vxy, j)) {
+      done = true;
+      first = orig[j];
+    }
+    if (__ballot(!done) == 0ull) break;
+  }
+  if (act) {
+    hit[i] = first >= 0 ? 1 : 0;
+    if (first_hit) first_hit[i] = first;
+  }
+}
+
+// pointInPolygon (MacMartin crossings), R/DRRT.jl:1009-1056
+__device__ bool point_in_polygon(double px, double py, const double *__restrict__ vxy, int b, int e) {
+  const int P = e - b;
+  if (P < 2) return false;
+  int crossings = 0;
+  double sx = vxy[2 * (e - 1)], sy = vxy[2 * (e - 1) + 1];
+  for (int v = b; v < e; ++v) {
+    double ex = vxy[2 * v], ey = vxy[2 * v + 1];
+    if ((sy > py && ey < py) || (sy < py && ey > py)) {
+      if (sx > px && ex > px) {
+        crossings += 1;
+      } else if (sx < px && ex < px) {
+      } else {
+        double T = 2 * jl_max(sx, ex);
+        double x = (-((sx * ey - sy * ex) * (px - T)) + ((sx - ex) * (px * py - py * T))) /
+                   ((sy - ey) * (px - T));
+        if (x > px) crossings += 1;
+      }
+    }
+    sx = ex; sy = ey;
+  }
+  return (crossings & 1) != 0;
+}
+
+// distToPolygonSqrd, R/DRRT.jl:1087-1106
+__device__ double dist_to_polygon_sqrd(double px, double py, const double *__restrict__ vxy, int b, int e) {
+  double best = __builtin_inf();
+  double sx = vxy[2 * (e - 1)], sy = vxy[2 * (e - 1) + 1];
+  for (int v = b; v < e; ++v) {
+    double ex = vxy[2 * v], ey = vxy[2 * v + 1];
+    double dd = dist_sqrd_point_to_segment(px, py, sx, sy, ex, ey);
+    if (dd < best) best = dd;
+    sx = ex; sy = ey;
+  }
+  return best;
+}
+
+// explicitPointCheck over polygons: quickCheck pass (R/DRRT.jl:1258-1284) then
+// explicitPointCheck2D (:1340-1427); Wdist over the first two coordinates.
+__global__ __launch_bounds__(256) void points_polygons_kernel(const double *__restrict__ p, int stride,
+                                                              long long np, const double *__restrict__ meta,
+                                                              const int32_t *__restrict__ off,
+                                                              const double *__restrict__ vxy, int m,
+                                                              double robot_radius,
+                                                              uint8_t *__restrict__ unsafe,
+                                                              double *__restrict__ clearance) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  const double px = p[i * stride + 0], py = p[i * stride + 1];
+  for (int j = 0; j < m; ++j) {
+    const double cx = meta[4 * j + 0], cy = meta[4 * j + 1], rad = meta[4 * j + 2];
+    const int kind = (int)meta[4 * j + 3];
+    if (sqrt_rn(sq2(cx, cy, px, py)) > rad) continue;
+    if (kind == 1 || (kind == 3 && point_in_polygon(px, py, vxy, off[j], off[j + 1]))) {
+      unsafe[i] = 1;
+      if (clearance) clearance[i] = 0.0;
+      return;
+    }
+  }
+  double ret_cert = __builtin_inf();
+  for (int j = 0; j < m; ++j) {
+    const double cx = meta[4 * j + 0], cy = meta[4 * j + 1], rad = meta[4 * j + 2];
+    const int kind = (int)meta[4 * j + 3];
+    double this_cert = ret_cert;
+    double this_dist = sqrt_rn(sq2(cx, cy, px, py)) - robot_radius;
+    if (!(this_dist - rad > ret_cert)) {
+      bool bad = false;
+      if (kind == 1) {
+        this_dist = this_dist - rad;
+        bad = this_dist < 0.0;
+      } else if (kind == 3) {
+        if (point_in_polygon(px, py, vxy, off[j], off[j + 1])) {
+          bad = true;
+        } else {
+          this_dist = sqrt_rn(dist_to_polygon_sqrd(px, py, vxy, off[j], off[j + 1])) - robot_radius;
+          bad = this_dist < 0.0;
+        }
+      }
+      if (bad) {
+        unsafe[i] = 1;
+        if (clearance) clearance[i] = 0.0;
+        return;
+      }
+      this_cert = jl_min(ret_cert, this_dist);
+    }
+    if (this_cert < ret_cert) ret_cert = this_cert;
+  }
+  unsafe[i] = 0;
+  if (clearance) clearance[i] = ret_cert;
+}
+
+// calculateTrajectory(S, ::SimpleEdge), R/DRRT_SimpleEdge_functions.jl:177-181
+__global__ void simple_steer_kernel(const double *__restrict__ s, const double *__restrict__ g, int dim,
+                                    long long ne, double *__restrict__ dist, double *__restrict__ wdist) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ne) return;
+  const double *a = s + i * dim, *b = g + i * dim;
+  double w = sq3(a[0], a[1], a[2], b[0], b[1], b[2]);
+  double d = w;
+  if (dim == 4) d = sq4(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
+  if (dist) dist[i] = sqrt_rn(d);
+  if (wdist) wdist[i] = sqrt_rn(w);
+}
+
+// one wave per 64-bit word: lane j supplies bit j
+__global__ __launch_bounds__(256) void pack_hits_kernel(const uint8_t *__restrict__ hit_out,
+                                                        const uint8_t *__restrict__ hit_in,
+                                                        const int64_t *__restrict__ n_valid, long long cap,
+                                                        long long n_words, unsigned long long *__restrict__ words) {
+  const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= n_words) return;
+  const int lane = threadIdx.x & 63;
+  const long long g = w * 64 + lane;
+  long long nv = *n_valid;
+  if (nv > cap) nv = cap;
+  bool bit = false;
+  if (g < cap) bit = (g < nv) && hit_out[g] != 0;
+  else if (g < 2 * cap) bit = (g - cap < nv) && hit_in[g - cap] != 0;
+  unsigned long long m = __ballot(bit);
+  if (lane == 0) words[w] = m;
+}
+
+// map a list-position range [begin, end) onto the packed active table
+void packed_range(const std::vector<int32_t> &orig, int begin, int end, int &pb, int &pe) {
+  pb = 0;
+  while (pb < (int)orig.size() && orig[pb] < begin) ++pb;
+  pe = pb;
+  while (pe < (int)orig.size() && orig[pe] < end) ++pe;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------- host glue -----
+
+int sync_spheres(rrtx_ctx *ctx, double robot_radius) {
+  if (!ctx->sph_dirty && ctx->sph_packed_rr == robot_radius) return RRTX_OK;
+  const int m = (int)ctx->sph_active.size();
+  std::vector<SphRec> rec;
+  std::vector<double> radius, thr_in;
+  std::vector<int32_t> orig;
+  for (int i = 0; i < m; ++i) {
+    if (!ctx->sph_active[i]) continue;
+    const double *c = &ctx->sph[4 * (size_t)i];
+    SphRec r;
+    r.cx = c[0]; r.cy = c[1]; r.cz = c[2];
+    r.thr = thr_first_gt(robot_radius + c[3]);
+    rec.push_back(r);
+    radius.push_back(c[3]);
+    thr_in.push_back(thr_first_gt(c[3]));
+    orig.push_back(i);
+  }
+  const int na = (int)rec.size();
+  ctx->sph_n_active = na;
+  if (na > 0) {
+    RRTX_HIP(ctx, ctx->d_sph.ensure(sizeof(SphRec) * na));
+    RRTX_HIP(ctx, ctx->d_sph_aux.ensure((sizeof(double) * 2 + sizeof(int32_t)) * na + 64));
+    // the packed tables may still be read by kernels in flight on the stream
+    RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RRTX_HIP(ctx, hipMemcpy(ctx->d_sph.p, rec.data(), sizeof(SphRec) * na, hipMemcpyHostToDevice));
+    char *aux = ctx->d_sph_aux.as<char>();
+    RRTX_HIP(ctx, hipMemcpy(aux, radius.data(), sizeof(double) * na, hipMemcpyHostToDevice));
+    RRTX_HIP(ctx, hipMemcpy(aux + sizeof(double) * na, thr_in.data(), sizeof(double) * na,
+                            hipMemcpyHostToDevice));
+    RRTX_HIP(ctx, hipMemcpy(aux + sizeof(double) * 2 * na, orig.data(), sizeof(int32_t) * na,
+                            hipMemcpyHostToDevice));
+  }
+  ctx->sph_dirty = false;
+  ctx->sph_packed_rr = robot_radius;
+  return RRTX_OK;
+}
+
+static const double *sph_radius_dev(rrtx_ctx *ctx) { return ctx->d_sph_aux.as<double>(); }
+static const double *sph_thr_in_dev(rrtx_ctx *ctx) { return ctx->d_sph_aux.as<double>() + ctx->sph_n_active; }
+static const int32_t *sph_orig_dev(rrtx_ctx *ctx) {
+  return reinterpret_cast<const int32_t *>(ctx->d_sph_aux.as<double>() + 2 * (size_t)ctx->sph_n_active);
+}
+
+static std::vector<int32_t> active_positions(const std::vector<uint8_t> &active) {
+  std::vector<int32_t> o;
+  for (int i = 0; i < (int)active.size(); ++i)
+    if (active[i]) o.push_back(i);
+  return o;
+}
+
+int sync_polygons(rrtx_ctx *ctx) {
+  if (!ctx->poly_dirty) return RRTX_OK;
+  const int m = (int)ctx->poly_active.size();
+  std::vector<double> meta;
+  std::vector<int32_t> off(1, 0), orig;
+  std::vector<double> vxy;
+  for (int i = 0; i < m; ++i) {
+    if (!ctx->poly_active[i]) continue;
+    meta.push_back(ctx->poly_cr[3 * (size_t)i + 0]);
+    meta.push_back(ctx->poly_cr[3 * (size_t)i + 1]);
+    meta.push_back(ctx->poly_cr[3 * (size_t)i + 2]);
+    meta.push_back((double)ctx->poly_kind[i]);
+    for (int v = ctx->poly_off[i]; v < ctx->poly_off[i + 1]; ++v) {
+      vxy.push_back(ctx->poly_vxy[2 * (size_t)v]);
+      vxy.push_back(ctx->poly_vxy[2 * (size_t)v + 1]);
+    }
+    off.push_back((int32_t)(vxy.size() / 2));
+    orig.push_back(i);
+  }
+  const int na = (int)orig.size();
+  ctx->poly_n_active = na;
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (na > 0) {
+    RRTX_HIP(ctx, ctx->d_poly_meta.ensure(sizeof(double) * meta.size()));
+    RRTX_HIP(ctx, ctx->d_poly_off.ensure(sizeof(int32_t) * off.size()));
+    RRTX_HIP(ctx, ctx->d_poly_vxy.ensure(sizeof(double) * (vxy.size() + 2)));
+    RRTX_HIP(ctx, ctx->d_poly_orig.ensure(sizeof(int32_t) * na));
+    RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_meta.p, meta.data(), sizeof(double) * meta.size(), hipMemcpyHostToDevice));
+    RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_off.p, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
+    if (!vxy.empty())
+      RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_vxy.p, vxy.data(), sizeof(double) * vxy.size(), hipMemcpyHostToDevice));
+    RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_orig.p, orig.data(), sizeof(int32_t) * na, hipMemcpyHostToDevice));
+  }
+  ctx->poly_dirty = false;
+  return RRTX_OK;
+}
+
+static int zero_outputs(rrtx_ctx *ctx, int64_t ne, uint8_t *hit_dev, int32_t *first_hit_dev) {
+  RRTX_HIP(ctx, hipMemsetAsync(hit_dev, 0, (size_t)ne, ctx->stream));
+  if (first_hit_dev) RRTX_HIP(ctx, hipMemsetAsync(first_hit_dev, 0xff, (size_t)ne * sizeof(int32_t), ctx->stream));
+  return RRTX_OK;
+}
+
+int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
+                         double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
+                         uint8_t *hit_dev, int32_t *first_hit_dev) {
+  if (ne <= 0) return RRTX_OK;
+  int rc = sync_spheres(ctx, robot_radius);
+  if (rc) return rc;
+  const int m = (int)ctx->sph_active.size();
+  if (obstacle_or_minus1 >= m) return fail(ctx, RRTX_E_INVALID, "obstacle index %d out of range (%d spheres)", obstacle_or_minus1, m);
+  if (obstacle_or_minus1 >= 0) { obs_begin = obstacle_or_minus1; obs_end = obstacle_or_minus1 + 1; }
+  if (obs_end < 0 || obs_end > m) obs_end = m;
+  if (obs_begin < 0) obs_begin = 0;
+  int pb, pe;
+  packed_range(active_positions(ctx->sph_active), obs_begin, obs_end, pb, pe);
+  if (pe <= pb) return zero_outputs(ctx, ne, hit_dev, first_hit_dev);
+  span_begin(ctx, KF_EDGES);
+  hipLaunchKernelGGL(edges_spheres_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
+                     p1_dev, ctx->dim, (long long)ne, ctx->d_sph.as<SphRec>(), sph_orig_dev(ctx), pb, pe, hit_dev,
+                     first_hit_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
+                           const int32_t *idx_dev, int64_t cap, double robot_radius, uint8_t *hit_out_dev,
+                           uint8_t *hit_in_dev) {
+  if (nq <= 0 || cap <= 0) return RRTX_OK;
+  int rc = sync_spheres(ctx, robot_radius);
+  if (rc) return rc;
+  span_begin(ctx, KF_EDGES);
+  // the grid covers the caller's capacity; lanes past offsets[nq] idle
+  hipLaunchKernelGGL(candidate_edges_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, q_dev,
+                     ctx->dim, offsets_dev, nq, idx_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                     (long long)cap, ctx->d_sph.as<SphRec>(), ctx->sph_n_active, hit_out_dev, hit_in_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+int launch_edges_polygons(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
+                          double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
+                          uint8_t *hit_dev, int32_t *first_hit_dev) {
+  if (ne <= 0) return RRTX_OK;
+  int rc = sync_polygons(ctx);
+  if (rc) return rc;
+  const int m = (int)ctx->poly_active.size();
+  if (obstacle_or_minus1 >= m) return fail(ctx, RRTX_E_INVALID, "obstacle index %d out of range (%d polygons)", obstacle_or_minus1, m);
+  if (obstacle_or_minus1 >= 0) { obs_begin = obstacle_or_minus1; obs_end = obstacle_or_minus1 + 1; }
+  if (obs_end < 0 || obs_end > m) obs_end = m;
+  if (obs_begin < 0) obs_begin = 0;
+  int pb, pe;
+  packed_range(active_positions(ctx->poly_active), obs_begin, obs_end, pb, pe);
+  if (pe <= pb) return zero_outputs(ctx, ne, hit_dev, first_hit_dev);
+  span_begin(ctx, KF_EDGES);
+  hipLaunchKernelGGL(edges_polygons_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
+                     p1_dev, ctx->dim, (long long)ne, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
+                     ctx->d_poly_vxy.as<double>(), ctx->d_poly_orig.as<int32_t>(), pb, pe, robot_radius, hit_dev,
+                     first_hit_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+int launch_points_spheres(rrtx_ctx *ctx, const double *p_dev, int64_t np, double robot_radius, int quick,
+                          uint8_t *unsafe_dev, double *clearance_dev) {
+  if (np <= 0) return RRTX_OK;
+  int rc = sync_spheres(ctx, robot_radius);
+  if (rc) return rc;
+  span_begin(ctx, KF_POINTS);
+  hipLaunchKernelGGL(points_spheres_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, p_dev,
+                     ctx->dim, (long long)np, ctx->d_sph.as<SphRec>(), sph_radius_dev(ctx), sph_thr_in_dev(ctx),
+                     ctx->sph_n_active, robot_radius, quick, unsafe_dev, clearance_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+int launch_points_polygons(rrtx_ctx *ctx, const double *p_dev, int64_t np, double robot_radius,
+                           uint8_t *unsafe_dev, double *clearance_dev) {
+  if (np <= 0) return RRTX_OK;
+  int rc = sync_polygons(ctx);
+  if (rc) return rc;
+  span_begin(ctx, KF_POINTS);
+  hipLaunchKernelGGL(points_polygons_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, p_dev,
+                     ctx->dim, (long long)np, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
+                     ctx->d_poly_vxy.as<double>(), ctx->poly_n_active, robot_radius, unsafe_dev, clearance_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+int launch_pack_hits(rrtx_ctx *ctx, const uint8_t *hit_out, const uint8_t *hit_in, const int64_t *n_valid_dev,
+                     int64_t cap, uint64_t *words) {
+  if (cap <= 0) return RRTX_OK;
+  const long long n_words = (2 * (long long)cap + 63) / 64;
+  span_begin(ctx, KF_EDGES);
+  hipLaunchKernelGGL(pack_hits_kernel, dim3((unsigned)((n_words + 3) / 4)), dim3(256), 0, ctx->stream, hit_out,
+                     hit_in, n_valid_dev, (long long)cap, n_words, reinterpret_cast<unsigned long long *>(words));
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+int launch_simple_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double *dist_dev,
+                        double *wdist_dev) {
+  if (ne <= 0) return RRTX_OK;
+  span_begin(ctx, KF_DUBINS);
+  hipLaunchKernelGGL(simple_steer_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, s_dev,
+                     g_dev, ctx->dim, (long long)ne, dist_dev, wdist_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+}  // namespace rrtx

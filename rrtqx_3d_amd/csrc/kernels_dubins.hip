@@ -1,0 +1,399 @@
+// kernels_dubins.hip -- Dubins steering (six-word shortest path) and the
+// two-stage Dubins edge check against polygon obstacles.  Replaces
+// calculateTrajectory(S, ::DubinsEdge) and explicitEdgeCheck(S, ::DubinsEdge, ob)
+// (R/DRRT_DubinsEdge_functions.jl:329-709, 750-774; helpers
+// R/DRRT_distance_functions.jl:62-80), space without time.  gfx950 only.
+//
+// Transcendentals come from the ROCm device library, not Julia's libm, so edge
+// costs carry the 1e-6 relative tolerance north_star allows; everything else
+// keeps the reference's operation order (no FMA contraction).
+#include "exact_math.hpp"
+#include "rrtx_internal.hpp"
+
+namespace rrtx {
+
+namespace {
+
+constexpr double kPi = 3.141592653589793;
+
+__device__ __forceinline__ double right_turn_dist(double ax, double ay, double bx, double by, double cx,
+                                                  double cy, double r) {
+  double theta = atan2(ay - cy, ax - cx) - atan2(by - cy, bx - cx);
+  if (theta < 0) theta = theta + 2 * kPi;
+  return theta * r;
+}
+__device__ __forceinline__ double left_turn_dist(double ax, double ay, double bx, double by, double cx,
+                                                 double cy, double r) {
+  double theta = atan2(by - cy, bx - cx) - atan2(ay - cy, ax - cx);
+  if (theta < 0) theta = theta + 2 * kPi;
+  return theta * r;
+}
+__device__ __forceinline__ double seg_len2(double ax, double ay, double bx, double by) {
+  return sqrt_rn(sq2(ax, ay, bx, by));
+}
+
+// one piece of the stored trajectory: an arc sampled every 0.1 rad or a straight
+// segment given by its two end points
+struct Piece {
+  double cx, cy;      // arc centre | line p1
+  double a, b;        // arc phi_start, step | line p2
+  int len;            // number of polyline rows
+  int is_line;
+};
+
+struct Steer {
+  double cost;
+  int word;           // 0 rsl 1 rsr 2 rlr 3 lsr 4 lsl 5 lrl 6 xxx
+  Piece pc[3];
+};
+
+// length of start:step:stop (Julia float range, literal fallback branch)
+__device__ __forceinline__ int julia_range_len(double start, double step, double stop) {
+  double lf = (stop - start) / step;
+  if (lf < 0) return 0;
+  if (lf == 0) return 1;
+  long long len = (long long)rint(lf) + 1;
+  double stop2 = start + (double)(len - 1) * step;
+  len -= ((start < stop && stop < stop2) ? 1 : 0) + ((start > stop && stop > stop2) ? 1 : 0);
+  return (int)len;
+}
+
+__device__ __forceinline__ Piece make_arc(double cx, double cy, double phi_start, double phi_end, double step) {
+  Piece p;
+  p.cx = cx; p.cy = cy; p.a = phi_start; p.b = step; p.is_line = 0;
+  p.len = (phi_end == phi_start) ? 1 : julia_range_len(phi_start, step, phi_end);
+  return p;
+}
+__device__ __forceinline__ Piece make_line(double x1, double y1, double x2, double y2) {
+  Piece p;
+  p.cx = x1; p.cy = y1; p.a = x2; p.b = y2; p.is_line = 1; p.len = 2;
+  return p;
+}
+
+template <bool WANT_TRAJ>
+__device__ void dubins_steer(const double *__restrict__ s, const double *__restrict__ g, double r_min,
+                             Steer &out) {
+  const double ilx = s[0], ily = s[1], it = s[3];
+  const double glx = g[0], gly = g[1], gt = g[3];
+  // circle centres (:348-357)
+  const double ircx = ilx + r_min * cos(it - kPi / 2.0), ircy = ily + r_min * sin(it - kPi / 2.0);
+  const double ilcx = ilx + r_min * cos(it + kPi / 2.0), ilcy = ily + r_min * sin(it + kPi / 2.0);
+  const double grcx = glx + r_min * cos(gt - kPi / 2.0), grcy = gly + r_min * sin(gt - kPi / 2.0);
+  const double glcx = glx + r_min * cos(gt + kPi / 2.0), glcy = gly + r_min * sin(gt + kPi / 2.0);
+
+  double best = __builtin_inf();
+  int word = 6;
+  double D, vx, vy, R, sq, a, b, first, second, third, len;
+
+  // rsl (:367-388)
+  double rsl1x = 0, rsl1y = 0, rsl2x = 0, rsl2y = 0;
+  {
+    double dx = glcx - ircx, dy = glcy - ircy;
+    D = sqrt_rn(dx * dx + dy * dy);
+    vx = dx / D; vy = dy / D;
+    R = -2.0 * r_min / D;
+    if (!(fabs(R) > 1.0)) {
+      sq = sqrt_rn(1.0 - R * R);
+      a = r_min * (R * vx + vy * sq);
+      b = r_min * (R * vy - vx * sq);
+      rsl1x = ircx - a; rsl2x = glcx + a;
+      rsl1y = ircy - b; rsl2y = glcy + b;
+      first = right_turn_dist(ilx, ily, rsl1x, rsl1y, ircx, ircy, r_min);
+      second = seg_len2(rsl2x, rsl2y, rsl1x, rsl1y);
+      third = left_turn_dist(rsl2x, rsl2y, glx, gly, glcx, glcy, r_min);
+      len = first + second + third;
+      if (best > len) { best = len; word = 0; }
+    }
+  }
+  // rsr (:394-407)
+  double rsr1x, rsr1y, rsr2x, rsr2y;
+  {
+    double dx = grcx - ircx, dy = grcy - ircy;
+    D = sqrt_rn(dx * dx + dy * dy);
+    vx = dx / D; vy = dy / D;
+    rsr1x = -r_min * vy + ircx; rsr2x = -r_min * vy + grcx;
+    rsr1y = r_min * vx + ircy;  rsr2y = r_min * vx + grcy;
+    first = right_turn_dist(ilx, ily, rsr1x, rsr1y, ircx, ircy, r_min);
+    second = seg_len2(rsr2x, rsr2y, rsr1x, rsr1y);
+    third = right_turn_dist(rsr2x, rsr2y, glx, gly, grcx, grcy, r_min);
+    len = first + second + third;
+    if (best > len) { best = len; word = 1; }
+  }
+  // rlr (:411-431; D, v from rsr)
+  double rlr_cx = 0, rlr_cy = 0, rlr_rlx = 0, rlr_rly = 0, rlr_lrx = 0, rlr_lry = 0;
+  if (D < 4.0 * r_min) {
+    double theta = -acos(D / (4 * r_min)) + atan2(vy, vx);
+    rlr_cx = ircx + 2 * r_min * cos(theta);
+    rlr_cy = ircy + 2 * r_min * sin(theta);
+    rlr_rlx = (rlr_cx + ircx) / 2.0; rlr_rly = (rlr_cy + ircy) / 2.0;
+    rlr_lrx = (rlr_cx + grcx) / 2.0; rlr_lry = (rlr_cy + grcy) / 2.0;
+    first = right_turn_dist(ilx, ily, rlr_rlx, rlr_rly, ircx, ircy, r_min);
+    second = left_turn_dist(rlr_rlx, rlr_rly, rlr_lrx, rlr_lry, rlr_cx, rlr_cy, r_min);
+    third = right_turn_dist(rlr_lrx, rlr_lry, glx, gly, grcx, grcy, r_min);
+    len = first + second + third;
+    if (best > len) { best = len; word = 2; }
+  }
+  // lsr (:436-458)
+  double lsr1x = 0, lsr1y = 0, lsr2x = 0, lsr2y = 0;
+  {
+    double dx = grcx - ilcx, dy = grcy - ilcy;
+    D = sqrt_rn(dx * dx + dy * dy);
+    vx = dx / D; vy = dy / D;
+    R = 2.0 * r_min / D;
+    if (!(fabs(R) > 1)) {
+      sq = sqrt_rn(1 - R * R);
+      a = R * vx + vy * sq;
+      b = R * vy - vx * sq;
+      lsr1x = ilcx + a * r_min; lsr2x = grcx - a * r_min;
+      lsr1y = ilcy + b * r_min; lsr2y = grcy - b * r_min;
+      first = left_turn_dist(ilx, ily, lsr1x, lsr1y, ilcx, ilcy, r_min);
+      second = seg_len2(lsr2x, lsr2y, lsr1x, lsr1y);
+      third = right_turn_dist(lsr2x, lsr2y, glx, gly, grcx, grcy, r_min);
+      len = first + second + third;
+      if (best > len) { best = len; word = 3; }
+    }
+  }
+  // lsl (:464-477)
+  double lsl1x, lsl1y, lsl2x, lsl2y;
+  {
+    double dx = glcx - ilcx, dy = glcy - ilcy;
+    D = sqrt_rn(dx * dx + dy * dy);
+    vx = dx / D; vy = dy / D;
+    lsl1x = r_min * vy + ilcx;  lsl2x = r_min * vy + glcx;
+    lsl1y = -r_min * vx + ilcy; lsl2y = -r_min * vx + glcy;
+    first = left_turn_dist(ilx, ily, lsl1x, lsl1y, ilcx, ilcy, r_min);
+    second = seg_len2(lsl2x, lsl2y, lsl1x, lsl1y);
+    third = left_turn_dist(lsl2x, lsl2y, glx, gly, glcx, glcy, r_min);
+    len = first + second + third;
+    if (best > len) { best = len; word = 4; }
+  }
+  // lrl (:481-501; D, v from lsl)
+  double lrl_cx = 0, lrl_cy = 0, lrl_lrx = 0, lrl_lry = 0, lrl_rlx = 0, lrl_rly = 0;
+  if (D < 4.0 * r_min) {
+    double theta = acos(D / (4 * r_min)) + atan2(vy, vx);
+    lrl_cx = ilcx + 2.0 * r_min * cos(theta);
+    lrl_cy = ilcy + 2.0 * r_min * sin(theta);
+    lrl_lrx = (lrl_cx + ilcx) / 2.0; lrl_lry = (lrl_cy + ilcy) / 2.0;
+    lrl_rlx = (lrl_cx + glcx) / 2.0; lrl_rly = (lrl_cy + glcy) / 2.0;
+    first = left_turn_dist(ilx, ily, lrl_lrx, lrl_lry, ilcx, ilcy, r_min);
+    second = right_turn_dist(lrl_lrx, lrl_lry, lrl_rlx, lrl_rly, lrl_cx, lrl_cy, r_min);
+    third = left_turn_dist(lrl_rlx, lrl_rly, glx, gly, glcx, glcy, r_min);
+    len = first + second + third;
+    if (best > len) { best = len; word = 5; }
+  }
+
+  out.cost = best;
+  out.word = word;
+  if (!WANT_TRAJ) return;
+  out.pc[0].len = out.pc[1].len = out.pc[2].len = 0;
+  if (word == 6 || best == __builtin_inf()) return;   // no trajectory is built (:661-662)
+
+  const double dphi = .1;
+  const bool fr = (word <= 2);                        // first letter 'r'
+  double px, py, phi_start, phi_end;
+  // first piece (:511-555)
+  if (fr) {
+    if (word == 0) { px = rsl1x; py = rsl1y; } else if (word == 1) { px = rsr1x; py = rsr1y; } else { px = rlr_rlx; py = rlr_rly; }
+    phi_start = atan2(ily - ircy, ilx - ircx);
+    phi_end = atan2(py - ircy, px - ircx);
+    if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi;
+    out.pc[0] = make_arc(ircx, ircy, phi_start, phi_end, -dphi);
+  } else {
+    if (word == 4) { px = lsl1x; py = lsl1y; } else if (word == 3) { px = lsr1x; py = lsr1y; } else { px = lrl_lrx; py = lrl_lry; }
+    phi_start = atan2(ily - ilcy, ilx - ilcx);
+    phi_end = atan2(py - ilcy, px - ilcx);
+    if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi;
+    out.pc[0] = make_arc(ilcx, ilcy, phi_start, phi_end, dphi);
+  }
+  // second piece (:559-608)
+  if (word == 0) out.pc[1] = make_line(rsl1x, rsl1y, rsl2x, rsl2y);
+  else if (word == 1) out.pc[1] = make_line(rsr1x, rsr1y, rsr2x, rsr2y);
+  else if (word == 3) out.pc[1] = make_line(lsr1x, lsr1y, lsr2x, lsr2y);
+  else if (word == 4) out.pc[1] = make_line(lsl1x, lsl1y, lsl2x, lsl2y);
+  else if (word == 5) {   // lrl: middle is a right turn
+    phi_start = atan2(lrl_lry - lrl_cy, lrl_lrx - lrl_cx);
+    phi_end = atan2(lrl_rly - lrl_cy, lrl_rlx - lrl_cx);
+    if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi;
+    out.pc[1] = make_arc(lrl_cx, lrl_cy, phi_start, phi_end, -dphi);
+  } else {                // rlr: middle is a left turn
+    phi_start = atan2(rlr_rly - rlr_cy, rlr_rlx - rlr_cx);
+    phi_end = atan2(rlr_lry - rlr_cy, rlr_lrx - rlr_cx);
+    if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi;
+    out.pc[1] = make_arc(rlr_cx, rlr_cy, phi_start, phi_end, dphi);
+  }
+  // third piece (:611-655)
+  const bool tr = (word == 1 || word == 3 || word == 2);   // last letter 'r'
+  if (tr) {
+    if (word == 1) { px = rsr2x; py = rsr2y; } else if (word == 3) { px = lsr2x; py = lsr2y; } else { px = rlr_lrx; py = rlr_lry; }
+    phi_start = atan2(py - grcy, px - grcx);
+    phi_end = atan2(gly - grcy, glx - grcx);
+    if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi;
+    out.pc[2] = make_arc(grcx, grcy, phi_start, phi_end, -dphi);
+  } else {
+    if (word == 4) { px = lsl2x; py = lsl2y; } else if (word == 0) { px = rsl2x; py = rsl2y; } else { px = lrl_rlx; py = lrl_rly; }
+    phi_start = atan2(py - glcy, px - glcx);
+    phi_end = atan2(gly - glcy, glx - glcx);
+    if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi;
+    out.pc[2] = make_arc(glcx, glcy, phi_start, phi_end, dphi);
+  }
+}
+
+__device__ __forceinline__ void piece_point(const Piece &p, int k, double r_min, double &x, double &y) {
+  if (p.is_line) {
+    x = (k == 0) ? p.cx : p.a;
+    y = (k == 0) ? p.cy : p.b;
+  } else {
+    double phi = p.a + (double)k * p.b;   // phi_start + i*step (StepRangeLen element)
+    x = p.cx + r_min * cos(phi);
+    y = p.cy + r_min * sin(phi);
+  }
+}
+
+__device__ __forceinline__ void write_word(uint8_t *__restrict__ word, long long i, int w) {
+  const char *tab = "rslrsrrlrlsrlsllrlxxx";
+  word[3 * i + 0] = (uint8_t)tab[3 * w + 0];
+  word[3 * i + 1] = (uint8_t)tab[3 * w + 1];
+  word[3 * i + 2] = (uint8_t)tab[3 * w + 2];
+}
+
+__global__ __launch_bounds__(256) void dubins_steer_kernel(const double *__restrict__ s,
+                                                           const double *__restrict__ g, long long ne,
+                                                           double r_min, double *__restrict__ cost,
+                                                           uint8_t *__restrict__ word) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ne) return;
+  Steer st;
+  dubins_steer<false>(s + 4 * i, g + 4 * i, r_min, st);
+  cost[i] = st.cost;
+  if (word) write_word(word, i, st.word);
+}
+
+// polygon helpers live in kernels_collide.hip; the Dubins check needs the same
+// arithmetic, restated here to keep the translation units independent.
+__device__ __forceinline__ double dspts(double px, double py, double ax, double ay, double bx, double by) {
+  double vx = px - ax, vy = py - ay;
+  double ux = bx - ax, uy = by - ay;
+  double det = vx * ux + vy * uy;
+  if (det <= 0) return vx * vx + vy * vy;
+  double len = ux * ux + uy * uy;
+  if (det >= len) { double ex = bx - px, ey = by - py; return ex * ex + ey * ey; }
+  double cr = ux * vy - uy * vx;
+  return (cr * cr) / len;
+}
+__device__ double seg_dist_sqrd(double pax, double pay, double pbx, double pby, double qax, double qay,
+                                double qbx, double qby) {
+  bool possible = true;
+  if (fabs(pbx - pax) < .000001) {
+    if ((qax >= pax && qbx >= pax) || (qax <= pax && qbx <= pax)) possible = false;
+  } else {
+    double m = (pby - pay) / (pbx - pax);
+    double diffA = (m * (qax - pax) + pay) - qay;
+    double diffB = (m * (qbx - pax) + pay) - qby;
+    if ((diffA > 0.0 && diffB > 0.0) || (diffA < 0.0 && diffB < 0.0)) possible = false;
+  }
+  if (possible) {
+    if (fabs(qbx - qax) < .000001) {
+      if ((pax >= qax && pbx >= qax) || (pax <= qax && pbx <= qax)) possible = false;
+    } else {
+      double m = (qby - qay) / (qbx - qax);
+      double diffA = (m * (pax - qax) + qay) - pay;
+      double diffB = (m * (pbx - qax) + qay) - pby;
+      if ((diffA > 0.0 && diffB > 0.0) || (diffA < 0.0 && diffB < 0.0)) possible = false;
+    }
+  }
+  if (possible) return 0.0;
+  double r = dspts(pax, pay, qax, qay, qbx, qby);
+  r = jl_min(r, dspts(pbx, pby, qax, qay, qbx, qby));
+  r = jl_min(r, dspts(qax, qay, pax, pay, pbx, pby));
+  r = jl_min(r, dspts(qbx, qby, pax, pay, pbx, pby));
+  return r;
+}
+__device__ bool seg_hits_polygon(double ax, double ay, double bx, double by, double robot_radius,
+                                 const double *__restrict__ meta, const int32_t *__restrict__ off,
+                                 const double *__restrict__ vxy, int j) {
+  const double cx = meta[4 * j + 0], cy = meta[4 * j + 1], rad = meta[4 * j + 2];
+  const int kind = (int)meta[4 * j + 3];
+  double dsq = dspts(cx, cy, ax, ay, bx, by);
+  double rr = robot_radius + rad;
+  if (dsq > rr * rr) return false;
+  if (kind == 1) return true;
+  if (kind == 3) {
+    const int b = off[j], e = off[j + 1];
+    if (e - b < 2) return false;
+    double Ax = vxy[2 * (e - 1)], Ay = vxy[2 * (e - 1) + 1];
+    const double rr2 = robot_radius * robot_radius;
+    for (int v = b; v < e; ++v) {
+      double Bx = vxy[2 * v], By = vxy[2 * v + 1];
+      if (seg_dist_sqrd(ax, ay, bx, by, Ax, Ay, Bx, By) < rr2) return true;
+      Ax = Bx; Ay = By;
+    }
+  }
+  return false;
+}
+
+// explicitEdgeCheck(S, ::DubinsEdge, ob) over the polygon list (:750-774):
+// stage 1 = straight chord with radius robotRadius + 2*minTurningRadius,
+// stage 2 = every stored polyline piece with robotRadius.
+__global__ __launch_bounds__(256) void dubins_edges_check_kernel(
+    const double *__restrict__ s, const double *__restrict__ g, long long ne, double r_min,
+    double robot_radius, const double *__restrict__ meta, const int32_t *__restrict__ off,
+    const double *__restrict__ vxy, int m, double *__restrict__ cost, uint8_t *__restrict__ word,
+    uint8_t *__restrict__ hit, int32_t *__restrict__ traj_len) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ne) return;
+  Steer st;
+  dubins_steer<true>(s + 4 * i, g + 4 * i, r_min, st);
+  if (cost) cost[i] = st.cost;
+  if (word) write_word(word, i, st.word);
+  const int P = st.pc[0].len + st.pc[1].len + st.pc[2].len;
+  if (traj_len) traj_len[i] = P;
+  const double sx = s[4 * i], sy = s[4 * i + 1], gx = g[4 * i], gy = g[4 * i + 1];
+  bool h = false;
+  for (int j = 0; j < m && !h; ++j) {
+    if (!seg_hits_polygon(sx, sy, gx, gy, robot_radius + 2 * r_min, meta, off, vxy, j)) continue;
+    double px = 0, py = 0;
+    int row = 0;
+    for (int pi = 0; pi < 3 && !h; ++pi) {
+      for (int k = 0; k < st.pc[pi].len; ++k, ++row) {
+        double x, y;
+        piece_point(st.pc[pi], k, r_min, x, y);
+        if (row > 0 && seg_hits_polygon(px, py, x, y, robot_radius, meta, off, vxy, j)) { h = true; break; }
+        px = x; py = y;
+      }
+    }
+  }
+  hit[i] = h ? 1 : 0;
+}
+
+}  // namespace
+
+int launch_dubins_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
+                        double *cost_dev, uint8_t *word_dev) {
+  if (ne <= 0) return RRTX_OK;
+  if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
+  span_begin(ctx, KF_DUBINS);
+  hipLaunchKernelGGL(dubins_steer_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, s_dev,
+                     g_dev, (long long)ne, r_min, cost_dev, word_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+int launch_dubins_edges_check(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
+                              double robot_radius, double *cost_dev, uint8_t *word_dev, uint8_t *hit_dev,
+                              int32_t *traj_len_dev) {
+  if (ne <= 0) return RRTX_OK;
+  if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
+  int rc = sync_polygons(ctx);
+  if (rc) return rc;
+  span_begin(ctx, KF_DUBINS);
+  hipLaunchKernelGGL(dubins_edges_check_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream,
+                     s_dev, g_dev, (long long)ne, r_min, robot_radius, ctx->d_poly_meta.as<double>(),
+                     ctx->d_poly_off.as<int32_t>(), ctx->d_poly_vxy.as<double>(), ctx->poly_n_active, cost_dev,
+                     word_dev, hit_dev, traj_len_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+}  // namespace rrtx

@@ -1,0 +1,563 @@
+// kernels_nn.hip -- batched brute-force nearest / radius search over the node SoA.
+// Replaces kdFindNearest / kdFindWithinRange (R/kdTree_general.jl:254-385,
+// 800-955) and the ghost-point handling for wrapped dimensions
+// (R/ghostPoint.jl:60-111).  gfx950 only: 64-lane waves, scalar (SMEM) query
+// stream, wave-ballot hit compaction.
+//
+// Radius search pipeline (all on ctx->stream, no host sync):
+//   pack    : queries -> slot table (query + ghosts) and the compact copy list
+//   scan    : every (copy, node) pair; lane = node (U nodes per lane held in
+//             VGPRs), the copy tile is streamed through SGPRs; rare hits are
+//             appended to a record buffer with one atomic per wave
+//   rootfix : the reference includes the root with <= instead of <
+//             (R/kdTree_general.jl:896 vs :830)
+//   offsets : exclusive scan of the per-query counts
+//   scatter : records -> per-query segments
+//   order   : per query: sort by node index, dist = sqrt(d2)
+#include "exact_math.hpp"
+#include "rrtx_internal.hpp"
+
+namespace rrtx {
+
+namespace {
+
+constexpr int kScanU = 4;        // nodes per lane
+constexpr int kScanThreads = 256;
+constexpr int kChunk = 64 * kScanU;  // nodes per wave per chunk
+
+// device scalars in ws_scalars
+struct Scalars {
+  unsigned long long total;   // records produced by scan + rootfix
+  int n_copies;               // valid query copies
+  int pad;
+};
+
+// ---------------------------------------------------------------- pack ------
+template <int D>
+__global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const double *__restrict__ thr_lt_arr,
+                               const double *__restrict__ thr_gt_arr, double thr_lt_s, double thr_gt_s,
+                               int n_wraps, int wd0, int wd1, int wd2, double wp0, double wp1, double wp2,
+                               SlotRec *__restrict__ slots, typename QRecT<D>::type *__restrict__ copies,
+                               int2 *__restrict__ meta, Scalars *__restrict__ sc) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  double p[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < D; ++k) p[k] = q[(size_t)i * D + k];
+  const double tlt = thr_lt_arr ? thr_lt_arr[i] : thr_lt_s;
+  const double tgt = thr_gt_arr ? thr_gt_arr[i] : thr_gt_s;
+  const int n_slots = 1 << n_wraps;
+  const int wd[3] = {wd0, wd1, wd2};
+  const double wp[3] = {wp0, wp1, wp2};
+  for (int k = 0; k < n_slots; ++k) {
+    // ghost k: bit pattern of k, the LAST wrapped dimension is the least
+    // significant bit (iteration order of getNextGhostPoint)
+    double g[4] = {p[0], p[1], p[2], p[3]};
+    double c[4] = {p[0], p[1], p[2], p[3]};
+    for (int w = 0; w < n_wraps; ++w) {
+      int bit = (k >> (n_wraps - 1 - w)) & 1;
+      if (!bit) continue;
+      int dimi = wd[w];
+      double dim_val = p[dimi];
+      double dim_closest = 0.0;
+      if (p[dimi] < wp[w] / 2.0) { dim_val += wp[w]; dim_closest += wp[w]; }
+      else { dim_val -= wp[w]; }
+      g[dimi] = dim_val;
+      c[dimi] = dim_closest;
+    }
+    bool valid = true;
+    if (k > 0) {
+      // skip when dist(closestUnwrappedPoint, ghost) > range  (R/ghostPoint.jl:104)
+      double s = (D == 4) ? sq4(c[0], c[1], c[2], c[3], g[0], g[1], g[2], g[3])
+                          : sq3(c[0], c[1], c[2], g[0], g[1], g[2]);
+      valid = !(s >= tgt);
+    }
+    SlotRec sr;
+    sr.x = g[0]; sr.y = g[1]; sr.z = g[2]; sr.w = g[3];
+    sr.thr_lt = valid ? tlt : -1.0;
+    sr.thr_gt = tgt;
+    sr.pad0 = 0.0; sr.pad1 = 0.0;
+    slots[(size_t)i * n_slots + k] = sr;
+    if (valid) {
+      int pos = (n_wraps == 0) ? i : atomicAdd(&sc->n_copies, 1);
+      typename QRecT<D>::type qr;
+      qr.x = g[0]; qr.y = g[1]; qr.z = g[2];
+      if constexpr (D == 4) { qr.w = g[3]; qr.pad0 = 0.0; qr.pad1 = 0.0; qr.pad2 = 0.0; }
+      qr.thr = tlt;
+      copies[pos] = qr;
+      meta[pos] = make_int2(i, k);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- scan ------
+// was this node already discovered by an earlier copy (slot < my slot) of the
+// same query?  (addToRangeList keeps the first discovery, R/kdTree_general.jl:765)
+template <int D>
+__device__ __noinline__ bool seen_by_earlier_slot(const SlotRec *__restrict__ slots, int n_slots, int owner,
+                                                  int slot, int node_idx, double x, double y, double z,
+                                                  double w) {
+  for (int j = 0; j < slot; ++j) {
+    SlotRec sr = slots[(size_t)owner * n_slots + j];
+    if (sr.thr_lt < 0.0) continue;
+    double s = (D == 4) ? sq4(sr.x, sr.y, sr.z, sr.w, x, y, z, w) : sq3(sr.x, sr.y, sr.z, x, y, z);
+    double thr = (j == 0 && node_idx == 0) ? sr.thr_gt : sr.thr_lt;  // root uses <=
+    if (s < thr) return true;
+  }
+  return false;
+}
+
+template <int D>
+__device__ __noinline__ void emit_hits(bool h, int owner, int slot, int node_idx, double s, double x,
+                                       double y, double z, double w, const SlotRec *__restrict__ slots,
+                                       int n_slots, HitRec *__restrict__ recs, long long cap,
+                                       Scalars *__restrict__ sc, int *__restrict__ count) {
+  if (slot > 0 && h) h = !seen_by_earlier_slot<D>(slots, n_slots, owner, slot, node_idx, x, y, z, w);
+  unsigned long long mask = __ballot(h);
+  if (mask == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  const int n = __popcll(mask);
+  unsigned long long base = 0;
+  if (lane == (__ffsll((long long)mask) - 1)) {
+    base = atomicAdd(&sc->total, (unsigned long long)n);
+    atomicAdd(&count[owner], n);
+  }
+  base = __shfl(base, __ffsll((long long)mask) - 1);
+  if (h) {
+    unsigned long long below = mask & ((1ull << lane) - 1ull);
+    long long pos = (long long)base + __popcll(below);
+    if (pos < cap) {
+      HitRec r;
+      r.owner = owner; r.idx = node_idx; r.d2 = s;
+      recs[pos] = r;
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
+    const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
+    const double *__restrict__ nw, int n_nodes, const typename QRecT<D>::type *__restrict__ copies,
+    const int2 *__restrict__ meta, const SlotRec *__restrict__ slots, int n_slots, int tile_q, int n_seg,
+    int seg_len, HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
+    int *__restrict__ count) {
+  // blocks b and b+8 share an XCD: the node segment is the fast-varying index so
+  // each XCD's L2 keeps re-serving the same 1/8th of the node arrays.
+  const int seg = blockIdx.x % n_seg;
+  const int tile = blockIdx.x / n_seg;
+  const int n_copies = sc->n_copies;
+  const int q0 = tile * tile_q;
+  if (q0 >= n_copies) return;
+  const int q1 = min(q0 + tile_q, n_copies);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int node_begin = seg * seg_len;
+  const int node_end = min(n_nodes, node_begin + seg_len);
+  const double kNaN = __builtin_nan("");
+
+  for (int base = node_begin + wave * kChunk; base < node_end; base += (kScanThreads / 64) * kChunk) {
+    double x[kScanU], y[kScanU], z[kScanU], w[kScanU];
+    int id[kScanU];
+#pragma unroll
+    for (int u = 0; u < kScanU; ++u) {
+      id[u] = base + u * 64 + lane;
+      bool ok = id[u] < node_end;
+      x[u] = ok ? nx[id[u]] : kNaN;   // NaN coordinates never compare < thr
+      y[u] = ok ? ny[id[u]] : kNaN;
+      z[u] = ok ? nz[id[u]] : kNaN;
+      if constexpr (D == 4) w[u] = ok ? nw[id[u]] : kNaN; else w[u] = 0.0;
+    }
+    for (int q = q0; q < q1; ++q) {
+      // wave-uniform address: s_load of the 32/64-byte copy record
+      const typename QRecT<D>::type c = copies[q];
+      double s[kScanU];
+      bool h[kScanU];
+      bool any = false;
+#pragma unroll
+      for (int u = 0; u < kScanU; ++u) {
+        if constexpr (D == 4) s[u] = sq4(c.x, c.y, c.z, c.w, x[u], y[u], z[u], w[u]);
+        else s[u] = sq3(c.x, c.y, c.z, x[u], y[u], z[u]);
+        h[u] = s[u] < c.thr;
+        any = any || h[u];
+      }
+      if (__ballot(any) != 0ull) {
+        const int2 m = meta[q];
+#pragma unroll
+        for (int u = 0; u < kScanU; ++u)
+          emit_hits<D>(h[u], m.x, m.y, id[u], s[u], x[u], y[u], z[u], w[u], slots, n_slots, recs, cap, sc,
+                       count);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------- rootfix ------
+// kdFindWithinRange adds the root when distToRoot <= range (R/kdTree_general.jl:896);
+// the scan found it only when < range.
+template <int D>
+__global__ void nn_rootfix_kernel(const double *__restrict__ nx, const double *__restrict__ ny,
+                                  const double *__restrict__ nz, const double *__restrict__ nw,
+                                  const SlotRec *__restrict__ slots, int n_slots, int nq,
+                                  HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
+                                  int *__restrict__ count) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  SlotRec sr = slots[(size_t)i * n_slots];
+  double s = (D == 4) ? sq4(sr.x, sr.y, sr.z, sr.w, nx[0], ny[0], nz[0], nw[0])
+                      : sq3(sr.x, sr.y, sr.z, nx[0], ny[0], nz[0]);
+  if (s >= sr.thr_lt && s < sr.thr_gt) {
+    unsigned long long pos = atomicAdd(&sc->total, 1ull);
+    atomicAdd(&count[i], 1);
+    if ((long long)pos < cap) {
+      HitRec r;
+      r.owner = i; r.idx = 0; r.d2 = s;
+      recs[pos] = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------- offsets ------
+__global__ __launch_bounds__(1024) void nn_offsets_kernel(const int *__restrict__ count, int nq,
+                                                          int64_t *__restrict__ offsets,
+                                                          int *__restrict__ cursor,
+                                                          const Scalars *__restrict__ sc,
+                                                          int64_t *__restrict__ needed) {
+  __shared__ long long part[1024];
+  const int t = threadIdx.x;
+  const int per = (nq + 1023) / 1024;
+  const int b = t * per;
+  const int e = min(nq, b + per);
+  long long sum = 0;
+  for (int i = b; i < e; ++i) sum += count[i];
+  part[t] = sum;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over 1024 partials
+  for (int off = 1; off < 1024; off <<= 1) {
+    long long v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  long long run = part[t] - sum;  // exclusive prefix of this thread's chunk
+  for (int i = b; i < e; ++i) {
+    offsets[i] = run;
+    cursor[i] = 0;
+    run += count[i];
+  }
+  if (t == 1023) offsets[nq] = part[1023];
+  if (t == 0 && needed) *needed = (int64_t)sc->total;
+}
+
+// ------------------------------------------------------------- scatter ------
+__global__ void nn_scatter_kernel(const HitRec *__restrict__ recs, long long cap,
+                                  const Scalars *__restrict__ sc, const int64_t *__restrict__ offsets,
+                                  int *__restrict__ cursor, int32_t *__restrict__ tmp_idx,
+                                  double *__restrict__ tmp_d2, long long out_cap) {
+  long long total = (long long)sc->total;
+  if (total > cap) total = cap;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    HitRec r = recs[i];
+    long long dst = offsets[r.owner] + atomicAdd(&cursor[r.owner], 1);
+    if (dst < out_cap) {
+      tmp_idx[dst] = r.idx;
+      tmp_d2[dst] = r.d2;
+    }
+  }
+}
+
+// --------------------------------------------------------------- order ------
+// one wave per query: rank each hit by node index, write idx ascending and
+// dist = sqrt(d2) (the key the reference stores, R/kdTree_general.jl:829-831)
+__global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict__ offsets, int nq,
+                                                       const int32_t *__restrict__ tmp_idx,
+                                                       const double *__restrict__ tmp_d2,
+                                                       int32_t *__restrict__ idx,
+                                                       double *__restrict__ dist, long long out_cap) {
+  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  const int lane = threadIdx.x & 63;
+  const long long b = offsets[q];
+  long long e = offsets[q + 1];
+  if (e > out_cap) e = out_cap;
+  const long long k = e - b;
+  if (k <= 0) return;
+  if (k <= 64) {
+    int my = (lane < k) ? tmp_idx[b + lane] : 0x7fffffff;
+    double d2 = (lane < k) ? tmp_d2[b + lane] : 0.0;
+    int rank = 0;
+    for (int j = 0; j < (int)k; ++j) {
+      int other = __shfl(my, j);
+      rank += (other < my) ? 1 : 0;
+    }
+    if (lane < k) {
+      idx[b + rank] = my;
+      dist[b + rank] = sqrt_rn(d2);
+    }
+  } else {
+    for (long long base = 0; base < k; base += 64) {
+      bool act = base + lane < k;
+      int my = act ? tmp_idx[b + base + lane] : 0x7fffffff;
+      double d2 = act ? tmp_d2[b + base + lane] : 0.0;
+      long long rank = 0;
+      for (long long j = 0; j < k; ++j) rank += (tmp_idx[b + j] < my) ? 1 : 0;
+      if (act) {
+        idx[b + rank] = my;
+        dist[b + rank] = sqrt_rn(d2);
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------- nearest -----
+// lane = query; nodes are streamed through SGPRs (wave-uniform loads).  Each
+// block handles 256 queries against one node segment and writes the segment's
+// best (d2, idx); nn_nearest_reduce picks the lexicographic minimum.
+template <int D>
+__global__ __launch_bounds__(256) void nn_nearest_partial_kernel(
+    const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
+    const double *__restrict__ nw, int n_nodes, const double *__restrict__ q, int nq, int n_wraps, int wd0,
+    int wd1, int wd2, double wp0, double wp1, double wp2, int seg_len, double *__restrict__ part_d2,
+    int32_t *__restrict__ part_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int seg = blockIdx.y;
+  const int node_begin = seg * seg_len;
+  const int node_end = min(n_nodes, node_begin + seg_len);
+  double p[4] = {0.0, 0.0, 0.0, 0.0};
+  if (i < nq) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) p[k] = q[(size_t)i * D + k];
+  }
+  const int wd[3] = {wd0, wd1, wd2};
+  const double wp[3] = {wp0, wp1, wp2};
+  double best = __builtin_inf();
+  int best_i = 0x7fffffff;
+  const int n_slots = 1 << n_wraps;
+  for (int k = 0; k < n_slots; ++k) {
+    double g[4] = {p[0], p[1], p[2], p[3]};
+    for (int w = 0; w < n_wraps; ++w) {
+      if (!((k >> (n_wraps - 1 - w)) & 1)) continue;
+      int dimi = wd[w];
+      g[dimi] = (p[dimi] < wp[w] / 2.0) ? (p[dimi] + wp[w]) : (p[dimi] - wp[w]);
+    }
+#pragma unroll 4
+    for (int n = node_begin; n < node_end; ++n) {
+      double s;
+      if constexpr (D == 4) s = sq4(g[0], g[1], g[2], g[3], nx[n], ny[n], nz[n], nw[n]);
+      else s = sq3(g[0], g[1], g[2], nx[n], ny[n], nz[n]);
+      bool better = (s < best) || (s == best && n < best_i);
+      best = better ? s : best;
+      best_i = better ? n : best_i;
+    }
+  }
+  if (i < nq) {
+    part_d2[(size_t)seg * nq + i] = best;
+    part_idx[(size_t)seg * nq + i] = best_i;
+  }
+}
+
+__global__ void nn_nearest_reduce_kernel(const double *__restrict__ part_d2,
+                                         const int32_t *__restrict__ part_idx, int nq, int n_seg,
+                                         int32_t *__restrict__ idx, double *__restrict__ dist) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  double best = __builtin_inf();
+  int best_i = 0x7fffffff;
+  for (int s = 0; s < n_seg; ++s) {
+    double d2 = part_d2[(size_t)s * nq + i];
+    int id = part_idx[(size_t)s * nq + i];
+    bool better = (d2 < best) || (d2 == best && id < best_i);
+    best = better ? d2 : best;
+    best_i = better ? id : best_i;
+  }
+  idx[i] = best_i;
+  dist[i] = sqrt_rn(best);
+}
+
+// nearest from the radius lists (valid when the list is non-empty): the first
+// minimum of the stored keys, ties to the lowest index (lists are index-sorted)
+__global__ void nn_nearest_from_lists_kernel(const int64_t *__restrict__ offsets, const int32_t *__restrict__ idx,
+                                             const double *__restrict__ dist, int nq,
+                                             int32_t *__restrict__ nearest_idx,
+                                             double *__restrict__ nearest_dist) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  double best = __builtin_inf();
+  int best_i = -1;
+  for (int64_t k = offsets[i]; k < offsets[i + 1]; ++k) {
+    double d = dist[k];
+    if (d < best) { best = d; best_i = idx[k]; }
+  }
+  nearest_idx[i] = best_i;   // -1: empty list, caller falls back to the full scan
+  nearest_dist[i] = best;
+}
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+// ------------------------------------------------------------- launchers ----
+int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr_lt, double r_scalar, int nq,
+                     int64_t *offsets_dev, int32_t *idx_dev, double *dist_dev, int64_t cap,
+                     int64_t *needed_dev) {
+  // r_dev_thr_lt: optional device array of 2*nq thresholds (thr_lt[nq] then thr_gt[nq])
+  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "radius search on an empty tree");
+  if (nq <= 0) return RRTX_OK;
+  const int D = ctx->dim;
+  const int n_slots = 1 << ctx->n_wraps;
+  hipStream_t st = ctx->stream;
+
+  double tlt = 0.0, tgt = 0.0;
+  if (!r_dev_thr_lt) {
+    if (ctx->thr_cache_r != r_scalar || std::isnan(r_scalar)) {
+      ctx->thr_cache_r = r_scalar;
+      ctx->thr_cache_lt = thr_first_ge(r_scalar);
+      ctx->thr_cache_gt = thr_first_gt(r_scalar);
+    }
+    tlt = ctx->thr_cache_lt;
+    tgt = ctx->thr_cache_gt;
+  }
+  const size_t n_copies_max = (size_t)nq * n_slots;
+  const size_t qrec_bytes = (D == 4) ? sizeof(QRec4) : sizeof(QRec3);
+  RRTX_HIP(ctx, ctx->ws_slots.ensure(n_copies_max * sizeof(SlotRec)));
+  RRTX_HIP(ctx, ctx->ws_copies.ensure(n_copies_max * qrec_bytes));
+  RRTX_HIP(ctx, ctx->ws_copy_meta.ensure(n_copies_max * sizeof(int2)));
+  RRTX_HIP(ctx, ctx->ws_counts.ensure((size_t)nq * 2 * sizeof(int)));
+  RRTX_HIP(ctx, ctx->ws_scalars.ensure(sizeof(Scalars)));
+  const long long rec_cap = (long long)(cap > 0 ? cap : 1);
+  RRTX_HIP(ctx, ctx->ws_recs.ensure((size_t)rec_cap * sizeof(HitRec)));
+  RRTX_HIP(ctx, ctx->ws_tmp_idx.ensure((size_t)rec_cap * sizeof(int32_t)));
+  RRTX_HIP(ctx, ctx->ws_tmp_d2.ensure((size_t)rec_cap * sizeof(double)));
+
+  Scalars *sc = ctx->ws_scalars.as<Scalars>();
+  int *count = ctx->ws_counts.as<int>();
+  int *cursor = count + nq;
+  Scalars init;
+  init.total = 0ull; init.n_copies = (ctx->n_wraps == 0) ? nq : 0; init.pad = 0;
+  RRTX_HIP(ctx, hipMemcpyAsync(sc, &init, sizeof(Scalars), hipMemcpyHostToDevice, st));
+  RRTX_HIP(ctx, hipMemsetAsync(count, 0, (size_t)nq * sizeof(int), st));
+
+  const double *thr_lt_arr = r_dev_thr_lt;
+  const double *thr_gt_arr = r_dev_thr_lt ? r_dev_thr_lt + nq : nullptr;
+
+  span_begin(ctx, KF_NN_FINISH);
+  {
+    dim3 grid((nq + 255) / 256), block(256);
+    if (D == 4)
+      hipLaunchKernelGGL(nn_pack_kernel<4>, grid, block, 0, st, q_dev, nq, thr_lt_arr, thr_gt_arr, tlt, tgt,
+                         ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1], ctx->wrap_dim[2],
+                         ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
+                         ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec4>(),
+                         ctx->ws_copy_meta.as<int2>(), sc);
+    else
+      hipLaunchKernelGGL(nn_pack_kernel<3>, grid, block, 0, st, q_dev, nq, thr_lt_arr, thr_gt_arr, tlt, tgt,
+                         ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1], ctx->wrap_dim[2],
+                         ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
+                         ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec3>(),
+                         ctx->ws_copy_meta.as<int2>(), sc);
+  }
+  span_end(ctx);
+
+  // ---- scan geometry: tiles of copies x node segments (segment = XCD-affine) ----
+  const int n_nodes = (int)ctx->n_nodes;
+  const int tile_q = 32;
+  const int n_tiles = (int)((n_copies_max + tile_q - 1) / tile_q);
+  const int wg_nodes = (kScanThreads / 64) * kChunk;  // nodes one workgroup covers per pass
+  int max_seg = (n_nodes + wg_nodes - 1) / wg_nodes;
+  int want_seg = (4096 + n_tiles - 1) / n_tiles;
+  int n_seg = want_seg < max_seg ? want_seg : max_seg;
+  if (n_seg < 1) n_seg = 1;
+  if (n_seg >= 8) n_seg = n_seg / 8 * 8;  // segment index == blockIdx % 8 class == XCD
+  int seg_len = round_up((n_nodes + n_seg - 1) / n_seg, kChunk);
+  n_seg = (n_nodes + seg_len - 1) / seg_len;
+
+  span_begin(ctx, KF_NN_SCAN);
+  {
+    dim3 grid((unsigned)n_tiles * (unsigned)n_seg), block(kScanThreads);
+    if (D == 4)
+      hipLaunchKernelGGL(nn_scan_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                         ctx->nodes[3], n_nodes, ctx->ws_copies.as<QRec4>(), ctx->ws_copy_meta.as<int2>(),
+                         ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len,
+                         ctx->ws_recs.as<HitRec>(), rec_cap, sc, count);
+    else
+      hipLaunchKernelGGL(nn_scan_kernel<3>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                         ctx->nodes[2], n_nodes, ctx->ws_copies.as<QRec3>(), ctx->ws_copy_meta.as<int2>(),
+                         ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len,
+                         ctx->ws_recs.as<HitRec>(), rec_cap, sc, count);
+  }
+  span_end(ctx);
+  ctx->last_pairs = (int64_t)n_copies_max * n_nodes;
+
+  span_begin(ctx, KF_NN_FINISH);
+  {
+    dim3 grid((nq + 255) / 256), block(256);
+    if (D == 4)
+      hipLaunchKernelGGL(nn_rootfix_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                         ctx->nodes[3], ctx->ws_slots.as<SlotRec>(), n_slots, nq, ctx->ws_recs.as<HitRec>(),
+                         rec_cap, sc, count);
+    else
+      hipLaunchKernelGGL(nn_rootfix_kernel<3>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                         ctx->nodes[2], ctx->ws_slots.as<SlotRec>(), n_slots, nq, ctx->ws_recs.as<HitRec>(),
+                         rec_cap, sc, count);
+    hipLaunchKernelGGL(nn_offsets_kernel, dim3(1), dim3(1024), 0, st, count, nq, offsets_dev, cursor, sc,
+                       needed_dev);
+    hipLaunchKernelGGL(nn_scatter_kernel, dim3(1024), dim3(256), 0, st, ctx->ws_recs.as<HitRec>(), rec_cap, sc,
+                       offsets_dev, cursor, ctx->ws_tmp_idx.as<int32_t>(), ctx->ws_tmp_d2.as<double>(),
+                       (long long)cap);
+    hipLaunchKernelGGL(nn_order_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, offsets_dev, nq,
+                       ctx->ws_tmp_idx.as<int32_t>(), ctx->ws_tmp_d2.as<double>(), idx_dev, dist_dev,
+                       (long long)cap);
+  }
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev) {
+  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "nearest search on an empty tree");
+  if (nq <= 0) return RRTX_OK;
+  const int n_nodes = (int)ctx->n_nodes;
+  const int qblocks = (nq + 255) / 256;
+  int want_seg = (2048 + qblocks - 1) / qblocks;
+  int max_seg = (n_nodes + 255) / 256;
+  int n_seg = want_seg < max_seg ? want_seg : max_seg;
+  if (n_seg < 1) n_seg = 1;
+  int seg_len = (n_nodes + n_seg - 1) / n_seg;
+  n_seg = (n_nodes + seg_len - 1) / seg_len;
+  RRTX_HIP(ctx, ctx->ws_partial.ensure((size_t)n_seg * nq * (sizeof(double) + sizeof(int32_t))));
+  double *pd2 = ctx->ws_partial.as<double>();
+  int32_t *pidx = reinterpret_cast<int32_t *>(pd2 + (size_t)n_seg * nq);
+  hipStream_t st = ctx->stream;
+  span_begin(ctx, KF_NN_NEAREST);
+  dim3 grid(qblocks, n_seg), block(256);
+  if (ctx->dim == 4)
+    hipLaunchKernelGGL(nn_nearest_partial_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
+                       ctx->nodes[2], ctx->nodes[3], n_nodes, q_dev, nq, ctx->n_wraps, ctx->wrap_dim[0],
+                       ctx->wrap_dim[1], ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1],
+                       ctx->wrap_period[2], seg_len, pd2, pidx);
+  else
+    hipLaunchKernelGGL(nn_nearest_partial_kernel<3>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
+                       ctx->nodes[2], ctx->nodes[2], n_nodes, q_dev, nq, ctx->n_wraps, ctx->wrap_dim[0],
+                       ctx->wrap_dim[1], ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1],
+                       ctx->wrap_period[2], seg_len, pd2, pidx);
+  hipLaunchKernelGGL(nn_nearest_reduce_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, pd2, pidx, nq, n_seg,
+                     idx_dev, dist_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+int launch_nearest_from_lists(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
+                              const int32_t *idx_dev, const double *dist_dev, int32_t *nearest_idx_dev,
+                              double *nearest_dist_dev) {
+  (void)q_dev;
+  if (nq <= 0) return RRTX_OK;
+  span_begin(ctx, KF_NN_FINISH);
+  hipLaunchKernelGGL(nn_nearest_from_lists_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream,
+                     offsets_dev, idx_dev, dist_dev, nq, nearest_idx_dev, nearest_dist_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+}  // namespace rrtx

@@ -1,0 +1,686 @@
+// rrtx_capi.hip -- the extern "C" surface of librrtx_hip.so (include/rrtx.h):
+// context lifetime, node/obstacle tables, host-buffer staging around the kernel
+// launchers.  gfx950 only; no CPU fallback: every compute entry point runs HIP
+// kernels or fails with RRTX_E_DEVICE.
+#include <cstdarg>
+#include <mutex>
+
+#include "exact_math.hpp"
+#include "rrtx_internal.hpp"
+
+namespace rrtx {
+
+int fail(rrtx_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+// ---- exact thresholds on squared distances ------------------------------------
+// sqrt is monotone non-decreasing under round-to-nearest, so {s : sqrt(s) >= r}
+// is an upper set of the non-negative doubles; its least element is found by a
+// few nextafter steps around r*r (bisection over the bit pattern as fallback).
+namespace {
+template <class Pred>
+double first_true(double guess, Pred pred) {
+  // pred is monotone (false ... false true ... true) over s in [0, +inf]
+  if (!(guess >= 0.0)) guess = 0.0;
+  double s = guess;
+  for (int it = 0; it < 16; ++it) {
+    if (pred(s)) {
+      if (s == 0.0) return 0.0;
+      double p = std::nextafter(s, -INFINITY);
+      if (!pred(p)) return s;
+      s = p;
+    } else {
+      double n = std::nextafter(s, INFINITY);
+      if (n == s) return std::nan("");  // s == +inf and pred false: never true
+      if (pred(n)) return n;
+      s = n;
+    }
+  }
+  // bisection on the IEEE bit pattern (monotone for non-negative doubles)
+  uint64_t lo = 0, hi = 0x7ff0000000000000ull;  // 0 .. +inf
+  auto val = [](uint64_t b) { double d; std::memcpy(&d, &b, 8); return d; };
+  if (pred(val(lo))) return 0.0;
+  if (!pred(val(hi))) return std::nan("");
+  while (hi - lo > 1) {
+    uint64_t mid = lo + (hi - lo) / 2;
+    if (pred(val(mid))) hi = mid; else lo = mid;
+  }
+  return val(hi);
+}
+}  // namespace
+
+double thr_first_ge(double r) {
+  if (std::isnan(r)) return std::nan("");  // sqrt(s) < NaN is never true
+  if (r <= 0.0) return 0.0;                // sqrt(s) >= r for every s >= 0
+  return first_true(r * r, [r](double s) { return std::sqrt(s) >= r; });
+}
+double thr_first_gt(double r) {
+  if (std::isnan(r)) return 0.0;           // sqrt(s) <= NaN never true: s < 0 never
+  if (r < 0.0) return 0.0;
+  return first_true(r * r, [r](double s) { return std::sqrt(s) > r; });
+}
+
+// ---- profiling spans -------------------------------------------------------------
+static hipEvent_t take_event(rrtx_ctx *ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void span_begin(rrtx_ctx *ctx, int family) {
+  ctx->fam_launches[family] += 1;
+  if (!ctx->profiling) return;
+  TimedSpan s;
+  s.a = take_event(ctx);
+  s.b = take_event(ctx);
+  s.family = family;
+  (void)hipEventRecord(s.a, ctx->stream);
+  ctx->spans.push_back(s);
+}
+
+void span_end(rrtx_ctx *ctx) {
+  if (!ctx->profiling || ctx->spans.empty()) return;
+  (void)hipEventRecord(ctx->spans.back().b, ctx->stream);
+}
+
+static void drain_spans(rrtx_ctx *ctx) {
+  for (auto &s : ctx->spans) {
+    float ms = 0.f;
+    if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess)
+      ctx->fam_ms[s.family] += ms;
+    ctx->event_pool.push_back(s.a);
+    ctx->event_pool.push_back(s.b);
+  }
+  ctx->spans.clear();
+}
+
+namespace {
+
+__global__ void aos_to_soa_kernel(const double *__restrict__ pos, int dim, long long n, long long base,
+                                  double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+                                  double *__restrict__ w) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  x[base + i] = pos[i * dim + 0];
+  y[base + i] = pos[i * dim + 1];
+  z[base + i] = pos[i * dim + 2];
+  if (dim == 4) w[base + i] = pos[i * dim + 3];
+}
+
+int grow_nodes(rrtx_ctx *ctx, int64_t need) {
+  if (need <= ctx->cap_nodes) return RRTX_OK;
+  int64_t nc = ctx->cap_nodes > 0 ? ctx->cap_nodes : 1024;
+  while (nc < need) nc *= 2;
+  if (nc > 0x7fffffffll) return fail(ctx, RRTX_E_CAPACITY, "node index space is int32 (%lld requested)", (long long)need);
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < ctx->dim; ++k) {
+    double *nb = nullptr;
+    hipError_t e = hipMalloc(&nb, sizeof(double) * (size_t)nc);
+    if (e != hipSuccess) return fail(ctx, RRTX_E_NOMEM, "hipMalloc of %lld node slots failed: %s", (long long)nc, hipGetErrorString(e));
+    if (ctx->n_nodes > 0)
+      RRTX_HIP(ctx, hipMemcpy(nb, ctx->nodes[k], sizeof(double) * (size_t)ctx->n_nodes, hipMemcpyDeviceToDevice));
+    if (ctx->nodes[k]) RRTX_HIP(ctx, hipFree(ctx->nodes[k]));
+    ctx->nodes[k] = nb;
+  }
+  ctx->cap_nodes = nc;
+  return RRTX_OK;
+}
+
+// stage a host array on the device workspace `buf`
+int stage_in(rrtx_ctx *ctx, DevBuf &buf, const void *host, size_t bytes) {
+  RRTX_HIP(ctx, buf.ensure(bytes ? bytes : 8));
+  if (bytes) RRTX_HIP(ctx, hipMemcpyAsync(buf.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return RRTX_OK;
+}
+
+std::string g_create_err;
+std::mutex g_create_mu;
+
+}  // namespace
+}  // namespace rrtx
+
+using namespace rrtx;
+
+#define CHECK_CTX(ctx)                 \
+  do {                                 \
+    if (!(ctx)) return RRTX_E_INVALID; \
+    hipError_t _sd = hipSetDevice((ctx)->device); \
+    if (_sd != hipSuccess) return fail((ctx), RRTX_E_DEVICE, "hipSetDevice(%d): %s", (ctx)->device, hipGetErrorString(_sd)); \
+  } while (0)
+
+extern "C" {
+
+const char *rrtx_create_error(void) { return g_create_err.c_str(); }
+
+int rrtx_create(rrtx_ctx **out, int dim, int device, int64_t node_capacity) {
+  std::lock_guard<std::mutex> lk(g_create_mu);
+  if (!out) { g_create_err = "out is NULL"; return RRTX_E_INVALID; }
+  *out = nullptr;
+  if (dim != 3 && dim != 4) { g_create_err = "dim must be 3 or 4"; return RRTX_E_INVALID; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_err = std::string("no HIP device available: ") + hipGetErrorString(e);
+    return RRTX_E_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { g_create_err = "device ordinal out of range"; return RRTX_E_INVALID; }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return RRTX_E_DEVICE; }
+  rrtx_ctx *ctx = new (std::nothrow) rrtx_ctx();
+  if (!ctx) { g_create_err = "out of host memory"; return RRTX_E_NOMEM; }
+  ctx->dim = dim;
+  ctx->device = device;
+  e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    g_create_err = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+    delete ctx;
+    return RRTX_E_DEVICE;
+  }
+  ctx->stream = ctx->own_stream;
+  int rc = grow_nodes(ctx, node_capacity > 0 ? node_capacity : 1024);
+  if (rc != RRTX_OK) {
+    g_create_err = ctx->err;
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return RRTX_OK;
+}
+
+int rrtx_destroy(rrtx_ctx *ctx) {
+  if (!ctx) return RRTX_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  drain_spans(ctx);
+  for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+  for (int k = 0; k < 4; ++k)
+    if (ctx->nodes[k]) (void)hipFree(ctx->nodes[k]);
+  DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
+                    &ctx->d_poly_orig, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
+                    &ctx->ws_copy_meta, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_scalars, &ctx->ws_tmp_idx,
+                    &ctx->ws_tmp_d2, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
+                    &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr};
+  for (auto b : bufs) b->release();
+  (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return RRTX_OK;
+}
+
+const char *rrtx_last_error(rrtx_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rrtx_set_stream(rrtx_ctx *ctx, void *hip_stream) {
+  CHECK_CTX(ctx);
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return RRTX_OK;
+}
+
+void *rrtx_get_stream(rrtx_ctx *ctx) { return ctx ? reinterpret_cast<void *>(ctx->stream) : nullptr; }
+
+int rrtx_sync(rrtx_ctx *ctx) {
+  CHECK_CTX(ctx);
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
+int rrtx_profile(rrtx_ctx *ctx, int enable) {
+  CHECK_CTX(ctx);
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  drain_spans(ctx);
+  for (int k = 0; k < KF_COUNT; ++k) { ctx->fam_ms[k] = 0.0; ctx->fam_launches[k] = 0; }
+  ctx->profiling = enable != 0;
+  return RRTX_OK;
+}
+
+int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out) {
+  CHECK_CTX(ctx);
+  if (!out) return fail(ctx, RRTX_E_INVALID, "stats: out is NULL");
+  drain_spans(ctx);
+  out->n_nodes = ctx->n_nodes;
+  out->dim = ctx->dim;
+  out->n_spheres = (int32_t)ctx->sph_active.size();
+  out->n_polygons = (int32_t)ctx->poly_active.size();
+  out->n_wraps = ctx->n_wraps;
+  out->ms_nn_scan = ctx->fam_ms[KF_NN_SCAN];       out->launches_nn_scan = ctx->fam_launches[KF_NN_SCAN];
+  out->ms_nn_finish = ctx->fam_ms[KF_NN_FINISH];   out->launches_nn_finish = ctx->fam_launches[KF_NN_FINISH];
+  out->ms_nn_nearest = ctx->fam_ms[KF_NN_NEAREST]; out->launches_nn_nearest = ctx->fam_launches[KF_NN_NEAREST];
+  out->ms_edges = ctx->fam_ms[KF_EDGES];           out->launches_edges = ctx->fam_launches[KF_EDGES];
+  out->ms_points = ctx->fam_ms[KF_POINTS];         out->launches_points = ctx->fam_launches[KF_POINTS];
+  out->ms_dubins = ctx->fam_ms[KF_DUBINS];         out->launches_dubins = ctx->fam_launches[KF_DUBINS];
+  out->last_pairs = ctx->last_pairs;
+  out->last_neighbors = ctx->last_neighbors;
+  return RRTX_OK;
+}
+
+// ---- tree ---------------------------------------------------------------------------
+int64_t rrtx_nodes_count(rrtx_ctx *ctx) { return ctx ? ctx->n_nodes : 0; }
+
+int rrtx_nodes_append_dev(rrtx_ctx *ctx, const double *pos_dev, int64_t n) {
+  CHECK_CTX(ctx);
+  if (n < 0 || (n > 0 && !pos_dev)) return fail(ctx, RRTX_E_INVALID, "nodes_append: bad arguments");
+  if (n == 0) return RRTX_OK;
+  int rc = grow_nodes(ctx, ctx->n_nodes + n);
+  if (rc) return rc;
+  hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev,
+                     ctx->dim, (long long)n, (long long)ctx->n_nodes, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                     ctx->nodes[ctx->dim == 4 ? 3 : 2]);
+  RRTX_HIP(ctx, hipGetLastError());
+  ctx->n_nodes += n;
+  return RRTX_OK;
+}
+
+int rrtx_nodes_append(rrtx_ctx *ctx, const double *pos, int64_t n, int64_t *first_index) {
+  CHECK_CTX(ctx);
+  if (n < 0 || (n > 0 && !pos)) return fail(ctx, RRTX_E_INVALID, "nodes_append: bad arguments");
+  if (first_index) *first_index = ctx->n_nodes;
+  if (n == 0) return RRTX_OK;
+  int rc = stage_in(ctx, ctx->ws_q, pos, sizeof(double) * (size_t)n * ctx->dim);
+  if (rc) return rc;
+  rc = rrtx_nodes_append_dev(ctx, ctx->ws_q.as<double>(), n);
+  if (rc) return rc;
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
+int rrtx_set_wrap(rrtx_ctx *ctx, int dim_index, double period) {
+  CHECK_CTX(ctx);
+  if (dim_index < 0 || dim_index >= ctx->dim || !(period > 0.0))
+    return fail(ctx, RRTX_E_INVALID, "set_wrap: dimension %d / period %g invalid", dim_index, period);
+  for (int w = 0; w < ctx->n_wraps; ++w)
+    if (ctx->wrap_dim[w] == dim_index) { ctx->wrap_period[w] = period; return RRTX_OK; }
+  if (ctx->n_wraps >= kMaxWraps) return fail(ctx, RRTX_E_CAPACITY, "at most %d wrapped dimensions", kMaxWraps);
+  ctx->wrap_dim[ctx->n_wraps] = dim_index;
+  ctx->wrap_period[ctx->n_wraps] = period;
+  ctx->n_wraps += 1;
+  return RRTX_OK;
+}
+
+// ---- obstacles -----------------------------------------------------------------------
+int rrtx_spheres_set(rrtx_ctx *ctx, const double *cxyzr, const uint8_t *active, int m) {
+  CHECK_CTX(ctx);
+  if (m < 0 || (m > 0 && !cxyzr)) return fail(ctx, RRTX_E_INVALID, "spheres_set: bad arguments");
+  ctx->sph.assign(cxyzr, cxyzr + 4 * (size_t)m);
+  ctx->sph_active.assign((size_t)m, 1);
+  if (active) for (int i = 0; i < m; ++i) ctx->sph_active[i] = active[i] ? 1 : 0;
+  ctx->sph_dirty = true;
+  return RRTX_OK;
+}
+
+int rrtx_obstacle_update(rrtx_ctx *ctx, int which, double radius, uint8_t active) {
+  CHECK_CTX(ctx);
+  if (which < 0 || which >= (int)ctx->sph_active.size())
+    return fail(ctx, RRTX_E_INVALID, "obstacle_update: index %d out of range", which);
+  ctx->sph[4 * (size_t)which + 3] = radius;
+  ctx->sph_active[which] = active ? 1 : 0;
+  ctx->sph_dirty = true;
+  return RRTX_OK;
+}
+
+int rrtx_polygons_set(rrtx_ctx *ctx, const int32_t *vert_off, const double *vxy, const double *centre_radius,
+                      const uint8_t *kind, const uint8_t *active, int m) {
+  CHECK_CTX(ctx);
+  if (m < 0 || (m > 0 && (!vert_off || !vxy))) return fail(ctx, RRTX_E_INVALID, "polygons_set: bad arguments");
+  for (int i = 0; i < m; ++i)
+    if (vert_off[i + 1] < vert_off[i]) return fail(ctx, RRTX_E_INVALID, "polygons_set: vert_off not monotone");
+  ctx->poly_off.assign(vert_off, vert_off + (m > 0 ? m + 1 : 0));
+  if (m == 0) ctx->poly_off.assign(1, 0);
+  const int nv = m > 0 ? vert_off[m] : 0;
+  ctx->poly_vxy.assign(vxy, vxy + 2 * (size_t)nv);
+  ctx->poly_kind.assign((size_t)m, 3);
+  ctx->poly_active.assign((size_t)m, 1);
+  if (kind) for (int i = 0; i < m; ++i) ctx->poly_kind[i] = kind[i];
+  if (active) for (int i = 0; i < m; ++i) ctx->poly_active[i] = active[i] ? 1 : 0;
+  ctx->poly_cr.assign(3 * (size_t)m, 0.0);
+  for (int i = 0; i < m; ++i) {
+    if (ctx->poly_kind[i] != 1 && ctx->poly_kind[i] != 3)
+      return fail(ctx, RRTX_E_INVALID, "polygons_set: obstacle kind %d not supported (1 or 3)", (int)ctx->poly_kind[i]);
+    if (centre_radius) {
+      for (int k = 0; k < 3; ++k) ctx->poly_cr[3 * (size_t)i + k] = centre_radius[3 * (size_t)i + k];
+      continue;
+    }
+    // Obstacle(kind, polygon) ctor, R/DRRT_data_structures.jl:229-241
+    const int b = vert_off[i], e = vert_off[i + 1];
+    if (e <= b) continue;
+    double maxx = vxy[2 * b], minx = maxx, maxy = vxy[2 * b + 1], miny = maxy;
+    for (int v = b + 1; v < e; ++v) {
+      maxx = std::fmax(maxx, vxy[2 * v]); minx = std::fmin(minx, vxy[2 * v]);
+      maxy = std::fmax(maxy, vxy[2 * v + 1]); miny = std::fmin(miny, vxy[2 * v + 1]);
+    }
+    const double px = (maxx + minx) / 2.0, py = (maxy + miny) / 2.0;
+    double best = 0.0;
+    for (int v = b; v < e; ++v) {
+      double dx = vxy[2 * v] - px, dy = vxy[2 * v + 1] - py;
+      double s = dx * dx + dy * dy;
+      if (v == b || s > best) best = s;
+    }
+    ctx->poly_cr[3 * (size_t)i + 0] = px;
+    ctx->poly_cr[3 * (size_t)i + 1] = py;
+    ctx->poly_cr[3 * (size_t)i + 2] = std::sqrt(best);
+  }
+  ctx->poly_dirty = true;
+  return RRTX_OK;
+}
+
+// ---- nearest neighbours ----------------------------------------------------------------
+int rrtx_nn_nearest_dev(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double *dist) {
+  CHECK_CTX(ctx);
+  if (nq < 0 || (nq > 0 && (!q || !idx || !dist))) return fail(ctx, RRTX_E_INVALID, "nn_nearest: bad arguments");
+  return launch_nn_nearest(ctx, q, nq, idx, dist);
+}
+
+int rrtx_nn_nearest(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double *dist) {
+  CHECK_CTX(ctx);
+  if (nq < 0 || (nq > 0 && (!q || !idx || !dist))) return fail(ctx, RRTX_E_INVALID, "nn_nearest: bad arguments");
+  if (nq == 0) return RRTX_OK;
+  int rc = stage_in(ctx, ctx->ws_q, q, sizeof(double) * (size_t)nq * ctx->dim);
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_idx.ensure(sizeof(int32_t) * (size_t)nq));
+  RRTX_HIP(ctx, ctx->ws_out_dist.ensure(sizeof(double) * (size_t)nq));
+  rc = launch_nn_nearest(ctx, ctx->ws_q.as<double>(), nq, ctx->ws_out_idx.as<int32_t>(), ctx->ws_out_dist.as<double>());
+  if (rc) return rc;
+  RRTX_HIP(ctx, hipMemcpyAsync(idx, ctx->ws_out_idx.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipMemcpyAsync(dist, ctx->ws_out_dist.p, sizeof(double) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
+int rrtx_nn_radius_dev(rrtx_ctx *ctx, const double *q, double r, int nq, int64_t *offsets, int32_t *idx,
+                       double *dist, int64_t cap, int64_t *needed_dev) {
+  CHECK_CTX(ctx);
+  if (nq < 0 || cap < 0 || (nq > 0 && (!q || !offsets)) || (cap > 0 && (!idx || !dist)))
+    return fail(ctx, RRTX_E_INVALID, "nn_radius: bad arguments");
+  return launch_nn_radius(ctx, q, nullptr, r, nq, offsets, idx, dist, cap, needed_dev);
+}
+
+int rrtx_nn_radius(rrtx_ctx *ctx, const double *q, const double *r, int r_stride, int nq, int64_t *offsets,
+                   int32_t *idx, double *dist, int64_t cap, int64_t *needed) {
+  CHECK_CTX(ctx);
+  if (nq < 0 || cap < 0 || (nq > 0 && (!q || !r || !offsets)) || (cap > 0 && (!idx || !dist)) ||
+      (r_stride != 0 && r_stride != 1))
+    return fail(ctx, RRTX_E_INVALID, "nn_radius: bad arguments");
+  if (nq == 0) { if (needed) *needed = 0; return RRTX_OK; }
+  int rc = stage_in(ctx, ctx->ws_q, q, sizeof(double) * (size_t)nq * ctx->dim);
+  if (rc) return rc;
+  const double *thr_dev = nullptr;
+  if (r_stride == 1) {
+    std::vector<double> thr(2 * (size_t)nq);
+    double last_r = std::nan(""), lt = 0, gt = 0;
+    for (int i = 0; i < nq; ++i) {
+      if (!(r[i] == last_r)) { last_r = r[i]; lt = thr_first_ge(r[i]); gt = thr_first_gt(r[i]); }
+      thr[i] = lt; thr[(size_t)nq + i] = gt;
+    }
+    rc = stage_in(ctx, ctx->ws_thr, thr.data(), sizeof(double) * thr.size());
+    if (rc) return rc;
+    RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // thr goes out of scope
+    thr_dev = ctx->ws_thr.as<double>();
+  }
+  const int64_t dcap = cap > 0 ? cap : 1;
+  RRTX_HIP(ctx, ctx->ws_out_off.ensure(sizeof(int64_t) * ((size_t)nq + 2)));
+  RRTX_HIP(ctx, ctx->ws_out_idx.ensure(sizeof(int32_t) * (size_t)dcap));
+  RRTX_HIP(ctx, ctx->ws_out_dist.ensure(sizeof(double) * (size_t)dcap));
+  int64_t *off_dev = ctx->ws_out_off.as<int64_t>();
+  int64_t *needed_dev = off_dev + nq + 1;
+  rc = launch_nn_radius(ctx, ctx->ws_q.as<double>(), thr_dev, r[0], nq, off_dev, ctx->ws_out_idx.as<int32_t>(),
+                        ctx->ws_out_dist.as<double>(), cap, needed_dev);
+  if (rc) return rc;
+  int64_t total = 0;
+  RRTX_HIP(ctx, hipMemcpyAsync(offsets, off_dev, sizeof(int64_t) * ((size_t)nq + 1), hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipMemcpyAsync(&total, needed_dev, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (needed) *needed = total;
+  ctx->last_neighbors = total;
+  if (total > cap) return fail(ctx, RRTX_E_CAPACITY, "nn_radius: %lld neighbours, capacity %lld", (long long)total, (long long)cap);
+  if (total > 0) {
+    RRTX_HIP(ctx, hipMemcpyAsync(idx, ctx->ws_out_idx.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipMemcpyAsync(dist, ctx->ws_out_dist.p, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return RRTX_OK;
+}
+
+// ---- collision ----------------------------------------------------------------------------
+int rrtx_edges_check_dev(rrtx_ctx *ctx, int kind, const double *p0, const double *p1, int64_t ne,
+                         double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end, uint8_t *hit,
+                         int32_t *first_hit) {
+  CHECK_CTX(ctx);
+  if (ne < 0 || (ne > 0 && (!p0 || !p1 || !hit)) || (kind != 0 && kind != 1))
+    return fail(ctx, RRTX_E_INVALID, "edges_check: bad arguments");
+  if (kind == 0)
+    return launch_edges_spheres(ctx, p0, p1, ne, robot_radius, obstacle_or_minus1, obs_begin, obs_end, hit, first_hit);
+  return launch_edges_polygons(ctx, p0, p1, ne, robot_radius, obstacle_or_minus1, obs_begin, obs_end, hit, first_hit);
+}
+
+int rrtx_edges_check(rrtx_ctx *ctx, int kind, const double *p0, const double *p1, int64_t ne, double robot_radius,
+                     int obstacle_or_minus1, uint8_t *hit, int32_t *first_hit) {
+  CHECK_CTX(ctx);
+  if (ne < 0 || (ne > 0 && (!p0 || !p1 || !hit)) || (kind != 0 && kind != 1))
+    return fail(ctx, RRTX_E_INVALID, "edges_check: bad arguments");
+  if (ne == 0) return RRTX_OK;
+  const size_t pb = sizeof(double) * (size_t)ne * ctx->dim;
+  int rc = stage_in(ctx, ctx->ws_q, p0, pb);
+  if (rc) return rc;
+  rc = stage_in(ctx, ctx->ws_q2, p1, pb);
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_u8a.ensure((size_t)ne));
+  RRTX_HIP(ctx, ctx->ws_out_i32.ensure(sizeof(int32_t) * (size_t)ne));
+  rc = rrtx_edges_check_dev(ctx, kind, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>(), ne, robot_radius,
+                            obstacle_or_minus1, -1, -1, ctx->ws_out_u8a.as<uint8_t>(),
+                            first_hit ? ctx->ws_out_i32.as<int32_t>() : nullptr);
+  if (rc) return rc;
+  RRTX_HIP(ctx, hipMemcpyAsync(hit, ctx->ws_out_u8a.p, (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  if (first_hit)
+    RRTX_HIP(ctx, hipMemcpyAsync(first_hit, ctx->ws_out_i32.p, sizeof(int32_t) * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
+int rrtx_points_check_dev(rrtx_ctx *ctx, int kind, const double *p, int64_t np, double robot_radius, int quick,
+                          uint8_t *unsafe, double *clearance) {
+  CHECK_CTX(ctx);
+  if (np < 0 || (np > 0 && (!p || !unsafe)) || (kind != 0 && kind != 1))
+    return fail(ctx, RRTX_E_INVALID, "points_check: bad arguments");
+  if (kind == 0) return launch_points_spheres(ctx, p, np, robot_radius, quick, unsafe, clearance);
+  return launch_points_polygons(ctx, p, np, robot_radius, unsafe, clearance);
+}
+
+int rrtx_points_check(rrtx_ctx *ctx, int kind, const double *p, int64_t np, double robot_radius, int quick,
+                      uint8_t *unsafe, double *clearance) {
+  CHECK_CTX(ctx);
+  if (np < 0 || (np > 0 && (!p || !unsafe)) || (kind != 0 && kind != 1))
+    return fail(ctx, RRTX_E_INVALID, "points_check: bad arguments");
+  if (np == 0) return RRTX_OK;
+  int rc = stage_in(ctx, ctx->ws_q, p, sizeof(double) * (size_t)np * ctx->dim);
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_u8a.ensure((size_t)np));
+  RRTX_HIP(ctx, ctx->ws_out_f64.ensure(sizeof(double) * (size_t)np));
+  rc = rrtx_points_check_dev(ctx, kind, ctx->ws_q.as<double>(), np, robot_radius, quick,
+                             ctx->ws_out_u8a.as<uint8_t>(), ctx->ws_out_f64.as<double>());
+  if (rc) return rc;
+  RRTX_HIP(ctx, hipMemcpyAsync(unsafe, ctx->ws_out_u8a.p, (size_t)np, hipMemcpyDeviceToHost, ctx->stream));
+  if (clearance)
+    RRTX_HIP(ctx, hipMemcpyAsync(clearance, ctx->ws_out_f64.p, sizeof(double) * (size_t)np, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
+// ---- steering -------------------------------------------------------------------------------
+int rrtx_simple_steer(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double *dist, double *wdist) {
+  CHECK_CTX(ctx);
+  if (ne < 0 || (ne > 0 && (!s || !g))) return fail(ctx, RRTX_E_INVALID, "simple_steer: bad arguments");
+  if (ne == 0) return RRTX_OK;
+  const size_t pb = sizeof(double) * (size_t)ne * ctx->dim;
+  int rc = stage_in(ctx, ctx->ws_q, s, pb);
+  if (rc) return rc;
+  rc = stage_in(ctx, ctx->ws_q2, g, pb);
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_dist.ensure(sizeof(double) * (size_t)ne));
+  RRTX_HIP(ctx, ctx->ws_out_f64.ensure(sizeof(double) * (size_t)ne));
+  rc = launch_simple_steer(ctx, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>(), ne, ctx->ws_out_dist.as<double>(),
+                           ctx->ws_out_f64.as<double>());
+  if (rc) return rc;
+  if (dist) RRTX_HIP(ctx, hipMemcpyAsync(dist, ctx->ws_out_dist.p, sizeof(double) * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  if (wdist) RRTX_HIP(ctx, hipMemcpyAsync(wdist, ctx->ws_out_f64.p, sizeof(double) * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
+static int dubins_common(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min,
+                         double robot_radius, bool check, double *cost, uint8_t *word, uint8_t *hit,
+                         int32_t *traj_len) {
+  if (ne < 0 || (ne > 0 && (!s || !g || !cost)) || (check && ne > 0 && !hit))
+    return fail(ctx, RRTX_E_INVALID, "dubins: bad arguments");
+  if (ne == 0) return RRTX_OK;
+  if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
+  const size_t pb = sizeof(double) * (size_t)ne * 4;
+  int rc = stage_in(ctx, ctx->ws_q, s, pb);
+  if (rc) return rc;
+  rc = stage_in(ctx, ctx->ws_q2, g, pb);
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_dist.ensure(sizeof(double) * (size_t)ne));
+  RRTX_HIP(ctx, ctx->ws_out_u8a.ensure(3 * (size_t)ne));
+  RRTX_HIP(ctx, ctx->ws_out_u8b.ensure((size_t)ne));
+  RRTX_HIP(ctx, ctx->ws_out_i32.ensure(sizeof(int32_t) * (size_t)ne));
+  if (check)
+    rc = launch_dubins_edges_check(ctx, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>(), ne, r_min, robot_radius,
+                                   ctx->ws_out_dist.as<double>(), ctx->ws_out_u8a.as<uint8_t>(),
+                                   ctx->ws_out_u8b.as<uint8_t>(), ctx->ws_out_i32.as<int32_t>());
+  else
+    rc = launch_dubins_steer(ctx, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>(), ne, r_min,
+                             ctx->ws_out_dist.as<double>(), ctx->ws_out_u8a.as<uint8_t>());
+  if (rc) return rc;
+  RRTX_HIP(ctx, hipMemcpyAsync(cost, ctx->ws_out_dist.p, sizeof(double) * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  if (word) RRTX_HIP(ctx, hipMemcpyAsync(word, ctx->ws_out_u8a.p, 3 * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  if (check) {
+    RRTX_HIP(ctx, hipMemcpyAsync(hit, ctx->ws_out_u8b.p, (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+    if (traj_len)
+      RRTX_HIP(ctx, hipMemcpyAsync(traj_len, ctx->ws_out_i32.p, sizeof(int32_t) * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
+int rrtx_dubins_steer(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min, double *cost,
+                      uint8_t *word) {
+  CHECK_CTX(ctx);
+  return dubins_common(ctx, s, g, ne, r_min, 0.0, false, cost, word, nullptr, nullptr);
+}
+
+int rrtx_dubins_edges_check(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min,
+                            double robot_radius, double *cost, uint8_t *word, uint8_t *hit, int32_t *traj_len) {
+  CHECK_CTX(ctx);
+  return dubins_common(ctx, s, g, ne, r_min, robot_radius, true, cost, word, hit, traj_len);
+}
+
+// ---- fused extend() preamble ------------------------------------------------------------------
+int rrtx_extend_candidates_dev(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius,
+                               int64_t *offsets, int32_t *idx, double *cost, uint8_t *hit_out, uint8_t *hit_in,
+                               int64_t cap, int64_t *needed_dev, int32_t *nearest_idx, double *nearest_dist,
+                               uint8_t *sample_unsafe) {
+  CHECK_CTX(ctx);
+  if (nq < 0 || cap < 0 || (nq > 0 && (!q || !offsets)) || (cap > 0 && (!idx || !cost || !hit_out || !hit_in)))
+    return fail(ctx, RRTX_E_INVALID, "extend_candidates: bad arguments");
+  if (ctx->dim != 3) return fail(ctx, RRTX_E_STATE, "extend_candidates is the SimpleEdge (dim=3) path");
+  if (nq == 0) return RRTX_OK;
+  int rc = launch_nn_radius(ctx, q, nullptr, r, nq, offsets, idx, cost, cap, needed_dev);
+  if (rc) return rc;
+  rc = launch_candidate_edges(ctx, q, nq, offsets, idx, cap, robot_radius, hit_out, hit_in);
+  if (rc) return rc;
+  if (nearest_idx && nearest_dist) {
+    rc = launch_nearest_from_lists(ctx, q, nq, offsets, idx, cost, nearest_idx, nearest_dist);
+    if (rc) return rc;
+    // TODO(round 2): samples whose ball is empty keep nearest_idx = -1 here; the
+    // host-pointer entry point below resolves them with the full nearest scan.
+  }
+  if (sample_unsafe) {
+    rc = launch_points_spheres(ctx, q, nq, robot_radius, 1, sample_unsafe, nullptr);
+    if (rc) return rc;
+  }
+  return RRTX_OK;
+}
+
+int rrtx_extend_candidates(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius, int64_t *offsets,
+                           int32_t *idx, double *cost, uint8_t *hit_out, uint8_t *hit_in, int64_t cap,
+                           int64_t *needed, int32_t *nearest_idx, double *nearest_dist, uint8_t *sample_unsafe) {
+  CHECK_CTX(ctx);
+  if (nq < 0 || cap < 0 || (nq > 0 && (!q || !offsets)) || (cap > 0 && (!idx || !cost || !hit_out || !hit_in)))
+    return fail(ctx, RRTX_E_INVALID, "extend_candidates: bad arguments");
+  if (nq == 0) { if (needed) *needed = 0; return RRTX_OK; }
+  int rc = stage_in(ctx, ctx->ws_q, q, sizeof(double) * (size_t)nq * ctx->dim);
+  if (rc) return rc;
+  const int64_t dcap = cap > 0 ? cap : 1;
+  RRTX_HIP(ctx, ctx->ws_out_off.ensure(sizeof(int64_t) * ((size_t)nq + 2)));
+  RRTX_HIP(ctx, ctx->ws_out_idx.ensure(sizeof(int32_t) * (size_t)dcap));
+  RRTX_HIP(ctx, ctx->ws_out_dist.ensure(sizeof(double) * (size_t)dcap));
+  RRTX_HIP(ctx, ctx->ws_out_u8a.ensure((size_t)dcap));
+  RRTX_HIP(ctx, ctx->ws_out_u8b.ensure((size_t)dcap + (size_t)nq));
+  RRTX_HIP(ctx, ctx->ws_out_i32.ensure(sizeof(int32_t) * (size_t)nq));
+  RRTX_HIP(ctx, ctx->ws_out_f64.ensure(sizeof(double) * (size_t)nq));
+  int64_t *off_dev = ctx->ws_out_off.as<int64_t>();
+  int64_t *needed_dev = off_dev + nq + 1;
+  uint8_t *unsafe_dev = ctx->ws_out_u8b.as<uint8_t>() + dcap;
+  rc = rrtx_extend_candidates_dev(ctx, ctx->ws_q.as<double>(), nq, r, robot_radius, off_dev,
+                                  ctx->ws_out_idx.as<int32_t>(), ctx->ws_out_dist.as<double>(),
+                                  ctx->ws_out_u8a.as<uint8_t>(), ctx->ws_out_u8b.as<uint8_t>(), cap, needed_dev,
+                                  ctx->ws_out_i32.as<int32_t>(), ctx->ws_out_f64.as<double>(),
+                                  sample_unsafe ? unsafe_dev : nullptr);
+  if (rc) return rc;
+  int64_t total = 0;
+  RRTX_HIP(ctx, hipMemcpyAsync(offsets, off_dev, sizeof(int64_t) * ((size_t)nq + 1), hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipMemcpyAsync(&total, needed_dev, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (needed) *needed = total;
+  ctx->last_neighbors = total;
+  if (total > cap) return fail(ctx, RRTX_E_CAPACITY, "extend_candidates: %lld neighbours, capacity %lld", (long long)total, (long long)cap);
+  if (total > 0) {
+    RRTX_HIP(ctx, hipMemcpyAsync(idx, ctx->ws_out_idx.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipMemcpyAsync(cost, ctx->ws_out_dist.p, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipMemcpyAsync(hit_out, ctx->ws_out_u8a.p, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipMemcpyAsync(hit_in, ctx->ws_out_u8b.p, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (sample_unsafe)
+    RRTX_HIP(ctx, hipMemcpyAsync(sample_unsafe, unsafe_dev, (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+  if (nearest_idx && nearest_dist) {
+    RRTX_HIP(ctx, hipMemcpyAsync(nearest_idx, ctx->ws_out_i32.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipMemcpyAsync(nearest_dist, ctx->ws_out_f64.p, sizeof(double) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (nearest_idx && nearest_dist) {
+    // samples with an empty ball: resolve with the full nearest scan
+    std::vector<int> miss;
+    for (int i = 0; i < nq; ++i) if (nearest_idx[i] < 0) miss.push_back(i);
+    if (!miss.empty()) {
+      std::vector<double> mq(miss.size() * (size_t)ctx->dim);
+      for (size_t k = 0; k < miss.size(); ++k)
+        std::memcpy(&mq[k * ctx->dim], q + (size_t)miss[k] * ctx->dim, sizeof(double) * ctx->dim);
+      std::vector<int32_t> mi(miss.size());
+      std::vector<double> md(miss.size());
+      rc = rrtx_nn_nearest(ctx, mq.data(), (int)miss.size(), mi.data(), md.data());
+      if (rc) return rc;
+      for (size_t k = 0; k < miss.size(); ++k) { nearest_idx[miss[k]] = mi[k]; nearest_dist[miss[k]] = md[k]; }
+    }
+  }
+  return RRTX_OK;
+}
+
+int rrtx_pack_hits_dev(rrtx_ctx *ctx, const uint8_t *hit_out, const uint8_t *hit_in, const int64_t *n_valid_dev,
+                       int64_t cap, uint64_t *words) {
+  CHECK_CTX(ctx);
+  if (cap < 0 || (cap > 0 && (!hit_out || !hit_in || !n_valid_dev || !words)))
+    return fail(ctx, RRTX_E_INVALID, "pack_hits: bad arguments");
+  return launch_pack_hits(ctx, hit_out, hit_in, n_valid_dev, cap, words);
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// rrtx_internal.hpp -- context, device buffers and launch declarations shared by
+// the HIP translation units of librrtx_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rrtx.h"
+
+namespace rrtx {
+
+constexpr int kMaxWraps = 3;
+constexpr int kMaxSlots = 1 << kMaxWraps;  // query copies per query (original + ghosts)
+
+// ---- records shared between host and device --------------------------------
+// One query copy as the scan kernel reads it with scalar loads.
+struct alignas(32) QRec3 { double x, y, z, thr; };                 // thr: hit <=> d2 < thr
+struct alignas(64) QRec4 { double x, y, z, w, thr, pad0, pad1, pad2; };
+template <int D> struct QRecT;
+template <> struct QRecT<3> { using type = QRec3; };
+template <> struct QRecT<4> { using type = QRec4; };
+
+// Fixed-slot table entry: slot j of query i lives at [i * n_slots + j].  Slot 0 is
+// the query itself, slots 1.. are its ghosts in the reference's iterator order
+// (R/ghostPoint.jl:60-111).  thr_lt < 0 marks a ghost the iterator skips.
+struct alignas(64) SlotRec { double x, y, z, w, thr_lt, thr_gt, pad0, pad1; };
+
+// One range-search hit: node `idx` is within range of query `owner`; d2 is the
+// squared distance to the copy that discovered it first.
+struct alignas(16) HitRec { int32_t owner; int32_t idx; double d2; };
+
+// Active sphere as the edge kernel reads it: centre + threshold on the squared
+// distance (hit <=> !(s >= thr), thr = first s with sqrt(s) > robotRadius+radius).
+struct alignas(32) SphRec { double cx, cy, cz, thr; };
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  hipError_t ensure(size_t need) {
+    if (need <= bytes) return hipSuccess;
+    size_t nb = bytes ? bytes : 4096;
+    while (nb < need) nb *= 2;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
+    hipError_t e = hipMalloc(&p, nb);
+    if (e == hipSuccess) bytes = nb;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+enum KernelFamily { KF_NN_SCAN = 0, KF_NN_FINISH, KF_NN_NEAREST, KF_EDGES, KF_POINTS, KF_DUBINS, KF_COUNT };
+
+struct TimedSpan { hipEvent_t a, b; int family; };
+
+}  // namespace rrtx
+
+struct rrtx_ctx {
+  int dim = 3;
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // node SoA (fp64), one array per coordinate
+  double *nodes[4] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t n_nodes = 0, cap_nodes = 0;
+
+  // wrapped dimensions
+  int n_wraps = 0;
+  int wrap_dim[rrtx::kMaxWraps] = {0, 0, 0};
+  double wrap_period[rrtx::kMaxWraps] = {0, 0, 0};
+
+  // sphere obstacles: host truth (list order) + packed active device copy
+  std::vector<double> sph;          // m x 4
+  std::vector<uint8_t> sph_active;  // m
+  bool sph_dirty = true;
+  double sph_packed_rr = -1.0;      // robot radius the packed thresholds were built for
+  int sph_n_active = 0;
+  rrtx::DevBuf d_sph;               // SphRec[n_active]
+  rrtx::DevBuf d_sph_aux;           // double radius[n_active] then int32 orig[n_active]
+
+  // polygon obstacles
+  std::vector<int32_t> poly_off;    // m+1
+  std::vector<double> poly_vxy;
+  std::vector<double> poly_cr;      // m x 3
+  std::vector<uint8_t> poly_kind, poly_active;
+  bool poly_dirty = true;
+  int poly_n_active = 0;
+  rrtx::DevBuf d_poly_off, d_poly_vxy, d_poly_meta; // meta: per active obstacle {cx, cy, radius, kind} doubles
+  rrtx::DevBuf d_poly_orig;
+
+  // workspaces
+  rrtx::DevBuf ws_q;        // staged queries / points
+  rrtx::DevBuf ws_q2;
+  rrtx::DevBuf ws_slots;    // SlotRec table
+  rrtx::DevBuf ws_copies;   // QRec copies
+  rrtx::DevBuf ws_copy_meta;// int32 owner, slot per copy
+  rrtx::DevBuf ws_recs;     // HitRec
+  rrtx::DevBuf ws_counts;   // int32 count[nq], cursor[nq]
+  rrtx::DevBuf ws_scalars;  // device scalars: total, n_copies, ...
+  rrtx::DevBuf ws_tmp_idx, ws_tmp_d2;
+  rrtx::DevBuf ws_out_off, ws_out_idx, ws_out_dist, ws_out_u8a, ws_out_u8b, ws_out_i32, ws_out_f64;
+  rrtx::DevBuf ws_partial;  // nearest partials
+  rrtx::DevBuf ws_thr;      // per-query thresholds
+
+  // radius -> threshold cache
+  double thr_cache_r = -1.0, thr_cache_lt = 0.0, thr_cache_gt = 0.0;
+
+  // profiling
+  bool profiling = false;
+  std::vector<rrtx::TimedSpan> spans;
+  std::vector<hipEvent_t> event_pool;
+  double fam_ms[rrtx::KF_COUNT] = {0};
+  int64_t fam_launches[rrtx::KF_COUNT] = {0};
+  int64_t last_pairs = 0, last_neighbors = 0;
+};
+
+namespace rrtx {
+
+int fail(rrtx_ctx *ctx, int code, const char *fmt, ...);
+
+#define RRTX_HIP(ctx, expr)                                                               \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return ::rrtx::fail((ctx), RRTX_E_DEVICE, "%s failed: %s (%s:%d)", #expr,           \
+                          hipGetErrorString(_e), __FILE__, __LINE__);                     \
+  } while (0)
+
+// profiling spans around a kernel family
+void span_begin(rrtx_ctx *ctx, int family);
+void span_end(rrtx_ctx *ctx);
+
+// thresholds on squared distances (host, exact):
+//   first_ge(r): smallest s >= 0 with sqrt(s) >= r   (sqrt(s) <  r  <=>  s <  first_ge(r))
+//   first_gt(r): smallest s >= 0 with sqrt(s) >  r   (sqrt(s) <= r  <=>  s <  first_gt(r))
+double thr_first_ge(double r);
+double thr_first_gt(double r);
+
+// ---- launchers (device pointers, enqueue on ctx->stream) ----------------------
+int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_or_null, double r_scalar,
+                     int nq, int64_t *offsets_dev, int32_t *idx_dev, double *dist_dev, int64_t cap,
+                     int64_t *needed_dev);
+int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev);
+int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
+                         double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
+                         uint8_t *hit_dev, int32_t *first_hit_dev);
+int launch_edges_polygons(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
+                          double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
+                          uint8_t *hit_dev, int32_t *first_hit_dev);
+int launch_points_spheres(rrtx_ctx *ctx, const double *p_dev, int64_t np, double robot_radius, int quick,
+                          uint8_t *unsafe_dev, double *clearance_dev);
+int launch_points_polygons(rrtx_ctx *ctx, const double *p_dev, int64_t np, double robot_radius,
+                           uint8_t *unsafe_dev, double *clearance_dev);
+int launch_simple_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne,
+                        double *dist_dev, double *wdist_dev);
+int launch_dubins_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
+                        double *cost_dev, uint8_t *word_dev);
+int launch_dubins_edges_check(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne,
+                              double r_min, double robot_radius, double *cost_dev, uint8_t *word_dev,
+                              uint8_t *hit_dev, int32_t *traj_len_dev);
+// candidate edges of extend(): for every CSR entry both directed edges vs the sphere list
+int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
+                           const int32_t *idx_dev, int64_t cap, double robot_radius, uint8_t *hit_out_dev,
+                           uint8_t *hit_in_dev);
+int launch_nearest_from_lists(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
+                              const int32_t *idx_dev, const double *dist_dev, int32_t *nearest_idx_dev,
+                              double *nearest_dist_dev);
+
+int launch_pack_hits(rrtx_ctx *ctx, const uint8_t *hit_out, const uint8_t *hit_in, const int64_t *n_valid_dev,
+                     int64_t cap, uint64_t *words);
+
+// make sure the packed obstacle tables on the device match the host truth
+int sync_spheres(rrtx_ctx *ctx, double robot_radius);
+int sync_polygons(rrtx_ctx *ctx);
+
+}  // namespace rrtx

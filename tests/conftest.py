@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU oracle (test infrastructure): builds oracle/_build/librrtx_oracle.so with gcc if stale."""
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """librrtx_hip.so must exist and load (cross-compiled by __graft_entry__.build())."""
+    from rrtqx_3d_amd import _capi
+    if not os.path.exists(_capi.LIB_PATH):
+        from rrtqx_3d_amd import build
+        build.build()
+    return _capi.load()

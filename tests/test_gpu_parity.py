@@ -1,0 +1,324 @@
+"""GPU parity tests: the HIP path (through the C-ABI of include/rrtx.h) against
+the CPU oracle on the same seeded inputs.
+
+Bar (north_star): bit-exact neighbour indices / stored distances and collision
+booleans; <= 1e-6 relative on Dubins costs (device libm != Julia libm).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from rrtqx_3d_amd import synth
+from rrtqx_3d_amd.context import Context
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL_DUBINS = 1e-6   # north_star tolerance for Dubins edge costs
+ROBOT_RADIUS = 0.5      # R/experimentsForRRTQX.jl:38
+
+
+@pytest.fixture(scope="module")
+def small3(oracle):
+    """N=10k nodes (config C2 scale), oracle kd-tree + GPU ctx."""
+    pts = synth.nodes(10_000, 3)
+    tree = oracle.KDTree(3)
+    tree.insert_many(pts)
+    ctx = Context(3)
+    first = ctx.nodes_append(pts)
+    assert first == 0 and ctx.n_nodes == 10_000
+    yield pts, tree, ctx
+    ctx.close()
+
+
+def _oracle_lists(tree, Q, r):
+    out = []
+    for i, q in enumerate(Q):
+        ri = r if np.isscalar(r) else r[i]
+        idx, key = tree.within_range(float(ri), q)
+        o = np.argsort(idx, kind="stable")
+        out.append((idx[o], key[o]))
+    return out
+
+
+def _check_csr(offsets, idx, dist, ref):
+    assert offsets[0] == 0 and offsets[-1] == len(idx)
+    for i, (ri, rk) in enumerate(ref):
+        a, b = offsets[i], offsets[i + 1]
+        assert np.array_equal(idx[a:b], ri), f"query {i}: neighbour set differs"
+        assert np.array_equal(dist[a:b], rk), f"query {i}: stored keys differ (bit-exact required)"
+
+
+def test_device_sqrt_div(hip_lib):
+    """fp64 sqrt and divide on gfx950 must be correctly rounded (the parity of every
+    stored distance and of t = dot/edgeLen rests on it).  simple_steer exposes sqrt."""
+    rng = np.random.default_rng(7)
+    with Context(3) as ctx:
+        a = np.zeros((200_000, 3))
+        b = np.zeros((200_000, 3))
+        b[:, 0] = rng.uniform(0, 100, 200_000)
+        b[:, 1] = rng.uniform(0, 1e-3, 200_000)
+        b[:, 2] = rng.uniform(0, 1e6, 200_000)
+        dist, _ = ctx.simple_steer(a, b)
+        ref = np.sqrt((b[:, 0] * b[:, 0] + b[:, 1] * b[:, 1]) + b[:, 2] * b[:, 2])
+        assert np.array_equal(dist, ref)
+
+
+def test_radius_c2_bit_exact(small3, oracle):
+    pts, tree, ctx = small3
+    Q = synth.queries(1024, 3)
+    r = synth.ball_radius(10_000, 3)
+    assert abs(r - 7.783652738915254) < 1e-12
+    offsets, idx, dist = ctx.nn_radius(Q, r)
+    _check_csr(offsets, idx, dist, _oracle_lists(tree, Q, r))
+    assert len(idx) > 1024  # non-trivial lists
+
+
+def test_radius_capacity_two_call(small3):
+    pts, tree, ctx = small3
+    Q = synth.queries(64, 3)
+    offsets, idx, dist = ctx.nn_radius(Q, 7.78, cap=8)   # forces RRTX_E_CAPACITY then retry
+    assert offsets[-1] == len(idx) > 8
+
+
+def test_radius_per_query_radii_and_edge_cases(small3, oracle):
+    pts, tree, ctx = small3
+    rng = np.random.default_rng(3)
+    Q = synth.queries(200, 3, seed=99)
+    r = rng.uniform(0.0, 12.0, 200)
+    r[0] = 0.0          # empty
+    r[1] = 1e-300
+    r[2] = 200.0        # everything
+    Q[3] = pts[17]      # query on a node: dist 0 < r
+    r[3] = 1e-9
+    offsets, idx, dist = ctx.nn_radius(Q, r)
+    _check_csr(offsets, idx, dist, _oracle_lists(tree, Q, r))
+    assert offsets[1] - offsets[0] == 0
+    assert offsets[3] - offsets[2] == 10_000
+
+
+def test_radius_root_inclusive_rule(oracle):
+    """K2: the root is included with <=, every other node with <."""
+    with Context(3) as ctx:
+        ctx.nodes_append([[0, 0, 0], [3, 4, 0]])
+        off, idx, dist = ctx.nn_radius([[0, 0, 0], [3, 4, 0]], 5.0)
+        assert list(idx[off[0]:off[1]]) == [0]
+        assert list(idx[off[1]:off[2]]) == [0, 1] and list(dist[off[1]:off[2]]) == [5.0, 0.0]
+
+
+def test_radius_single_query_large_ball(small3, oracle):
+    """obstacle sweep style query: one centre, r = robotRadius + delta + ob.radius (R/DRRT_Q.jl:3203)"""
+    pts, tree, ctx = small3
+    q = np.array([[1.0, -2.0, 3.0]])
+    r = 0.5 + 8.0 + 3.5
+    offsets, idx, dist = ctx.nn_radius(q, r)
+    _check_csr(offsets, idx, dist, _oracle_lists(tree, q, r))
+    assert len(idx) > 64   # exercises the k > 64 ordering path
+
+
+def test_nearest_c2(small3):
+    pts, tree, ctx = small3
+    Q = synth.queries(1024, 3)
+    idx, dist = ctx.nn_nearest(Q)
+    for i, q in enumerate(Q):
+        ri, rd = tree.nearest(q)
+        assert idx[i] == ri and dist[i] == rd
+
+
+def test_edges_spheres_bit_exact(small3, oracle):
+    pts, tree, ctx = small3
+    sph = synth.spheres(32)
+    active = np.ones(32, dtype=np.uint8)
+    active[5] = 0
+    ctx.spheres_set(sph, active)
+    osph, m = oracle.make_spheres(sph, active)
+    Q = synth.queries(256, 3)
+    r = synth.ball_radius(10_000, 3)
+    offsets, idx, _ = ctx.nn_radius(Q, r)
+    p0, p1 = synth.candidate_edges(Q, pts, offsets, idx)
+    hit, first = ctx.edges_check(p0, p1, ROBOT_RADIUS)
+    rh, rf = oracle.edges_check_spheres(osph, m, p0, p1, ROBOT_RADIUS)
+    assert np.array_equal(hit, rh)
+    assert np.array_equal(first, rf)
+    assert 0 < hit.sum() < len(hit)
+    # direction dependence of the reference's dot/edgeLen formula shows up
+    n = len(idx)
+    assert (hit[:n] != hit[n:]).any()
+    # single-obstacle form (explicitEdgeCheck(S, edge, ob))
+    h7, _ = ctx.edges_check(p0, p1, ROBOT_RADIUS, obstacle=7)
+    one, m1 = oracle.make_spheres(sph[7:8])
+    r7, _ = oracle.edges_check_spheres(one, m1, p0, p1, ROBOT_RADIUS)
+    assert np.array_equal(h7, r7)
+    h5, _ = ctx.edges_check(p0, p1, ROBOT_RADIUS, obstacle=5)   # inactive obstacle
+    assert h5.sum() == 0
+
+
+def test_edges_spheres_kats(oracle):
+    """K3-K6 of SURVEY.md 8(c) through the GPU path."""
+    with Context(3) as ctx:
+        ctx.nodes_append([[0, 0, 0]])
+        ctx.spheres_set([[0, 0, 0, 1.0]])
+        p0 = np.array([[-2, 1.4, 0], [0.9, 0, 0], [10, 10, 10]], dtype=np.float64)
+        p1 = np.array([[2, 1.4, 0], [1.4, 0, 0], [10, 10, 10]], dtype=np.float64)
+        hit, first = ctx.edges_check(p0, p1, ROBOT_RADIUS)
+        assert list(hit) == [0, 1, 1]       # K3 quirk no-hit, K4 hit, K5 zero-length => NaN => hit
+        assert list(first) == [-1, 0, 0]
+        ctx.spheres_set([[0, 0, 0, 1.0]], active=[0])
+        hit, _ = ctx.edges_check(p0, p1, ROBOT_RADIUS)
+        assert hit.sum() == 0               # K6
+
+
+def test_obstacle_update(small3, oracle):
+    pts, tree, ctx = small3
+    sph = synth.spheres(32)
+    ctx.spheres_set(sph)
+    Q = synth.queries(64, 3)
+    offsets, idx, _ = ctx.nn_radius(Q, 7.78)
+    p0, p1 = synth.candidate_edges(Q, pts, offsets, idx)
+    ctx.obstacle_update(3, sph[3, 3] + 2.0, True)       # obstacleAugmentation
+    ctx.obstacle_update(4, sph[4, 3], False)            # expiry
+    sph2 = sph.copy()
+    sph2[3, 3] += 2.0
+    act = np.ones(32, dtype=np.uint8)
+    act[4] = 0
+    osph, m = oracle.make_spheres(sph2, act)
+    hit, first = ctx.edges_check(p0, p1, ROBOT_RADIUS)
+    rh, rf = oracle.edges_check_spheres(osph, m, p0, p1, ROBOT_RADIUS)
+    assert np.array_equal(hit, rh) and np.array_equal(first, rf)
+
+
+def test_points_spheres(small3, oracle):
+    pts, tree, ctx = small3
+    sph = synth.spheres(64)
+    ctx.spheres_set(sph)
+    osph, m = oracle.make_spheres(sph)
+    P = synth.queries(4096, 3, seed=5)
+    for quick in (True, False):
+        unsafe, clr = ctx.points_check(P, ROBOT_RADIUS, quick=quick)
+        ru, rc = oracle.points_check_spheres(osph, m, P, ROBOT_RADIUS, quick=quick)
+        assert np.array_equal(unsafe, ru)
+        assert np.array_equal(clr, rc)
+    assert 0 < unsafe.sum() < len(unsafe)
+
+
+def test_extend_candidates_matches_parts(small3, oracle):
+    pts, tree, ctx = small3
+    sph = synth.spheres(32)
+    ctx.spheres_set(sph)
+    osph, m = oracle.make_spheres(sph)
+    Q = synth.queries(512, 3)
+    r = synth.ball_radius(10_000, 3)
+    out = ctx.extend_candidates(Q, r, ROBOT_RADIUS)
+    ref = _oracle_lists(tree, Q, r)
+    _check_csr(out["offsets"], out["idx"], out["cost"], ref)
+    p0, p1 = synth.candidate_edges(Q, pts, out["offsets"], out["idx"])
+    rh, _ = oracle.edges_check_spheres(osph, m, p0, p1, ROBOT_RADIUS)
+    n = len(out["idx"])
+    assert np.array_equal(out["hit_out"], rh[:n])
+    assert np.array_equal(out["hit_in"], rh[n:])
+    for i, q in enumerate(Q):
+        ri, rd = tree.nearest(q)
+        assert out["nearest_idx"][i] == ri and out["nearest_dist"][i] == rd
+    ru, _ = oracle.points_check_spheres(osph, m, Q, ROBOT_RADIUS, quick=True)
+    assert np.array_equal(out["sample_unsafe"], ru)
+
+
+def test_polygons_edges_and_points(oracle):
+    polys = synth.polygons(64)
+    ps = oracle.PolygonSet(polys)
+    with Context(4) as ctx:
+        ctx.nodes_append(synth.nodes(16, 4))
+        ctx.polygons_set(polys)
+        rng = np.random.default_rng(11)
+        p0 = synth.nodes(4096, 4, seed=21)
+        step = rng.normal(0, 6.0, size=(4096, 2))
+        p1 = p0.copy()
+        p1[:, :2] += step
+        p1[:64, 0] = p0[:64, 0]          # near-vertical edges exercise the abs(dx) < 1e-6 branch
+        hit, first = ctx.edges_check(p0, p1, ROBOT_RADIUS, kind=1)
+        rh, rf = oracle.edges_check_polygons(ps, p0, p1, ROBOT_RADIUS)
+        assert np.array_equal(hit, rh) and np.array_equal(first, rf)
+        assert 0 < hit.sum() < len(hit)
+        unsafe, clr = ctx.points_check(p0, ROBOT_RADIUS, kind=1)
+        ru = np.zeros(len(p0), dtype=np.uint8)
+        rc = np.zeros(len(p0))
+        for i in range(len(p0)):
+            u, c = oracle.point_check_polygons(ps, p0[i], ROBOT_RADIUS)
+            ru[i], rc[i] = u, c
+        assert np.array_equal(unsafe, ru)
+        assert np.array_equal(clr, rc)
+
+
+def test_polygon_kat_k7(oracle):
+    with Context(3) as ctx:
+        ctx.nodes_append([[0, 0, 0]])
+        ctx.polygons_set([[[0, 0], [1, 0], [1, 1], [0, 1]]])
+        hit, _ = ctx.edges_check([[-1, .5, 0], [-1, 2, 0]], [[2, .5, 0], [2, 2, 0]], 0.1, kind=1)
+        assert list(hit) == [1, 0]
+
+
+def test_radius_wrapped_theta_c3(oracle):
+    """Dubins space [x y 0 theta], theta wraps at 2*pi (R/DRRT.jl:3312): ghost rule + dedupe."""
+    n = 20_000
+    pts = synth.nodes(n, 4)
+    tree = oracle.KDTree(4, wraps=[3], wrap_points=[2.0 * math.pi])
+    tree.insert_many(pts)
+    with Context(4) as ctx:
+        ctx.set_wrap(3, 2.0 * math.pi)
+        ctx.nodes_append(pts)
+        Q = synth.queries(256, 4)
+        for r in (10.0, 2.5):     # r > pi: both copies can see the same node; r < pi: ghosts mostly skipped
+            offsets, idx, dist = ctx.nn_radius(Q, r)
+            _check_csr(offsets, idx, dist, _oracle_lists(tree, Q, r))
+        idx, dist = ctx.nn_nearest(Q)
+        for i, q in enumerate(Q):
+            ri, rd = tree.nearest(q)
+            assert idx[i] == ri and dist[i] == rd
+
+
+def test_dubins_steer_tolerance(oracle):
+    rng = np.random.default_rng(5)
+    ne = 4096
+    s = synth.nodes(ne, 4, seed=31)
+    g = s.copy()
+    g[:, :2] += rng.normal(0, 4.0, size=(ne, 2))
+    g[:, 3] = rng.uniform(0, 2 * math.pi, ne)
+    with Context(4) as ctx:
+        ctx.nodes_append(s[:4])
+        for r_min in (1.0, 2.0):
+            cost, word = ctx.dubins_steer(s, g, r_min)
+            words_differ = 0
+            for i in range(ne):
+                c, w, _ = oracle.dubins_steer(s[i], g[i], r_min, want_traj=False)
+                assert abs(cost[i] - c) <= REL_TOL_DUBINS * max(1.0, abs(c)), (i, cost[i], c)
+                words_differ += (w != word[i])
+            # the word may only differ on a numerical tie between two candidates
+            assert words_differ <= ne // 200
+
+
+def test_dubins_edges_check(oracle):
+    polys = synth.polygons(64)
+    ps = oracle.PolygonSet(polys)
+    rng = np.random.default_rng(6)
+    ne = 2048
+    s = synth.nodes(ne, 4, seed=41)
+    g = s.copy()
+    g[:, :2] += rng.normal(0, 5.0, size=(ne, 2))
+    g[:, 3] = rng.uniform(0, 2 * math.pi, ne)
+    r_min = 1.0
+    with Context(4) as ctx:
+        ctx.nodes_append(s[:4])
+        ctx.polygons_set(polys)
+        cost, word, hit, tl = ctx.dubins_edges_check(s, g, r_min, ROBOT_RADIUS)
+        mism = 0
+        len_mism = 0
+        for i in range(ne):
+            c, w, traj = oracle.dubins_steer(s[i], g[i], r_min)
+            h, _ = oracle.dubins_edge_check_polygons(ps, s[i], g[i], traj, ROBOT_RADIUS, r_min)
+            assert abs(cost[i] - c) <= REL_TOL_DUBINS * max(1.0, abs(c))
+            mism += (bool(hit[i]) != h)
+            len_mism += (tl[i] != traj.shape[0])
+        # booleans may flip only on knife edges (libm last-bit differences in the polyline)
+        assert mism <= 2, mism
+        assert len_mism <= ne // 100, len_mism
+        assert 0 < hit.sum() < ne
