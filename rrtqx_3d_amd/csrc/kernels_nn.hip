@@ -107,31 +107,25 @@ __device__ __noinline__ bool seen_by_earlier_slot(const SlotRec *__restrict__ sl
   return false;
 }
 
-template <int D>
-__device__ __noinline__ void emit_hits(bool h, int owner, int slot, int node_idx, double s, double x,
-                                       double y, double z, double w, const SlotRec *__restrict__ slots,
-                                       int n_slots, HitRec *__restrict__ recs, long long cap,
-                                       Scalars *__restrict__ sc, int *__restrict__ count) {
-  if (slot > 0 && h) h = !seen_by_earlier_slot<D>(slots, n_slots, owner, slot, node_idx, x, y, z, w);
-  unsigned long long mask = __ballot(h);
-  if (mask == 0ull) return;
+constexpr int kStageCap = 128;   // hit records staged in LDS per wave before one global append
+
+// Flush a wave's staged records with ONE atomic on the global counter (a single
+// word sustains only ~88 returning atomics/us on MI355X, so per-hit atomics
+// would serialise the whole kernel).
+__device__ __forceinline__ void flush_stage(HitRec *stage, int &wn, HitRec *__restrict__ recs, long long cap,
+                                            Scalars *__restrict__ sc) {
+  if (wn == 0) return;
   const int lane = threadIdx.x & 63;
-  const int n = __popcll(mask);
   unsigned long long base = 0;
-  if (lane == (__ffsll((long long)mask) - 1)) {
-    base = atomicAdd(&sc->total, (unsigned long long)n);
-    atomicAdd(&count[owner], n);
+  if (lane == 0) base = atomicAdd(&sc->total, (unsigned long long)wn);
+  base = __shfl(base, 0);
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < wn; i += 64) {
+    long long pos = (long long)base + i;
+    if (pos < cap) recs[pos] = stage[i];
   }
-  base = __shfl(base, __ffsll((long long)mask) - 1);
-  if (h) {
-    unsigned long long below = mask & ((1ull << lane) - 1ull);
-    long long pos = (long long)base + __popcll(below);
-    if (pos < cap) {
-      HitRec r;
-      r.owner = owner; r.idx = node_idx; r.d2 = s;
-      recs[pos] = r;
-    }
-  }
+  __builtin_amdgcn_wave_barrier();
+  wn = 0;
 }
 
 template <int D>
@@ -141,6 +135,7 @@ __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
     const int2 *__restrict__ meta, const SlotRec *__restrict__ slots, int n_slots, int tile_q, int n_seg,
     int seg_len, HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
     int *__restrict__ count) {
+  __shared__ HitRec stage_all[kScanThreads / 64][kStageCap];
   // blocks b and b+8 share an XCD: the node segment is the fast-varying index so
   // each XCD's L2 keeps re-serving the same 1/8th of the node arrays.
   const int seg = blockIdx.x % n_seg;
@@ -151,6 +146,8 @@ __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
   const int q1 = min(q0 + tile_q, n_copies);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  HitRec *stage = stage_all[wave];
+  int wn = 0;   // wave-uniform number of staged records
   const int node_begin = seg * seg_len;
   const int node_end = min(n_nodes, node_begin + seg_len);
   const double kNaN = __builtin_nan("");
@@ -180,15 +177,30 @@ __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
         h[u] = s[u] < c.thr;
         any = any || h[u];
       }
-      if (__ballot(any) != 0ull) {
+      if (__builtin_expect(__ballot(any) != 0ull, 0)) {
+        // rare path (k/N of the pairs): stage the hits of this wave in LDS
         const int2 m = meta[q];
 #pragma unroll
-        for (int u = 0; u < kScanU; ++u)
-          emit_hits<D>(h[u], m.x, m.y, id[u], s[u], x[u], y[u], z[u], w[u], slots, n_slots, recs, cap, sc,
-                       count);
+        for (int u = 0; u < kScanU; ++u) {
+          bool hu = h[u];
+          if (m.y > 0 && hu)
+            hu = !seen_by_earlier_slot<D>(slots, n_slots, m.x, m.y, id[u], x[u], y[u], z[u], w[u]);
+          const unsigned long long mask = __ballot(hu);
+          if (mask == 0ull) continue;
+          const int n = __popcll(mask);
+          if (wn + n > kStageCap) flush_stage(stage, wn, recs, cap, sc);
+          if (hu) {
+            HitRec r;
+            r.owner = m.x; r.idx = id[u]; r.d2 = s[u];
+            stage[wn + __popcll(mask & ((1ull << lane) - 1ull))] = r;
+          }
+          if (lane == 0) atomicAdd(&count[m.x], n);   // no-return atomic, one address per query
+          wn += n;
+        }
       }
     }
   }
+  flush_stage(stage, wn, recs, cap, sc);
 }
 
 // ------------------------------------------------------------- rootfix ------
