@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/.
+
+Run in the build container (where /root/reference exists):
+    python tests/golden/make_golden.py
+
+What it writes
+  env_inputs.json   the reference's own environment DATA files parsed to numbers
+                    (environments/building2.txt: 31 spheres; rand_Static.txt: 35
+                    polygons).  These are inputs the reference ships, not code.
+  hotpath_v1.npz    seeded inputs + expected outputs of the hot path computed by
+                    the CPU oracle (oracle/rrtx_oracle.c).  The reference itself
+                    is Julia and cannot run here, and it ships no expected
+                    outputs for this path, so these vectors pin the ORACLE's
+                    behaviour over time (and let the GPU box check the HIP path
+                    without the oracle); they are not outputs of the reference.
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O            # noqa: E402
+from rrtqx_3d_amd import envio, synth     # noqa: E402
+
+REF_ENV = "/root/reference/code_RRTQx_3D/environments"
+
+
+def main():
+    b2 = envio.read_sphere_obstacles(os.path.join(REF_ENV, "building2.txt"))
+    rs = envio.read_polygon_obstacles(os.path.join(REF_ENV, "rand_Static.txt"))
+    json.dump({
+        "source": "environments/building2.txt and environments/rand_Static.txt of jnetter6/RRTQX_3D (data files)",
+        "building2_spheres": b2.cxyzr.tolist(), "building2_behaviour": b2.behaviour.tolist(),
+        "rand_Static_polygons": [p.tolist() for p in rs.polygons], "rand_Static_behaviour": rs.behaviour.tolist(),
+    }, open(os.path.join(HERE, "env_inputs.json"), "w"))
+
+    out = {}
+    # ---- 3-D SimpleEdge slice: N=2000 nodes in the script's own 40^3 world, building2 spheres -------
+    rng = np.random.default_rng(synth.SEED)
+    n, b = 2000, 64
+    pts = rng.uniform(-20, 20, (n, 3))
+    Q = rng.uniform(-20, 20, (b, 3))
+    r = synth.ball_radius(n, 3)               # = delta = 8 at this size
+    sph, _ = b2.list_order()
+    act = np.ones(len(sph), dtype=np.uint8)   # all sensed (obstacleUnused = false)
+    act[3] = 0
+    tree = O.KDTree(3)
+    tree.insert_many(pts)
+    osph, m = O.make_spheres(sph, act)
+    offs, idxs, keys = [0], [], []
+    nidx, ndist = [], []
+    for q in Q:
+        i, k = tree.within_range(r, q)
+        o = np.argsort(i)
+        idxs.append(i[o]); keys.append(k[o]); offs.append(offs[-1] + len(i))
+        a, d = tree.nearest(q)
+        nidx.append(a); ndist.append(d)
+    idx = np.concatenate(idxs); key = np.concatenate(keys); off = np.array(offs, dtype=np.int64)
+    p0, p1 = synth.candidate_edges(Q, pts, off, idx)
+    hit, first = O.edges_check_spheres(osph, m, p0, p1, 0.5)
+    unsafe, clr = O.points_check_spheres(osph, m, Q, 0.5, quick=True)
+    out.update(s_nodes=pts, s_queries=Q, s_radius=np.float64(r), s_spheres=sph, s_active=act,
+               s_offsets=off, s_idx=idx.astype(np.int32), s_key=key, s_nearest_idx=np.array(nidx, dtype=np.int32),
+               s_nearest_dist=np.array(ndist), s_hit=hit, s_first=first, s_unsafe=unsafe, s_clearance=clr)
+
+    # ---- polygon slice: rand_Static polygons, 512 straight 2-D edges --------------------------------
+    polys, pact = rs.list_order()
+    ps = O.PolygonSet(polys, active=pact)
+    e0 = rng.uniform(-50, 50, (512, 2))
+    e1 = e0 + rng.normal(0, 8.0, (512, 2))
+    e0 = np.concatenate([e0, np.zeros((512, 2))], 1)
+    e1 = np.concatenate([e1, np.zeros((512, 2))], 1)
+    ph, pf = O.edges_check_polygons(ps, e0, e1, 0.5)
+    pu = np.zeros(512, dtype=np.uint8); pc = np.zeros(512)
+    for i in range(512):
+        u, c = O.point_check_polygons(ps, e0[i], 0.5)
+        pu[i], pc[i] = u, c
+    out.update(p_edges0=e0, p_edges1=e1, p_hit=ph, p_first=pf, p_unsafe=pu, p_clearance=pc,
+               p_centre_radius=ps.centre_radius())
+
+    # ---- Dubins slice: 256 steers + two-stage checks against the same polygons -----------------------
+    s = np.concatenate([rng.uniform(-50, 50, (256, 2)), np.zeros((256, 1)), rng.uniform(0, 2 * math.pi, (256, 1))], 1)
+    g = s.copy()
+    g[:, :2] += rng.normal(0, 5.0, (256, 2))
+    g[:, 3] = rng.uniform(0, 2 * math.pi, 256)
+    dc = np.zeros(256); dh = np.zeros(256, dtype=np.uint8); dl = np.zeros(256, dtype=np.int32); dw = []
+    for i in range(256):
+        c, w, traj = O.dubins_steer(s[i], g[i], 1.0)
+        h, _ = O.dubins_edge_check_polygons(ps, s[i], g[i], traj, 0.5, 1.0)
+        dc[i], dh[i], dl[i] = c, h, traj.shape[0]
+        dw.append(w)
+    out.update(d_start=s, d_goal=g, d_cost=dc, d_hit=dh, d_traj_len=dl, d_word=np.array(dw, dtype="S3"))
+
+    # ---- wrapped (theta) range search -----------------------------------------------------------------
+    wn = 3000
+    wp = np.concatenate([rng.uniform(-20, 20, (wn, 2)), np.zeros((wn, 1)), rng.uniform(0, 2 * math.pi, (wn, 1))], 1)
+    wq = np.concatenate([rng.uniform(-20, 20, (32, 2)), np.zeros((32, 1)), rng.uniform(0, 2 * math.pi, (32, 1))], 1)
+    wt = O.KDTree(4, wraps=[3], wrap_points=[2 * math.pi])
+    wt.insert_many(wp)
+    woff, widx, wkey = [0], [], []
+    for q in wq:
+        i, k = wt.within_range(6.0, q)
+        o = np.argsort(i)
+        widx.append(i[o]); wkey.append(k[o]); woff.append(woff[-1] + len(i))
+    out.update(w_nodes=wp, w_queries=wq, w_radius=np.float64(6.0), w_offsets=np.array(woff, dtype=np.int64),
+               w_idx=np.concatenate(widx).astype(np.int32), w_key=np.concatenate(wkey))
+
+    np.savez_compressed(os.path.join(HERE, "hotpath_v1.npz"), **out)
+    print("wrote", os.path.join(HERE, "hotpath_v1.npz"), os.path.getsize(os.path.join(HERE, "hotpath_v1.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

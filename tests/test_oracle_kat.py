@@ -1,0 +1,233 @@
+"""Pins the CPU oracle (oracle/rrtx_oracle.c).
+
+The reference holds no golden vectors or asserting tests for this path
+(SURVEY.md 8(c)), and Julia is not available to run it, so the oracle is pinned
+by (1) the known answers K1-K10 derived by hand from the reference source and
+(2) the reference's own differential design: kd-tree search == naive scan
+(R/kdTree_general.jl:1039-1148, commented testCase/testGhost).
+"""
+import math
+
+import numpy as np
+import pytest
+
+
+def test_k1_euclid(oracle):
+    assert oracle.euclid([0, 0, 0], [3, 4, 0]) == 5.0
+
+
+def test_k2_range_inclusivity(oracle):
+    t = oracle.KDTree(3)
+    t.insert([0, 0, 0])
+    t.insert([3, 4, 0])
+    idx, key = t.within_range(5.0, [0, 0, 0])
+    assert list(idx) == [0] and list(key) == [0.0]           # A: 5.0 < 5.0 is false
+    idx, key = t.within_range(5.0, [3, 4, 0])
+    assert sorted(idx) == [0, 1]                              # root: 5.0 <= 5.0
+    assert dict(zip(idx, key)) == {0: 5.0, 1: 0.0}
+
+
+def test_k3_to_k6_sphere_edge_quirks(oracle):
+    sp, m = oracle.make_spheres([[0, 0, 0, 1.0]])
+    # K3: t = dot/L (not L^2) pushes the foot point to p1 => no hit although the true distance is 1.4 < 1.5
+    assert oracle.edge_check_spheres(sp, m, [-2, 1.4, 0], [2, 1.4, 0], 0.5) == (False, -1)
+    assert oracle.distance_point_to_segment3([0, 0, 0], [-2, 1.4, 0], [2, 1.4, 0]) == math.sqrt(4 + 1.4 * 1.4)
+    # K4: short edge, t clamps to 0
+    assert oracle.edge_check_spheres(sp, m, [0.9, 0, 0], [1.4, 0, 0], 0.5) == (True, 0)
+    assert oracle.distance_point_to_segment3([0, 0, 0], [0.9, 0, 0], [1.4, 0, 0]) == 0.9
+    # K5: zero-length edge => 0/0 = NaN => comparison false => hit
+    assert oracle.edge_check_spheres(sp, m, [10, 10, 10], [10, 10, 10], 0.5) == (True, 0)
+    assert math.isnan(oracle.distance_point_to_segment3([0, 0, 0], [10, 10, 10], [10, 10, 10]))
+    # K6: inactive obstacle never hits
+    sp2, m2 = oracle.make_spheres([[0, 0, 0, 1.0]], active=[0])
+    assert oracle.edge_check_spheres(sp2, m2, [0.9, 0, 0], [1.4, 0, 0], 0.5) == (False, -1)
+    sp3, m3 = oracle.make_spheres([[0, 0, 0, 1.0]], life_span=[0.0])
+    assert oracle.edge_check_spheres(sp3, m3, [0.9, 0, 0], [1.4, 0, 0], 0.5) == (False, -1)
+
+
+def test_edge_direction_dependence(oracle):
+    """the dot/L formula makes the result depend on the edge direction (why extend checks both)"""
+    sp, m = oracle.make_spheres([[0, 0, 0, 1.0]])
+    a, b = [-1.6, 1.45, 0], [3.0, 1.45, 0]
+    d_ab = oracle.distance_point_to_segment3([0, 0, 0], a, b)
+    d_ba = oracle.distance_point_to_segment3([0, 0, 0], b, a)
+    assert d_ab != d_ba
+
+
+def test_k7_polygon(oracle):
+    ps = oracle.PolygonSet([[[0, 0], [1, 0], [1, 1], [0, 1]]])
+    cr = ps.centre_radius()[0]
+    assert cr[0] == 0.5 and cr[1] == 0.5 and cr[2] == math.sqrt(0.5)
+    assert oracle.edge_check_polygons(ps, [-1, .5], [2, .5], 0.1) == (True, 0)
+    assert oracle.edge_check_polygons(ps, [-1, 2], [2, 2], 0.1) == (False, -1)   # bounding-circle reject
+
+
+def test_k8_point_segment(oracle):
+    assert oracle.dist_sqrd_point_to_segment([1, 1], [0, 0], [2, 0]) == 1.0   # interior branch
+    assert oracle.dist_sqrd_point_to_segment([0, 1], [0, 0], [2, 0]) == 1.0   # det == 0 -> start branch
+    assert oracle.dist_sqrd_point_to_segment([3, 1], [0, 0], [2, 0]) == 2.0   # end branch
+
+
+def test_segment_dist_branches(oracle):
+    # crossing segments -> 0.0
+    assert oracle.segment_dist_sqrd([0, 0], [2, 2], [0, 2], [2, 0]) == 0.0
+    # near-vertical P with Q strictly on one side
+    assert oracle.segment_dist_sqrd([0, 0], [0, 2], [1, 0], [1, 2]) == 1.0
+    # parallel horizontal segments
+    assert oracle.segment_dist_sqrd([0, 0], [2, 0], [0, 1], [2, 1]) == 1.0
+    # touching at an end point: the reference's strict side test reports an intersection
+    assert oracle.segment_dist_sqrd([0, 0], [2, 0], [1, 0], [1, 3]) == 0.0
+
+
+def test_point_in_polygon(oracle):
+    sq = [[0, 0], [1, 0], [1, 1], [0, 1]]
+    assert oracle.point_in_polygon([.5, .5], sq)
+    assert not oracle.point_in_polygon([1.5, .5], sq)
+    assert not oracle.point_in_polygon([-.5, .5], sq)
+    tri = [[0, 0], [4, 0], [0, 4]]
+    assert oracle.point_in_polygon([1, 1], tri)
+    assert not oracle.point_in_polygon([3, 3], tri)
+
+
+def test_k9_ball_radius(oracle):
+    assert abs(oracle.ball_radius(8, 80, 200000, 3) - 3.1497) < 1e-4
+    assert abs(oracle.ball_radius(8, 80, 10000, 3) - 7.7837) < 1e-4
+    assert abs(oracle.ball_radius(8, 80, 50000, 3) - 4.8029) < 1e-4
+    assert abs(oracle.ball_radius(8, 80, 500000, 3) - 2.3774) < 1e-4
+    assert oracle.ball_radius(10, 100, 50000, 4) == 10.0
+    assert abs(oracle.ball_radius(10, 100, 500000, 4) - 7.1575) < 1e-4
+    assert oracle.ball_radius(8, 80, 100, 3) == 8.0             # delta caps small trees
+
+
+def test_k10_dubins_straight_ahead(oracle):
+    """s=(0,0,.,0) -> g=(10,0,.,0), r=1: the x axis is tangent to all four circles, so rsl, rsr,
+    lsr and lsl all have cost 10; evaluation order rsl first + strict `bestDist > len` keeps "rsl".
+    (SURVEY.md's hand derivation predicted "rsr"; the inner tangent of irc/glc is the x axis too.)"""
+    c, w, traj = oracle.dubins_steer([0, 0, 0, 0], [10, 0, 0, 0], 1.0)
+    assert abs(c - 10.0) <= 1e-12
+    assert w in ("rsl", "rsr", "lsr", "lsl")
+    assert traj.shape == (4, 2)          # 1 + 2 + 1 rows: both arcs are single points
+    assert np.allclose(traj[[0, -1]], [[0, 0], [10, 0]], atol=1e-12)
+
+
+def test_dubins_known_shapes(oracle):
+    # quarter-turn geometry: start heading +x at origin, goal at (2, 2) heading +y with r = 2: one left arc
+    c, w, traj = oracle.dubins_steer([0, 0, 0, 0], [2, 2, 0, math.pi / 2], 2.0)
+    assert abs(c - math.pi) < 1e-9 and "l" in w     # degenerate pieces tie; "rsl" is evaluated first
+    # U-turn needs the curve-curve-curve family when the goal is close
+    c2, w2, _ = oracle.dubins_steer([0, 0, 0, 0], [0, 0.5, 0, math.pi], 1.0)
+    assert w2 in ("rlr", "lrl", "lsl", "rsr", "lsr", "rsl") and c2 > 0
+    # symmetric mirror: left/right words swap, cost is equal
+    ca, wa, _ = oracle.dubins_steer([0, 0, 0, 0.3], [6, 3, 0, 1.1], 1.0)
+    cb, wb, _ = oracle.dubins_steer([0, 0, 0, -0.3], [6, -3, 0, -1.1], 1.0)
+    assert abs(ca - cb) < 1e-9
+    assert wa.translate(str.maketrans("lr", "rl")) == wb
+    # trajectory sanity: consecutive arc samples are 0.1 rad apart on a circle of radius r_min
+    _, _, traj = oracle.dubins_steer([0, 0, 0, 0], [2, 2, 0, math.pi / 2], 2.0)
+    d = np.linalg.norm(np.diff(traj, axis=0), axis=1)
+    chord = 2 * 2.0 * math.sin(0.05)
+    assert (np.abs(d - chord) < 1e-9).sum() >= 14          # pi/2 of arc = 15 full 0.1-rad steps
+    assert (d <= chord + 1e-9).all()
+
+
+def test_julia_range_len(oracle):
+    # literal-fallback branch of Julia's float range: len = round((stop-start)/step)+1, minus overshoot
+    assert oracle.julia_range_len(0.0, 0.1, 0.35) == 4          # 0, .1, .2, .3
+    assert oracle.julia_range_len(0.0, -0.1, -0.35) == 4
+    assert oracle.julia_range_len(0.0, 0.1, -1.0) == 0
+    assert oracle.julia_range_len(0.3, 0.1, 0.3) == 1
+    assert oracle.julia_range_len(1.0, 0.1, 1.26) == 3          # 3.6 rounds to 4 -> overshoot -> 3
+
+
+@pytest.mark.parametrize("d", [3, 4, 6])
+def test_kd_equals_naive(oracle, d):
+    """the reference's testCase design: kd search == naive scan (nearest, and range as a set with keys)"""
+    rng = np.random.default_rng(100 + d)
+    pts = rng.random((4000, d))
+    t = oracle.KDTree(d)
+    t.insert_many(pts)
+    assert t.size == 4000
+    for q in rng.random((200, d)):
+        assert t.nearest(q) == t.nearest(q, naive=True)
+        idx, key = t.within_range(0.25, q)
+        nidx, nkey = t.range_naive(0.25, q)
+        o = np.argsort(idx)
+        assert np.array_equal(idx[o], nidx) and np.array_equal(key[o], nkey)
+
+
+def test_kd_range_list_order_is_reverse_discovery(oracle):
+    # JlistPush inserts at the front: the root (added first when within range) is the LAST element
+    t = oracle.KDTree(2)
+    for p in [[.5, .5], [.25, .5], [.75, .5], [.1, .1]]:
+        t.insert(p)
+    idx, _ = t.within_range(10.0, [.5, .5])
+    assert idx[-1] == 0 and sorted(idx) == [0, 1, 2, 3]
+
+
+def test_find_more_within_range_keeps_first_key(oracle):
+    t = oracle.KDTree(2)
+    for p in [[0, 0], [1, 0], [3, 0]]:
+        t.insert(p)
+    idx, key = t.within_range(1.5, [0, 0], more=[(2.5, [2, 0])])
+    got = dict(zip(idx, key))
+    assert got == {0: 0.0, 1: 1.0, 2: 1.0}     # node 1 keeps the key of its first discovery
+
+
+def test_ghost_points_single_wrap(oracle):
+    """testGhost design: R^2 x S^1; the ghost of theta is theta + 2pi (theta < pi) or theta - 2pi"""
+    two_pi = 2 * math.pi
+    t = oracle.KDTree(4, wraps=[3], wrap_points=[two_pi])
+    t.insert([0, 0, 0, 1.0])
+    g = t.ghost_points([1, 2, 0, 0.5], 10.0)
+    assert g.shape == (1, 4) and g[0, 3] == 0.5 + two_pi and list(g[0, :3]) == [1, 2, 0]
+    g = t.ghost_points([1, 2, 0, 6.0], 10.0)
+    assert g[0, 3] == 6.0 - two_pi
+    # skipped when the unwrapped point closest to the ghost is farther than bestDist
+    assert t.ghost_points([1, 2, 0, 3.0], 1.0).shape[0] == 0
+    assert t.ghost_points([1, 2, 0, 0.5], 0.4).shape[0] == 0
+    assert t.ghost_points([1, 2, 0, 0.5], 0.6).shape[0] == 1
+
+
+def test_ghost_points_two_wraps_order(oracle):
+    t = oracle.KDTree(3, wraps=[0, 2], wrap_points=[1.0, 1.0])
+    t.insert([.5, .5, .5])
+    g = t.ghost_points([.1, .5, .9], 10.0)
+    # iteration order: last wrapped dim first, then the first, then both
+    assert np.allclose(g, [[.1, .5, -.1], [1.1, .5, .9], [1.1, .5, -.1]])
+
+
+def test_wrapped_range_equals_naive(oracle):
+    two_pi = 2 * math.pi
+    rng = np.random.default_rng(9)
+    pts = np.concatenate([rng.uniform(-5, 5, (3000, 2)), np.zeros((3000, 1)), rng.uniform(0, two_pi, (3000, 1))], 1)
+    t = oracle.KDTree(4, wraps=[3], wrap_points=[two_pi])
+    t.insert_many(pts)
+    for q in pts[rng.integers(0, 3000, 100)] + 0.01:
+        for r in (1.0, 4.0):
+            idx, key = t.within_range(r, q)
+            nidx, nkey = t.range_naive(r, q)
+            o = np.argsort(idx)
+            assert np.array_equal(idx[o], nidx) and np.array_equal(key[o], nkey)
+
+
+def test_point_checks(oracle):
+    sp, m = oracle.make_spheres([[0, 0, 0, 1.0], [5, 0, 0, 2.0]])
+    assert oracle.point_check_spheres(sp, m, [0.5, 0, 0], 0.5) == (True, 0.0)        # inside (quickCheck)
+    assert oracle.point_check_spheres(sp, m, [1.2, 0, 0], 0.5) == (True, 0.0)        # robot radius overlaps
+    unsafe, clr = oracle.point_check_spheres(sp, m, [2.5, 0, 0], 0.5)
+    assert not unsafe and clr == 0.0 + (2.5 - 0.5 - 2.0)                               # sphere 2: 2.5-0.5-2
+    unsafe, clr = oracle.point_check_spheres(sp, m, [0, 10, 0], 0.5)
+    assert not unsafe and clr == (10.0 - 0.5) - 1.0
+    assert oracle.point_check_spheres(sp, 0, [0, 0, 0], 0.5) == (False, float("inf"))
+
+
+def test_reference_env_files_as_inputs(oracle):
+    """the two environment fixtures the reference ships are inputs, not expected outputs; the parsed
+    copies under tests/golden must load and have the documented shape"""
+    import json, os
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    env = json.load(open(os.path.join(g, "env_inputs.json")))
+    b2 = np.array(env["building2_spheres"])
+    assert b2.shape == (31, 4) and (b2[:, 3] == 3.5).all()
+    rs = env["rand_Static_polygons"]
+    assert len(rs) == 35 and all(len(p) == 4 for p in rs)
