@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nn-filter", type=int, default=1, help="1: fp32 prefilter + exact fp64 confirm (default); 0: exact scan")
     args = ap.parse_args()
 
     import torch
@@ -99,6 +100,8 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)          # kernels, events and torch share one stream
     ctx.spheres_set(sph)
+    from rrtqx_3d_amd import _capi
+    ctx.set_option(_capi.RRTX_OPT_NN_FILTER, args.nn_filter)
 
     # ---- inputs resident in HBM before the timed region -----------------------
     d_pts = torch.from_numpy(pts).to(dev)

@@ -75,6 +75,12 @@ void *rrtx_get_stream(rrtx_ctx *ctx);
 int rrtx_sync(rrtx_ctx *ctx);
 int rrtx_profile(rrtx_ctx *ctx, int enable); /* per-kernel HIP-event timing on/off (resets sums) */
 int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
+/* tuning switches; none of them changes a result.
+ *   RRTX_OPT_NN_FILTER (default 1): range search screens (query, node) pairs with a
+ *   conservative fp32 bound before the exact unfused fp64 test; 0 = exact test on
+ *   every pair. */
+#define RRTX_OPT_NN_FILTER 1
+int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value);
 
 /* ---- tree (A2, A5) --------------------------------------------------------- */
 /* kdInsert (R/kdTree_general.jl:121-170): appends n nodes; *first_index receives

@@ -19,6 +19,7 @@ RRTX_E_CAPACITY = -2
 RRTX_E_DEVICE = -3
 RRTX_E_NOMEM = -4
 RRTX_E_STATE = -5
+RRTX_OPT_NN_FILTER = 1
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -58,6 +59,7 @@ SYMBOLS = [
     ("rrtx_sync", C.c_int, [_VP]),
     ("rrtx_profile", C.c_int, [_VP, C.c_int]),
     ("rrtx_stats", C.c_int, [_VP, C.POINTER(Stats)]),
+    ("rrtx_set_option", C.c_int, [_VP, C.c_int, C.c_int64]),
     ("rrtx_nodes_append", C.c_int, [_VP, _VP, C.c_int64, c_int64_p]),
     ("rrtx_nodes_count", C.c_int64, [_VP]),
     ("rrtx_nodes_append_dev", C.c_int, [_VP, _VP, C.c_int64]),

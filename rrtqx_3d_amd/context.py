@@ -64,6 +64,9 @@ class Context:
     def profile(self, enable: bool):
         self._check(self._lib.rrtx_profile(self._h, 1 if enable else 0))
 
+    def set_option(self, option: int, value: int):
+        self._check(self._lib.rrtx_set_option(self._h, option, value))
+
     def stats(self) -> Stats:
         s = Stats()
         self._check(self._lib.rrtx_stats(self._h, C.byref(s)))

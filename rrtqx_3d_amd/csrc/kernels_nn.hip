@@ -27,10 +27,23 @@ constexpr int kChunk = 64 * kScanU;  // nodes per wave per chunk
 
 // device scalars in ws_scalars
 struct Scalars {
-  unsigned long long total;   // records produced by scan + rootfix
-  int n_copies;               // valid query copies
+  unsigned long long total;        // records produced by scan + rootfix
+  int n_copies;                    // valid query copies
   int pad;
+  unsigned long long q_absmax;     // bit pattern of max |coordinate| over the query copies
 };
+
+// fp32 copy record for the prefilter: 16 B (D=3) / 32 B (D=4), one scalar load
+struct alignas(16) QRecF3 { float x, y, z, thr; };
+struct alignas(32) QRecF4 { float x, y, z, w, thr, pad0, pad1, pad2; };
+template <int D> struct QRecFT;
+template <> struct QRecFT<3> { using type = QRecF3; };
+template <> struct QRecFT<4> { using type = QRecF4; };
+
+constexpr int kTileQExact = 32;            // query copies per workgroup tile, exact fp64 scan
+constexpr int kTileQFilter = 32;           // ... fp32-prefilter scan
+constexpr int kScanFU = 8;                 // nodes per lane in the fp32-prefilter scan
+constexpr int kChunkF = 64 * kScanFU;
 
 // ---------------------------------------------------------------- pack ------
 template <int D>
@@ -79,6 +92,9 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
     sr.pad0 = 0.0; sr.pad1 = 0.0;
     slots[(size_t)i * n_slots + k] = sr;
     if (valid) {
+      unsigned long long am = 0ull;
+      for (int c2 = 0; c2 < D; ++c2) am = max(am, (unsigned long long)__double_as_longlong(fabs(g[c2])));
+      atomicMax(&sc->q_absmax, am);
       int pos = (n_wraps == 0) ? i : atomicAdd(&sc->n_copies, 1);
       typename QRecT<D>::type qr;
       qr.x = g[0]; qr.y = g[1]; qr.z = g[2];
@@ -198,6 +214,137 @@ __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
           wn += n;
         }
       }
+    }
+  }
+  flush_stage(stage, wn, recs, cap, sc);
+}
+
+// ------------------------------------------------------ fp32 prefilter ------
+// Conservative screen: a pair may only be DROPPED when it provably fails the
+// exact test.  With C = max |coordinate| (nodes and query copies), eps = 2^-24:
+//   |d~_i - d_i| <= delta = 4.1*eps*C      (two fp32 conversions + one fp32 subtract)
+//   S~ <= (1+4eps) * (R + sqrt(3)*delta)^2 whenever the exact fp64 s < thr, R = sqrt(thr)*(1+1e-15)
+// so "S~ > thr_f" with thr_f = that bound rounded UP to fp32 proves s >= thr.
+// Pairs that survive are re-tested with the exact unfused fp64 arithmetic, which
+// alone decides membership ("fp32 prefilter").
+template <int D>
+__global__ void nn_filter_prep_kernel(const typename QRecT<D>::type *__restrict__ copies,
+                                      const Scalars *__restrict__ sc,
+                                      const unsigned long long *__restrict__ node_absmax, int n_copies_max,
+                                      typename QRecFT<D>::type *__restrict__ copies_f) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_copies_max || i >= sc->n_copies) return;
+  const typename QRecT<D>::type c = copies[i];
+  unsigned long long cb = max(*node_absmax, sc->q_absmax);
+  const double C = __longlong_as_double((long long)cb);
+  float thr_f;
+  if (!(C <= 1e30)) {
+    thr_f = __builtin_inff();              // non-finite or huge coordinates: screen nothing
+  } else if (!(c.thr > 0.0)) {
+    thr_f = -1.0f;                          // exact test can never pass (s >= 0 > thr or thr NaN)
+  } else {
+    const double eps = 5.9604644775390625e-08;   // 2^-24
+    const double delta = 4.1 * eps * C + 1e-37;
+    const double R = sqrt_rn(c.thr) * (1.0 + 1e-15);
+    const double b = R + 1.7320508075688774 * delta;
+    const double T = (1.0 + 4.0 * eps) * (b * b);
+    thr_f = __double2float_ru(T);
+    if (!(thr_f >= 0.0f)) thr_f = __builtin_inff();
+  }
+  typename QRecFT<D>::type f;
+  f.x = (float)c.x; f.y = (float)c.y; f.z = (float)c.z;
+  if constexpr (D == 4) { f.w = (float)c.w; f.pad0 = 0.f; f.pad1 = 0.f; f.pad2 = 0.f; }
+  f.thr = thr_f;
+  copies_f[i] = f;
+}
+
+template <int D>
+__global__ __launch_bounds__(kScanThreads) void nn_scan_f32_kernel(
+    const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
+    const double *__restrict__ nw, const float *__restrict__ fx, const float *__restrict__ fy,
+    const float *__restrict__ fz, const float *__restrict__ fw, int n_nodes,
+    const typename QRecT<D>::type *__restrict__ copies, const typename QRecFT<D>::type *__restrict__ copies_f,
+    const int2 *__restrict__ meta, const SlotRec *__restrict__ slots, int n_slots, int tile_q, int n_seg,
+    int seg_len, HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
+    int *__restrict__ count) {
+  __shared__ HitRec stage_all[kScanThreads / 64][kStageCap];
+  const int seg = blockIdx.x % n_seg;      // XCD-affine node segment (see nn_scan_kernel)
+  const int tile = blockIdx.x / n_seg;
+  const int n_copies = sc->n_copies;
+  const int q0 = tile * tile_q;
+  if (q0 >= n_copies) return;
+  const int q1 = min(q0 + tile_q, n_copies);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  HitRec *stage = stage_all[wave];
+  int wn = 0;
+  const int node_begin = seg * seg_len;
+  const int node_end = min(n_nodes, node_begin + seg_len);
+  const float kInf = __builtin_inff();
+
+  for (int base = node_begin + wave * kChunkF; base < node_end; base += (kScanThreads / 64) * kChunkF) {
+    float x[kScanFU], y[kScanFU], z[kScanFU], w[kScanFU];
+#pragma unroll
+    for (int u = 0; u < kScanFU; ++u) {
+      const int id = base + u * 64 + lane;
+      const bool ok = id < node_end;
+      x[u] = ok ? fx[id] : kInf;          // +inf padding: S~ = inf never survives a finite bound
+      y[u] = ok ? fy[id] : kInf;
+      z[u] = ok ? fz[id] : kInf;
+      if constexpr (D == 4) w[u] = ok ? fw[id] : kInf; else w[u] = 0.f;
+    }
+    typename QRecFT<D>::type c = copies_f[q0];
+    for (int q = q0; q < q1; ++q) {
+      // software pipeline: the next copy record is requested before this one is used
+      const typename QRecFT<D>::type cn = copies_f[min(q + 1, q1 - 1)];
+      // hot loop: 7 fp32 VALU ops per pair; survivors are collected as wave masks on the SALU
+      unsigned long long anym = 0ull;
+#pragma unroll
+      for (int u = 0; u < kScanFU; ++u) {
+        float dx = c.x - x[u], dy = c.y - y[u], dz = c.z - z[u];
+        float sf = dx * dx;
+        sf = __builtin_fmaf(dy, dy, sf);
+        sf = __builtin_fmaf(dz, dz, sf);
+        if constexpr (D == 4) { float dw = c.w - w[u]; sf = __builtin_fmaf(dw, dw, sf); }
+        anym |= __ballot(!(sf > c.thr));
+      }
+      if (__builtin_expect(anym != 0ull, 0)) {
+        // rare path: exact unfused fp64 test on the survivors decides
+        const typename QRecT<D>::type ce = copies[q];
+        const int2 m = meta[q];
+#pragma unroll
+        for (int u = 0; u < kScanFU; ++u) {
+          float dx = c.x - x[u], dy = c.y - y[u], dz = c.z - z[u];
+          float sf = dx * dx;
+          sf = __builtin_fmaf(dy, dy, sf);
+          sf = __builtin_fmaf(dz, dz, sf);
+          if constexpr (D == 4) { float dw = c.w - w[u]; sf = __builtin_fmaf(dw, dw, sf); }
+          const bool pu = !(sf > c.thr);
+          if (__ballot(pu) == 0ull) continue;
+          const int id = base + u * 64 + lane;
+          bool hu = false;
+          double s = 0.0, ex = 0.0, ey = 0.0, ez = 0.0, ew = 0.0;
+          if (pu && id < node_end) {
+            ex = nx[id]; ey = ny[id]; ez = nz[id];
+            if constexpr (D == 4) { ew = nw[id]; s = sq4(ce.x, ce.y, ce.z, ce.w, ex, ey, ez, ew); }
+            else s = sq3(ce.x, ce.y, ce.z, ex, ey, ez);
+            hu = s < ce.thr;
+            if (m.y > 0 && hu) hu = !seen_by_earlier_slot<D>(slots, n_slots, m.x, m.y, id, ex, ey, ez, ew);
+          }
+          const unsigned long long mask = __ballot(hu);
+          if (mask == 0ull) continue;
+          const int n = __popcll(mask);
+          if (wn + n > kStageCap) flush_stage(stage, wn, recs, cap, sc);
+          if (hu) {
+            HitRec r;
+            r.owner = m.x; r.idx = id; r.d2 = s;
+            stage[wn + __popcll(mask & ((1ull << lane) - 1ull))] = r;
+          }
+          if (lane == 0) atomicAdd(&count[m.x], n);
+          wn += n;
+        }
+      }
+      c = cn;
     }
   }
   flush_stage(stage, wn, recs, cap, sc);
@@ -445,7 +592,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   int *count = ctx->ws_counts.as<int>();
   int *cursor = count + nq;
   Scalars init;
-  init.total = 0ull; init.n_copies = (ctx->n_wraps == 0) ? nq : 0; init.pad = 0;
+  init.total = 0ull; init.n_copies = (ctx->n_wraps == 0) ? nq : 0; init.pad = 0; init.q_absmax = 0ull;
   RRTX_HIP(ctx, hipMemcpyAsync(sc, &init, sizeof(Scalars), hipMemcpyHostToDevice, st));
   RRTX_HIP(ctx, hipMemsetAsync(count, 0, (size_t)nq * sizeof(int), st));
 
@@ -472,21 +619,51 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
 
   // ---- scan geometry: tiles of copies x node segments (segment = XCD-affine) ----
   const int n_nodes = (int)ctx->n_nodes;
-  const int tile_q = 32;
+  const bool use_filter = ctx->opt_nn_filter != 0;
+  const int chunk = use_filter ? kChunkF : kChunk;
+  const int tile_q = use_filter ? kTileQFilter : kTileQExact;
   const int n_tiles = (int)((n_copies_max + tile_q - 1) / tile_q);
-  const int wg_nodes = (kScanThreads / 64) * kChunk;  // nodes one workgroup covers per pass
+  const int wg_nodes = (kScanThreads / 64) * chunk;  // nodes one workgroup covers per pass
   int max_seg = (n_nodes + wg_nodes - 1) / wg_nodes;
   int want_seg = (4096 + n_tiles - 1) / n_tiles;
   int n_seg = want_seg < max_seg ? want_seg : max_seg;
   if (n_seg < 1) n_seg = 1;
   if (n_seg >= 8) n_seg = n_seg / 8 * 8;  // segment index == blockIdx % 8 class == XCD
-  int seg_len = round_up((n_nodes + n_seg - 1) / n_seg, kChunk);
+  int seg_len = round_up((n_nodes + n_seg - 1) / n_seg, chunk);
   n_seg = (n_nodes + seg_len - 1) / seg_len;
+  ctx->last_tile_q = tile_q;
+
+  if (use_filter) {
+    const size_t qf_bytes = (D == 4) ? sizeof(QRecF4) : sizeof(QRecF3);
+    RRTX_HIP(ctx, ctx->ws_copies_f.ensure(n_copies_max * qf_bytes));
+    span_begin(ctx, KF_NN_FINISH);
+    dim3 grid((unsigned)((n_copies_max + 255) / 256)), block(256);
+    if (D == 4)
+      hipLaunchKernelGGL(nn_filter_prep_kernel<4>, grid, block, 0, st, ctx->ws_copies.as<QRec4>(), sc,
+                         ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->ws_copies_f.as<QRecF4>());
+    else
+      hipLaunchKernelGGL(nn_filter_prep_kernel<3>, grid, block, 0, st, ctx->ws_copies.as<QRec3>(), sc,
+                         ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->ws_copies_f.as<QRecF3>());
+    span_end(ctx);
+  }
 
   span_begin(ctx, KF_NN_SCAN);
   {
     dim3 grid((unsigned)n_tiles * (unsigned)n_seg), block(kScanThreads);
-    if (D == 4)
+    if (use_filter) {
+      if (D == 4)
+        hipLaunchKernelGGL(nn_scan_f32_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                           ctx->nodes[3], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[3], n_nodes,
+                           ctx->ws_copies.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(), ctx->ws_copy_meta.as<int2>(),
+                           ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len, ctx->ws_recs.as<HitRec>(),
+                           rec_cap, sc, count);
+      else
+        hipLaunchKernelGGL(nn_scan_f32_kernel<3>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                           ctx->nodes[2], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[2], n_nodes,
+                           ctx->ws_copies.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(), ctx->ws_copy_meta.as<int2>(),
+                           ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len, ctx->ws_recs.as<HitRec>(),
+                           rec_cap, sc, count);
+    } else if (D == 4)
       hipLaunchKernelGGL(nn_scan_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
                          ctx->nodes[3], n_nodes, ctx->ws_copies.as<QRec4>(), ctx->ws_copy_meta.as<int2>(),
                          ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len,

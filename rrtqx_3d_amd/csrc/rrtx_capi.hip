@@ -108,15 +108,35 @@ static void drain_spans(rrtx_ctx *ctx) {
 
 namespace {
 
-__global__ void aos_to_soa_kernel(const double *__restrict__ pos, int dim, long long n, long long base,
-                                  double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
-                                  double *__restrict__ w) {
+// row-major points -> SoA (fp64 + fp32 shadow) and the running max |coordinate|
+// (bit pattern of a non-negative double orders like the value; NaN sorts above inf)
+__global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restrict__ pos, int dim, long long n,
+                                                         long long base, double *__restrict__ x,
+                                                         double *__restrict__ y, double *__restrict__ z,
+                                                         double *__restrict__ w, float *__restrict__ xf,
+                                                         float *__restrict__ yf, float *__restrict__ zf,
+                                                         float *__restrict__ wf,
+                                                         unsigned long long *__restrict__ absmax) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  x[base + i] = pos[i * dim + 0];
-  y[base + i] = pos[i * dim + 1];
-  z[base + i] = pos[i * dim + 2];
-  if (dim == 4) w[base + i] = pos[i * dim + 3];
+  unsigned long long m = 0ull;
+  if (i < n) {
+    double a = pos[i * dim + 0], b = pos[i * dim + 1], c = pos[i * dim + 2];
+    x[base + i] = a; y[base + i] = b; z[base + i] = c;
+    xf[base + i] = (float)a; yf[base + i] = (float)b; zf[base + i] = (float)c;
+    m = max(max((unsigned long long)__double_as_longlong(fabs(a)), (unsigned long long)__double_as_longlong(fabs(b))),
+            (unsigned long long)__double_as_longlong(fabs(c)));
+    if (dim == 4) {
+      double d = pos[i * dim + 3];
+      w[base + i] = d;
+      wf[base + i] = (float)d;
+      m = max(m, (unsigned long long)__double_as_longlong(fabs(d)));
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned long long o = __shfl_xor(m, off);
+    m = max(m, o);
+  }
+  if ((threadIdx.x & 63) == 0 && m != 0ull) atomicMax(absmax, m);
 }
 
 int grow_nodes(rrtx_ctx *ctx, int64_t need) {
@@ -133,6 +153,17 @@ int grow_nodes(rrtx_ctx *ctx, int64_t need) {
       RRTX_HIP(ctx, hipMemcpy(nb, ctx->nodes[k], sizeof(double) * (size_t)ctx->n_nodes, hipMemcpyDeviceToDevice));
     if (ctx->nodes[k]) RRTX_HIP(ctx, hipFree(ctx->nodes[k]));
     ctx->nodes[k] = nb;
+    float *nf = nullptr;
+    e = hipMalloc(&nf, sizeof(float) * (size_t)nc);
+    if (e != hipSuccess) return fail(ctx, RRTX_E_NOMEM, "hipMalloc of %lld node slots failed: %s", (long long)nc, hipGetErrorString(e));
+    if (ctx->n_nodes > 0)
+      RRTX_HIP(ctx, hipMemcpy(nf, ctx->nodes_f[k], sizeof(float) * (size_t)ctx->n_nodes, hipMemcpyDeviceToDevice));
+    if (ctx->nodes_f[k]) RRTX_HIP(ctx, hipFree(ctx->nodes_f[k]));
+    ctx->nodes_f[k] = nf;
+  }
+  if (!ctx->d_absmax.p) {
+    RRTX_HIP(ctx, ctx->d_absmax.ensure(sizeof(unsigned long long)));
+    RRTX_HIP(ctx, hipMemset(ctx->d_absmax.p, 0, sizeof(unsigned long long)));
   }
   ctx->cap_nodes = nc;
   return RRTX_OK;
@@ -208,9 +239,12 @@ int rrtx_destroy(rrtx_ctx *ctx) {
   for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
   for (int k = 0; k < 4; ++k)
     if (ctx->nodes[k]) (void)hipFree(ctx->nodes[k]);
+  for (int k = 0; k < 4; ++k)
+    if (ctx->nodes_f[k]) (void)hipFree(ctx->nodes_f[k]);
+  ctx->d_absmax.release();
   DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
                     &ctx->d_poly_orig, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
-                    &ctx->ws_copy_meta, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_scalars, &ctx->ws_tmp_idx,
+                    &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_scalars, &ctx->ws_tmp_idx,
                     &ctx->ws_tmp_d2, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
                     &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr};
   for (auto b : bufs) b->release();
@@ -245,6 +279,14 @@ int rrtx_profile(rrtx_ctx *ctx, int enable) {
   return RRTX_OK;
 }
 
+int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value) {
+  CHECK_CTX(ctx);
+  switch (option) {
+    case RRTX_OPT_NN_FILTER: ctx->opt_nn_filter = value != 0; return RRTX_OK;
+    default: return fail(ctx, RRTX_E_INVALID, "set_option: unknown option %d", option);
+  }
+}
+
 int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out) {
   CHECK_CTX(ctx);
   if (!out) return fail(ctx, RRTX_E_INVALID, "stats: out is NULL");
@@ -276,7 +318,8 @@ int rrtx_nodes_append_dev(rrtx_ctx *ctx, const double *pos_dev, int64_t n) {
   if (rc) return rc;
   hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev,
                      ctx->dim, (long long)n, (long long)ctx->n_nodes, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                     ctx->nodes[ctx->dim == 4 ? 3 : 2]);
+                     ctx->nodes[ctx->dim == 4 ? 3 : 2], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2],
+                     ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->d_absmax.as<unsigned long long>());
   RRTX_HIP(ctx, hipGetLastError());
   ctx->n_nodes += n;
   return RRTX_OK;

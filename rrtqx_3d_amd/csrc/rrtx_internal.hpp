@@ -70,7 +70,14 @@ struct rrtx_ctx {
 
   // node SoA (fp64), one array per coordinate
   double *nodes[4] = {nullptr, nullptr, nullptr, nullptr};
+  // fp32 shadow of the node SoA for the conservative range prefilter
+  // (kernels_nn.hip, nn_scan_f32_kernel); never used to decide a result
+  float *nodes_f[4] = {nullptr, nullptr, nullptr, nullptr};
   int64_t n_nodes = 0, cap_nodes = 0;
+  rrtx::DevBuf d_absmax;            // uint64: bit pattern of max |coordinate| over all nodes
+
+  // options (rrtx_set_option)
+  int opt_nn_filter = 1;            // 1: fp32 prefilter + exact fp64 confirm, 0: exact fp64 scan
 
   // wrapped dimensions
   int n_wraps = 0;
@@ -101,6 +108,7 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_q2;
   rrtx::DevBuf ws_slots;    // SlotRec table
   rrtx::DevBuf ws_copies;   // QRec copies
+  rrtx::DevBuf ws_copies_f; // fp32 prefilter copies
   rrtx::DevBuf ws_copy_meta;// int32 owner, slot per copy
   rrtx::DevBuf ws_recs;     // HitRec
   rrtx::DevBuf ws_counts;   // int32 count[nq], cursor[nq]
@@ -120,6 +128,7 @@ struct rrtx_ctx {
   double fam_ms[rrtx::KF_COUNT] = {0};
   int64_t fam_launches[rrtx::KF_COUNT] = {0};
   int64_t last_pairs = 0, last_neighbors = 0;
+  int last_tile_q = 0;
 };
 
 namespace rrtx {

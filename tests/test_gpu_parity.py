@@ -97,6 +97,63 @@ def test_radius_per_query_radii_and_edge_cases(small3, oracle):
     assert offsets[3] - offsets[2] == 10_000
 
 
+@pytest.mark.parametrize("scale", [1.0, 1e3, 1e6])
+def test_radius_prefilter_is_conservative(oracle, scale):
+    """fp32 prefilter + exact confirm == exact scan == oracle, on inputs built to sit on the range
+    boundary (|dist - r| ~ ulps) and on coordinates far from the origin (fp32 cancellation)."""
+    from rrtqx_3d_amd import _capi
+    rng = np.random.default_rng(123)
+    nq, per = 32, 400
+    r = 3.1497206024977595
+    Q = rng.uniform(-50, 50, (nq, 3)) * scale
+    pts = [np.zeros((1, 3))]
+    for q in Q:
+        u = rng.normal(size=(per, 3))
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        # distances straddling r by 0, +-1e-15 ... +-1e-9 relative, plus clear in/out points
+        rel = rng.choice([0.0, 1e-16, -1e-16, 1e-15, -1e-15, 1e-13, -1e-13, 1e-9, -1e-9, 0.3, -0.3], per)
+        pts.append(q + u * (r * (1.0 + rel))[:, None])
+    pts = np.concatenate(pts, 0)
+    tree = oracle.KDTree(3)
+    tree.insert_many(pts)
+    ref = _oracle_lists(tree, Q, r)
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        for flt in (1, 0):
+            ctx.set_option(_capi.RRTX_OPT_NN_FILTER, flt)
+            offsets, idx, dist = ctx.nn_radius(Q, r)
+            _check_csr(offsets, idx, dist, ref)
+    if scale == 1.0:
+        on_edge = sum(int(np.sum(np.abs(k - r) < 1e-12)) for _, k in ref)
+        assert on_edge > 100     # the boundary cases really are exercised
+
+
+def test_radius_filter_off_matches(small3, oracle):
+    from rrtqx_3d_amd import _capi
+    pts, tree, ctx = small3
+    Q = synth.queries(256, 3)
+    r = synth.ball_radius(10_000, 3)
+    ctx.set_option(_capi.RRTX_OPT_NN_FILTER, 0)
+    try:
+        offsets, idx, dist = ctx.nn_radius(Q, r)
+    finally:
+        ctx.set_option(_capi.RRTX_OPT_NN_FILTER, 1)
+    _check_csr(offsets, idx, dist, _oracle_lists(tree, Q, r))
+
+
+def test_radius_nonfinite_coordinates(oracle):
+    """inf / NaN / 1e300 coordinates switch the screen off (thr_f = inf); results still exact"""
+    pts = np.array([[0, 0, 0], [1, 0, 0], [1e300, 0, 0], [1e300, 1, 0], [np.inf, 0, 0], [np.nan, 0, 0]])
+    tree = oracle.KDTree(3)
+    tree.insert_many(pts)
+    Q = np.array([[0.5, 0, 0], [1e300, 0.5, 0]])
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        offsets, idx, dist = ctx.nn_radius(Q, 2.0)
+        _check_csr(offsets, idx, dist, _oracle_lists(tree, Q, 2.0))
+        assert list(idx) == [0, 1, 2, 3]
+
+
 def test_radius_root_inclusive_rule(oracle):
     """K2: the root is included with <=, every other node with <."""
     with Context(3) as ctx:
