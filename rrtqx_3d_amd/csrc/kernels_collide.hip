@@ -8,6 +8,8 @@
 #include "exact_math.hpp"
 #include "rrtx_internal.hpp"
 
+#include <limits>
+
 namespace rrtx {
 
 namespace {
@@ -27,9 +29,40 @@ __device__ __forceinline__ bool edge_hits_sphere(double p0x, double p0y, double 
   return !(s >= ob.thr);
 }
 
+// ---- conservative reach test (never decides a result) ---------------------------
+// A sphere can only collide with an edge if its centre is within
+//   |c - mid| <= L/2 + (robotRadius + radius) (+ rounding slack)
+// of the edge midpoint: the reference's foot point q = p0 + t*(p1-p0), t in [0,1],
+// lies on the segment whatever t is (the dot/edgeLen quirk moves it along the
+// segment, not off it).  Pairs failing this bound are skipped; every other pair
+// gets the exact unfused evaluation above.  Degenerate edges (L == 0 -> t = NaN
+// -> "hit", R/DRRT_Q.jl:1208) and non-finite/huge coordinates disable the test.
+struct EdgeReach {
+  double mx, my, mz;   // midpoint
+  double hls;          // (L/2 + slack) inflated, or +inf when the test is disabled
+};
+__device__ __forceinline__ EdgeReach edge_reach(double ax, double ay, double az, double ex, double ey,
+                                                double ez, double edge_len) {
+  EdgeReach r;
+  r.mx = 0.5 * (ax + ex); r.my = 0.5 * (ay + ey); r.mz = 0.5 * (az + ez);
+  double cmax = fmax(fmax(fmax(fabs(ax), fabs(ay)), fmax(fabs(az), fabs(ex))), fmax(fabs(ey), fabs(ez)));
+  bool usable = (edge_len > 0.0) && (edge_len < 1e100) && (cmax < 1e100) &&
+                (ax == ax) && (ay == ay) && (az == az) && (ex == ex) && (ey == ey) && (ez == ez);
+  r.hls = usable ? (0.5 * edge_len + 1e-12 * (cmax + 1.0)) * (1.0 + 1e-12) : __builtin_inf();
+  return r;
+}
+// true = the pair must be evaluated exactly (NaN-safe: NaN compares pass)
+__device__ __forceinline__ bool may_touch(const EdgeReach &r, const SphRec &b) {
+  double dx = b.cx - r.mx, dy = b.cy - r.my, dz = b.cz - r.mz;
+  double dm2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+  double bound = r.hls + b.thr;   // b.thr holds the inflated reach of the sphere here
+  return !(dm2 > bound * bound);
+}
+
 __global__ __launch_bounds__(256) void edges_spheres_kernel(const double *__restrict__ p0,
                                                             const double *__restrict__ p1, int stride,
                                                             long long ne, const SphRec *__restrict__ sph,
+                                                            const SphRec *__restrict__ reach,
                                                             const int32_t *__restrict__ orig, int m_begin,
                                                             int m_end, uint8_t *__restrict__ hit,
                                                             int32_t *__restrict__ first_hit) {
@@ -42,12 +75,32 @@ __global__ __launch_bounds__(256) void edges_spheres_kernel(const double *__rest
   }
   const double bx = ex - ax, by = ey - ay, bz = ez - az;
   const double edge_len = sqrt_rn(sq3(ax, ay, az, ex, ey, ez));
+  const EdgeReach er = edge_reach(ax, ay, az, ex, ey, ez, edge_len);
   bool done = !act;
   int first = -1;
-  for (int j = m_begin; j < m_end; ++j) {
-    const SphRec ob = sph[j];   // wave-uniform -> scalar load
-    bool h = edge_hits_sphere(ax, ay, az, bx, by, bz, edge_len, ob);
-    if (!done && h) { done = true; first = orig[j]; }
+  if (__ballot(act) == 0ull) return;
+  // groups of 4 obstacles: the four wave-uniform reach records are requested
+  // together (one SMEM round trip per group instead of per obstacle)
+  for (int j0 = m_begin; j0 < m_end; j0 += 4) {
+    SphRec rb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rb[g] = reach[min(j0 + g, m_end - 1)];
+    bool cand[4];
+    bool anyc = false;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      cand[g] = !done && (j0 + g < m_end) && may_touch(er, rb[g]);
+      anyc = anyc || cand[g];
+    }
+    if (__ballot(anyc) == 0ull) continue;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (__ballot(cand[g]) == 0ull) continue;
+      if (cand[g] && !done) {
+        const SphRec ob = sph[j0 + g];
+        if (edge_hits_sphere(ax, ay, az, bx, by, bz, edge_len, ob)) { done = true; first = orig[j0 + g]; }
+      }
+    }
     if (__ballot(!done) == 0ull) break;   // every edge of this wave already collides
   }
   if (act) {
@@ -57,39 +110,55 @@ __global__ __launch_bounds__(256) void edges_spheres_kernel(const double *__rest
 }
 
 // Candidate edges of extend(): CSR entry e = (query qi, node idx[e]); checks
-// sample->near and near->sample (R/DRRT_Q.jl:1951-1963, 2600-2602).
+// sample->near and near->sample (R/DRRT_Q.jl:1951-1963, 2600-2602).  Both
+// directions share the segment, so one reach test serves both.
 __global__ __launch_bounds__(256) void candidate_edges_kernel(
     const double *__restrict__ q, int stride, const int64_t *__restrict__ offsets, int nq,
-    const int32_t *__restrict__ idx, const double *__restrict__ nx, const double *__restrict__ ny,
-    const double *__restrict__ nz, long long cap, const SphRec *__restrict__ sph, int m,
-    uint8_t *__restrict__ hit_out, uint8_t *__restrict__ hit_in) {
+    const int32_t *__restrict__ idx, const int32_t *__restrict__ owner, const double *__restrict__ nx,
+    const double *__restrict__ ny, const double *__restrict__ nz, long long cap,
+    const SphRec *__restrict__ sph, const SphRec *__restrict__ reach, int m, uint8_t *__restrict__ hit_out,
+    uint8_t *__restrict__ hit_in) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long total = offsets[nq];
   if (total > cap) total = cap;
   const bool act = e < total;
   double sx = 0, sy = 0, sz = 0, tx = 0, ty = 0, tz = 0;
   if (act) {
-    // owning query: binary search over the offsets
-    int lo = 0, hi = nq;
-    while (hi - lo > 1) {
-      int mid = (lo + hi) >> 1;
-      if (offsets[mid] <= e) lo = mid; else hi = mid;
-    }
+    const int lo = owner[e];   // owning query (written by nn_order_kernel)
     sx = q[(size_t)lo * stride + 0]; sy = q[(size_t)lo * stride + 1]; sz = q[(size_t)lo * stride + 2];
     const int n = idx[e];
     tx = nx[n]; ty = ny[n]; tz = nz[n];
   }
-  // out: sample -> near ; in: near -> sample.  edgeLen is the same expression
-  // either way (squares of negated differences), the direction vector flips.
+  // out: sample -> near ; in: near -> sample.  edgeLen is the same value either
+  // way (squares of negated differences); the direction vector flips.
   const double bx = tx - sx, by = ty - sy, bz = tz - sz;
   const double cx = sx - tx, cy = sy - ty, cz = sz - tz;
-  const double len_out = sqrt_rn(sq3(sx, sy, sz, tx, ty, tz));
-  const double len_in = sqrt_rn(sq3(tx, ty, tz, sx, sy, sz));
+  const double len = sqrt_rn(sq3(sx, sy, sz, tx, ty, tz));
+  const EdgeReach er = edge_reach(sx, sy, sz, tx, ty, tz, len);
   bool out_hit = false, in_hit = false;
-  for (int j = 0; j < m; ++j) {
-    const SphRec ob = sph[j];
-    if (!out_hit) out_hit = edge_hits_sphere(sx, sy, sz, bx, by, bz, len_out, ob);
-    if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len_in, ob);
+  if (__ballot(act) == 0ull) return;   // the grid covers the caller's capacity, most waves are past the end
+  for (int j0 = 0; j0 < m; j0 += 4) {
+    SphRec rb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rb[g] = reach[min(j0 + g, m - 1)];
+    bool cand[4];
+    bool anyc = false;
+    const bool need = act && !(out_hit && in_hit);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      cand[g] = need && (j0 + g < m) && may_touch(er, rb[g]);
+      anyc = anyc || cand[g];
+    }
+    if (__ballot(anyc) == 0ull) continue;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (__ballot(cand[g]) == 0ull) continue;
+      if (cand[g]) {
+        const SphRec ob = sph[j0 + g];
+        if (!out_hit) out_hit = edge_hits_sphere(sx, sy, sz, bx, by, bz, len, ob);
+        if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len, ob);
+      }
+    }
     if (__ballot(act && !(out_hit && in_hit)) == 0ull) break;
   }
   if (act) {
@@ -100,6 +169,10 @@ __global__ __launch_bounds__(256) void candidate_edges_kernel(
 
 // explicitPointCheck over spheres (R/DRRT_Q.jl:1520-1590).  aux holds, per
 // active sphere, radius and thr_in = first s with sqrt(s) > radius.
+// 16 lanes share one point and stride over the obstacle list; the reference's
+// sequential loop is order-independent except for which of two equal clearances
+// (+-0.0) survives, so the lane combine prefers the lower list position.
+constexpr int kPtLanes = 16;
 __global__ __launch_bounds__(256) void points_spheres_kernel(const double *__restrict__ p, int stride,
                                                              long long np, const SphRec *__restrict__ sph,
                                                              const double *__restrict__ radius,
@@ -107,37 +180,36 @@ __global__ __launch_bounds__(256) void points_spheres_kernel(const double *__res
                                                              double robot_radius, int quick,
                                                              uint8_t *__restrict__ unsafe,
                                                              double *__restrict__ clearance) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= np) return;
-  const double px = p[i * stride + 0], py = p[i * stride + 1], pz = p[i * stride + 2];
-  if (quick) {
-    // quickCheck: inside any sphere  (Wdist > radius => outside, :1410)
-    for (int j = 0; j < m; ++j) {
-      double s = sq3(sph[j].cx, sph[j].cy, sph[j].cz, px, py, pz);
-      if (!(s >= thr_in[j])) {
-        unsafe[i] = 1;
-        if (clearance) clearance[i] = 0.0;
-        return;
-      }
-    }
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = gid / kPtLanes;
+  const int sub = (int)(gid % kPtLanes);
+  const bool act = i < np;
+  double px = 0, py = 0, pz = 0;
+  if (act) { px = p[i * stride + 0]; py = p[i * stride + 1]; pz = p[i * stride + 2]; }
+  bool bad = false;
+  double best = __builtin_inf();
+  int best_j = 0x7fffffff;
+  for (int j = sub; j < m; j += kPtLanes) {
+    const double s = sq3(sph[j].cx, sph[j].cy, sph[j].cz, px, py, pz);
+    // quickCheck: inside the sphere  (Wdist > radius => outside, :1410)
+    if (quick && !(s >= thr_in[j])) bad = true;
+    // explicitPointCheck2D: thisDist = Wdist - robotRadius; thisDist - radius < 0 => collision
+    const double td = (sqrt_rn(s) - robot_radius) - radius[j];
+    if (td < 0.0) bad = true;
+    if (td < best) { best = td; best_j = j; }
   }
-  double ret_cert = __builtin_inf();
-  for (int j = 0; j < m; ++j) {
-    double this_dist = sqrt_rn(sq3(sph[j].cx, sph[j].cy, sph[j].cz, px, py, pz)) - robot_radius;
-    double this_cert = ret_cert;
-    if (!(this_dist - radius[j] > ret_cert)) {
-      this_dist = this_dist - radius[j];
-      if (this_dist < 0.0) {
-        unsafe[i] = 1;
-        if (clearance) clearance[i] = 0.0;
-        return;
-      }
-      this_cert = jl_min(ret_cert, this_dist);
-    }
-    if (this_cert < ret_cert) ret_cert = this_cert;
+#pragma unroll
+  for (int off = kPtLanes / 2; off > 0; off >>= 1) {
+    const double ob = __shfl_xor(best, off);
+    const int oj = __shfl_xor(best_j, off);
+    const bool obad = __shfl_xor((int)bad, off) != 0;
+    bad = bad || obad;
+    if ((ob < best) || (ob == best && oj < best_j)) { best = ob; best_j = oj; }
   }
-  unsafe[i] = 0;
-  if (clearance) clearance[i] = ret_cert;
+  if (act && sub == 0) {
+    unsafe[i] = bad ? 1 : 0;
+    if (clearance) clearance[i] = bad ? 0.0 : best;
+  }
 }
 
 // ------------------------------------------------------------ polygons ------
@@ -384,7 +456,7 @@ void packed_range(const std::vector<int32_t> &orig, int begin, int end, int &pb,
 int sync_spheres(rrtx_ctx *ctx, double robot_radius) {
   if (!ctx->sph_dirty && ctx->sph_packed_rr == robot_radius) return RRTX_OK;
   const int m = (int)ctx->sph_active.size();
-  std::vector<SphRec> rec;
+  std::vector<SphRec> rec, reach;
   std::vector<double> radius, thr_in;
   std::vector<int32_t> orig;
   for (int i = 0; i < m; ++i) {
@@ -394,6 +466,14 @@ int sync_spheres(rrtx_ctx *ctx, double robot_radius) {
     r.cx = c[0]; r.cy = c[1]; r.cz = c[2];
     r.thr = thr_first_gt(robot_radius + c[3]);
     rec.push_back(r);
+    // inflated reach for the conservative midpoint test (kernel: may_touch)
+    SphRec rb = r;
+    const double R = robot_radius + c[3];
+    const double cm = std::fmax(std::fmax(std::fabs(c[0]), std::fabs(c[1])), std::fabs(c[2]));
+    const bool usable = std::isfinite(R) && std::isfinite(cm) && cm < 1e100 && std::fabs(R) < 1e100;
+    rb.thr = usable ? (std::fmax(R, 0.0) * (1.0 + 1e-12) + 1e-12 * (cm + 1.0)) * (1.0 + 1e-12)
+                    : std::numeric_limits<double>::infinity();
+    reach.push_back(rb);
     radius.push_back(c[3]);
     thr_in.push_back(thr_first_gt(c[3]));
     orig.push_back(i);
@@ -406,6 +486,8 @@ int sync_spheres(rrtx_ctx *ctx, double robot_radius) {
     // the packed tables may still be read by kernels in flight on the stream
     RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     RRTX_HIP(ctx, hipMemcpy(ctx->d_sph.p, rec.data(), sizeof(SphRec) * na, hipMemcpyHostToDevice));
+    RRTX_HIP(ctx, ctx->d_sph_reach.ensure(sizeof(SphRec) * na));
+    RRTX_HIP(ctx, hipMemcpy(ctx->d_sph_reach.p, reach.data(), sizeof(SphRec) * na, hipMemcpyHostToDevice));
     char *aux = ctx->d_sph_aux.as<char>();
     RRTX_HIP(ctx, hipMemcpy(aux, radius.data(), sizeof(double) * na, hipMemcpyHostToDevice));
     RRTX_HIP(ctx, hipMemcpy(aux + sizeof(double) * na, thr_in.data(), sizeof(double) * na,
@@ -490,7 +572,7 @@ int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_d
   if (pe <= pb) return zero_outputs(ctx, ne, hit_dev, first_hit_dev);
   span_begin(ctx, KF_EDGES);
   hipLaunchKernelGGL(edges_spheres_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
-                     p1_dev, ctx->dim, (long long)ne, ctx->d_sph.as<SphRec>(), sph_orig_dev(ctx), pb, pe, hit_dev,
+                     p1_dev, ctx->dim, (long long)ne, ctx->d_sph.as<SphRec>(), ctx->d_sph_reach.as<SphRec>(), sph_orig_dev(ctx), pb, pe, hit_dev,
                      first_hit_dev);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
@@ -498,16 +580,17 @@ int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_d
 }
 
 int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
-                           const int32_t *idx_dev, int64_t cap, double robot_radius, uint8_t *hit_out_dev,
-                           uint8_t *hit_in_dev) {
+                           const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap, double robot_radius,
+                           uint8_t *hit_out_dev, uint8_t *hit_in_dev) {
   if (nq <= 0 || cap <= 0) return RRTX_OK;
   int rc = sync_spheres(ctx, robot_radius);
   if (rc) return rc;
   span_begin(ctx, KF_EDGES);
   // the grid covers the caller's capacity; lanes past offsets[nq] idle
   hipLaunchKernelGGL(candidate_edges_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, q_dev,
-                     ctx->dim, offsets_dev, nq, idx_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                     (long long)cap, ctx->d_sph.as<SphRec>(), ctx->sph_n_active, hit_out_dev, hit_in_dev);
+                     ctx->dim, offsets_dev, nq, idx_dev, owner_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                     (long long)cap, ctx->d_sph.as<SphRec>(), ctx->d_sph_reach.as<SphRec>(), ctx->sph_n_active,
+                     hit_out_dev, hit_in_dev);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
@@ -543,7 +626,7 @@ int launch_points_spheres(rrtx_ctx *ctx, const double *p_dev, int64_t np, double
   int rc = sync_spheres(ctx, robot_radius);
   if (rc) return rc;
   span_begin(ctx, KF_POINTS);
-  hipLaunchKernelGGL(points_spheres_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, p_dev,
+  hipLaunchKernelGGL(points_spheres_kernel, dim3((unsigned)((np * kPtLanes + 255) / 256)), dim3(256), 0, ctx->stream, p_dev,
                      ctx->dim, (long long)np, ctx->d_sph.as<SphRec>(), sph_radius_dev(ctx), sph_thr_in_dev(ctx),
                      ctx->sph_n_active, robot_radius, quick, unsafe_dev, clearance_dev);
   span_end(ctx);

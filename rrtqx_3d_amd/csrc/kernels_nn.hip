@@ -381,30 +381,38 @@ __global__ __launch_bounds__(1024) void nn_offsets_kernel(const int *__restrict_
                                                           int *__restrict__ cursor,
                                                           const Scalars *__restrict__ sc,
                                                           int64_t *__restrict__ needed) {
-  __shared__ long long part[1024];
-  const int t = threadIdx.x;
-  const int per = (nq + 1023) / 1024;
-  const int b = t * per;
-  const int e = min(nq, b + per);
-  long long sum = 0;
-  for (int i = b; i < e; ++i) sum += count[i];
-  part[t] = sum;
+  // single workgroup: coalesced strips of 1024 counts, wave-shuffle inclusive scan,
+  // 16 wave totals through LDS, running carry across strips
+  __shared__ long long wave_tot[16];
+  __shared__ long long carry_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) carry_s = 0;
   __syncthreads();
-  // Hillis-Steele inclusive scan over 1024 partials
-  for (int off = 1; off < 1024; off <<= 1) {
-    long long v = (t >= off) ? part[t - off] : 0;
+  for (int base = 0; base < nq; base += 1024) {
+    const int i = base + t;
+    const long long c = (i < nq) ? (long long)count[i] : 0ll;
+    long long v = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      long long o = __shfl_up(v, off);
+      if (lane >= off) v += o;
+    }
+    if (lane == 63) wave_tot[wave] = v;
     __syncthreads();
-    part[t] += v;
+    long long prefix = carry_s;
+    for (int w = 0; w < wave; ++w) prefix += wave_tot[w];
+    if (i < nq) {
+      offsets[i] = prefix + v - c;
+      cursor[i] = 0;
+    }
+    __syncthreads();
+    if (t == 1023) carry_s = prefix + v;
     __syncthreads();
   }
-  long long run = part[t] - sum;  // exclusive prefix of this thread's chunk
-  for (int i = b; i < e; ++i) {
-    offsets[i] = run;
-    cursor[i] = 0;
-    run += count[i];
+  if (t == 0) {
+    offsets[nq] = carry_s;
+    if (needed) *needed = (int64_t)sc->total;
   }
-  if (t == 1023) offsets[nq] = part[1023];
-  if (t == 0 && needed) *needed = (int64_t)sc->total;
 }
 
 // ------------------------------------------------------------- scatter ------
@@ -427,12 +435,17 @@ __global__ void nn_scatter_kernel(const HitRec *__restrict__ recs, long long cap
 
 // --------------------------------------------------------------- order ------
 // one wave per query: rank each hit by node index, write idx ascending and
-// dist = sqrt(d2) (the key the reference stores, R/kdTree_general.jl:829-831)
+// dist = sqrt(d2) (the key the reference stores, R/kdTree_general.jl:829-831).
+// Optionally also: owner[e] = query of CSR entry e, and the nearest node of the
+// list (lexicographic minimum of (d2, idx); -1 when the list is empty).
 __global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict__ offsets, int nq,
                                                        const int32_t *__restrict__ tmp_idx,
                                                        const double *__restrict__ tmp_d2,
                                                        int32_t *__restrict__ idx,
-                                                       double *__restrict__ dist, long long out_cap) {
+                                                       double *__restrict__ dist, long long out_cap,
+                                                       int32_t *__restrict__ owner,
+                                                       int32_t *__restrict__ nearest_idx,
+                                                       double *__restrict__ nearest_dist) {
   const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (q >= nq) return;
   const int lane = threadIdx.x & 63;
@@ -440,10 +453,11 @@ __global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict
   long long e = offsets[q + 1];
   if (e > out_cap) e = out_cap;
   const long long k = e - b;
-  if (k <= 0) return;
-  if (k <= 64) {
+  double best = __builtin_inf();
+  int best_i = 0x7fffffff;
+  if (k > 0 && k <= 64) {
     int my = (lane < k) ? tmp_idx[b + lane] : 0x7fffffff;
-    double d2 = (lane < k) ? tmp_d2[b + lane] : 0.0;
+    double d2 = (lane < k) ? tmp_d2[b + lane] : __builtin_inf();
     int rank = 0;
     for (int j = 0; j < (int)k; ++j) {
       int other = __shfl(my, j);
@@ -452,18 +466,34 @@ __global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict
     if (lane < k) {
       idx[b + rank] = my;
       dist[b + rank] = sqrt_rn(d2);
+      if (owner) owner[b + rank] = q;
     }
-  } else {
+    best = d2; best_i = my;
+  } else if (k > 64) {
     for (long long base = 0; base < k; base += 64) {
       bool act = base + lane < k;
       int my = act ? tmp_idx[b + base + lane] : 0x7fffffff;
-      double d2 = act ? tmp_d2[b + base + lane] : 0.0;
+      double d2 = act ? tmp_d2[b + base + lane] : __builtin_inf();
       long long rank = 0;
       for (long long j = 0; j < k; ++j) rank += (tmp_idx[b + j] < my) ? 1 : 0;
       if (act) {
         idx[b + rank] = my;
         dist[b + rank] = sqrt_rn(d2);
+        if (owner) owner[b + rank] = q;
+        if ((d2 < best) || (d2 == best && my < best_i)) { best = d2; best_i = my; }
       }
+    }
+  }
+  if (nearest_idx) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      double ob = __shfl_xor(best, off);
+      int oi = __shfl_xor(best_i, off);
+      if ((ob < best) || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+    }
+    if (lane == 0) {
+      nearest_idx[q] = (k > 0) ? best_i : -1;
+      nearest_dist[q] = (k > 0) ? sqrt_rn(best) : __builtin_inf();
     }
   }
 }
@@ -558,7 +588,8 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 // ------------------------------------------------------------- launchers ----
 int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr_lt, double r_scalar, int nq,
                      int64_t *offsets_dev, int32_t *idx_dev, double *dist_dev, int64_t cap,
-                     int64_t *needed_dev) {
+                     int64_t *needed_dev, int32_t *owner_dev, int32_t *nearest_idx_dev,
+                     double *nearest_dist_dev) {
   // r_dev_thr_lt: optional device array of 2*nq thresholds (thr_lt[nq] then thr_gt[nq])
   if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "radius search on an empty tree");
   if (nq <= 0) return RRTX_OK;
@@ -695,7 +726,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
                        (long long)cap);
     hipLaunchKernelGGL(nn_order_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, offsets_dev, nq,
                        ctx->ws_tmp_idx.as<int32_t>(), ctx->ws_tmp_d2.as<double>(), idx_dev, dist_dev,
-                       (long long)cap);
+                       (long long)cap, owner_dev, nearest_idx_dev, nearest_dist_dev);
   }
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());

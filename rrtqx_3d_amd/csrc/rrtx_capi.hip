@@ -242,10 +242,10 @@ int rrtx_destroy(rrtx_ctx *ctx) {
   for (int k = 0; k < 4; ++k)
     if (ctx->nodes_f[k]) (void)hipFree(ctx->nodes_f[k]);
   ctx->d_absmax.release();
-  DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
+  DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_reach, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
                     &ctx->d_poly_orig, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
                     &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_scalars, &ctx->ws_tmp_idx,
-                    &ctx->ws_tmp_d2, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
+                    &ctx->ws_tmp_d2, &ctx->ws_owner, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
                     &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr};
   for (auto b : bufs) b->release();
   (void)hipStreamDestroy(ctx->own_stream);
@@ -637,16 +637,18 @@ int rrtx_extend_candidates_dev(rrtx_ctx *ctx, const double *q, int nq, double r,
     return fail(ctx, RRTX_E_INVALID, "extend_candidates: bad arguments");
   if (ctx->dim != 3) return fail(ctx, RRTX_E_STATE, "extend_candidates is the SimpleEdge (dim=3) path");
   if (nq == 0) return RRTX_OK;
-  int rc = launch_nn_radius(ctx, q, nullptr, r, nq, offsets, idx, cost, cap, needed_dev);
+  RRTX_HIP(ctx, ctx->ws_owner.ensure(sizeof(int32_t) * (size_t)(cap > 0 ? cap : 1)));
+  const bool want_nearest = nearest_idx && nearest_dist;
+  // nearest falls out of the radius lists (kdFindNearest's answer lies inside the ball whenever
+  // the ball is non-empty); samples with an empty ball get nearest_idx = -1 here and are
+  // resolved with the full nearest scan by the host-pointer entry point below.
+  int rc = launch_nn_radius(ctx, q, nullptr, r, nq, offsets, idx, cost, cap, needed_dev,
+                            ctx->ws_owner.as<int32_t>(), want_nearest ? nearest_idx : nullptr,
+                            want_nearest ? nearest_dist : nullptr);
   if (rc) return rc;
-  rc = launch_candidate_edges(ctx, q, nq, offsets, idx, cap, robot_radius, hit_out, hit_in);
+  rc = launch_candidate_edges(ctx, q, nq, offsets, idx, ctx->ws_owner.as<int32_t>(), cap, robot_radius, hit_out,
+                              hit_in);
   if (rc) return rc;
-  if (nearest_idx && nearest_dist) {
-    rc = launch_nearest_from_lists(ctx, q, nq, offsets, idx, cost, nearest_idx, nearest_dist);
-    if (rc) return rc;
-    // TODO(round 2): samples whose ball is empty keep nearest_idx = -1 here; the
-    // host-pointer entry point below resolves them with the full nearest scan.
-  }
   if (sample_unsafe) {
     rc = launch_points_spheres(ctx, q, nq, robot_radius, 1, sample_unsafe, nullptr);
     if (rc) return rc;

@@ -91,6 +91,7 @@ struct rrtx_ctx {
   double sph_packed_rr = -1.0;      // robot radius the packed thresholds were built for
   int sph_n_active = 0;
   rrtx::DevBuf d_sph;               // SphRec[n_active]
+  rrtx::DevBuf d_sph_reach;         // SphRec[n_active]: centre + inflated reach (conservative skip test)
   rrtx::DevBuf d_sph_aux;           // double radius[n_active] then int32 orig[n_active]
 
   // polygon obstacles
@@ -114,6 +115,7 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_counts;   // int32 count[nq], cursor[nq]
   rrtx::DevBuf ws_scalars;  // device scalars: total, n_copies, ...
   rrtx::DevBuf ws_tmp_idx, ws_tmp_d2;
+  rrtx::DevBuf ws_owner;    // int32 owner query of every CSR entry (extend_candidates)
   rrtx::DevBuf ws_out_off, ws_out_idx, ws_out_dist, ws_out_u8a, ws_out_u8b, ws_out_i32, ws_out_f64;
   rrtx::DevBuf ws_partial;  // nearest partials
   rrtx::DevBuf ws_thr;      // per-query thresholds
@@ -156,7 +158,8 @@ double thr_first_gt(double r);
 // ---- launchers (device pointers, enqueue on ctx->stream) ----------------------
 int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_or_null, double r_scalar,
                      int nq, int64_t *offsets_dev, int32_t *idx_dev, double *dist_dev, int64_t cap,
-                     int64_t *needed_dev);
+                     int64_t *needed_dev, int32_t *owner_dev = nullptr, int32_t *nearest_idx_dev = nullptr,
+                     double *nearest_dist_dev = nullptr);
 int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev);
 int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
                          double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
@@ -177,8 +180,8 @@ int launch_dubins_edges_check(rrtx_ctx *ctx, const double *s_dev, const double *
                               uint8_t *hit_dev, int32_t *traj_len_dev);
 // candidate edges of extend(): for every CSR entry both directed edges vs the sphere list
 int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
-                           const int32_t *idx_dev, int64_t cap, double robot_radius, uint8_t *hit_out_dev,
-                           uint8_t *hit_in_dev);
+                           const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap, double robot_radius,
+                           uint8_t *hit_out_dev, uint8_t *hit_in_dev);
 int launch_nearest_from_lists(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
                               const int32_t *idx_dev, const double *dist_dev, int32_t *nearest_idx_dev,
                               double *nearest_dist_dev);
