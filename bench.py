@@ -32,7 +32,6 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s FMA-counted vector fp64 => 39.3 T unfused op/s
 ROBOT_RADIUS = 0.5             # R/experimentsForRRTQX.jl:38
-SCAN_TILE_Q = 32               # query copies sharing one streamed pass of the node arrays (kernels_nn.hip)
 
 
 def cpu_baseline(cfg, pts, Q, sph, r, budget_s=10.0):
@@ -67,6 +66,9 @@ def main():
     ap.add_argument("--config", default="C4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nn-filter", type=int, default=1, help="1: fp32 prefilter + exact fp64 confirm (default); 0: exact scan")
+    ap.add_argument("--scan-blocks", type=int, default=0, help="tuning: target workgroups of the range scan")
+    ap.add_argument("--scan-items", type=int, default=0, help="tuning: target (tile, segment) work items")
+    ap.add_argument("--tile-q", type=int, default=0, help="tuning: query copies per workgroup tile")
     args = ap.parse_args()
 
     import torch
@@ -102,6 +104,12 @@ def main():
     ctx.spheres_set(sph)
     from rrtqx_3d_amd import _capi
     ctx.set_option(_capi.RRTX_OPT_NN_FILTER, args.nn_filter)
+    if args.scan_blocks:
+        ctx.set_option(_capi.RRTX_OPT_SCAN_BLOCKS, args.scan_blocks)
+    if args.scan_items:
+        ctx.set_option(_capi.RRTX_OPT_SCAN_ITEMS, args.scan_items)
+    if args.tile_q:
+        ctx.set_option(_capi.RRTX_OPT_SCAN_TILE_Q, args.tile_q)
 
     # ---- inputs resident in HBM before the timed region -----------------------
     d_pts = torch.from_numpy(pts).to(dev)
@@ -167,7 +175,8 @@ def main():
     if rank == 0:
         ms_step = 1e3 * t_max / args.steps
         scan_ms = st.ms_nn_scan / max(st.launches_nn_scan, 1)
-        n_tiles = (B + SCAN_TILE_Q - 1) // SCAN_TILE_Q
+        tile_q = int(st.last_tile_q)   # query copies sharing one streamed pass of the node arrays
+        n_tiles = (B + tile_q - 1) // tile_q
         bytes_streamed = n_tiles * N * 24 + B * 32 + k_total * 16      # node passes + queries + hit records
         achieved = bytes_streamed / (scan_ms * 1e-3) / 1e9
         valu_ops = B * N * 9                                           # 3 sub, 3 mul, 2 add, 1 cmp per (query, node)
@@ -195,11 +204,11 @@ def main():
                 "points": st.ms_points / args.steps,
             },
             "roofline": {
-                "kernel": "nn_scan_kernel<3>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "kernel": "nn_scan_f32_kernel<3>" if args.nn_filter else "nn_scan_kernel<3>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": bytes_streamed, "tile_q": SCAN_TILE_Q,
+                "algorithmic_bytes_per_launch": bytes_streamed, "tile_q": tile_q,
                 "valu_fp64_frac": valu_ops / (scan_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS,
-                "note": "kernel is fp64-VALU bound (9 unfused ops per pair); see DESIGN.md",
+                "note": "VALU-issue bound, node arrays are L2-resident (PMC traffic ~0.02 GB/launch); see DESIGN.md",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -57,6 +57,8 @@ typedef struct {
   /* work counters of the last rrtx_nn_radius* / rrtx_extend_candidates* call */
   int64_t last_pairs;        /* (query copy, node) visits */
   int64_t last_neighbors;    /* sum of k */
+  int32_t last_tile_q;       /* query copies that shared one streamed pass of the node arrays */
+  int32_t reserved;
 } rrtx_stats_t;
 
 /* ---- lifetime ------------------------------------------------------------ */
@@ -80,6 +82,11 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
  *   conservative fp32 bound before the exact unfused fp64 test; 0 = exact test on
  *   every pair. */
 #define RRTX_OPT_NN_FILTER 1
+/*   RRTX_OPT_SCAN_BLOCKS: target workgroup count of the range scan (launch geometry);
+ *   RRTX_OPT_SCAN_TILE_Q: query copies per workgroup tile, 0 = default. */
+#define RRTX_OPT_SCAN_BLOCKS 2
+#define RRTX_OPT_SCAN_TILE_Q 3
+#define RRTX_OPT_SCAN_ITEMS 4  /* target number of (tile, node segment) work items */
 int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value);
 
 /* ---- tree (A2, A5) --------------------------------------------------------- */

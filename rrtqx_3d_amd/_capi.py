@@ -20,6 +20,9 @@ RRTX_E_DEVICE = -3
 RRTX_E_NOMEM = -4
 RRTX_E_STATE = -5
 RRTX_OPT_NN_FILTER = 1
+RRTX_OPT_SCAN_BLOCKS = 2
+RRTX_OPT_SCAN_TILE_Q = 3
+RRTX_OPT_SCAN_ITEMS = 4
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -44,6 +47,7 @@ class Stats(C.Structure):
         ("ms_points", C.c_double), ("launches_points", C.c_int64),
         ("ms_dubins", C.c_double), ("launches_dubins", C.c_int64),
         ("last_pairs", C.c_int64), ("last_neighbors", C.c_int64),
+        ("last_tile_q", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -41,8 +41,9 @@ template <> struct QRecFT<3> { using type = QRecF3; };
 template <> struct QRecFT<4> { using type = QRecF4; };
 
 constexpr int kTileQExact = 32;            // query copies per workgroup tile, exact fp64 scan
-constexpr int kTileQFilter = 32;           // ... fp32-prefilter scan
+constexpr int kTileQFilter = 64;           // ... fp32-prefilter scan
 constexpr int kScanFU = 8;                 // nodes per lane in the fp32-prefilter scan
+constexpr int kQPI = 4;                    // query copies per inner iteration (amortises loop/branch/SMEM overhead)
 constexpr int kChunkF = 64 * kScanFU;
 
 // ---------------------------------------------------------------- pack ------
@@ -50,6 +51,7 @@ template <int D>
 __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const double *__restrict__ thr_lt_arr,
                                const double *__restrict__ thr_gt_arr, double thr_lt_s, double thr_gt_s,
                                int n_wraps, int wd0, int wd1, int wd2, double wp0, double wp1, double wp2,
+                               double ox, double oy, double oz, double ow,
                                SlotRec *__restrict__ slots, typename QRecT<D>::type *__restrict__ copies,
                                int2 *__restrict__ meta, Scalars *__restrict__ sc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,8 +94,10 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
     sr.pad0 = 0.0; sr.pad1 = 0.0;
     slots[(size_t)i * n_slots + k] = sr;
     if (valid) {
+      // max |copy - origin| feeds the prefilter's rounding bound
+      const double og[4] = {ox, oy, oz, ow};
       unsigned long long am = 0ull;
-      for (int c2 = 0; c2 < D; ++c2) am = max(am, (unsigned long long)__double_as_longlong(fabs(g[c2])));
+      for (int c2 = 0; c2 < D; ++c2) am = max(am, (unsigned long long)__double_as_longlong(fabs(g[c2] - og[c2])));
       atomicMax(&sc->q_absmax, am);
       int pos = (n_wraps == 0) ? i : atomicAdd(&sc->n_copies, 1);
       typename QRecT<D>::type qr;
@@ -221,133 +225,235 @@ __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
 
 // ------------------------------------------------------ fp32 prefilter ------
 // Conservative screen: a pair may only be DROPPED when it provably fails the
-// exact test.  With C = max |coordinate| (nodes and query copies), eps = 2^-24:
-//   |d~_i - d_i| <= delta = 4.1*eps*C      (two fp32 conversions + one fp32 subtract)
-//   S~ <= (1+4eps) * (R + sqrt(3)*delta)^2 whenever the exact fp64 s < thr, R = sqrt(thr)*(1+1e-15)
-// so "S~ > thr_f" with thr_f = that bound rounded UP to fp32 proves s >= thr.
-// Pairs that survive are re-tested with the exact unfused fp64 arithmetic, which
-// alone decides membership ("fp32 prefilter").
+// exact test; pairs that survive are re-tested with the exact unfused fp64
+// arithmetic, which alone decides membership ("fp32 prefilter").
+//
+// Norm expansion on coordinates shifted by the context origin o (P = p - o,
+// Q = q - o, p~ = fl32(P), q~ = fl32(Q), eps = 2^-24, C >= max |P_i|, |Q_i|):
+//     t = fma(ax, p~x, fma(ay, p~y, fma(az, p~z, pp))),  a = -2 q~,  pp = fl32(|p~|^2)
+//   |t - (|p~|^2 - 2 q~.p~)| <= K eps C^2      K = D + sum_{k<=D} (D + 2k)  (24 / 40), used: 26 / 42
+//   |q~ - p~| <= |Q - P| + 2 sqrt(D) eps C
+// so whenever the exact fp64 s < thr (=> |Q - P| <= R = sqrt(thr)(1 + 1e-15)):
+//     t <= (R + 2 sqrt(D) eps C)^2 + K eps C^2 - |q~|^2  =: thr'   (rounded UP to fp32)
+// and "t > thr'" proves s >= thr.  Non-finite or huge C disables the screen.
 template <int D>
 __global__ void nn_filter_prep_kernel(const typename QRecT<D>::type *__restrict__ copies,
                                       const Scalars *__restrict__ sc,
                                       const unsigned long long *__restrict__ node_absmax, int n_copies_max,
+                                      double ox, double oy, double oz, double ow,
                                       typename QRecFT<D>::type *__restrict__ copies_f) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_copies_max || i >= sc->n_copies) return;
+  const int n_copies = sc->n_copies;
+  if (i >= n_copies) {
+    // pad to a multiple of kQPI with records that never pass (the scan reads kQPI at a time)
+    if (i < ((n_copies + kQPI - 1) / kQPI) * kQPI) {
+      typename QRecFT<D>::type f;
+      f.x = 0.f; f.y = 0.f; f.z = 0.f;
+      if constexpr (D == 4) { f.w = 0.f; f.pad0 = 0.f; f.pad1 = 0.f; f.pad2 = 0.f; }
+      f.thr = -__builtin_inff();
+      copies_f[i] = f;
+    }
+    return;
+  }
   const typename QRecT<D>::type c = copies[i];
   unsigned long long cb = max(*node_absmax, sc->q_absmax);
   const double C = __longlong_as_double((long long)cb);
+  const float qx = (float)(c.x - ox), qy = (float)(c.y - oy), qz = (float)(c.z - oz);
+  float qw = 0.f;
+  double qq = (double)qx * (double)qx + (double)qy * (double)qy + (double)qz * (double)qz;
+  if constexpr (D == 4) { qw = (float)(c.w - ow); qq += (double)qw * (double)qw; }
   float thr_f;
-  if (!(C <= 1e30)) {
+  if (!(C <= 1e15)) {
     thr_f = __builtin_inff();              // non-finite or huge coordinates: screen nothing
   } else if (!(c.thr > 0.0)) {
-    thr_f = -1.0f;                          // exact test can never pass (s >= 0 > thr or thr NaN)
+    thr_f = -__builtin_inff();              // exact test can never pass (s >= 0 >= thr, or thr NaN)
   } else {
     const double eps = 5.9604644775390625e-08;   // 2^-24
-    const double delta = 4.1 * eps * C + 1e-37;
+    const double K = (D == 4) ? 42.0 : 26.0;
+    const double two_sqrt_d = (D == 4) ? 4.0 : 3.4641016151377544;
     const double R = sqrt_rn(c.thr) * (1.0 + 1e-15);
-    const double b = R + 1.7320508075688774 * delta;
-    const double T = (1.0 + 4.0 * eps) * (b * b);
+    const double b = R + two_sqrt_d * eps * C * (1.0 + 1e-6);
+    const double T = b * b * (1.0 + 1e-12) + K * eps * C * C + 1e-30 - qq * (1.0 - 1e-14);
     thr_f = __double2float_ru(T);
-    if (!(thr_f >= 0.0f)) thr_f = __builtin_inff();
+    if (thr_f != thr_f) thr_f = __builtin_inff();
   }
   typename QRecFT<D>::type f;
-  f.x = (float)c.x; f.y = (float)c.y; f.z = (float)c.z;
-  if constexpr (D == 4) { f.w = (float)c.w; f.pad0 = 0.f; f.pad1 = 0.f; f.pad2 = 0.f; }
+  f.x = -2.0f * qx; f.y = -2.0f * qy; f.z = -2.0f * qz;
+  if constexpr (D == 4) { f.w = -2.0f * qw; f.pad0 = 0.f; f.pad1 = 0.f; f.pad2 = 0.f; }
   f.thr = thr_f;
   copies_f[i] = f;
 }
 
+constexpr int kCandCap = 192;   // (copy, node) candidates queued in LDS per wave
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Exact confirmation of a wave's queued candidates, 64 at a time with every lane
+// busy: unfused fp64 distance, the reference's strict compare, first-discovery
+// rule for ghosts; survivors go to the global record buffer with one atomic on
+// the shared counter per 64 candidates.
 template <int D>
-__global__ __launch_bounds__(kScanThreads) void nn_scan_f32_kernel(
+__device__ __forceinline__ void drain_candidates(const int2 *cand, int &wn, const double *__restrict__ nx,
+                                                 const double *__restrict__ ny, const double *__restrict__ nz,
+                                                 const double *__restrict__ nw,
+                                                 const typename QRecT<D>::type *__restrict__ copies,
+                                                 const int2 *__restrict__ meta, const SlotRec *__restrict__ slots,
+                                                 int n_slots, HitRec *__restrict__ recs, long long cap,
+                                                 Scalars *__restrict__ sc, int *__restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_wave_barrier();
+  for (int i0 = 0; i0 < wn; i0 += 64) {
+    const int i = i0 + lane;
+    bool hu = false;
+    double s = 0.0;
+    int owner = 0, id = 0;
+    if (i < wn) {
+      const int2 c = cand[i];
+      id = c.y;
+      const typename QRecT<D>::type ce = copies[c.x];
+      const int2 m = meta[c.x];
+      owner = m.x;
+      const double ex = nx[id], ey = ny[id], ez = nz[id];
+      double ew = 0.0;
+      if constexpr (D == 4) { ew = nw[id]; s = sq4(ce.x, ce.y, ce.z, ce.w, ex, ey, ez, ew); }
+      else s = sq3(ce.x, ce.y, ce.z, ex, ey, ez);
+      hu = s < ce.thr;
+      if (m.y > 0 && hu) hu = !seen_by_earlier_slot<D>(slots, n_slots, m.x, m.y, id, ex, ey, ez, ew);
+    }
+    const unsigned long long mask = __ballot(hu);
+    if (mask == 0ull) continue;
+    const int n = __popcll(mask);
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(&sc->total, (unsigned long long)n);
+    base = __shfl(base, leader);
+    if (hu) {
+      const long long pos = (long long)base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (pos < cap) {
+        HitRec r;
+        r.owner = owner; r.idx = id; r.d2 = s;
+        recs[pos] = r;
+      }
+      atomicAdd(&count[owner], 1);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  wn = 0;
+}
+
+
+// t values of one copy against the lane's 8 nodes: D packed fp32 FMAs per PAIR of
+// nodes (v_pk_fma_f32).  Plain v_fma_f32 issues once per 4 cycles per SIMD like
+// the fp64 ops; only the packed form reaches the fp32 vector rate.
+template <int D>
+__device__ __forceinline__ void screen8(const typename QRecFT<D>::type &c, const float *x, const float *y,
+                                        const float *z, const float *w, const float *pp, float *t) {
+  const f32x2 cx2 = {c.x, c.x}, cy2 = {c.y, c.y}, cz2 = {c.z, c.z};
+#pragma unroll
+  for (int v = 0; v < kScanFU / 2; ++v) {
+    f32x2 a = {pp[2 * v], pp[2 * v + 1]};
+    const f32x2 xz = {z[2 * v], z[2 * v + 1]}, xy = {y[2 * v], y[2 * v + 1]}, xx = {x[2 * v], x[2 * v + 1]};
+    a = __builtin_elementwise_fma(cz2, xz, a);
+    if constexpr (D == 4) {
+      const f32x2 cw2 = {c.w, c.w}, xw = {w[2 * v], w[2 * v + 1]};
+      a = __builtin_elementwise_fma(cw2, xw, a);
+    }
+    a = __builtin_elementwise_fma(cy2, xy, a);
+    a = __builtin_elementwise_fma(cx2, xx, a);
+    t[2 * v] = a.x; t[2 * v + 1] = a.y;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
     const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
     const double *__restrict__ nw, const float *__restrict__ fx, const float *__restrict__ fy,
-    const float *__restrict__ fz, const float *__restrict__ fw, int n_nodes,
+    const float *__restrict__ fz, const float *__restrict__ fw, const float *__restrict__ fpp, int n_nodes,
     const typename QRecT<D>::type *__restrict__ copies, const typename QRecFT<D>::type *__restrict__ copies_f,
     const int2 *__restrict__ meta, const SlotRec *__restrict__ slots, int n_slots, int tile_q, int n_seg,
     int seg_len, HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
     int *__restrict__ count) {
-  __shared__ HitRec stage_all[kScanThreads / 64][kStageCap];
-  const int seg = blockIdx.x % n_seg;      // XCD-affine node segment (see nn_scan_kernel)
-  const int tile = blockIdx.x / n_seg;
+  // copies_f is padded to a multiple of kQPI records (thr = -inf) by the launcher.
+  // Persistent workgroups: block b walks work items b, b + gridDim.x, ... where
+  // item = tile * n_seg + seg.  gridDim.x and n_seg are multiples of 8, so a block keeps
+  // the same (item % 8) class: blocks b and b+8 share an XCD, hence each XCD's L2 keeps
+  // serving the same node segments.  Waves never synchronise; the candidate queue lives
+  // across items and is drained only when full and once at the end.
+  __shared__ int2 cand_all[kScanThreads / 64][kCandCap];
   const int n_copies = sc->n_copies;
-  const int q0 = tile * tile_q;
-  if (q0 >= n_copies) return;
-  const int q1 = min(q0 + tile_q, n_copies);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  HitRec *stage = stage_all[wave];
-  int wn = 0;
+  int2 *cand = cand_all[wave];
+  int wn = 0;                               // wave-uniform queue length
+  const float kInf = __builtin_inff();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int n_tiles = (n_copies + tile_q - 1) / tile_q;
+  const int n_items = n_tiles * n_seg;
+
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+  const int seg = item % n_seg;
+  const int tile = item / n_seg;
+  const int q0 = tile * tile_q;
+  const int q1 = min(q0 + tile_q, n_copies);
   const int node_begin = seg * seg_len;
   const int node_end = min(n_nodes, node_begin + seg_len);
-  const float kInf = __builtin_inff();
 
   for (int base = node_begin + wave * kChunkF; base < node_end; base += (kScanThreads / 64) * kChunkF) {
-    float x[kScanFU], y[kScanFU], z[kScanFU], w[kScanFU];
+    float x[kScanFU], y[kScanFU], z[kScanFU], w[kScanFU], pp[kScanFU];
 #pragma unroll
     for (int u = 0; u < kScanFU; ++u) {
       const int id = base + u * 64 + lane;
       const bool ok = id < node_end;
-      x[u] = ok ? fx[id] : kInf;          // +inf padding: S~ = inf never survives a finite bound
-      y[u] = ok ? fy[id] : kInf;
-      z[u] = ok ? fz[id] : kInf;
-      if constexpr (D == 4) w[u] = ok ? fw[id] : kInf; else w[u] = 0.f;
+      const int idc = ok ? id : node_end - 1;   // clamped: no divergent load
+      x[u] = fx[idc];
+      y[u] = fy[idc];
+      z[u] = fz[idc];
+      if constexpr (D == 4) w[u] = fw[idc]; else w[u] = 0.f;
+      pp[u] = ok ? fpp[idc] : kInf;        // +inf padding: t = +inf never survives a finite bound
     }
-    typename QRecFT<D>::type c = copies_f[q0];
-    for (int q = q0; q < q1; ++q) {
-      // software pipeline: the next copy record is requested before this one is used
-      const typename QRecFT<D>::type cn = copies_f[min(q + 1, q1 - 1)];
-      // hot loop: 7 fp32 VALU ops per pair; survivors are collected as wave masks on the SALU
+    for (int q = q0; q < q1; q += kQPI) {
+      // kQPI wave-uniform copy records per iteration (scalar loads); tile_q % kQPI == 0
+      typename QRecFT<D>::type c[kQPI];
+#pragma unroll
+      for (int k = 0; k < kQPI; ++k) c[k] = copies_f[q + k];
+      unsigned long long mk[kQPI];      // wave masks stay on the SALU (no short-circuit control flow)
       unsigned long long anym = 0ull;
 #pragma unroll
-      for (int u = 0; u < kScanFU; ++u) {
-        float dx = c.x - x[u], dy = c.y - y[u], dz = c.z - z[u];
-        float sf = dx * dx;
-        sf = __builtin_fmaf(dy, dy, sf);
-        sf = __builtin_fmaf(dz, dz, sf);
-        if constexpr (D == 4) { float dw = c.w - w[u]; sf = __builtin_fmaf(dw, dw, sf); }
-        anym |= __ballot(!(sf > c.thr));
+      for (int k = 0; k < kQPI; ++k) {
+        float t[kScanFU];
+        screen8<D>(c[k], x, y, z, w, pp, t);
+        const float m1 = fminf(fminf(t[0], t[1]), t[2]);          // v_min3_f32 x3 + v_min_f32
+        const float m2 = fminf(fminf(t[3], t[4]), t[5]);
+        const float m3 = fminf(fminf(t[6], t[7]), m1);
+        const float tmin = fminf(m2, m3);
+        mk[k] = __ballot(!(tmin > c[k].thr));
+        anym |= mk[k];
       }
       if (__builtin_expect(anym != 0ull, 0)) {
-        // rare path: exact unfused fp64 test on the survivors decides
-        const typename QRecT<D>::type ce = copies[q];
-        const int2 m = meta[q];
+        // rare path: recompute the flagged copies, queue the surviving (copy, node) pairs;
+        // exactness is decided in drain_candidates
 #pragma unroll
-        for (int u = 0; u < kScanFU; ++u) {
-          float dx = c.x - x[u], dy = c.y - y[u], dz = c.z - z[u];
-          float sf = dx * dx;
-          sf = __builtin_fmaf(dy, dy, sf);
-          sf = __builtin_fmaf(dz, dz, sf);
-          if constexpr (D == 4) { float dw = c.w - w[u]; sf = __builtin_fmaf(dw, dw, sf); }
-          const bool pu = !(sf > c.thr);
-          if (__ballot(pu) == 0ull) continue;
-          const int id = base + u * 64 + lane;
-          bool hu = false;
-          double s = 0.0, ex = 0.0, ey = 0.0, ez = 0.0, ew = 0.0;
-          if (pu && id < node_end) {
-            ex = nx[id]; ey = ny[id]; ez = nz[id];
-            if constexpr (D == 4) { ew = nw[id]; s = sq4(ce.x, ce.y, ce.z, ce.w, ex, ey, ez, ew); }
-            else s = sq3(ce.x, ce.y, ce.z, ex, ey, ez);
-            hu = s < ce.thr;
-            if (m.y > 0 && hu) hu = !seen_by_earlier_slot<D>(slots, n_slots, m.x, m.y, id, ex, ey, ez, ew);
+        for (int k = 0; k < kQPI; ++k) {
+          if (mk[k] == 0ull || q + k >= q1) continue;
+          const typename QRecFT<D>::type ck = copies_f[q + k];
+          float t[kScanFU];
+          screen8<D>(ck, x, y, z, w, pp, t);
+#pragma unroll
+          for (int u = 0; u < kScanFU; ++u) {
+            const int id = base + u * 64 + lane;
+            const unsigned long long m = __ballot(!(t[u] > ck.thr) && id < node_end);
+            if (m == 0ull) continue;
+            const int n = __popcll(m);
+            if (wn + n > kCandCap)
+              drain_candidates<D>(cand, wn, nx, ny, nz, nw, copies, meta, slots, n_slots, recs, cap, sc, count);
+            if ((m >> lane) & 1ull) cand[wn + __popcll(m & lt_mask)] = make_int2(q + k, id);
+            wn += n;
           }
-          const unsigned long long mask = __ballot(hu);
-          if (mask == 0ull) continue;
-          const int n = __popcll(mask);
-          if (wn + n > kStageCap) flush_stage(stage, wn, recs, cap, sc);
-          if (hu) {
-            HitRec r;
-            r.owner = m.x; r.idx = id; r.d2 = s;
-            stage[wn + __popcll(mask & ((1ull << lane) - 1ull))] = r;
-          }
-          if (lane == 0) atomicAdd(&count[m.x], n);
-          wn += n;
         }
       }
-      c = cn;
     }
   }
-  flush_stage(stage, wn, recs, cap, sc);
+  }  // items
+  drain_candidates<D>(cand, wn, nx, ny, nz, nw, copies, meta, slots, n_slots, recs, cap, sc, count);
 }
 
 // ------------------------------------------------------------- rootfix ------
@@ -637,12 +743,14 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
       hipLaunchKernelGGL(nn_pack_kernel<4>, grid, block, 0, st, q_dev, nq, thr_lt_arr, thr_gt_arr, tlt, tgt,
                          ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1], ctx->wrap_dim[2],
                          ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
+                         ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
                          ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec4>(),
                          ctx->ws_copy_meta.as<int2>(), sc);
     else
       hipLaunchKernelGGL(nn_pack_kernel<3>, grid, block, 0, st, q_dev, nq, thr_lt_arr, thr_gt_arr, tlt, tgt,
                          ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1], ctx->wrap_dim[2],
                          ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
+                         ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
                          ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec3>(),
                          ctx->ws_copy_meta.as<int2>(), sc);
   }
@@ -652,11 +760,12 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   const int n_nodes = (int)ctx->n_nodes;
   const bool use_filter = ctx->opt_nn_filter != 0;
   const int chunk = use_filter ? kChunkF : kChunk;
-  const int tile_q = use_filter ? kTileQFilter : kTileQExact;
+  int tile_q = use_filter ? kTileQFilter : kTileQExact;
+  if (ctx->opt_tile_q > 0) tile_q = (ctx->opt_tile_q + kQPI - 1) / kQPI * kQPI;
   const int n_tiles = (int)((n_copies_max + tile_q - 1) / tile_q);
   const int wg_nodes = (kScanThreads / 64) * chunk;  // nodes one workgroup covers per pass
   int max_seg = (n_nodes + wg_nodes - 1) / wg_nodes;
-  int want_seg = (4096 + n_tiles - 1) / n_tiles;
+  int want_seg = ((use_filter ? ctx->opt_scan_items : 4096) + n_tiles - 1) / n_tiles;
   int n_seg = want_seg < max_seg ? want_seg : max_seg;
   if (n_seg < 1) n_seg = 1;
   if (n_seg >= 8) n_seg = n_seg / 8 * 8;  // segment index == blockIdx % 8 class == XCD
@@ -666,15 +775,17 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
 
   if (use_filter) {
     const size_t qf_bytes = (D == 4) ? sizeof(QRecF4) : sizeof(QRecF3);
-    RRTX_HIP(ctx, ctx->ws_copies_f.ensure(n_copies_max * qf_bytes));
+    RRTX_HIP(ctx, ctx->ws_copies_f.ensure((n_copies_max + kQPI) * qf_bytes));
     span_begin(ctx, KF_NN_FINISH);
-    dim3 grid((unsigned)((n_copies_max + 255) / 256)), block(256);
+    dim3 grid((unsigned)((n_copies_max + kQPI + 255) / 256)), block(256);
     if (D == 4)
       hipLaunchKernelGGL(nn_filter_prep_kernel<4>, grid, block, 0, st, ctx->ws_copies.as<QRec4>(), sc,
-                         ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->ws_copies_f.as<QRecF4>());
+                         ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
+                         ctx->origin[2], ctx->origin[3], ctx->ws_copies_f.as<QRecF4>());
     else
       hipLaunchKernelGGL(nn_filter_prep_kernel<3>, grid, block, 0, st, ctx->ws_copies.as<QRec3>(), sc,
-                         ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->ws_copies_f.as<QRecF3>());
+                         ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
+                         ctx->origin[2], ctx->origin[3], ctx->ws_copies_f.as<QRecF3>());
     span_end(ctx);
   }
 
@@ -682,15 +793,19 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   {
     dim3 grid((unsigned)n_tiles * (unsigned)n_seg), block(kScanThreads);
     if (use_filter) {
+      // persistent grid: opt_scan_blocks workgroups (multiple of 8) striding over the items
+      unsigned pg = (unsigned)ctx->opt_scan_blocks / 8u * 8u;
+      if (pg < 8u) pg = 8u;
+      if (pg < grid.x) grid.x = pg;
       if (D == 4)
         hipLaunchKernelGGL(nn_scan_f32_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                           ctx->nodes[3], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[3], n_nodes,
+                           ctx->nodes[3], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[3], ctx->nodes_pp, n_nodes,
                            ctx->ws_copies.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(), ctx->ws_copy_meta.as<int2>(),
                            ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len, ctx->ws_recs.as<HitRec>(),
                            rec_cap, sc, count);
       else
         hipLaunchKernelGGL(nn_scan_f32_kernel<3>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                           ctx->nodes[2], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[2], n_nodes,
+                           ctx->nodes[2], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[2], ctx->nodes_pp, n_nodes,
                            ctx->ws_copies.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(), ctx->ws_copy_meta.as<int2>(),
                            ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len, ctx->ws_recs.as<HitRec>(),
                            rec_cap, sc, count);

@@ -108,29 +108,39 @@ static void drain_spans(rrtx_ctx *ctx) {
 
 namespace {
 
-// row-major points -> SoA (fp64 + fp32 shadow) and the running max |coordinate|
-// (bit pattern of a non-negative double orders like the value; NaN sorts above inf)
+// row-major points -> SoA.  fp64 arrays hold the coordinates as given; the fp32
+// shadow (prefilter only) holds coordinates relative to the context origin plus
+// |p~|^2, and absmax tracks max |p - origin| (bit pattern of a non-negative double
+// orders like the value; NaN sorts above inf).
 __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restrict__ pos, int dim, long long n,
-                                                         long long base, double *__restrict__ x,
+                                                         long long base, double ox, double oy, double oz,
+                                                         double ow, double *__restrict__ x,
                                                          double *__restrict__ y, double *__restrict__ z,
                                                          double *__restrict__ w, float *__restrict__ xf,
                                                          float *__restrict__ yf, float *__restrict__ zf,
-                                                         float *__restrict__ wf,
+                                                         float *__restrict__ wf, float *__restrict__ ppf,
                                                          unsigned long long *__restrict__ absmax) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long m = 0ull;
   if (i < n) {
-    double a = pos[i * dim + 0], b = pos[i * dim + 1], c = pos[i * dim + 2];
+    const double a = pos[i * dim + 0], b = pos[i * dim + 1], c = pos[i * dim + 2];
     x[base + i] = a; y[base + i] = b; z[base + i] = c;
-    xf[base + i] = (float)a; yf[base + i] = (float)b; zf[base + i] = (float)c;
-    m = max(max((unsigned long long)__double_as_longlong(fabs(a)), (unsigned long long)__double_as_longlong(fabs(b))),
-            (unsigned long long)__double_as_longlong(fabs(c)));
+    const double sa = a - ox, sb = b - oy, sc = c - oz;
+    const float fa = (float)sa, fb = (float)sb, fc = (float)sc;
+    xf[base + i] = fa; yf[base + i] = fb; zf[base + i] = fc;
+    double pp = (double)fa * (double)fa + (double)fb * (double)fb + (double)fc * (double)fc;
+    m = max(max((unsigned long long)__double_as_longlong(fabs(sa)), (unsigned long long)__double_as_longlong(fabs(sb))),
+            (unsigned long long)__double_as_longlong(fabs(sc)));
     if (dim == 4) {
-      double d = pos[i * dim + 3];
+      const double d = pos[i * dim + 3];
       w[base + i] = d;
-      wf[base + i] = (float)d;
-      m = max(m, (unsigned long long)__double_as_longlong(fabs(d)));
+      const double sd = d - ow;
+      const float fd = (float)sd;
+      wf[base + i] = fd;
+      pp += (double)fd * (double)fd;
+      m = max(m, (unsigned long long)__double_as_longlong(fabs(sd)));
     }
+    ppf[base + i] = (float)pp;
   }
   for (int off = 32; off > 0; off >>= 1) {
     unsigned long long o = __shfl_xor(m, off);
@@ -160,6 +170,15 @@ int grow_nodes(rrtx_ctx *ctx, int64_t need) {
       RRTX_HIP(ctx, hipMemcpy(nf, ctx->nodes_f[k], sizeof(float) * (size_t)ctx->n_nodes, hipMemcpyDeviceToDevice));
     if (ctx->nodes_f[k]) RRTX_HIP(ctx, hipFree(ctx->nodes_f[k]));
     ctx->nodes_f[k] = nf;
+  }
+  {
+    float *nf = nullptr;
+    hipError_t e = hipMalloc(&nf, sizeof(float) * (size_t)nc);
+    if (e != hipSuccess) return fail(ctx, RRTX_E_NOMEM, "hipMalloc of %lld node slots failed: %s", (long long)nc, hipGetErrorString(e));
+    if (ctx->n_nodes > 0)
+      RRTX_HIP(ctx, hipMemcpy(nf, ctx->nodes_pp, sizeof(float) * (size_t)ctx->n_nodes, hipMemcpyDeviceToDevice));
+    if (ctx->nodes_pp) RRTX_HIP(ctx, hipFree(ctx->nodes_pp));
+    ctx->nodes_pp = nf;
   }
   if (!ctx->d_absmax.p) {
     RRTX_HIP(ctx, ctx->d_absmax.ensure(sizeof(unsigned long long)));
@@ -241,6 +260,7 @@ int rrtx_destroy(rrtx_ctx *ctx) {
     if (ctx->nodes[k]) (void)hipFree(ctx->nodes[k]);
   for (int k = 0; k < 4; ++k)
     if (ctx->nodes_f[k]) (void)hipFree(ctx->nodes_f[k]);
+  if (ctx->nodes_pp) (void)hipFree(ctx->nodes_pp);
   ctx->d_absmax.release();
   DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_reach, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
                     &ctx->d_poly_orig, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
@@ -283,6 +303,9 @@ int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value) {
   CHECK_CTX(ctx);
   switch (option) {
     case RRTX_OPT_NN_FILTER: ctx->opt_nn_filter = value != 0; return RRTX_OK;
+    case RRTX_OPT_SCAN_BLOCKS: ctx->opt_scan_blocks = value > 0 ? (int)value : 2048; return RRTX_OK;
+    case RRTX_OPT_SCAN_ITEMS: ctx->opt_scan_items = value > 0 ? (int)value : 4096; return RRTX_OK;
+    case RRTX_OPT_SCAN_TILE_Q: ctx->opt_tile_q = value > 0 ? (int)value : 0; return RRTX_OK;
     default: return fail(ctx, RRTX_E_INVALID, "set_option: unknown option %d", option);
   }
 }
@@ -304,6 +327,8 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out) {
   out->ms_dubins = ctx->fam_ms[KF_DUBINS];         out->launches_dubins = ctx->fam_launches[KF_DUBINS];
   out->last_pairs = ctx->last_pairs;
   out->last_neighbors = ctx->last_neighbors;
+  out->last_tile_q = ctx->last_tile_q;
+  out->reserved = 0;
   return RRTX_OK;
 }
 
@@ -316,10 +341,19 @@ int rrtx_nodes_append_dev(rrtx_ctx *ctx, const double *pos_dev, int64_t n) {
   if (n == 0) return RRTX_OK;
   int rc = grow_nodes(ctx, ctx->n_nodes + n);
   if (rc) return rc;
+  if (!ctx->origin_set) {
+    // origin of the fp32 shadow = the first node (the tree root); one small read-back, once per ctx
+    double first[4] = {0, 0, 0, 0};
+    RRTX_HIP(ctx, hipMemcpyAsync(first, pos_dev, sizeof(double) * ctx->dim, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < ctx->dim; ++k) ctx->origin[k] = std::isfinite(first[k]) ? first[k] : 0.0;
+    ctx->origin_set = true;
+  }
   hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev,
-                     ctx->dim, (long long)n, (long long)ctx->n_nodes, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                     ctx->dim, (long long)n, (long long)ctx->n_nodes, ctx->origin[0], ctx->origin[1], ctx->origin[2],
+                     ctx->origin[3], ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
                      ctx->nodes[ctx->dim == 4 ? 3 : 2], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2],
-                     ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->d_absmax.as<unsigned long long>());
+                     ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->d_absmax.as<unsigned long long>());
   RRTX_HIP(ctx, hipGetLastError());
   ctx->n_nodes += n;
   return RRTX_OK;

@@ -73,11 +73,17 @@ struct rrtx_ctx {
   // fp32 shadow of the node SoA for the conservative range prefilter
   // (kernels_nn.hip, nn_scan_f32_kernel); never used to decide a result
   float *nodes_f[4] = {nullptr, nullptr, nullptr, nullptr};
+  float *nodes_pp = nullptr;        // |p~|^2 of the shifted fp32 coordinates
+  double origin[4] = {0, 0, 0, 0};  // shift applied before the fp32 conversion (first node)
+  bool origin_set = false;
   int64_t n_nodes = 0, cap_nodes = 0;
   rrtx::DevBuf d_absmax;            // uint64: bit pattern of max |coordinate| over all nodes
 
   // options (rrtx_set_option)
   int opt_nn_filter = 1;            // 1: fp32 prefilter + exact fp64 confirm, 0: exact fp64 scan
+  int opt_scan_blocks = 2048;       // persistent workgroups of the range scan (256 CUs x 8)
+  int opt_scan_items = 4096;        // target number of (tile, segment) work items
+  int opt_tile_q = 0;               // query copies per workgroup tile (0 = kernel default)
 
   // wrapped dimensions
   int n_wraps = 0;
