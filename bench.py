@@ -125,7 +125,8 @@ def main():
     d_nidx = torch.empty(B, dtype=torch.int32, device=dev)
     d_ndist = torch.empty(B, dtype=torch.float64, device=dev)
     d_unsafe = torch.empty(B, dtype=torch.uint8, device=dev)
-    words_per_rank = (2 * cap + 63) // 64
+    from rrtqx_3d_amd import parallel
+    words_per_rank = parallel.words_for(cap)
     d_bits = torch.zeros(world * words_per_rank, dtype=torch.int64, device=dev)
 
     def step():
@@ -134,10 +135,9 @@ def main():
                                   d_needed.data_ptr(), d_nidx.data_ptr(), d_ndist.data_ptr(), d_unsafe.data_ptr())
         if world > 1:
             # per-edge collision bitmask exchange: each rank fills its slice, one RCCL all-reduce
-            d_bits.zero_()
             ctx.pack_hits_dev(d_hout.data_ptr(), d_hin.data_ptr(), d_off.data_ptr() + 8 * B, cap,
                               d_bits.data_ptr() + 8 * rank * words_per_rank)
-            dist.all_reduce(d_bits, op=dist.ReduceOp.SUM)   # slices are disjoint: SUM == OR
+            parallel.exchange_hit_bitmasks(d_bits, rank, world, words_per_rank)   # disjoint slices: SUM == OR
 
     def fence():
         if world > 1:
@@ -163,14 +163,8 @@ def main():
     ctx.profile(False)
 
     # ---- aggregate over ranks ----------------------------------------------------
-    t_max, e_sum, q_sum = dt, edges_per_step, B
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max = float(t.item())
-        c = torch.tensor([edges_per_step, B], dtype=torch.int64, device=dev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        e_sum, q_sum = int(c[0].item()), int(c[1].item())
+    e_sum, t_max = parallel.reduce_throughput(edges_per_step, dt, device=dev)
+    q_sum = B * world
 
     if rank == 0:
         ms_step = 1e3 * t_max / args.steps

@@ -1,0 +1,116 @@
+"""The reference-named host interface (rrtqx_3d_amd/drrt.py) on the GPU, written the way the
+reference's own (commented) tests are: R/kdTree_general.jl:1039-1087 `testCase` inserts random
+points and compares kdFindNearest / kdFindWithinRange with the naive versions; :1089-1148
+`testGhost` does the same on R^2 x S^1.  The naive side here is the CPU oracle."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_testCase_kd_vs_naive(oracle):
+    from rrtqx_3d_amd.drrt import (KDTree, RRTNode, emptyRangeList, kdFindNearest, kdFindWithinRange, kdInsert,
+                                   kdInsertMany, popFromRangeList)
+    rng = np.random.default_rng(0)
+    d = 3
+    pts = rng.random((5000, d))
+    T = KDTree(d)
+    ref = oracle.KDTree(d)
+    kdInsert(T, RRTNode(pts[0]))                      # one-at-a-time insert, as the planner does
+    kdInsertMany(T, [RRTNode(p) for p in pts[1:]])    # and the batched form
+    ref.insert_many(pts)
+    assert T.treeSize == 5000 and T.root.index == 0
+    for query in rng.random((50, d)):
+        node, dist = kdFindNearest(T, query)
+        ni, nd = ref.nearest(query, naive=True)
+        assert node.index == ni and dist == nd
+        L = kdFindWithinRange(T, 0.1, query)
+        nidx, nkey = ref.range_naive(0.1, query)
+        assert L.length == len(nidx)
+        got = {n.data.index: n.key for n in L}
+        assert got == dict(zip(nidx.tolist(), nkey.tolist()))
+        assert all(n.data.inHeap for n in L)
+        if L.length:
+            node, key = popFromRangeList(L)
+            assert not node.inHeap
+        emptyRangeList(L)                             # the caller must clear the flags
+        assert L.length == 0 and not any(n.inHeap for n in T.nodes)
+
+
+def test_find_more_within_range_merges(oracle):
+    from rrtqx_3d_amd.drrt import KDTree, RRTNode, emptyRangeList, kdFindMoreWithinRange, kdFindWithinRange, kdInsert
+    T = KDTree(3)
+    for p in [[0, 0, 0], [1, 0, 0], [3, 0, 0]]:
+        kdInsert(T, RRTNode(p))
+    L = kdFindWithinRange(T, 1.5, [0, 0, 0])
+    kdFindMoreWithinRange(T, 2.5, [2, 0, 0], L)
+    got = {n.data.index: n.key for n in L}
+    assert got == {0: 0.0, 1: 1.0, 2: 1.0}            # node 1 keeps the key of its first discovery
+    emptyRangeList(L)
+
+
+def test_testGhost_wrapped_theta(oracle):
+    from rrtqx_3d_amd.drrt import KDTree, RRTNode, emptyRangeList, kdFindWithinRange, kdInsertMany
+    rng = np.random.default_rng(1)
+    two_pi = 2.0 * math.pi
+    pts = np.concatenate([rng.uniform(-5, 5, (4000, 2)), np.zeros((4000, 1)), rng.uniform(0, two_pi, (4000, 1))], 1)
+    T = KDTree(4, None, [4], [two_pi])                # wraps are 1-based dimension numbers (R/DRRT.jl:3312)
+    ref = oracle.KDTree(4, wraps=[3], wrap_points=[two_pi])
+    kdInsertMany(T, [RRTNode(p) for p in pts])
+    ref.insert_many(pts)
+    for q in pts[:40] + 0.01:
+        L = kdFindWithinRange(T, 2.0, q)
+        nidx, nkey = ref.range_naive(2.0, q)
+        assert {n.data.index: n.key for n in L} == dict(zip(nidx.tolist(), nkey.tolist()))
+        emptyRangeList(L)
+
+
+def test_cspace_edge_and_point_checks(oracle):
+    from rrtqx_3d_amd import synth
+    from rrtqx_3d_amd.drrt import (CSpace, RRTNode, SphereObstacle, addObsToCSpace, calculateTrajectory,
+                                   explicitEdgeCheck, explicitEdgeChecks, explicitNodeCheck, newEdge, validMove)
+    S = CSpace(3, -1.0, [-50] * 3, [50] * 3, [0] * 3, [1] * 3)
+    S.robotRadius = 0.5
+    sph = synth.spheres(16)
+    for row in sph:
+        addObsToCSpace(S, SphereObstacle(row[:3], row[3]))        # listPush: list order = reverse of this loop
+    list_order = sph[::-1]
+    osph, m = oracle.make_spheres(list_order)
+    rng = np.random.default_rng(2)
+    a = [RRTNode(p) for p in rng.uniform(-50, 50, (300, 3))]
+    b = [RRTNode(n.position + rng.normal(0, 4, (1, 3))) for n in a]
+    edges = [newEdge(x, y) for x, y in zip(a, b)]
+    hits = explicitEdgeChecks(S, edges)
+    for e, h in zip(edges, hits):
+        rh, _ = oracle.edge_check_spheres(osph, m, e.startNode.position, e.endNode.position, 0.5)
+        assert bool(h) == rh
+    e = edges[0]
+    calculateTrajectory(S, e)
+    assert e.dist == oracle.euclid(e.startNode.position, e.endNode.position) == e.distOriginal == e.Wdist
+    assert validMove(S, e)
+    # explicitEdgeCheck(S, edge, ob): one obstacle
+    ob = list(S.obstacles)[3]
+    one, m1 = oracle.make_spheres(list_order[3:4])
+    for e in edges[:50]:
+        assert explicitEdgeCheck(S, e, ob) == oracle.edge_check_spheres(one, m1, e.startNode.position,
+                                                                        e.endNode.position, 0.5)[0]
+    # obstacleUnused / warm-up behave like the reference (R/DRRT_Q.jl:1777, 1805)
+    ob.obstacleUnused = True
+    assert not any(explicitEdgeCheck(S, e, ob) for e in edges[:50])
+    u, c = explicitNodeCheck(S, a[0])
+    act = np.ones(16, dtype=np.uint8)
+    act[3] = 0
+    o2, m2 = oracle.make_spheres(list_order, act)
+    assert (u, c) == oracle.point_check_spheres(o2, m2, a[0].position, 0.5, quick=True)
+    S.inWarmupTime = True
+    assert not explicitEdgeChecks(S, edges).any()
+    assert explicitNodeCheck(S, a[0]) == (False, float("inf"))
+
+
+def test_error_idiom():
+    from rrtqx_3d_amd.drrt import KDTree, kdFindNearest
+    T = KDTree(3)
+    with pytest.raises(RuntimeError):      # the reference error()s; an empty tree is a state error here
+        kdFindNearest(T, [0, 0, 0])

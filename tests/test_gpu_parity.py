@@ -379,3 +379,27 @@ def test_dubins_edges_check(oracle):
         assert mism <= 2, mism
         assert len_mism <= ne // 100, len_mism
         assert 0 < hit.sum() < ne
+
+
+def test_pack_hits_layout():
+    """rrtx_pack_hits_dev (the payload of the multi-GPU bitmask all-reduce): bit e = hit_out[e],
+    bit cap+e = hit_in[e], entries at or beyond n_valid read 0."""
+    import torch
+    from rrtqx_3d_amd import parallel
+    cap, n_valid = 1000, 777
+    rng = np.random.default_rng(4)
+    ho = (rng.random(cap) < 0.4).astype(np.uint8)
+    hi = (rng.random(cap) < 0.4).astype(np.uint8)
+    dev = torch.device("cuda", 0)
+    d_ho, d_hi = torch.from_numpy(ho).to(dev), torch.from_numpy(hi).to(dev)
+    d_nv = torch.tensor([n_valid], dtype=torch.int64, device=dev)
+    words = torch.zeros(parallel.words_for(cap), dtype=torch.int64, device=dev)
+    with Context(3) as ctx:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.pack_hits_dev(d_ho.data_ptr(), d_hi.data_ptr(), d_nv.data_ptr(), cap, words.data_ptr())
+        ctx.sync()
+        ctx.set_stream(None)
+    flags = np.zeros(parallel.words_for(cap) * 64, dtype=np.uint8)
+    flags[:n_valid] = ho[:n_valid]
+    flags[cap:cap + n_valid] = hi[:n_valid]
+    assert np.array_equal(words.cpu().numpy(), np.packbits(flags, bitorder="little").view(np.int64))
