@@ -201,10 +201,21 @@ def main():
                 "kernel": "nn_scan_f32_kernel<3>" if args.nn_filter else "nn_scan_kernel<3>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": bytes_streamed, "tile_q": tile_q,
-                "valu_fp64_frac": valu_ops / (scan_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS,
+                "pairs_per_s": B * N / (scan_ms * 1e-3),
+                "valu_fp64_frac": (valu_ops / (scan_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS) if not args.nn_filter else None,
                 "note": "VALU-issue bound, node arrays are L2-resident (PMC traffic ~0.02 GB/launch); see DESIGN.md",
             },
         }
+        if world == 1:
+            # the same step through the host-pointer entry point (what a ccall from Julia pays):
+            # H2D of the samples, kernels, D2H of lists/costs/flags.  Reported, never `value`.
+            ctx.set_stream(None)
+            ctx.extend_candidates(Q, r, ROBOT_RADIUS, cap=cap)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                ctx.extend_candidates(Q, r, ROBOT_RADIUS, cap=cap)
+            out["host_buffer_path"] = {"edges_per_s": edges_per_step * 5 / (time.perf_counter() - t1),
+                                       "note": "PCIe-inclusive: host numpy in/out through rrtx_extend_candidates"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, pts, Q, sph, r)
         print(json.dumps(out))

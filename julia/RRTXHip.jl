@@ -1,0 +1,255 @@
+# RRTXHip.jl -- Julia-side drop-in for the RRT^X extend/rewire hot path of
+# jnetter6/RRTQX_3D, bound to librrtx_hip.so (include/rrtx.h) with ccall.
+#
+# Usage inside the reference (after its own includes, e.g. at the end of the
+# include list of experimentsForRRTQX.jl):
+#
+#     include("DRRT_data_structures.jl"); include("jlist.jl"); ...   # unchanged reference files
+#     include("/path/to/julia/RRTXHip.jl")
+#     KD = HipTree{RRTNode{Float64}}(3)                 # instead of KDTree{RRTNode{Float64}}(d, KDdist)
+#
+# Every method below has the name, arity and return shape of the reference
+# function it replaces, so extend()/findBestParent()/addNewObstacle() run
+# unchanged on a HipTree.  NOTE: Julia is not installed in the build image, so
+# this file has been written against Julia 1.0 semantics but not executed; the
+# same C-ABI is exercised through ctypes by tests/ (rrtqx_3d_amd/_capi.py).
+
+const LIBRRTX = get(ENV, "RRTX_HIP_LIB", "librrtx_hip.so")
+
+const RRTX_OK = Cint(0)
+const RRTX_E_CAPACITY = Cint(-2)
+
+mutable struct HipTree{T}
+  d::Int                       # fields the planner reads (R/rrtqx.jl:382, R/DRRT_Q.jl:2624,2631)
+  treeSize::Int
+  numWraps::Int
+  root::T
+  ctx::Ptr{Cvoid}
+  nodes::Vector{T}             # device index (0-based) + 1 -> node; the reference has no node ids
+  obsSig::UInt64               # signature of the obstacle list last uploaded
+
+  function HipTree{T}(d::Int; device::Int = 0, capacity::Int = 1 << 16) where {T}
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:rrtx_create, LIBRRTX), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Int64), ref, d, device, capacity)
+    rc == RRTX_OK || error(unsafe_string(ccall((:rrtx_create_error, LIBRRTX), Cstring, ())))
+    t = new{T}(d, 0, 0)
+    t.ctx = ref[]
+    t.nodes = Vector{T}()
+    t.obsSig = UInt64(0)
+    finalizer(x -> ccall((:rrtx_destroy, LIBRRTX), Cint, (Ptr{Cvoid},), x.ctx), t)
+    return t
+  end
+end
+
+# KDTree{T}(d, f, wraps, wrapPoints)  (R/kdTree_general.jl:108); wraps are 1-based dimensions
+function HipTree{T}(d::Int, f::Function, wraps::Array{Int}, wrapPoints::Array{Float64}) where {T}
+  t = HipTree{T}(d)
+  for i = 1:length(wraps)
+    rrtx_check(t, ccall((:rrtx_set_wrap, LIBRRTX), Cint, (Ptr{Cvoid}, Cint, Cdouble), t.ctx, wraps[i] - 1, wrapPoints[i]))
+  end
+  t.numWraps = length(wraps)
+  return t
+end
+HipTree{T}(d::Int, f::Function) where {T} = HipTree{T}(d)
+
+# non-zero status -> error(), the reference's only failure idiom (R/rrtqx.jl:70,91)
+function rrtx_check(t::HipTree, rc::Cint)
+  rc == RRTX_OK && return
+  error(unsafe_string(ccall((:rrtx_last_error, LIBRRTX), Cstring, (Ptr{Cvoid},), t.ctx)))
+end
+
+# ---------------------------------------------------------------------------
+# kdInsert (R/kdTree_general.jl:121-170)
+function kdInsert(tree::HipTree{T}, node::T) where {T}
+  if node.kdInTree
+    return
+  end
+  node.kdInTree = true
+  pos = vec(convert(Array{Float64}, node.position))          # 1 x d row -> d contiguous doubles
+  first = Ref{Int64}(0)
+  GC.@preserve pos rrtx_check(tree, ccall((:rrtx_nodes_append, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Ref{Int64}), tree.ctx, pos, 1, first))
+  push!(tree.nodes, node)
+  if tree.treeSize == 0
+    tree.root = node
+  end
+  tree.treeSize += 1
+end
+
+# kdFindNearest (R/kdTree_general.jl:357-385) -> (node, dist)
+function kdFindNearest(tree::HipTree{T}, queryPoint::Array{Float64}) where {T}
+  q = vec(queryPoint)
+  idx = Ref{Int32}(0); dist = Ref{Float64}(0.0)
+  GC.@preserve q rrtx_check(tree, ccall((:rrtx_nn_nearest, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Int32}, Ref{Float64}), tree.ctx, q, 1, idx, dist))
+  return (tree.nodes[idx[] + 1], dist[])
+end
+
+# addToRangeList (R/kdTree_general.jl:765-771)
+function addToRangeList(S::Tlist, thisNode::T, key::Float64) where {Tlist, T}
+  if thisNode.inHeap
+    return
+  end
+  thisNode.inHeap = true
+  JlistPush(S, thisNode, key)
+end
+
+# kdFindMoreWithinRange (R/kdTree_general.jl:927-955): neighbours are appended to L with
+# key = distance; membership and keys equal the reference's, list order is by node index.
+function kdFindMoreWithinRange(tree::HipTree{T}, range::Float64, queryPoint::Array{Float64}, L::TL) where {T, TL}
+  q = vec(queryPoint)
+  r = [range]
+  offsets = Vector{Int64}(undef, 2)
+  cap = 256
+  while true
+    idx = Vector{Int32}(undef, cap); dist = Vector{Float64}(undef, cap)
+    needed = Ref{Int64}(0)
+    rc = GC.@preserve q r offsets idx dist ccall((:rrtx_nn_radius, LIBRRTX), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Ptr{Int64}, Ptr{Int32}, Ptr{Cdouble}, Int64, Ref{Int64}),
+        tree.ctx, q, r, 0, 1, offsets, idx, dist, cap, needed)
+    if rc == RRTX_E_CAPACITY            # two-call pattern: retry with the size the library reports
+      cap = Int(needed[])
+      continue
+    end
+    rrtx_check(tree, rc)
+    for k = Int(needed[]):-1:1           # push in reverse so the list reads in ascending index order
+      addToRangeList(L, tree.nodes[idx[k] + 1], dist[k])
+    end
+    return L
+  end
+end
+
+# kdFindWithinRange (R/kdTree_general.jl:889-919)
+function kdFindWithinRange(tree::HipTree{T}, range::Float64, queryPoint::Array{Float64}) where {T}
+  L = JList{T}()
+  return kdFindMoreWithinRange(tree, range, queryPoint, L)
+end
+# popFromRangeList / emptyRangeList (R/kdTree_general.jl:774-787) work on the JList unchanged.
+
+# ---------------------------------------------------------------------------
+# obstacle list upload: CSpace.obstacles in list order (front first, R/list.jl:53-58)
+function syncObstacles(tree::HipTree, S::TS) where {TS}
+  m = S.obstacles.length
+  cxyzr = Array{Float64}(undef, 4, m)       # column-major 4 x m == row-major m x 4 on the C side
+  active = Vector{UInt8}(undef, m)
+  sig = UInt64(m)
+  ptr = S.obstacles.front
+  for i = 1:m
+    ob = ptr.data
+    cxyzr[1:3, i] = ob.position[1:3]
+    cxyzr[4, i] = ob.radius
+    active[i] = (ob.obstacleUnused || ob.lifeSpan <= 0) ? 0x00 : 0x01   # R/DRRT_Q.jl:1777
+    sig = hash((objectid(ob), ob.radius, active[i]), sig)
+    ptr = ptr.child
+  end
+  if sig != tree.obsSig
+    GC.@preserve cxyzr active rrtx_check(tree, ccall((:rrtx_spheres_set, LIBRRTX), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{UInt8}, Cint), tree.ctx, cxyzr, active, m))
+    tree.obsSig = sig
+  end
+end
+
+# explicitEdgeCheck(C, edge) (R/DRRT_Q.jl:1802-1826) for SimpleEdge on sphere obstacles.
+# The tree travels in a global per agent because the reference signature has no tree argument.
+const HIP_TREE_OF = IdDict{Any, Any}()          # CSpace -> HipTree (set once per agent)
+bindTree(S, tree::HipTree) = (HIP_TREE_OF[S] = tree)
+
+function explicitEdgeCheckHip(S::TS, startPos::Array{Float64}, endPos::Array{Float64}, which::Int) where {TS}
+  tree = HIP_TREE_OF[S]
+  syncObstacles(tree, S)
+  p0 = vec(startPos); p1 = vec(endPos)
+  hit = Ref{UInt8}(0)
+  GC.@preserve p0 p1 rrtx_check(tree, ccall((:rrtx_edges_check, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cint, Ref{UInt8}, Ptr{Int32}),
+      tree.ctx, 0, p0, p1, 1, S.robotRadius, which, hit, C_NULL))
+  return hit[] != 0x00
+end
+
+function explicitEdgeCheck(S::CSpace{T}, edge::SimpleEdge, verbose::Bool = false) where {T}
+  if S.inWarmupTime                                # R/DRRT_Q.jl:1805-1807
+    return false
+  end
+  return explicitEdgeCheckHip(S, edge.startNode.position, edge.endNode.position, -1)
+end
+
+# explicitEdgeCheck(S, edge, obstacle) (R/DRRT_SimpleEdge_functions.jl:210-212)
+function explicitEdgeCheck(S::CSpace{T}, edge::SimpleEdge, obstacle::SphereObstacle) where {T}
+  which = -1
+  ptr = S.obstacles.front
+  for i = 1:S.obstacles.length
+    if ptr.data === obstacle
+      which = i - 1
+      break
+    end
+    ptr = ptr.child
+  end
+  which >= 0 || error("obstacle is not in CSpace.obstacles")
+  return explicitEdgeCheckHip(S, edge.startNode.position, edge.endNode.position, which)
+end
+
+# explicitPointCheck (R/DRRT_Q.jl:1520-1556) -> (Bool, Float64)
+function explicitPointCheck(S::CSpace{T}, point::Array{Float64}) where {T}
+  if S.inWarmupTime
+    return (false, Inf)
+  end
+  tree = HIP_TREE_OF[S]
+  syncObstacles(tree, S)
+  p = vec(point)
+  unsafe = Ref{UInt8}(0); clr = Ref{Float64}(0.0)
+  GC.@preserve p rrtx_check(tree, ccall((:rrtx_points_check, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Int64, Cdouble, Cint, Ref{UInt8}, Ref{Float64}),
+      tree.ctx, 0, p, 1, S.robotRadius, 1, unsafe, clr))
+  return (unsafe[] != 0x00, clr[])
+end
+
+# calculateTrajectory(S, ::SimpleEdge) (R/DRRT_SimpleEdge_functions.jl:177-181)
+function calculateTrajectory(S::TS, edge::SimpleEdge) where {TS}
+  tree = HIP_TREE_OF[S]
+  s = vec(edge.startNode.position); g = vec(edge.endNode.position)
+  d = Ref{Float64}(0.0); w = Ref{Float64}(0.0)
+  GC.@preserve s g rrtx_check(tree, ccall((:rrtx_simple_steer, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Ref{Float64}, Ref{Float64}), tree.ctx, s, g, 1, d, w))
+  edge.dist = d[]
+  edge.distOriginal = edge.dist
+  edge.Wdist = w[]
+end
+
+# ---------------------------------------------------------------------------
+# Batched preamble of extend()/findBestParent (R/DRRT_Q.jl:1927-1979, 2546-2642): one call per
+# batch of samples returns, per sample, the neighbour list with SimpleEdge costs and both directed
+# collision flags, the nearest node and the sample's own point check.  findBestParent/extend then
+# only do their list and heap bookkeeping.
+struct ExtendCandidates
+  offsets::Vector{Int64}      # nq + 1
+  idx::Vector{Int32}          # 0-based node indices (tree.nodes[idx + 1])
+  cost::Vector{Float64}       # edge.dist for both directions (SimpleEdge)
+  hitOut::Vector{UInt8}       # explicitEdgeCheck(newNode -> near)
+  hitIn::Vector{UInt8}        # explicitEdgeCheck(near -> newNode)
+  nearestIdx::Vector{Int32}
+  nearestDist::Vector{Float64}
+  sampleUnsafe::Vector{UInt8}
+end
+
+function extend_candidates(tree::HipTree, S::TS, positions::Array{Float64,2}, hyberBallRad::Float64) where {TS}
+  syncObstacles(tree, S)
+  nq = size(positions, 2)                     # d x nq, each sample contiguous
+  offsets = Vector{Int64}(undef, nq + 1)
+  nidx = Vector{Int32}(undef, nq); ndist = Vector{Float64}(undef, nq); unsafe = Vector{UInt8}(undef, nq)
+  cap = 64 * nq
+  while true
+    idx = Vector{Int32}(undef, cap); cost = Vector{Float64}(undef, cap)
+    hout = Vector{UInt8}(undef, cap); hin = Vector{UInt8}(undef, cap)
+    needed = Ref{Int64}(0)
+    rc = GC.@preserve positions offsets idx cost hout hin nidx ndist unsafe ccall((:rrtx_extend_candidates, LIBRRTX), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cdouble, Cdouble, Ptr{Int64}, Ptr{Int32}, Ptr{Cdouble}, Ptr{UInt8}, Ptr{UInt8},
+         Int64, Ref{Int64}, Ptr{Int32}, Ptr{Cdouble}, Ptr{UInt8}),
+        tree.ctx, positions, nq, hyberBallRad, S.robotRadius, offsets, idx, cost, hout, hin, cap, needed, nidx, ndist, unsafe)
+    if rc == RRTX_E_CAPACITY
+      cap = Int(needed[])
+      continue
+    end
+    rrtx_check(tree, rc)
+    n = Int(needed[])
+    return ExtendCandidates(offsets, idx[1:n], cost[1:n], hout[1:n], hin[1:n], nidx, ndist, unsafe)
+  end
+end
