@@ -1,0 +1,146 @@
+"""BASELINE.json's full-size configurations on the GPU.  The oracle cannot run whole batches at
+these sizes in seconds, so parity is established through (1) size-independent properties of the
+domain, (2) bit-identity of the two independent device paths (fp32-screened vs exact fp64 scan),
+(3) oracle spot checks on a random subset of the batch."""
+import math
+
+import numpy as np
+import pytest
+
+from rrtqx_3d_amd import _capi, synth
+from rrtqx_3d_amd.context import Context
+
+pytestmark = pytest.mark.gpu
+ROBOT_RADIUS = 0.5
+
+
+def _lists(off, idx):
+    return [idx[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+@pytest.mark.parametrize("cfg_name", ["C4", "C5"])
+def test_radius_full_size_properties(oracle, cfg_name):
+    cfg = synth.CONFIGS[cfg_name]
+    N, B = cfg.n_nodes, cfg.batch
+    pts = synth.nodes(N, 3)
+    r = synth.ball_radius(N, 3)
+    Q = synth.queries(B, 3)
+    with Context(3, node_capacity=N) as ctx:
+        ctx.nodes_append(pts)
+        off, idx, dist = ctx.nn_radius(Q, r)
+        # (2) the exact fp64 scan gives the identical CSR (different kernel, same contract)
+        ctx.set_option(_capi.RRTX_OPT_NN_FILTER, 0)
+        off0, idx0, dist0 = ctx.nn_radius(Q, r)
+        ctx.set_option(_capi.RRTX_OPT_NN_FILTER, 1)
+        assert np.array_equal(off, off0) and np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+        # (1a) every list is strictly ascending in node index, every key is < r and equals the metric
+        owner = np.repeat(np.arange(B), np.diff(off))
+        assert (dist < r).all()
+        d = Q[owner] - pts[idx]
+        ref = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+        assert np.array_equal(dist, ref)
+        same = owner[1:] == owner[:-1]
+        assert (idx[1:][same] > idx[:-1][same]).all()
+        # (1b) expected neighbour count k = N * (4/3) pi r^3 / V within 5 %
+        k_mean = len(idx) / B
+        k_exp = N * (4.0 / 3.0) * math.pi * r ** 3 / 100.0 ** 3
+        assert 0.8 * k_exp < k_mean < 1.05 * k_exp          # boundary clipping lowers it slightly
+        # (1c) symmetry: querying at node positions, j in N(i) <=> i in N(j)
+        sub = np.arange(0, 2048)
+        offs, idxs, _ = ctx.nn_radius(pts[sub], r)
+        nb = _lists(offs, idxs)
+        sets = [set(x.tolist()) for x in nb]
+        for i in range(len(sub)):
+            assert i in sets[i]                              # a node finds itself (dist 0 < r)
+            for j in nb[i]:
+                if j < len(sub):
+                    assert i in sets[j]
+        # (3) oracle spot check on 48 random samples of the batch
+        tree = oracle.KDTree(3)
+        tree.insert_many(pts)
+        rng = np.random.default_rng(0)
+        for i in rng.choice(B, 48, replace=False):
+            ri, rk = tree.within_range(r, Q[i])
+            o = np.argsort(ri)
+            assert np.array_equal(idx[off[i]:off[i + 1]], ri[o]) and np.array_equal(dist[off[i]:off[i + 1]], rk[o])
+            ni, nd = tree.nearest(Q[i])
+            if off[i + 1] > off[i]:
+                k = off[i] + np.argmin(dist[off[i]:off[i + 1]])
+                assert idx[k] == ni and dist[k] == nd
+
+
+def test_extend_candidates_c4_full(oracle):
+    cfg = synth.CONFIGS["C4"]
+    N, M, B = cfg.n_nodes, cfg.n_obstacles, cfg.batch
+    pts = synth.nodes(N, 3)
+    sph = synth.spheres(M)
+    r = synth.ball_radius(N, 3)
+    Q = synth.queries(B, 3)
+    osph, m = oracle.make_spheres(sph)
+    with Context(3, node_capacity=N) as ctx:
+        ctx.nodes_append(pts)
+        ctx.spheres_set(sph)
+        out = ctx.extend_candidates(Q, r, ROBOT_RADIUS)
+        off, idx = out["offsets"], out["idx"]
+        n = len(idx)
+        assert n == off[-1] > 10 * B
+        # the fused call agrees with the generic edge kernel on the same edges (different kernel)
+        p0, p1 = synth.candidate_edges(Q, pts, off, idx)
+        hit, first = ctx.edges_check(p0, p1, ROBOT_RADIUS)
+        assert np.array_equal(out["hit_out"], hit[:n]) and np.array_equal(out["hit_in"], hit[n:])
+        # a colliding edge names an obstacle that really is within reach of the segment
+        hh = np.nonzero(hit)[0]
+        c = sph[first[hh], :3]
+        mid = 0.5 * (p0[hh] + p1[hh])
+        L = np.linalg.norm(p1[hh] - p0[hh], axis=1)
+        assert (np.linalg.norm(c - mid, axis=1) <= 0.5 * L + ROBOT_RADIUS + sph[first[hh], 3] + 1e-9).all()
+        # end points inside an inflated sphere always collide (t clamps onto the segment)
+        # oracle spot check on 4096 random directed edges
+        rng = np.random.default_rng(1)
+        pick = rng.choice(2 * n, 4096, replace=False)
+        rh, rf = oracle.edges_check_spheres(osph, m, p0[pick], p1[pick], ROBOT_RADIUS)
+        assert np.array_equal(hit[pick], rh) and np.array_equal(first[pick], rf)
+        # sample point checks vs oracle on a subset
+        ru, _ = oracle.points_check_spheres(osph, m, Q[:2048], ROBOT_RADIUS, quick=True)
+        assert np.array_equal(out["sample_unsafe"][:2048], ru)
+
+
+def test_c3_dubins_full(oracle):
+    cfg = synth.CONFIGS["C3"]
+    N, M, B = cfg.n_nodes, cfg.n_obstacles, cfg.batch
+    pts = synth.nodes(N, 4)
+    Q = synth.queries(B, 4)
+    r = synth.ball_radius(N, 4, gamma=100.0, delta=10.0)      # R/dubinsExperimentsForPaper.jl:102
+    assert r == 10.0
+    polys = synth.polygons(M)
+    ps = oracle.PolygonSet(polys)
+    with Context(4, node_capacity=N) as ctx:
+        ctx.set_wrap(3, 2.0 * math.pi)
+        ctx.nodes_append(pts)
+        ctx.polygons_set(polys)
+        off, idx, dist = ctx.nn_radius(Q, r)
+        ctx.set_option(_capi.RRTX_OPT_NN_FILTER, 0)
+        off0, idx0, dist0 = ctx.nn_radius(Q, r)
+        ctx.set_option(_capi.RRTX_OPT_NN_FILTER, 1)
+        assert np.array_equal(off, off0) and np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+        tree = oracle.KDTree(4, wraps=[3], wrap_points=[2.0 * math.pi])
+        tree.insert_many(pts)
+        rng = np.random.default_rng(2)
+        for i in rng.choice(B, 32, replace=False):
+            ri, rk = tree.within_range(r, Q[i])
+            o = np.argsort(ri)
+            assert np.array_equal(idx[off[i]:off[i + 1]], ri[o]) and np.array_equal(dist[off[i]:off[i + 1]], rk[o])
+        # candidate Dubins edges of the first 64 samples: steer + two-stage check vs oracle
+        sel = np.arange(64)
+        owner = np.repeat(sel, np.diff(off)[sel])
+        nb = np.concatenate([idx[off[i]:off[i + 1]] for i in sel])
+        s, g = Q[owner], pts[nb]
+        cost, word, hit, tl = ctx.dubins_edges_check(s, g, 1.0, ROBOT_RADIUS)
+        step = max(1, len(s) // 400)
+        mism = 0
+        for k in range(0, len(s), step):
+            c, w, traj = oracle.dubins_steer(s[k], g[k], 1.0)
+            h, _ = oracle.dubins_edge_check_polygons(ps, s[k], g[k], traj, ROBOT_RADIUS, 1.0)
+            assert abs(cost[k] - c) <= 1e-6 * max(1.0, abs(c))          # north_star tolerance
+            mism += (bool(hit[k]) != h)
+        assert mism <= 1
