@@ -142,6 +142,14 @@ int rrtx_nn_radius(rrtx_ctx *ctx, const double *q, const double *r, int r_stride
  * first colliding obstacle or -1 (may be NULL). */
 int rrtx_edges_check(rrtx_ctx *ctx, int kind, const double *p0, const double *p1, int64_t ne,
                      double robot_radius, int obstacle_or_minus1, uint8_t *hit, int32_t *first_hit);
+/* The same test for edges given as NODE INDEX pairs (the planner's graph edges), as the obstacle
+ * sweeps need it: addNewObstacle tests every out-edge of the nodes near a new obstacle against
+ * that one obstacle (R/DRRT_Q.jl:3220-3290: obstacle_or_minus1 = its list position); removeObstacle
+ * re-tests freed edges against the OTHER obstacles that are active in their time window
+ * (R/DRRT_Q.jl:3321-3337: obstacle_mask[i] != 0 selects them; NULL = all).  Sphere list only. */
+int rrtx_edges_check_idx(rrtx_ctx *ctx, const int32_t *start_idx, const int32_t *end_idx, int64_t ne,
+                         double robot_radius, int obstacle_or_minus1, const uint8_t *obstacle_mask,
+                         uint8_t *hit, int32_t *first_hit);
 /* explicitPointCheck (R/DRRT_Q.jl:1520-1556; quick=0: explicitPointCheck3D,
  * :1558-1590).  unsafe[i] in {0,1}; clearance[i] = the returned certificate
  * (0.0 when unsafe). kind as above. */

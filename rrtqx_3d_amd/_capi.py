@@ -74,6 +74,7 @@ SYMBOLS = [
     ("rrtx_nn_nearest", C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     ("rrtx_nn_radius", C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP, C.c_int64, c_int64_p]),
     ("rrtx_edges_check", C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP]),
+    ("rrtx_edges_check_idx", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP, _VP]),
     ("rrtx_points_check", C.c_int, [_VP, C.c_int, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP]),
     ("rrtx_simple_steer", C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP]),
     ("rrtx_dubins_steer", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP]),

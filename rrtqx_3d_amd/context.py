@@ -259,3 +259,16 @@ class Context:
 
     def pack_hits_dev(self, hit_out_ptr: int, hit_in_ptr: int, n_valid_ptr: int, cap: int, words_ptr: int):
         self._check(self._lib.rrtx_pack_hits_dev(self._h, hit_out_ptr, hit_in_ptr, n_valid_ptr, cap, words_ptr))
+
+    def edges_check_idx(self, start_idx, end_idx, robot_radius: float, obstacle: int = -1, obstacle_mask=None,
+                        want_first: bool = True):
+        """Edges as node-index pairs (obstacle sweeps, R/DRRT_Q.jl:3220-3362)."""
+        s = np.ascontiguousarray(start_idx, dtype=np.int32)
+        e = np.ascontiguousarray(end_idx, dtype=np.int32)
+        ne = s.shape[0]
+        hit = np.empty(ne, dtype=np.uint8)
+        first = np.empty(ne, dtype=np.int32) if want_first else None
+        mask = None if obstacle_mask is None else np.ascontiguousarray(obstacle_mask, dtype=np.uint8)
+        self._check(self._lib.rrtx_edges_check_idx(self._h, _capi._ptr(s), _capi._ptr(e), ne, robot_radius, obstacle,
+                                                   _capi._ptr(mask), _capi._ptr(hit), _capi._ptr(first)))
+        return hit, first

@@ -59,10 +59,19 @@ __device__ __forceinline__ bool may_touch(const EdgeReach &r, const SphRec &b) {
   return !(dm2 > bound * bound);
 }
 
+// Edges are given either as positions (p0/p1, `stride` doubles per point) or, when sidx != NULL,
+// as node index pairs into the node SoA (the planner's graph edges in obstacle sweeps).
+// maskp (optional, one byte per packed obstacle) restricts the test to obstacles with mask != 0.
 __global__ __launch_bounds__(256) void edges_spheres_kernel(const double *__restrict__ p0,
                                                             const double *__restrict__ p1, int stride,
+                                                            const int32_t *__restrict__ sidx,
+                                                            const int32_t *__restrict__ eidx,
+                                                            const double *__restrict__ nx,
+                                                            const double *__restrict__ ny,
+                                                            const double *__restrict__ nz,
                                                             long long ne, const SphRec *__restrict__ sph,
                                                             const SphRec *__restrict__ reach,
+                                                            const uint8_t *__restrict__ maskp,
                                                             const int32_t *__restrict__ orig, int m_begin,
                                                             int m_end, uint8_t *__restrict__ hit,
                                                             int32_t *__restrict__ first_hit) {
@@ -70,8 +79,14 @@ __global__ __launch_bounds__(256) void edges_spheres_kernel(const double *__rest
   const bool act = i < ne;
   double ax = 0, ay = 0, az = 0, ex = 0, ey = 0, ez = 0;
   if (act) {
-    ax = p0[i * stride + 0]; ay = p0[i * stride + 1]; az = p0[i * stride + 2];
-    ex = p1[i * stride + 0]; ey = p1[i * stride + 1]; ez = p1[i * stride + 2];
+    if (sidx) {
+      const int a = sidx[i], b = eidx[i];
+      ax = nx[a]; ay = ny[a]; az = nz[a];
+      ex = nx[b]; ey = ny[b]; ez = nz[b];
+    } else {
+      ax = p0[i * stride + 0]; ay = p0[i * stride + 1]; az = p0[i * stride + 2];
+      ex = p1[i * stride + 0]; ey = p1[i * stride + 1]; ez = p1[i * stride + 2];
+    }
   }
   const double bx = ex - ax, by = ey - ay, bz = ez - az;
   const double edge_len = sqrt_rn(sq3(ax, ay, az, ex, ey, ez));
@@ -89,7 +104,9 @@ __global__ __launch_bounds__(256) void edges_spheres_kernel(const double *__rest
     bool anyc = false;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      cand[g] = !done && (j0 + g < m_end) && may_touch(er, rb[g]);
+      const int jj = min(j0 + g, m_end - 1);
+      const bool allowed = (j0 + g < m_end) && (maskp == nullptr || maskp[jj] != 0);
+      cand[g] = !done && allowed && may_touch(er, rb[g]);
       anyc = anyc || cand[g];
     }
     if (__ballot(anyc) == 0ull) continue;
@@ -558,10 +575,22 @@ static int zero_outputs(rrtx_ctx *ctx, int64_t ne, uint8_t *hit_dev, int32_t *fi
 
 int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
                          double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
-                         uint8_t *hit_dev, int32_t *first_hit_dev) {
+                         uint8_t *hit_dev, int32_t *first_hit_dev, const int32_t *sidx_dev,
+                         const int32_t *eidx_dev, const uint8_t *mask_host) {
   if (ne <= 0) return RRTX_OK;
   int rc = sync_spheres(ctx, robot_radius);
   if (rc) return rc;
+  const uint8_t *maskp = nullptr;
+  if (mask_host) {
+    // list-order mask -> packed (active-only) order, uploaded per call
+    std::vector<int32_t> pos = active_positions(ctx->sph_active);
+    std::vector<uint8_t> packed(pos.size() + 1, 0);
+    for (size_t k = 0; k < pos.size(); ++k) packed[k] = mask_host[pos[k]] ? 1 : 0;
+    RRTX_HIP(ctx, ctx->ws_mask.ensure(packed.size()));
+    RRTX_HIP(ctx, hipMemcpyAsync(ctx->ws_mask.p, packed.data(), packed.size(), hipMemcpyHostToDevice, ctx->stream));
+    RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `packed` is a local
+    maskp = ctx->ws_mask.as<uint8_t>();
+  }
   const int m = (int)ctx->sph_active.size();
   if (obstacle_or_minus1 >= m) return fail(ctx, RRTX_E_INVALID, "obstacle index %d out of range (%d spheres)", obstacle_or_minus1, m);
   if (obstacle_or_minus1 >= 0) { obs_begin = obstacle_or_minus1; obs_end = obstacle_or_minus1 + 1; }
@@ -572,7 +601,8 @@ int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_d
   if (pe <= pb) return zero_outputs(ctx, ne, hit_dev, first_hit_dev);
   span_begin(ctx, KF_EDGES);
   hipLaunchKernelGGL(edges_spheres_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
-                     p1_dev, ctx->dim, (long long)ne, ctx->d_sph.as<SphRec>(), ctx->d_sph_reach.as<SphRec>(), sph_orig_dev(ctx), pb, pe, hit_dev,
+                     p1_dev, ctx->dim, sidx_dev, eidx_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], (long long)ne,
+                     ctx->d_sph.as<SphRec>(), ctx->d_sph_reach.as<SphRec>(), maskp, sph_orig_dev(ctx), pb, pe, hit_dev,
                      first_hit_dev);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());

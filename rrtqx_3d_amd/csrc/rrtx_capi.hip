@@ -266,7 +266,7 @@ int rrtx_destroy(rrtx_ctx *ctx) {
                     &ctx->d_poly_orig, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
                     &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_scalars, &ctx->ws_tmp_idx,
                     &ctx->ws_tmp_d2, &ctx->ws_owner, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
-                    &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr};
+                    &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr, &ctx->ws_mask, &ctx->ws_i32a, &ctx->ws_i32b};
   for (auto b : bufs) b->release();
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -556,6 +556,34 @@ int rrtx_edges_check(rrtx_ctx *ctx, int kind, const double *p0, const double *p1
   rc = rrtx_edges_check_dev(ctx, kind, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>(), ne, robot_radius,
                             obstacle_or_minus1, -1, -1, ctx->ws_out_u8a.as<uint8_t>(),
                             first_hit ? ctx->ws_out_i32.as<int32_t>() : nullptr);
+  if (rc) return rc;
+  RRTX_HIP(ctx, hipMemcpyAsync(hit, ctx->ws_out_u8a.p, (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  if (first_hit)
+    RRTX_HIP(ctx, hipMemcpyAsync(first_hit, ctx->ws_out_i32.p, sizeof(int32_t) * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
+int rrtx_edges_check_idx(rrtx_ctx *ctx, const int32_t *start_idx, const int32_t *end_idx, int64_t ne,
+                         double robot_radius, int obstacle_or_minus1, const uint8_t *obstacle_mask, uint8_t *hit,
+                         int32_t *first_hit) {
+  CHECK_CTX(ctx);
+  if (ne < 0 || (ne > 0 && (!start_idx || !end_idx || !hit)))
+    return fail(ctx, RRTX_E_INVALID, "edges_check_idx: bad arguments");
+  if (ne == 0) return RRTX_OK;
+  for (int64_t i = 0; i < ne; ++i)
+    if (start_idx[i] < 0 || start_idx[i] >= ctx->n_nodes || end_idx[i] < 0 || end_idx[i] >= ctx->n_nodes)
+      return fail(ctx, RRTX_E_INVALID, "edges_check_idx: edge %lld references a node outside [0, %lld)",
+                  (long long)i, (long long)ctx->n_nodes);
+  int rc = stage_in(ctx, ctx->ws_i32a, start_idx, sizeof(int32_t) * (size_t)ne);
+  if (rc) return rc;
+  rc = stage_in(ctx, ctx->ws_i32b, end_idx, sizeof(int32_t) * (size_t)ne);
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_u8a.ensure((size_t)ne));
+  RRTX_HIP(ctx, ctx->ws_out_i32.ensure(sizeof(int32_t) * (size_t)ne));
+  rc = launch_edges_spheres(ctx, nullptr, nullptr, ne, robot_radius, obstacle_or_minus1, -1, -1,
+                            ctx->ws_out_u8a.as<uint8_t>(), first_hit ? ctx->ws_out_i32.as<int32_t>() : nullptr,
+                            ctx->ws_i32a.as<int32_t>(), ctx->ws_i32b.as<int32_t>(), obstacle_mask);
   if (rc) return rc;
   RRTX_HIP(ctx, hipMemcpyAsync(hit, ctx->ws_out_u8a.p, (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
   if (first_hit)

@@ -125,6 +125,8 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_out_off, ws_out_idx, ws_out_dist, ws_out_u8a, ws_out_u8b, ws_out_i32, ws_out_f64;
   rrtx::DevBuf ws_partial;  // nearest partials
   rrtx::DevBuf ws_thr;      // per-query thresholds
+  rrtx::DevBuf ws_mask;     // per-call obstacle mask (packed order)
+  rrtx::DevBuf ws_i32a, ws_i32b;  // staged index arrays
 
   // radius -> threshold cache
   double thr_cache_r = -1.0, thr_cache_lt = 0.0, thr_cache_gt = 0.0;
@@ -169,7 +171,8 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_or_
 int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev);
 int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
                          double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
-                         uint8_t *hit_dev, int32_t *first_hit_dev);
+                         uint8_t *hit_dev, int32_t *first_hit_dev, const int32_t *sidx_dev = nullptr,
+                         const int32_t *eidx_dev = nullptr, const uint8_t *mask_host = nullptr);
 int launch_edges_polygons(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
                           double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
                           uint8_t *hit_dev, int32_t *first_hit_dev);

@@ -493,3 +493,52 @@ def extend_candidates(tree: HipTree, S: CSpace, newPositions, hyberBallRad_: flo
         out["hit_in"][:] = 0
         out["sample_unsafe"][:] = 0
     return out
+
+
+# ------------------------------------------------------- obstacle sweeps ----
+def findPointsInConflictWithObstacle(S: CSpace, KD: HipTree, ob, root=None) -> JList:
+    """R/DRRT_Q.jl:3195-3215: nodes within robotRadius + delta + ob.radius of the obstacle."""
+    if S.spaceHasTime:
+        error("this type of obstacle not coded for this type of space")
+    if not S.spaceHasTheta:
+        searchRange = S.robotRadius + S.delta + ob.radius
+        return kdFindWithinRange(KD, searchRange, ob.position)
+    searchRange = S.robotRadius + S.delta + ob.radius + math.pi        # Dubins [x y 0 theta]
+    centre = np.array([ob.position[0], ob.position[1], 0.0, math.pi])
+    return kdFindWithinRange(KD, searchRange, centre)
+
+
+def _list_position(S: CSpace, ob) -> int:
+    for i, o in enumerate(S.obstacles):
+        if o is ob:
+            return i
+    error("obstacle is not in CSpace.obstacles")
+
+
+def obstacleSweepEdgeChecks(S: CSpace, KD: HipTree, edges: Sequence[SimpleEdge], ob=None, others_of=None,
+                            timeElapsed: Optional[float] = None) -> np.ndarray:
+    """Batched body of the edge loops in addNewObstacle / removeObstacle (R/DRRT_Q.jl:3220-3362).
+
+      ob given        -> explicitEdgeCheck(S, edge, ob) for every edge (addNewObstacle :3248, :3257;
+                         first test of removeObstacle :3321)
+      others_of given -> "conflictsWithOtherObs": any obstacle other than `others_of` that is not
+                         unused and, when timeElapsed is given, inside its time window
+                         startTime <= timeElapsed <= startTime + lifeSpan (:3326-3337)
+    Edges are graph edges between nodes already in the tree; only their node indices travel."""
+    if not edges:
+        return np.zeros(0, dtype=bool)
+    S.bind(KD)
+    _sync_obstacles(S)
+    s = [e.startNode.index for e in edges]
+    g = [e.endNode.index for e in edges]
+    if ob is not None:
+        hit, _ = S.ctx.edges_check_idx(s, g, S.robotRadius, obstacle=_list_position(S, ob), want_first=False)
+        return hit.astype(bool)
+    mask = []
+    for o in S.obstacles:
+        ok = (o is not others_of) and not o.obstacleUnused
+        if ok and timeElapsed is not None:
+            ok = o.startTime <= timeElapsed <= (o.startTime + o.lifeSpan)
+        mask.append(1 if ok else 0)
+    hit, _ = S.ctx.edges_check_idx(s, g, S.robotRadius, obstacle=-1, obstacle_mask=mask, want_first=False)
+    return hit.astype(bool)

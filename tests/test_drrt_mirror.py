@@ -114,3 +114,49 @@ def test_error_idiom():
     T = KDTree(3)
     with pytest.raises(RuntimeError):      # the reference error()s; an empty tree is a state error here
         kdFindNearest(T, [0, 0, 0])
+
+
+def test_obstacle_sweeps(oracle):
+    """addNewObstacle / removeObstacle edge loops (R/DRRT_Q.jl:3220-3362) as batched calls."""
+    from rrtqx_3d_amd import synth
+    from rrtqx_3d_amd.drrt import (CSpace, KDTree, RRTNode, SphereObstacle, addObsToCSpace, emptyRangeList,
+                                   findPointsInConflictWithObstacle, kdInsertMany, newEdge, obstacleSweepEdgeChecks)
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-20, 20, (6000, 3))               # the live script's 40^3 world
+    KD = KDTree(3)
+    nodes = [RRTNode(p) for p in pts]
+    kdInsertMany(KD, nodes)
+    S = CSpace(3, -1.0, [-20] * 3, [20] * 3, [0] * 3, [1] * 3)
+    S.robotRadius, S.delta = 0.5, 8.0
+    sph = np.concatenate([rng.uniform(-20, 20, (12, 3)), rng.uniform(1.0, 3.5, (12, 1))], 1)
+    obs = [SphereObstacle(r[:3], r[3]) for r in sph]
+    for o in obs:
+        addObsToCSpace(S, o)
+    obs[5].obstacleUnused = True
+    obs[7].startTime, obs[7].lifeSpan = 100.0, 5.0       # outside its time window at t = 10
+    new_ob = obs[2]
+    # nodes in conflict: radius query around the obstacle centre
+    L = findPointsInConflictWithObstacle(S, KD, new_ob)
+    ref_tree = oracle.KDTree(3)
+    ref_tree.insert_many(pts)
+    ridx, _ = ref_tree.range_naive(0.5 + 8.0 + new_ob.radius, new_ob.position)
+    conflict = sorted(n.data.index for n in L)
+    assert conflict == ridx.tolist() and len(conflict) > 50
+    emptyRangeList(L)
+    # graph edges: each conflict node to 6 random other nodes
+    edges = [newEdge(nodes[i], nodes[int(j)]) for i in conflict for j in rng.integers(0, 6000, 6)]
+    # addNewObstacle: explicitEdgeCheck(S, edge, ob)
+    hit = obstacleSweepEdgeChecks(S, KD, edges, ob=new_ob)
+    one, m1 = oracle.make_spheres(sph[2:3])
+    for e, h in zip(edges, hit):
+        assert bool(h) == oracle.edge_check_spheres(one, m1, e.startNode.position, e.endNode.position, 0.5)[0]
+    assert hit.any() and not hit.all()
+    # removeObstacle: conflictsWithOtherObs over the obstacles active in their time window
+    others = obstacleSweepEdgeChecks(S, KD, edges, others_of=new_ob, timeElapsed=10.0)
+    list_order = list(S.obstacles)
+    keep = [o for o in list_order if o is not new_ob and not o.obstacleUnused
+            and o.startTime <= 10.0 <= o.startTime + o.lifeSpan]
+    assert len(keep) == 9
+    ko, mk = oracle.make_spheres(np.array([[*o.position, o.radius] for o in keep]))
+    for e, h in zip(edges, others):
+        assert bool(h) == oracle.edge_check_spheres(ko, mk, e.startNode.position, e.endNode.position, 0.5)[0]
