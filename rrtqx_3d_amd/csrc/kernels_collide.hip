@@ -154,23 +154,24 @@ __global__ __launch_bounds__(256) void candidate_edges_kernel(
   const EdgeReach er = edge_reach(sx, sy, sz, tx, ty, tz, len);
   bool out_hit = false, in_hit = false;
   if (__ballot(act) == 0ull) return;   // the grid covers the caller's capacity, most waves are past the end
-  for (int j0 = 0; j0 < m; j0 += 4) {
-    SphRec rb[4];
+  // groups of 8 obstacles: eight wave-uniform reach records per SMEM round trip, eight reach
+  // tests as straight-line VALU code, ONE wave-level branch per group (the per-obstacle
+  // exec-mask bookkeeping was twice the VALU work in SALU instructions)
+  constexpr int G = 8;
+  for (int j0 = 0; j0 < m; j0 += G) {
+    SphRec rb[G];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) rb[g] = reach[min(j0 + g, m - 1)];
-    bool cand[4];
-    bool anyc = false;
-    const bool need = act && !(out_hit && in_hit);
+    for (int g = 0; g < G; ++g) rb[g] = reach[min(j0 + g, m - 1)];
+    unsigned touch = 0u;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      cand[g] = need && (j0 + g < m) && may_touch(er, rb[g]);
-      anyc = anyc || cand[g];
-    }
-    if (__ballot(anyc) == 0ull) continue;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (__ballot(cand[g]) == 0ull) continue;
-      if (cand[g]) {
+    for (int g = 0; g < G; ++g) touch |= (may_touch(er, rb[g]) ? 1u : 0u) << g;
+    if (j0 + G > m) touch &= (1u << (m - j0)) - 1u;
+    if (!act) touch = 0u;
+    if (__ballot(touch != 0u) == 0ull) continue;
+    // rare: some lane is within reach of one of these spheres -> exact evaluation for that lane
+    for (int g = 0; g < G; ++g) {
+      if (__ballot((touch >> g) & 1u) == 0ull) continue;
+      if (((touch >> g) & 1u) && !(out_hit && in_hit)) {
         const SphRec ob = sph[j0 + g];
         if (!out_hit) out_hit = edge_hits_sphere(sx, sy, sz, bx, by, bz, len, ob);
         if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len, ob);

@@ -403,7 +403,8 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
     for (int u = 0; u < kScanFU; ++u) {
       const int id = base + u * 64 + lane;
       const bool ok = id < node_end;
-      const int idc = ok ? id : node_end - 1;   // clamped: no divergent load
+      const unsigned idc = (unsigned)(ok ? id : node_end - 1);   // clamped (no divergent load), unsigned
+                                                                  // 32-bit index -> global_load saddr form
       x[u] = fx[idc];
       y[u] = fy[idc];
       z[u] = fz[idc];
@@ -460,63 +461,74 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
 // kdFindWithinRange adds the root when distToRoot <= range (R/kdTree_general.jl:896);
 // the scan found it only when < range.
 template <int D>
-__global__ void nn_rootfix_kernel(const double *__restrict__ nx, const double *__restrict__ ny,
+__global__ __launch_bounds__(256) void nn_rootfix_kernel(const double *__restrict__ nx, const double *__restrict__ ny,
                                   const double *__restrict__ nz, const double *__restrict__ nw,
                                   const SlotRec *__restrict__ slots, int n_slots, int nq,
                                   HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
-                                  int *__restrict__ count) {
+                                  int *__restrict__ count, long long *__restrict__ block_sum) {
+  __shared__ long long wsum[4];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nq) return;
-  SlotRec sr = slots[(size_t)i * n_slots];
-  double s = (D == 4) ? sq4(sr.x, sr.y, sr.z, sr.w, nx[0], ny[0], nz[0], nw[0])
-                      : sq3(sr.x, sr.y, sr.z, nx[0], ny[0], nz[0]);
-  if (s >= sr.thr_lt && s < sr.thr_gt) {
-    unsigned long long pos = atomicAdd(&sc->total, 1ull);
-    atomicAdd(&count[i], 1);
-    if ((long long)pos < cap) {
-      HitRec r;
-      r.owner = i; r.idx = 0; r.d2 = s;
-      recs[pos] = r;
+  int c = 0;
+  if (i < nq) {
+    SlotRec sr = slots[(size_t)i * n_slots];
+    double s = (D == 4) ? sq4(sr.x, sr.y, sr.z, sr.w, nx[0], ny[0], nz[0], nw[0])
+                        : sq3(sr.x, sr.y, sr.z, nx[0], ny[0], nz[0]);
+    c = count[i];               // final: the scan kernel has completed
+    if (s >= sr.thr_lt && s < sr.thr_gt) {
+      unsigned long long pos = atomicAdd(&sc->total, 1ull);
+      c += 1;
+      count[i] = c;
+      if ((long long)pos < cap) {
+        HitRec r;
+        r.owner = i; r.idx = 0; r.d2 = s;
+        recs[pos] = r;
+      }
     }
   }
+  // per-block sum of the final counts: first level of the offsets scan
+  long long v = c;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // ------------------------------------------------------------- offsets ------
-__global__ __launch_bounds__(1024) void nn_offsets_kernel(const int *__restrict__ count, int nq,
-                                                          int64_t *__restrict__ offsets,
-                                                          int *__restrict__ cursor,
-                                                          const Scalars *__restrict__ sc,
-                                                          int64_t *__restrict__ needed) {
-  // single workgroup: coalesced strips of 1024 counts, wave-shuffle inclusive scan,
-  // 16 wave totals through LDS, running carry across strips
-  __shared__ long long wave_tot[16];
-  __shared__ long long carry_s;
+__global__ __launch_bounds__(256) void nn_offsets_kernel(const int *__restrict__ count, int nq,
+                                                         const long long *__restrict__ block_sum,
+                                                         int64_t *__restrict__ offsets,
+                                                         int *__restrict__ cursor,
+                                                         const Scalars *__restrict__ sc,
+                                                         int64_t *__restrict__ needed) {
+  // block b covers counts [256 b, 256 b + 256): prefix = sum of the preceding block sums
+  // (written by nn_rootfix_kernel), then a shuffle scan inside the block.  No inter-block sync.
+  __shared__ long long red[4];
+  __shared__ long long wave_tot[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < nq; base += 1024) {
-    const int i = base + t;
-    const long long c = (i < nq) ? (long long)count[i] : 0ll;
-    long long v = c;
+  long long p = 0;
+  for (int j = t; j < (int)blockIdx.x; j += 256) p += block_sum[j];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      long long o = __shfl_up(v, off);
-      if (lane >= off) v += o;
-    }
-    if (lane == 63) wave_tot[wave] = v;
-    __syncthreads();
-    long long prefix = carry_s;
-    for (int w = 0; w < wave; ++w) prefix += wave_tot[w];
-    if (i < nq) {
-      offsets[i] = prefix + v - c;
-      cursor[i] = 0;
-    }
-    __syncthreads();
-    if (t == 1023) carry_s = prefix + v;
-    __syncthreads();
+  for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
+  if (lane == 0) red[wave] = p;
+  const int i = blockIdx.x * 256 + t;
+  const long long c = (i < nq) ? (long long)count[i] : 0ll;
+  long long v = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    long long o = __shfl_up(v, off);
+    if (lane >= off) v += o;
   }
-  if (t == 0) {
-    offsets[nq] = carry_s;
+  if (lane == 63) wave_tot[wave] = v;
+  __syncthreads();
+  long long prefix = red[0] + red[1] + red[2] + red[3];
+  for (int w = 0; w < wave; ++w) prefix += wave_tot[w];
+  if (i < nq) {
+    offsets[i] = prefix + v - c;
+    cursor[i] = 0;
+  }
+  if (i == nq - 1) {
+    offsets[nq] = prefix + v;
     if (needed) *needed = (int64_t)sc->total;
   }
 }
@@ -823,19 +835,21 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   span_end(ctx);
   ctx->last_pairs = (int64_t)n_copies_max * n_nodes;
 
+  RRTX_HIP(ctx, ctx->ws_bsum.ensure(sizeof(long long) * (size_t)((nq + 255) / 256)));
+  long long *bsum = ctx->ws_bsum.as<long long>();
   span_begin(ctx, KF_NN_FINISH);
   {
     dim3 grid((nq + 255) / 256), block(256);
     if (D == 4)
       hipLaunchKernelGGL(nn_rootfix_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
                          ctx->nodes[3], ctx->ws_slots.as<SlotRec>(), n_slots, nq, ctx->ws_recs.as<HitRec>(),
-                         rec_cap, sc, count);
+                         rec_cap, sc, count, bsum);
     else
       hipLaunchKernelGGL(nn_rootfix_kernel<3>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
                          ctx->nodes[2], ctx->ws_slots.as<SlotRec>(), n_slots, nq, ctx->ws_recs.as<HitRec>(),
-                         rec_cap, sc, count);
-    hipLaunchKernelGGL(nn_offsets_kernel, dim3(1), dim3(1024), 0, st, count, nq, offsets_dev, cursor, sc,
-                       needed_dev);
+                         rec_cap, sc, count, bsum);
+    hipLaunchKernelGGL(nn_offsets_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, count, nq, bsum, offsets_dev,
+                       cursor, sc, needed_dev);
     hipLaunchKernelGGL(nn_scatter_kernel, dim3(1024), dim3(256), 0, st, ctx->ws_recs.as<HitRec>(), rec_cap, sc,
                        offsets_dev, cursor, ctx->ws_tmp_idx.as<int32_t>(), ctx->ws_tmp_d2.as<double>(),
                        (long long)cap);

@@ -119,6 +119,7 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_copy_meta;// int32 owner, slot per copy
   rrtx::DevBuf ws_recs;     // HitRec
   rrtx::DevBuf ws_counts;   // int32 count[nq], cursor[nq]
+  rrtx::DevBuf ws_bsum;     // int64 per-256-query sums of count (first level of the offsets scan)
   rrtx::DevBuf ws_scalars;  // device scalars: total, n_copies, ...
   rrtx::DevBuf ws_tmp_idx, ws_tmp_d2;
   rrtx::DevBuf ws_owner;    // int32 owner query of every CSR entry (extend_candidates)
