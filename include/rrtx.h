@@ -89,6 +89,13 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
 #define RRTX_OPT_SCAN_ITEMS 4  /* target number of (tile, node segment) work items */
 int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value);
 
+/* Host-only helper (no GPU needed): the exact thresholds on SQUARED distances the kernels
+ * compare against, so that no device sqrt sits on a decision path:
+ *   *first_ge = min{ s >= 0 : sqrt(s) >= r }   (sqrt(s) <  r  <=>  s < *first_ge)
+ *   *first_gt = min{ s >= 0 : sqrt(s) >  r }   (sqrt(s) <= r  <=>  s < *first_gt)
+ * (NaN when no such s exists).  Exposed for testing the host logic. */
+int rrtx_sq_thresholds(double r, double *first_ge, double *first_gt);
+
 /* ---- tree (A2, A5) --------------------------------------------------------- */
 /* kdInsert (R/kdTree_general.jl:121-170): appends n nodes; *first_index receives
  * the index of the first one (== treeSize before the call). */

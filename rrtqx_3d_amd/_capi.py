@@ -58,6 +58,7 @@ SYMBOLS = [
     ("rrtx_destroy", C.c_int, [_VP]),
     ("rrtx_last_error", C.c_char_p, [_VP]),
     ("rrtx_create_error", C.c_char_p, []),
+    ("rrtx_sq_thresholds", C.c_int, [C.c_double, c_double_p, c_double_p]),
     ("rrtx_set_stream", C.c_int, [_VP, _VP]),
     ("rrtx_get_stream", _VP, [_VP]),
     ("rrtx_sync", C.c_int, [_VP]),

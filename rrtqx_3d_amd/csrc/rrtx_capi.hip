@@ -214,6 +214,13 @@ extern "C" {
 
 const char *rrtx_create_error(void) { return g_create_err.c_str(); }
 
+int rrtx_sq_thresholds(double r, double *first_ge, double *first_gt) {
+  if (!first_ge || !first_gt) return RRTX_E_INVALID;
+  *first_ge = thr_first_ge(r);
+  *first_gt = thr_first_gt(r);
+  return RRTX_OK;
+}
+
 int rrtx_create(rrtx_ctx **out, int dim, int device, int64_t node_capacity) {
   std::lock_guard<std::mutex> lk(g_create_mu);
   if (!out) { g_create_err = "out is NULL"; return RRTX_E_INVALID; }
