@@ -103,7 +103,7 @@ def write_sphere_obstacles(path: str, env: SphereEnv):
     with open(path, "w") as f:
         f.write(f"{env.cxyzr.shape[0]}\n")
         for (x, y, z, r), b in zip(env.cxyzr, env.behaviour):
-            f.write(f"{x!r}, {y!r}, {z!r}\n{r!r}\n{int(b)}\n")
+            f.write(f"{float(x)!r}, {float(y)!r}, {float(z)!r}\n{float(r)!r}\n{int(b)}\n")
 
 
 def write_polygon_obstacles(path: str, env: PolygonEnv):
