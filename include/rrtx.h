@@ -180,6 +180,13 @@ int rrtx_dubins_edges_check(rrtx_ctx *ctx, const double *s, const double *g, int
                             double r_min, double robot_radius, double *cost, uint8_t *word,
                             uint8_t *hit, int32_t *traj_len);
 
+/* edge.trajectory of calculateTrajectory(S, ::DubinsEdge) (:506-701): the discretised polyline
+ * (0.1 rad arc steps, Julia float-range length rule), P_i rows of (x, y) per edge, CSR layout:
+ * traj_off[ne+1] (rows), traj_xy[2 * total rows].  Two-call pattern: if the total exceeds
+ * cap_rows the call returns RRTX_E_CAPACITY with *needed_rows set (traj_off is still valid). */
+int rrtx_dubins_trajectory(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min,
+                           int64_t *traj_off, double *traj_xy, int64_t cap_rows, int64_t *needed_rows);
+
 /* ---- fused per-sample preamble of extend() (A13) ----------------------------- */
 /* For each of nq samples: kdFindWithinRange + for every neighbour both directed
  * SimpleEdges sample->near and near->sample: calculateTrajectory cost and

@@ -187,7 +187,7 @@ class Context:
         word = np.empty((ne, 3), dtype=np.uint8)
         self._check(self._lib.rrtx_dubins_steer(self._h, _capi._ptr(s), _capi._ptr(g), ne, r_min, _capi._ptr(cost),
                                                 _capi._ptr(word)))
-        return cost, [bytes(w).decode() for w in word]
+        return cost, word.view("S3").ravel()      # numpy bytes array: b"rsl", b"rsr", ...
 
     def dubins_edges_check(self, s, g, r_min: float, robot_radius: float):
         s = f64(s, (-1, 4))
@@ -200,7 +200,25 @@ class Context:
         self._check(self._lib.rrtx_dubins_edges_check(self._h, _capi._ptr(s), _capi._ptr(g), ne, r_min,
                                                       robot_radius, _capi._ptr(cost), _capi._ptr(word),
                                                       _capi._ptr(hit), _capi._ptr(tl)))
-        return cost, [bytes(w).decode() for w in word], hit, tl
+        return cost, word.view("S3").ravel(), hit, tl
+
+    def dubins_trajectory(self, s, g, r_min: float):
+        """edge.trajectory of every Dubins edge: (traj_off[ne+1] in rows, traj_xy[rows, 2])."""
+        s = f64(s, (-1, 4))
+        g = f64(g, (-1, 4))
+        ne = s.shape[0]
+        off = np.empty(ne + 1, dtype=np.int64)
+        cap = max(64 * ne, 64)
+        while True:
+            xy = np.empty((cap, 2), dtype=np.float64)
+            needed = C.c_int64()
+            rc = self._lib.rrtx_dubins_trajectory(self._h, _capi._ptr(s), _capi._ptr(g), ne, r_min, _capi._ptr(off),
+                                                  _capi._ptr(xy), cap, C.byref(needed))
+            if rc == _capi.RRTX_E_CAPACITY:
+                cap = int(needed.value)
+                continue
+            self._check(rc)
+            return off, xy[: int(needed.value)]
 
     # ---- fused extend() preamble --------------------------------------------------------------
     def extend_candidates(self, q, r: float, robot_radius: float, cap: Optional[int] = None):

@@ -365,7 +365,44 @@ __global__ __launch_bounds__(256) void dubins_edges_check_kernel(
   hit[i] = h ? 1 : 0;
 }
 
+// edge.trajectory (R/DRRT_DubinsEdge_functions.jl:699-701): the P x 2 polyline of every edge,
+// written at traj_off[i] (row units); mode 0 only reports P per edge.
+__global__ __launch_bounds__(256) void dubins_trajectory_kernel(const double *__restrict__ s,
+                                                                const double *__restrict__ g, long long ne,
+                                                                double r_min, const int64_t *__restrict__ traj_off,
+                                                                double *__restrict__ traj_xy, long long cap_rows,
+                                                                int32_t *__restrict__ traj_len) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ne) return;
+  Steer st;
+  dubins_steer<true>(s + 4 * i, g + 4 * i, r_min, st);
+  const int P = st.pc[0].len + st.pc[1].len + st.pc[2].len;
+  if (traj_len) traj_len[i] = P;
+  if (!traj_xy) return;
+  long long row = traj_off[i];
+  for (int pi = 0; pi < 3; ++pi)
+    for (int k = 0; k < st.pc[pi].len; ++k, ++row) {
+      double x, y;
+      piece_point(st.pc[pi], k, r_min, x, y);
+      if (row < cap_rows) { traj_xy[2 * row] = x; traj_xy[2 * row + 1] = y; }
+    }
+}
+
 }  // namespace
+
+int launch_dubins_trajectory(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
+                             const int64_t *traj_off_dev, double *traj_xy_dev, int64_t cap_rows,
+                             int32_t *traj_len_dev) {
+  if (ne <= 0) return RRTX_OK;
+  if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
+  span_begin(ctx, KF_DUBINS);
+  hipLaunchKernelGGL(dubins_trajectory_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream,
+                     s_dev, g_dev, (long long)ne, r_min, traj_off_dev, traj_xy_dev, (long long)cap_rows,
+                     traj_len_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
 
 int launch_dubins_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
                         double *cost_dev, uint8_t *word_dev) {

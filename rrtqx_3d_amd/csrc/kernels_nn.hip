@@ -563,7 +563,8 @@ __global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict
                                                        double *__restrict__ dist, long long out_cap,
                                                        int32_t *__restrict__ owner,
                                                        int32_t *__restrict__ nearest_idx,
-                                                       double *__restrict__ nearest_dist) {
+                                                       double *__restrict__ nearest_dist,
+                                                       int *__restrict__ big_list, int *__restrict__ big_count) {
   const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (q >= nq) return;
   const int lane = threadIdx.x & 63;
@@ -588,19 +589,9 @@ __global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict
     }
     best = d2; best_i = my;
   } else if (k > 64) {
-    for (long long base = 0; base < k; base += 64) {
-      bool act = base + lane < k;
-      int my = act ? tmp_idx[b + base + lane] : 0x7fffffff;
-      double d2 = act ? tmp_d2[b + base + lane] : __builtin_inf();
-      long long rank = 0;
-      for (long long j = 0; j < k; ++j) rank += (tmp_idx[b + j] < my) ? 1 : 0;
-      if (act) {
-        idx[b + rank] = my;
-        dist[b + rank] = sqrt_rn(d2);
-        if (owner) owner[b + rank] = q;
-        if ((d2 < best) || (d2 == best && my < best_i)) { best = d2; best_i = my; }
-      }
-    }
+    // long list (obstacle sweeps, Dubins balls): queued for nn_order_big_kernel
+    if (lane == 0) big_list[atomicAdd(big_count, 1)] = q;
+    return;
   }
   if (nearest_idx) {
 #pragma unroll
@@ -613,6 +604,98 @@ __global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict
       nearest_idx[q] = (k > 0) ? best_i : -1;
       nearest_dist[q] = (k > 0) ? sqrt_rn(best) : __builtin_inf();
     }
+  }
+}
+
+// Lists longer than one wave: one workgroup per list, striding over the queue written by
+// nn_order_kernel.  Up to kBigSort entries are sorted by node index with a bitonic network in
+// LDS; longer lists fall back to rank counting with all 256 threads.
+constexpr int kBigSort = 2048;
+__global__ __launch_bounds__(256) void nn_order_big_kernel(const int64_t *__restrict__ offsets,
+                                                           const int32_t *__restrict__ tmp_idx,
+                                                           const double *__restrict__ tmp_d2,
+                                                           int32_t *__restrict__ idx, double *__restrict__ dist,
+                                                           long long out_cap, int32_t *__restrict__ owner,
+                                                           int32_t *__restrict__ nearest_idx,
+                                                           double *__restrict__ nearest_dist,
+                                                           const int *__restrict__ big_list,
+                                                           const int *__restrict__ big_count) {
+  __shared__ int s_idx[kBigSort];
+  __shared__ double s_d2[kBigSort];
+  __shared__ double r_best[4];
+  __shared__ int r_besti[4];
+  const int t = threadIdx.x;
+  const int n_big = *big_count;
+  for (int item = blockIdx.x; item < n_big; item += gridDim.x) {
+    const int q = big_list[item];
+    const long long b = offsets[q];
+    long long e = offsets[q + 1];
+    if (e > out_cap) e = out_cap;
+    const int k = (int)(e - b);
+    double best = __builtin_inf();
+    int best_i = 0x7fffffff;
+    if (k <= kBigSort) {
+      int n2 = 64;
+      while (n2 < k) n2 <<= 1;
+      for (int i = t; i < n2; i += 256) {
+        s_idx[i] = (i < k) ? tmp_idx[b + i] : 0x7fffffff;
+        s_d2[i] = (i < k) ? tmp_d2[b + i] : __builtin_inf();
+      }
+      __syncthreads();
+      for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+          for (int i = t; i < n2; i += 256) {
+            const int j = i ^ stride;
+            if (j > i) {
+              const bool up = (i & size) == 0;
+              const int a = s_idx[i], c = s_idx[j];
+              if ((a > c) == up) {
+                s_idx[i] = c; s_idx[j] = a;
+                const double da = s_d2[i];
+                s_d2[i] = s_d2[j]; s_d2[j] = da;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      for (int i = t; i < k; i += 256) {
+        const int my = s_idx[i];
+        const double d2 = s_d2[i];
+        idx[b + i] = my;
+        dist[b + i] = sqrt_rn(d2);
+        if (owner) owner[b + i] = q;
+        if ((d2 < best) || (d2 == best && my < best_i)) { best = d2; best_i = my; }
+      }
+    } else {
+      for (int i = t; i < k; i += 256) {
+        const int my = tmp_idx[b + i];
+        const double d2 = tmp_d2[b + i];
+        int rank = 0;
+        for (int j = 0; j < k; ++j) rank += (tmp_idx[b + j] < my) ? 1 : 0;
+        idx[b + rank] = my;
+        dist[b + rank] = sqrt_rn(d2);
+        if (owner) owner[b + rank] = q;
+        if ((d2 < best) || (d2 == best && my < best_i)) { best = d2; best_i = my; }
+      }
+    }
+    if (nearest_idx) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        double ob = __shfl_xor(best, off);
+        int oi = __shfl_xor(best_i, off);
+        if ((ob < best) || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+      }
+      if ((t & 63) == 0) { r_best[t >> 6] = best; r_besti[t >> 6] = best_i; }
+      __syncthreads();
+      if (t == 0) {
+        for (int w = 1; w < 4; ++w)
+          if ((r_best[w] < best) || (r_best[w] == best && r_besti[w] < best_i)) { best = r_best[w]; best_i = r_besti[w]; }
+        nearest_idx[q] = best_i;
+        nearest_dist[q] = sqrt_rn(best);
+      }
+    }
+    __syncthreads();   // LDS is reused by the next list
   }
 }
 
@@ -730,7 +813,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   RRTX_HIP(ctx, ctx->ws_slots.ensure(n_copies_max * sizeof(SlotRec)));
   RRTX_HIP(ctx, ctx->ws_copies.ensure(n_copies_max * qrec_bytes));
   RRTX_HIP(ctx, ctx->ws_copy_meta.ensure(n_copies_max * sizeof(int2)));
-  RRTX_HIP(ctx, ctx->ws_counts.ensure((size_t)nq * 2 * sizeof(int)));
+  RRTX_HIP(ctx, ctx->ws_counts.ensure(((size_t)nq * 3 + 2) * sizeof(int)));
   RRTX_HIP(ctx, ctx->ws_scalars.ensure(sizeof(Scalars)));
   const long long rec_cap = (long long)(cap > 0 ? cap : 1);
   RRTX_HIP(ctx, ctx->ws_recs.ensure((size_t)rec_cap * sizeof(HitRec)));
@@ -739,11 +822,13 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
 
   Scalars *sc = ctx->ws_scalars.as<Scalars>();
   int *count = ctx->ws_counts.as<int>();
-  int *cursor = count + nq;
+  int *big_count = count + nq;          // zeroed together with count
+  int *cursor = count + nq + 1;
+  int *big_list = cursor + nq;
   Scalars init;
   init.total = 0ull; init.n_copies = (ctx->n_wraps == 0) ? nq : 0; init.pad = 0; init.q_absmax = 0ull;
   RRTX_HIP(ctx, hipMemcpyAsync(sc, &init, sizeof(Scalars), hipMemcpyHostToDevice, st));
-  RRTX_HIP(ctx, hipMemsetAsync(count, 0, (size_t)nq * sizeof(int), st));
+  RRTX_HIP(ctx, hipMemsetAsync(count, 0, ((size_t)nq + 1) * sizeof(int), st));
 
   const double *thr_lt_arr = r_dev_thr_lt;
   const double *thr_gt_arr = r_dev_thr_lt ? r_dev_thr_lt + nq : nullptr;
@@ -855,7 +940,11 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
                        (long long)cap);
     hipLaunchKernelGGL(nn_order_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, offsets_dev, nq,
                        ctx->ws_tmp_idx.as<int32_t>(), ctx->ws_tmp_d2.as<double>(), idx_dev, dist_dev,
-                       (long long)cap, owner_dev, nearest_idx_dev, nearest_dist_dev);
+                       (long long)cap, owner_dev, nearest_idx_dev, nearest_dist_dev, big_list, big_count);
+    // lists longer than one wave (queued by nn_order_kernel); exits at once when there are none
+    hipLaunchKernelGGL(nn_order_big_kernel, dim3(nq < 1024 ? nq : 1024), dim3(256), 0, st, offsets_dev,
+                       ctx->ws_tmp_idx.as<int32_t>(), ctx->ws_tmp_d2.as<double>(), idx_dev, dist_dev, (long long)cap,
+                       owner_dev, nearest_idx_dev, nearest_dist_dev, big_list, big_count);
   }
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());

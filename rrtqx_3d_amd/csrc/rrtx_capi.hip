@@ -495,7 +495,7 @@ int rrtx_nn_radius(rrtx_ctx *ctx, const double *q, const double *r, int r_stride
   if (nq < 0 || cap < 0 || (nq > 0 && (!q || !r || !offsets)) || (cap > 0 && (!idx || !dist)) ||
       (r_stride != 0 && r_stride != 1))
     return fail(ctx, RRTX_E_INVALID, "nn_radius: bad arguments");
-  if (nq == 0) { if (needed) *needed = 0; return RRTX_OK; }
+  if (nq == 0) { if (needed) *needed = 0; if (offsets) offsets[0] = 0; return RRTX_OK; }
   int rc = stage_in(ctx, ctx->ws_q, q, sizeof(double) * (size_t)nq * ctx->dim);
   if (rc) return rc;
   const double *thr_dev = nullptr;
@@ -696,6 +696,44 @@ int rrtx_dubins_edges_check(rrtx_ctx *ctx, const double *s, const double *g, int
   return dubins_common(ctx, s, g, ne, r_min, robot_radius, true, cost, word, hit, traj_len);
 }
 
+int rrtx_dubins_trajectory(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min,
+                           int64_t *traj_off, double *traj_xy, int64_t cap_rows, int64_t *needed_rows) {
+  CHECK_CTX(ctx);
+  if (ne < 0 || cap_rows < 0 || (ne > 0 && (!s || !g || !traj_off)) || (cap_rows > 0 && !traj_xy))
+    return fail(ctx, RRTX_E_INVALID, "dubins_trajectory: bad arguments");
+  if (ne == 0) { if (needed_rows) *needed_rows = 0; if (traj_off) traj_off[0] = 0; return RRTX_OK; }
+  if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
+  const size_t pb = sizeof(double) * (size_t)ne * 4;
+  int rc = stage_in(ctx, ctx->ws_q, s, pb);
+  if (rc) return rc;
+  rc = stage_in(ctx, ctx->ws_q2, g, pb);
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_i32.ensure(sizeof(int32_t) * (size_t)ne));
+  // pass 1: rows per edge
+  rc = launch_dubins_trajectory(ctx, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>(), ne, r_min, nullptr, nullptr, 0,
+                                ctx->ws_out_i32.as<int32_t>());
+  if (rc) return rc;
+  std::vector<int32_t> len((size_t)ne);
+  RRTX_HIP(ctx, hipMemcpyAsync(len.data(), ctx->ws_out_i32.p, sizeof(int32_t) * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  traj_off[0] = 0;
+  for (int64_t i = 0; i < ne; ++i) traj_off[i + 1] = traj_off[i] + len[(size_t)i];
+  const int64_t total = traj_off[ne];
+  if (needed_rows) *needed_rows = total;
+  if (total > cap_rows) return fail(ctx, RRTX_E_CAPACITY, "dubins_trajectory: %lld rows, capacity %lld", (long long)total, (long long)cap_rows);
+  if (total == 0) return RRTX_OK;
+  // pass 2: write the polylines
+  rc = stage_in(ctx, ctx->ws_out_off, traj_off, sizeof(int64_t) * ((size_t)ne + 1));
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_f64.ensure(sizeof(double) * 2 * (size_t)total));
+  rc = launch_dubins_trajectory(ctx, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>(), ne, r_min,
+                                ctx->ws_out_off.as<int64_t>(), ctx->ws_out_f64.as<double>(), total, nullptr);
+  if (rc) return rc;
+  RRTX_HIP(ctx, hipMemcpyAsync(traj_xy, ctx->ws_out_f64.p, sizeof(double) * 2 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
 // ---- fused extend() preamble ------------------------------------------------------------------
 int rrtx_extend_candidates_dev(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius,
                                int64_t *offsets, int32_t *idx, double *cost, uint8_t *hit_out, uint8_t *hit_in,
@@ -731,7 +769,7 @@ int rrtx_extend_candidates(rrtx_ctx *ctx, const double *q, int nq, double r, dou
   CHECK_CTX(ctx);
   if (nq < 0 || cap < 0 || (nq > 0 && (!q || !offsets)) || (cap > 0 && (!idx || !cost || !hit_out || !hit_in)))
     return fail(ctx, RRTX_E_INVALID, "extend_candidates: bad arguments");
-  if (nq == 0) { if (needed) *needed = 0; return RRTX_OK; }
+  if (nq == 0) { if (needed) *needed = 0; if (offsets) offsets[0] = 0; return RRTX_OK; }
   int rc = stage_in(ctx, ctx->ws_q, q, sizeof(double) * (size_t)nq * ctx->dim);
   if (rc) return rc;
   const int64_t dcap = cap > 0 ? cap : 1;

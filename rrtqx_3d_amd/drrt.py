@@ -408,7 +408,7 @@ def calculateTrajectories(S: CSpace, edges: Sequence[SimpleEdge]):
     if isinstance(edges[0], DubinsEdge):
         cost, word = ctx.dubins_steer(s, g, S.minTurningRadius)
         for e, c, w in zip(edges, cost, word):
-            e.dubinsType = w
+            e.dubinsType = w.decode()
             e.Wdist = float(c)
             e.dist = float(c)
             e.distOriginal = e.dist

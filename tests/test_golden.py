@@ -99,7 +99,7 @@ def test_gpu_reproduces_polygon_dubins_wrapped_slices(gold, env):
         cost, word, dh, tl = ctx.dubins_edges_check(gold["d_start"], gold["d_goal"], 1.0, 0.5)
         # Dubins: 1e-6 relative (north_star tolerance; device libm != host libm)
         assert np.all(np.abs(cost - gold["d_cost"]) <= 1e-6 * np.maximum(1.0, np.abs(gold["d_cost"])))
-        assert (np.array([w.encode() for w in word]) != gold["d_word"]).sum() <= 2
+        assert (word != gold["d_word"]).sum() <= 2
         assert (dh != gold["d_hit"]).sum() <= 1
         off, idx, key = ctx.nn_radius(gold["w_queries"], float(gold["w_radius"]))
         assert np.array_equal(off, gold["w_offsets"]) and np.array_equal(idx, gold["w_idx"])

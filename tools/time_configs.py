@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Times the hot-path entry points on BASELINE.json's other configurations (C2, C3, C5) and the
+stand-alone nearest kernel at C4.  Host-pointer API (PCIe-inclusive wall time) plus the per-kernel
+device time from the library's HIP-event spans.  Prints one JSON line per case."""
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rrtqx_3d_amd import synth  # noqa: E402
+from rrtqx_3d_amd.context import Context  # noqa: E402
+
+
+def spans(st):
+    return {k: round(getattr(st, "ms_" + k), 4) for k in ("nn_scan", "nn_finish", "nn_nearest", "edges", "points", "dubins")}
+
+
+def timed(ctx, fn, reps=5):
+    fn()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    wall = (time.perf_counter() - t0) / reps
+    st = ctx.stats()
+    ctx.profile(False)
+    return out, wall * 1e3, {k: round(v / reps, 4) for k, v in spans(st).items()}
+
+
+def main():
+    for name in ("C2", "C4", "C5"):
+        cfg = synth.CONFIGS[name]
+        pts, Q, sph = synth.nodes(cfg.n_nodes, 3), synth.queries(cfg.batch, 3), synth.spheres(cfg.n_obstacles)
+        r = synth.ball_radius(cfg.n_nodes, 3)
+        with Context(3, node_capacity=cfg.n_nodes) as ctx:
+            ctx.nodes_append(pts)
+            ctx.spheres_set(sph)
+            out, wall, k = timed(ctx, lambda: ctx.extend_candidates(Q, r, 0.5, cap=96 * cfg.batch))
+            print(json.dumps({"case": f"{name} extend_candidates (host buffers)", "N": cfg.n_nodes, "M": cfg.n_obstacles,
+                              "B": cfg.batch, "neighbors": int(len(out["idx"])), "wall_ms": round(wall, 3), "kernel_ms": k}))
+            if name == "C4":
+                _, wall, k = timed(ctx, lambda: ctx.nn_nearest(Q))
+                print(json.dumps({"case": "C4 nn_nearest (full scan)", "wall_ms": round(wall, 3), "kernel_ms": k}))
+    cfg = synth.CONFIGS["C3"]
+    pts, Q = synth.nodes(cfg.n_nodes, 4), synth.queries(cfg.batch, 4)
+    polys = synth.polygons(cfg.n_obstacles)
+    r = synth.ball_radius(cfg.n_nodes, 4, gamma=100.0, delta=10.0)
+    with Context(4, node_capacity=cfg.n_nodes) as ctx:
+        ctx.set_wrap(3, 2 * math.pi)
+        ctx.nodes_append(pts)
+        ctx.polygons_set(polys)
+        (off, idx, dist), wall, k = timed(ctx, lambda: ctx.nn_radius(Q, r, cap=4_000_000), reps=3)
+        print(json.dumps({"case": "C3 nn_radius wrapped theta", "N": cfg.n_nodes, "B": cfg.batch, "r": r,
+                          "neighbors": int(len(idx)), "wall_ms": round(wall, 3), "kernel_ms": k}))
+        owner = np.repeat(np.arange(cfg.batch), np.diff(off))
+        ne = min(len(idx), 262144)
+        s, g = Q[owner[:ne]], pts[idx[:ne]]
+        _, wall, k = timed(ctx, lambda: ctx.dubins_steer(s, g, 1.0), reps=3)
+        print(json.dumps({"case": "C3 dubins_steer", "edges": ne, "wall_ms": round(wall, 3), "kernel_ms": k}))
+        _, wall, k = timed(ctx, lambda: ctx.dubins_edges_check(s, g, 1.0, 0.5), reps=3)
+        print(json.dumps({"case": "C3 dubins_edges_check (64 polygons)", "edges": ne, "wall_ms": round(wall, 3), "kernel_ms": k}))
+
+
+if __name__ == "__main__":
+    main()
