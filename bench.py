@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--config", default="C4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nn-filter", type=int, default=1, help="1: fp32 prefilter + exact fp64 confirm (default); 0: exact scan")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsal)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: all ranks on cuda:0")
     ap.add_argument("--scan-blocks", type=int, default=0, help="tuning: target workgroups of the range scan")
     ap.add_argument("--scan-items", type=int, default=0, help="tuning: target (tile, segment) work items")
     ap.add_argument("--tile-q", type=int, default=0, help="tuning: query copies per workgroup tile")
@@ -84,11 +86,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.share_device:            # rehearsal of the N>1 code path on a one-GPU box (with --backend gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend)
 
     cfg = synth.CONFIGS[args.config]
     assert cfg.dim == 3, "the bench line is the SimpleEdge path"
@@ -126,37 +133,66 @@ def main():
     d_ndist = torch.empty(B, dtype=torch.float64, device=dev)
     d_unsafe = torch.empty(B, dtype=torch.uint8, device=dev)
     from rrtqx_3d_amd import parallel
-    words_per_rank = parallel.words_for(cap)
-    d_bits = torch.zeros(world * words_per_rank, dtype=torch.int64, device=dev)
 
-    def step():
+    def compute():
         ctx.extend_candidates_dev(d_q.data_ptr(), B, r, ROBOT_RADIUS, d_off.data_ptr(), d_idx.data_ptr(),
                                   d_cost.data_ptr(), d_hout.data_ptr(), d_hin.data_ptr(), cap,
                                   d_needed.data_ptr(), d_nidx.data_ptr(), d_ndist.data_ptr(), d_unsafe.data_ptr())
-        if world > 1:
-            # per-edge collision bitmask exchange: each rank fills its slice, one RCCL all-reduce
-            ctx.pack_hits_dev(d_hout.data_ptr(), d_hin.data_ptr(), d_off.data_ptr() + 8 * B, cap,
-                              d_bits.data_ptr() + 8 * rank * words_per_rank)
-            parallel.exchange_hit_bitmasks(d_bits, rank, world, words_per_rank)   # disjoint slices: SUM == OR
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    # sizing pass (part of the warm-up): number of candidate entries of this rank's batch
+    compute()
     fence()
     k_total = int(d_needed.item())
     if k_total > cap:
         raise SystemExit(f"candidate capacity too small: {k_total} > {cap}")
     edges_per_step = 2 * k_total
 
+    # exchange buffers sized for the largest shard: 2 bits (out, in) per candidate entry and rank
+    k_max = k_total
+    if world > 1:
+        t = torch.tensor([k_total], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        k_max = int(t.item())
+    bit_cap = (k_max + 4095) // 4096 * 4096
+    words_per_rank = parallel.words_for(bit_cap)
+    d_bits = [torch.zeros(world * words_per_rank, dtype=torch.int64, device=dev) for _ in range(2)]
+    pending = [None, None]
+
+    def step(i):
+        compute()
+        if world > 1:
+            # per-edge collision bitmask exchange: each rank fills its slice, one RCCL all-reduce
+            # (disjoint slices: SUM == OR).  Double-buffered and asynchronous: the exchange of step i
+            # runs on RCCL's stream while step i+1 computes.
+            b = i & 1
+            if pending[b] is not None:
+                pending[b].wait()
+            ctx.pack_hits_dev(d_hout.data_ptr(), d_hin.data_ptr(), d_off.data_ptr() + 8 * B, bit_cap,
+                              d_bits[b].data_ptr() + 8 * rank * words_per_rank)
+            pending[b] = parallel.exchange_hit_bitmasks(d_bits[b], rank, world, words_per_rank, async_op=True)
+
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    fence()
+
     ctx.profile(True)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
+    drain()
     fence()
     dt = time.perf_counter() - t0
     st = ctx.stats()

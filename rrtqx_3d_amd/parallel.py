@@ -34,20 +34,22 @@ def words_for(cap: int) -> int:
     return (2 * cap + 63) // 64
 
 
-def exchange_hit_bitmasks(bits: torch.Tensor, rank: int, world: int, words_per_rank: int, group=None) -> torch.Tensor:
+def exchange_hit_bitmasks(bits: torch.Tensor, rank: int, world: int, words_per_rank: int, group=None,
+                          async_op: bool = False):
     """bits: int64[world * words_per_rank]; this rank has filled its own slice
     [rank*wpr, (rank+1)*wpr).  Other slices are zeroed, then one all-reduce(SUM) makes every
-    slice visible on every rank.  Returns bits (in place)."""
+    slice visible on every rank (in place).  Returns bits, or with async_op=True the work handle
+    (None when world == 1) so the exchange can overlap the next step's compute."""
     assert bits.numel() == world * words_per_rank and bits.dtype == torch.int64
     if world == 1:
-        return bits
+        return None if async_op else bits
     lo = rank * words_per_rank
     if lo > 0:
         bits[:lo].zero_()
     if lo + words_per_rank < bits.numel():
         bits[lo + words_per_rank:].zero_()
-    dist.all_reduce(bits, op=dist.ReduceOp.SUM, group=group)
-    return bits
+    work = dist.all_reduce(bits, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work if async_op else bits
 
 
 def rank_slice(bits: torch.Tensor, r: int, words_per_rank: int) -> torch.Tensor:

@@ -50,6 +50,12 @@ def _worker(rank, world, port, cap, q):
             eo = (rr.random(nv) < 0.3).astype(np.uint8)
             ei = (rr.random(nv) < 0.3).astype(np.uint8)
             ok &= np.array_equal(parallel.rank_slice(bits, r, wpr).numpy(), _pack(eo, ei, cap))
+        # asynchronous form (what bench.py uses to overlap the exchange with the next step)
+        bits2 = torch.zeros(world * wpr, dtype=torch.int64)
+        parallel.rank_slice(bits2, rank, wpr).copy_(torch.from_numpy(_pack(ho, hi, cap)))
+        work = parallel.exchange_hit_bitmasks(bits2, rank, world, wpr, async_op=True)
+        work.wait()
+        ok &= torch.equal(bits2, bits)
         units, tmax = parallel.reduce_throughput(1000 + rank, 0.5 + rank)
         ok &= (units == sum(1000 + r for r in range(world))) and (tmax == 0.5 + world - 1)
         q.put((rank, bool(ok)))
