@@ -475,6 +475,18 @@ int rrtx_nn_nearest(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double
   RRTX_HIP(ctx, ctx->ws_out_dist.ensure(sizeof(double) * (size_t)nq));
   rc = launch_nn_nearest(ctx, ctx->ws_q.as<double>(), nq, ctx->ws_out_idx.as<int32_t>(), ctx->ws_out_dist.as<double>());
   if (rc) return rc;
+  if (ctx->last_nearest_cap > 0) {
+    // the screened scan keeps ~ln(n) candidates per query and segment; an adversarial visiting order
+    // (nodes sorted by decreasing distance) can exceed the record buffer -> exact scan instead
+    long long total = 0;
+    rc = nearest_candidates(ctx, &total);
+    if (rc) return rc;
+    if (total > ctx->last_nearest_cap) {
+      rc = launch_nn_nearest(ctx, ctx->ws_q.as<double>(), nq, ctx->ws_out_idx.as<int32_t>(),
+                             ctx->ws_out_dist.as<double>(), true);
+      if (rc) return rc;
+    }
+  }
   RRTX_HIP(ctx, hipMemcpyAsync(idx, ctx->ws_out_idx.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
   RRTX_HIP(ctx, hipMemcpyAsync(dist, ctx->ws_out_dist.p, sizeof(double) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -140,6 +140,7 @@ struct rrtx_ctx {
   int64_t fam_launches[rrtx::KF_COUNT] = {0};
   int64_t last_pairs = 0, last_neighbors = 0;
   int last_tile_q = 0;
+  long long last_nearest_cap = 0;   // record capacity of the last screened nearest call (0: exact scan ran)
 };
 
 namespace rrtx {
@@ -169,7 +170,9 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_or_
                      int nq, int64_t *offsets_dev, int32_t *idx_dev, double *dist_dev, int64_t cap,
                      int64_t *needed_dev, int32_t *owner_dev = nullptr, int32_t *nearest_idx_dev = nullptr,
                      double *nearest_dist_dev = nullptr);
-int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev);
+int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev,
+                      bool exact = false);
+int nearest_candidates(rrtx_ctx *ctx, long long *total);
 int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
                          double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
                          uint8_t *hit_dev, int32_t *first_hit_dev, const int32_t *sidx_dev = nullptr,

@@ -182,6 +182,43 @@ def test_nearest_c2(small3):
         assert idx[i] == ri and dist[i] == rd
 
 
+def test_nearest_screened_vs_exact_and_adversarial_order(oracle):
+    """the screened nearest scan == the exact fp64 scan == the oracle, including (a) exact ties in
+    distance (lowest index wins), (b) a visiting order that makes every node a new running minimum
+    (nodes sorted by decreasing distance: candidate overflow -> automatic exact fallback),
+    (c) coordinates far from the origin."""
+    from rrtqx_3d_amd import _capi
+    rng = np.random.default_rng(21)
+    for scale, n in ((1.0, 20_000), (1e4, 5_000)):
+        pts = rng.uniform(-50, 50, (n, 3)) * scale
+        pts[100] = pts[7]                                   # exact duplicate: tie on d2, index 7 must win
+        Q = np.concatenate([rng.uniform(-50, 50, (500, 3)) * scale, pts[7:8] + 1e-3 * scale, pts[200:201]])
+        tree = oracle.KDTree(3)
+        tree.insert_many(pts)
+        with Context(3) as ctx:
+            ctx.nodes_append(pts)
+            i1, d1 = ctx.nn_nearest(Q)
+            ctx.set_option(_capi.RRTX_OPT_NN_FILTER, 0)
+            i0, d0 = ctx.nn_nearest(Q)
+            assert np.array_equal(i1, i0) and np.array_equal(d1, d0)
+            for k in range(0, len(Q), 7):
+                ri, rd = tree.nearest(Q[k], naive=True)
+                assert d1[k] == rd and (i1[k] == ri or np.array_equal(pts[i1[k]], pts[ri]))
+            assert i1[500] == 7 and i1[501] == 200 and d1[501] == 0.0
+    # adversarial order: distances to the query strictly decreasing with the index
+    n = 60_000
+    q = np.zeros((4, 3))
+    radii = np.linspace(90.0, 1.0, n)
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    pts = u * radii[:, None]
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        idx, dist = ctx.nn_nearest(q)                       # overflows the candidate buffer -> exact scan
+        ref = np.sqrt((pts[:, 0] * pts[:, 0] + pts[:, 1] * pts[:, 1]) + pts[:, 2] * pts[:, 2])
+        assert (idx == np.argmin(ref)).all() and (dist == ref.min()).all()
+
+
 def test_edges_spheres_bit_exact(small3, oracle):
     pts, tree, ctx = small3
     sph = synth.spheres(32)
