@@ -210,6 +210,13 @@ def main():
         bytes_streamed = n_tiles * N * 24 + B * 32 + k_total * 16      # node passes + queries + hit records
         achieved = bytes_streamed / (scan_ms * 1e-3) / 1e9
         valu_ops = B * N * 9                                           # 3 sub, 3 mul, 2 add, 1 cmp per (query, node)
+        # HBM-side bytes per launch of this kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE,
+        # rocprofv3 --pmc, scripts_gpu_pmc.sh); PMC counters cannot be read inside this process.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if args.config == "C4" and args.nn_filter and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 PMC passes)"
         out = {
             "metric": "collision-checked edges/sec + radius-NN queries/sec at N=200k nodes, 256 obs",
             "value": e_sum * args.steps / t_max,
@@ -235,7 +242,8 @@ def main():
             },
             "roofline": {
                 "kernel": "nn_scan_f32_kernel<3>" if args.nn_filter else "nn_scan_kernel<3>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_streamed, "tile_q": tile_q,
                 "pairs_per_s": B * N / (scan_ms * 1e-3),
                 "valu_fp64_frac": (valu_ops / (scan_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS) if not args.nn_filter else None,
