@@ -75,7 +75,9 @@ const char *rrtx_create_error(void);
 int rrtx_set_stream(rrtx_ctx *ctx, void *hip_stream);
 void *rrtx_get_stream(rrtx_ctx *ctx);
 int rrtx_sync(rrtx_ctx *ctx);
-int rrtx_profile(rrtx_ctx *ctx, int enable); /* per-kernel HIP-event timing on/off (resets sums) */
+/* per-kernel-family HIP-event timing (resets the sums): 0 = off, 1 = only the range-scan kernel
+ * (two event records per call), 2 = every family (each record costs ~10 us between kernels) */
+int rrtx_profile(rrtx_ctx *ctx, int enable);
 int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
 /* tuning switches; none of them changes a result.
  *   RRTX_OPT_NN_FILTER (default 1): range search screens (query, node) pairs with a

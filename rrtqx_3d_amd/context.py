@@ -61,8 +61,10 @@ class Context:
     def sync(self):
         self._check(self._lib.rrtx_sync(self._h))
 
-    def profile(self, enable: bool):
-        self._check(self._lib.rrtx_profile(self._h, 1 if enable else 0))
+    def profile(self, level):
+        """0/False off, 1 range-scan kernel only, 2/True every kernel family."""
+        lvl = 2 if level is True else int(level)
+        self._check(self._lib.rrtx_profile(self._h, lvl))
 
     def set_option(self, option: int, value: int):
         self._check(self._lib.rrtx_set_option(self._h, option, value))

@@ -48,6 +48,20 @@ constexpr int kScanFU = 8;                 // nodes per lane in the fp32-prefilt
 constexpr int kQPI = 4;                    // query copies per inner iteration (amortises loop/branch/SMEM overhead)
 constexpr int kChunkF = 64 * kScanFU;
 
+// ---------------------------------------------------------------- init ------
+// per-call device state in one launch (a 24-byte H2D copy from pageable memory plus a memset were
+// three runtime kernels and ~20 us)
+__global__ void nn_init_kernel(Scalars *__restrict__ sc, int n_copies_init, int *__restrict__ zero_i32, int n_i32,
+                               unsigned long long *__restrict__ fill_u64, int n_u64, unsigned long long v_u64,
+                               int *__restrict__ fill_i32, int n_fill_i32, int v_i32) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int stride = gridDim.x * blockDim.x;
+  if (i == 0) { sc->total = 0ull; sc->n_copies = n_copies_init; sc->pad = 0; sc->q_absmax = 0ull; }
+  for (int k = i; k < n_i32; k += stride) zero_i32[k] = 0;
+  for (int k = i; k < n_u64; k += stride) fill_u64[k] = v_u64;
+  for (int k = i; k < n_fill_i32; k += stride) fill_i32[k] = v_i32;
+}
+
 // ---------------------------------------------------------------- pack ------
 template <int D>
 __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const double *__restrict__ thr_lt_arr,
@@ -1006,10 +1020,9 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   int *big_count = count + nq;          // zeroed together with count
   int *cursor = count + nq + 1;
   int *big_list = cursor + nq;
-  Scalars init;
-  init.total = 0ull; init.n_copies = (ctx->n_wraps == 0) ? nq : 0; init.pad = 0; init.q_absmax = 0ull;
-  RRTX_HIP(ctx, hipMemcpyAsync(sc, &init, sizeof(Scalars), hipMemcpyHostToDevice, st));
-  RRTX_HIP(ctx, hipMemsetAsync(count, 0, ((size_t)nq + 1) * sizeof(int), st));
+  hipLaunchKernelGGL(nn_init_kernel, dim3((nq + 1 + 255) / 256 < 64 ? (nq + 1 + 255) / 256 : 64), dim3(256), 0, st, sc,
+                     (ctx->n_wraps == 0) ? nq : 0, count, nq + 1, (unsigned long long *)nullptr, 0, 0ull,
+                     (int *)nullptr, 0, 0);
 
   const double *thr_lt_arr = r_dev_thr_lt;
   const double *thr_gt_arr = r_dev_thr_lt ? r_dev_thr_lt + nq : nullptr;
@@ -1187,11 +1200,8 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
   unsigned long long *best_bits = ctx->ws_partial.as<unsigned long long>();
   int *best_idx = reinterpret_cast<int *>(best_bits + nq);
   Scalars *sc = ctx->ws_scalars.as<Scalars>();
-  Scalars init;
-  init.total = 0ull; init.n_copies = (ctx->n_wraps == 0) ? nq : 0; init.pad = 0; init.q_absmax = 0ull;
-  RRTX_HIP(ctx, hipMemcpyAsync(sc, &init, sizeof(Scalars), hipMemcpyHostToDevice, st));
-  RRTX_HIP(ctx, hipMemsetAsync(best_bits, 0xff, (size_t)nq * sizeof(unsigned long long), st));
-  RRTX_HIP(ctx, hipMemsetAsync(best_idx, 0x7f, (size_t)nq * sizeof(int), st));   // 0x7f7f7f7f, above any index
+  hipLaunchKernelGGL(nn_init_kernel, dim3((nq + 255) / 256 < 64 ? (nq + 255) / 256 : 64), dim3(256), 0, st, sc,
+                     (ctx->n_wraps == 0) ? nq : 0, (int *)nullptr, 0, best_bits, nq, ~0ull, best_idx, nq, 0x7fffffff);
   const double inf = std::numeric_limits<double>::infinity();
   const double nan = std::numeric_limits<double>::quiet_NaN();
 

@@ -133,7 +133,8 @@ struct rrtx_ctx {
   double thr_cache_r = -1.0, thr_cache_lt = 0.0, thr_cache_gt = 0.0;
 
   // profiling
-  bool profiling = false;
+  int profiling = 0;                // 0 off, 1 range-scan family only, 2 every family
+  bool span_open = false;
   std::vector<rrtx::TimedSpan> spans;
   std::vector<hipEvent_t> event_pool;
   double fam_ms[rrtx::KF_COUNT] = {0};

@@ -21,13 +21,13 @@ def spans(st):
 
 def timed(ctx, fn, reps=5):
     fn()
-    ctx.profile(True)
+    ctx.profile(2)
     t0 = time.perf_counter()
     for _ in range(reps):
         out = fn()
     wall = (time.perf_counter() - t0) / reps
     st = ctx.stats()
-    ctx.profile(False)
+    ctx.profile(0)
     return out, wall * 1e3, {k: round(v / reps, 4) for k, v in spans(st).items()}
 
 
