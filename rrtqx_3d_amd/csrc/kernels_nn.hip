@@ -455,15 +455,25 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
           const typename QRecFT<D>::type ck = copies_f[q + k];
           float t[kScanFU];
           screen8<D>(ck, x, y, z, w, pp, t);
+          // per-lane 8-bit survivor mask (VALU only), then one short scalar loop over the few
+          // lanes that have survivors; each such lane appends its own nodes to the queue
+          unsigned pm = 0u;
 #pragma unroll
-          for (int u = 0; u < kScanFU; ++u) {
-            const int id = base + u * 64 + lane;
-            const unsigned long long m = __ballot(!(t[u] > ck.thr) && id < node_end);
-            if (m == 0ull) continue;
-            const int n = __popcll(m);
+          for (int u = 0; u < kScanFU; ++u)
+            pm |= ((!(t[u] > ck.thr) && (base + u * 64 + lane) < node_end) ? 1u : 0u) << u;
+          unsigned long long lm = __ballot(pm != 0u);
+          while (lm != 0ull) {
+            const int L = __ffsll((long long)lm) - 1;
+            lm &= lm - 1ull;
+            const unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)pm, L);
+            const int n = __popc(bits);
             if (wn + n > kCandCap)
               drain_candidates<D>(cand, wn, nx, ny, nz, nw, copies, meta, slots, n_slots, recs, cap, sc, count);
-            if ((m >> lane) & 1ull) cand[wn + __popcll(m & lt_mask)] = make_int2(q + k, id);
+            if (lane == L) {
+              int wpos = wn;
+              for (int u = 0; u < kScanFU; ++u)
+                if ((bits >> u) & 1u) cand[wpos++] = make_int2(q + k, base + u * 64 + L);
+            }
             wn += n;
           }
         }
