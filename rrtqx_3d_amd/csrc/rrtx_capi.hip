@@ -314,8 +314,8 @@ int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value) {
   CHECK_CTX(ctx);
   switch (option) {
     case RRTX_OPT_NN_FILTER: ctx->opt_nn_filter = value != 0; return RRTX_OK;
-    case RRTX_OPT_SCAN_BLOCKS: ctx->opt_scan_blocks = value > 0 ? (int)value : 2048; return RRTX_OK;
-    case RRTX_OPT_SCAN_ITEMS: ctx->opt_scan_items = value > 0 ? (int)value : 4096; return RRTX_OK;
+    case RRTX_OPT_SCAN_BLOCKS: ctx->opt_scan_blocks = value > 0 ? (int)value : 1280; return RRTX_OK;
+    case RRTX_OPT_SCAN_ITEMS: ctx->opt_scan_items = value > 0 ? (int)value : 2048; return RRTX_OK;
     case RRTX_OPT_SCAN_TILE_Q: ctx->opt_tile_q = value > 0 ? (int)value : 0; return RRTX_OK;
     default: return fail(ctx, RRTX_E_INVALID, "set_option: unknown option %d", option);
   }

@@ -81,8 +81,8 @@ struct rrtx_ctx {
 
   // options (rrtx_set_option)
   int opt_nn_filter = 1;            // 1: fp32 prefilter + exact fp64 confirm, 0: exact fp64 scan
-  int opt_scan_blocks = 2048;       // persistent workgroups of the range scan (256 CUs x 8)
-  int opt_scan_items = 4096;        // target number of (tile, segment) work items
+  int opt_scan_blocks = 1280;       // persistent workgroups of the range scan (256 CUs x 5 resident)
+  int opt_scan_items = 2048;        // target number of (tile, segment) work items
   int opt_tile_q = 0;               // query copies per workgroup tile (0 = kernel default)
 
   // wrapped dimensions

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tuning sweep of the range-scan launch geometry (prints one line per point)
 mkdir -p gpurun_out
-for sb in 1024 1280 1536 2048; do for it in 4096 10240 20480; do for tq in 32 64 128; do
+for sb in 1280 2048 2560 4096; do for it in 2048 4096 8192; do for tq in 32 64 128; do
 timeout -k 10 120 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --scan-blocks $sb --scan-items $it --tile-q $tq > gpurun_out/sweep.json 2>> gpurun_out/bench_err.log
 python - "$sb" "$it" "$tq" <<'PY'
 import json, sys
