@@ -201,6 +201,17 @@ int rrtx_extend_candidates(rrtx_ctx *ctx, const double *q, int nq, double r, dou
                            uint8_t *hit_in, int64_t cap, int64_t *needed, int32_t *nearest_idx,
                            double *nearest_dist, uint8_t *sample_unsafe);
 
+/* The same preamble for Edge = DubinsEdge (BASELINE config 3; R/dubinsExperimentsForPaper.jl): tree in
+ * [x y t theta] with theta wrapped (rrtx_set_wrap), polygon obstacle list.  Per neighbour entry:
+ * key = the KDdist the range search stores, Dubins cost and word for sample->near (out) and
+ * near->sample (in), and the two-stage Dubins collision flags (R/DRRT_DubinsEdge_functions.jl:750-774).
+ * word_out / word_in (3 bytes per entry) and nearest_* / sample_unsafe may be NULL. */
+int rrtx_extend_candidates_dubins(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius,
+                                  double r_min, int64_t *offsets, int32_t *idx, double *key, double *cost_out,
+                                  double *cost_in, uint8_t *word_out, uint8_t *word_in, uint8_t *hit_out,
+                                  uint8_t *hit_in, int64_t cap, int64_t *needed, int32_t *nearest_idx,
+                                  double *nearest_dist, uint8_t *sample_unsafe);
+
 /* ---- device-resident variants (inputs/outputs are DEVICE pointers) ------------ */
 int rrtx_nn_nearest_dev(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double *dist);
 int rrtx_nn_radius_dev(rrtx_ctx *ctx, const double *q, double r, int nq, int64_t *offsets,

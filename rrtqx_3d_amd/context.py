@@ -250,6 +250,39 @@ class Context:
             return dict(offsets=offsets, idx=idx[:n], cost=cost[:n], hit_out=hout[:n], hit_in=hin[:n],
                         nearest_idx=nidx, nearest_dist=ndist, sample_unsafe=unsafe)
 
+    def extend_candidates_dubins(self, q, r: float, robot_radius: float, r_min: float, cap: Optional[int] = None):
+        """Fused extend() preamble for Edge = DubinsEdge (dim 4, theta wrapped, polygon obstacles)."""
+        q = f64(q, (-1, 4))
+        nq = q.shape[0]
+        if cap is None:
+            cap = max(256 * nq, 1024)
+        offsets = np.empty(nq + 1, dtype=np.int64)
+        nidx = np.empty(nq, dtype=np.int32)
+        ndist = np.empty(nq, dtype=np.float64)
+        unsafe = np.empty(nq, dtype=np.uint8)
+        while True:
+            idx = np.empty(cap, dtype=np.int32)
+            key = np.empty(cap, dtype=np.float64)
+            co = np.empty(cap, dtype=np.float64)
+            ci = np.empty(cap, dtype=np.float64)
+            wo = np.empty((cap, 3), dtype=np.uint8)
+            wi = np.empty((cap, 3), dtype=np.uint8)
+            ho = np.empty(cap, dtype=np.uint8)
+            hi = np.empty(cap, dtype=np.uint8)
+            needed = C.c_int64()
+            rc = self._lib.rrtx_extend_candidates_dubins(
+                self._h, _capi._ptr(q), nq, r, robot_radius, r_min, _capi._ptr(offsets), _capi._ptr(idx),
+                _capi._ptr(key), _capi._ptr(co), _capi._ptr(ci), _capi._ptr(wo), _capi._ptr(wi), _capi._ptr(ho),
+                _capi._ptr(hi), cap, C.byref(needed), _capi._ptr(nidx), _capi._ptr(ndist), _capi._ptr(unsafe))
+            if rc == _capi.RRTX_E_CAPACITY:
+                cap = int(needed.value)
+                continue
+            self._check(rc)
+            n = int(needed.value)
+            return dict(offsets=offsets, idx=idx[:n], key=key[:n], cost_out=co[:n], cost_in=ci[:n],
+                        word_out=wo[:n].view("S3").ravel(), word_in=wi[:n].view("S3").ravel(), hit_out=ho[:n],
+                        hit_in=hi[:n], nearest_idx=nidx, nearest_dist=ndist, sample_unsafe=unsafe)
+
     # ---- device-pointer variants (pointers are ints, e.g. torch.Tensor.data_ptr()) ----------------
     def nn_nearest_dev(self, q_ptr: int, nq: int, idx_ptr: int, dist_ptr: int):
         self._check(self._lib.rrtx_nn_nearest_dev(self._h, q_ptr, nq, idx_ptr, dist_ptr))

@@ -331,6 +331,56 @@ __device__ bool seg_hits_polygon(double ax, double ay, double bx, double by, dou
   return false;
 }
 
+// two-stage test of one steered edge against the polygon list (:750-774)
+__device__ bool dubins_collides(const Steer &st, double sx, double sy, double gx, double gy, double r_min,
+                                double robot_radius, const double *__restrict__ meta,
+                                const int32_t *__restrict__ off, const double *__restrict__ vxy, int m) {
+  for (int j = 0; j < m; ++j) {
+    if (!seg_hits_polygon(sx, sy, gx, gy, robot_radius + 2 * r_min, meta, off, vxy, j)) continue;
+    double px = 0, py = 0;
+    int row = 0;
+    for (int pi = 0; pi < 3; ++pi) {
+      for (int k = 0; k < st.pc[pi].len; ++k, ++row) {
+        double x, y;
+        piece_point(st.pc[pi], k, r_min, x, y);
+        if (row > 0 && seg_hits_polygon(px, py, x, y, robot_radius, meta, off, vxy, j)) return true;
+        px = x; py = y;
+      }
+    }
+  }
+  return false;
+}
+
+// Candidate Dubins edges of extend(): CSR entry e = (sample qi, node idx[e]); both directed edges
+// sample->near and near->sample are steered and checked (R/DRRT_Q.jl:1951-1963, 2600-2602 with
+// Edge = DubinsEdge).
+__global__ __launch_bounds__(256) void candidate_dubins_kernel(
+    const double *__restrict__ q, const int64_t *__restrict__ offsets, int nq, const int32_t *__restrict__ idx,
+    const int32_t *__restrict__ owner, const double *__restrict__ nx, const double *__restrict__ ny,
+    const double *__restrict__ nz, const double *__restrict__ nw, long long cap, double r_min,
+    double robot_radius, const double *__restrict__ meta, const int32_t *__restrict__ off,
+    const double *__restrict__ vxy, int m, double *__restrict__ cost_out, double *__restrict__ cost_in,
+    uint8_t *__restrict__ word_out, uint8_t *__restrict__ word_in, uint8_t *__restrict__ hit_out,
+    uint8_t *__restrict__ hit_in) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = offsets[nq];
+  if (total > cap) total = cap;
+  if (e >= total) return;
+  const int qi = owner[e];
+  const int n = idx[e];
+  double s[4] = {q[4 * (size_t)qi], q[4 * (size_t)qi + 1], q[4 * (size_t)qi + 2], q[4 * (size_t)qi + 3]};
+  double g[4] = {nx[n], ny[n], nz[n], nw[n]};
+  Steer st;
+  dubins_steer<true>(s, g, r_min, st);
+  cost_out[e] = st.cost;
+  if (word_out) write_word(word_out, e, st.word);
+  hit_out[e] = dubins_collides(st, s[0], s[1], g[0], g[1], r_min, robot_radius, meta, off, vxy, m) ? 1 : 0;
+  dubins_steer<true>(g, s, r_min, st);
+  cost_in[e] = st.cost;
+  if (word_in) write_word(word_in, e, st.word);
+  hit_in[e] = dubins_collides(st, g[0], g[1], s[0], s[1], r_min, robot_radius, meta, off, vxy, m) ? 1 : 0;
+}
+
 // explicitEdgeCheck(S, ::DubinsEdge, ob) over the polygon list (:750-774):
 // stage 1 = straight chord with radius robotRadius + 2*minTurningRadius,
 // stage 2 = every stored polyline piece with robotRadius.
@@ -348,20 +398,7 @@ __global__ __launch_bounds__(256) void dubins_edges_check_kernel(
   const int P = st.pc[0].len + st.pc[1].len + st.pc[2].len;
   if (traj_len) traj_len[i] = P;
   const double sx = s[4 * i], sy = s[4 * i + 1], gx = g[4 * i], gy = g[4 * i + 1];
-  bool h = false;
-  for (int j = 0; j < m && !h; ++j) {
-    if (!seg_hits_polygon(sx, sy, gx, gy, robot_radius + 2 * r_min, meta, off, vxy, j)) continue;
-    double px = 0, py = 0;
-    int row = 0;
-    for (int pi = 0; pi < 3 && !h; ++pi) {
-      for (int k = 0; k < st.pc[pi].len; ++k, ++row) {
-        double x, y;
-        piece_point(st.pc[pi], k, r_min, x, y);
-        if (row > 0 && seg_hits_polygon(px, py, x, y, robot_radius, meta, off, vxy, j)) { h = true; break; }
-        px = x; py = y;
-      }
-    }
-  }
+  const bool h = dubins_collides(st, sx, sy, gx, gy, r_min, robot_radius, meta, off, vxy, m);
   hit[i] = h ? 1 : 0;
 }
 
@@ -389,6 +426,25 @@ __global__ __launch_bounds__(256) void dubins_trajectory_kernel(const double *__
 }
 
 }  // namespace
+
+int launch_candidate_dubins(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
+                            const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap, double r_min,
+                            double robot_radius, double *cost_out, double *cost_in, uint8_t *word_out,
+                            uint8_t *word_in, uint8_t *hit_out, uint8_t *hit_in) {
+  if (nq <= 0 || cap <= 0) return RRTX_OK;
+  if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
+  int rc = sync_polygons(ctx);
+  if (rc) return rc;
+  span_begin(ctx, KF_DUBINS);
+  hipLaunchKernelGGL(candidate_dubins_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, q_dev,
+                     offsets_dev, nq, idx_dev, owner_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[3],
+                     (long long)cap, r_min, robot_radius, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
+                     ctx->d_poly_vxy.as<double>(), ctx->poly_n_active, cost_out, cost_in, word_out, word_in, hit_out,
+                     hit_in);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
 
 int launch_dubins_trajectory(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
                              const int64_t *traj_off_dev, double *traj_xy_dev, int64_t cap_rows,

@@ -469,6 +469,21 @@ int rrtx_nn_nearest_dev(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, do
   return launch_nn_nearest(ctx, q, nq, idx, dist);
 }
 
+// nearest on device buffers with the host-side overflow check of the screened scan
+static int nearest_with_fallback(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev) {
+  int rc = launch_nn_nearest(ctx, q_dev, nq, idx_dev, dist_dev);
+  if (rc) return rc;
+  if (ctx->last_nearest_cap > 0) {
+    // the screened scan keeps ~ln(n) candidates per query and segment; an adversarial visiting order
+    // (nodes sorted by decreasing distance) can exceed the record buffer -> exact scan instead
+    long long total = 0;
+    rc = nearest_candidates(ctx, &total);
+    if (rc) return rc;
+    if (total > ctx->last_nearest_cap) return launch_nn_nearest(ctx, q_dev, nq, idx_dev, dist_dev, true);
+  }
+  return RRTX_OK;
+}
+
 int rrtx_nn_nearest(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double *dist) {
   CHECK_CTX(ctx);
   if (nq < 0 || (nq > 0 && (!q || !idx || !dist))) return fail(ctx, RRTX_E_INVALID, "nn_nearest: bad arguments");
@@ -477,20 +492,8 @@ int rrtx_nn_nearest(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double
   if (rc) return rc;
   RRTX_HIP(ctx, ctx->ws_out_idx.ensure(sizeof(int32_t) * (size_t)nq));
   RRTX_HIP(ctx, ctx->ws_out_dist.ensure(sizeof(double) * (size_t)nq));
-  rc = launch_nn_nearest(ctx, ctx->ws_q.as<double>(), nq, ctx->ws_out_idx.as<int32_t>(), ctx->ws_out_dist.as<double>());
+  rc = nearest_with_fallback(ctx, ctx->ws_q.as<double>(), nq, ctx->ws_out_idx.as<int32_t>(), ctx->ws_out_dist.as<double>());
   if (rc) return rc;
-  if (ctx->last_nearest_cap > 0) {
-    // the screened scan keeps ~ln(n) candidates per query and segment; an adversarial visiting order
-    // (nodes sorted by decreasing distance) can exceed the record buffer -> exact scan instead
-    long long total = 0;
-    rc = nearest_candidates(ctx, &total);
-    if (rc) return rc;
-    if (total > ctx->last_nearest_cap) {
-      rc = launch_nn_nearest(ctx, ctx->ws_q.as<double>(), nq, ctx->ws_out_idx.as<int32_t>(),
-                             ctx->ws_out_dist.as<double>(), true);
-      if (rc) return rc;
-    }
-  }
   RRTX_HIP(ctx, hipMemcpyAsync(idx, ctx->ws_out_idx.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
   RRTX_HIP(ctx, hipMemcpyAsync(dist, ctx->ws_out_dist.p, sizeof(double) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -759,6 +762,9 @@ int rrtx_extend_candidates_dev(rrtx_ctx *ctx, const double *q, int nq, double r,
   if (nq < 0 || cap < 0 || (nq > 0 && (!q || !offsets)) || (cap > 0 && (!idx || !cost || !hit_out || !hit_in)))
     return fail(ctx, RRTX_E_INVALID, "extend_candidates: bad arguments");
   if (ctx->dim != 3) return fail(ctx, RRTX_E_STATE, "extend_candidates is the SimpleEdge (dim=3) path");
+  if (ctx->n_wraps != 0)
+    return fail(ctx, RRTX_E_STATE, "extend_candidates reads kdFindNearest off the range lists, which is only valid "
+                                   "without wrapped dimensions (use rrtx_extend_candidates_dubins / the separate calls)");
   if (nq == 0) return RRTX_OK;
   RRTX_HIP(ctx, ctx->ws_owner.ensure(sizeof(int32_t) * (size_t)(cap > 0 ? cap : 1)));
   const bool want_nearest = nearest_idx && nearest_dist;
@@ -833,6 +839,93 @@ int rrtx_extend_candidates(rrtx_ctx *ctx, const double *q, int nq, double r, dou
       std::vector<double> mq(miss.size() * (size_t)ctx->dim);
       for (size_t k = 0; k < miss.size(); ++k)
         std::memcpy(&mq[k * ctx->dim], q + (size_t)miss[k] * ctx->dim, sizeof(double) * ctx->dim);
+      std::vector<int32_t> mi(miss.size());
+      std::vector<double> md(miss.size());
+      rc = rrtx_nn_nearest(ctx, mq.data(), (int)miss.size(), mi.data(), md.data());
+      if (rc) return rc;
+      for (size_t k = 0; k < miss.size(); ++k) { nearest_idx[miss[k]] = mi[k]; nearest_dist[miss[k]] = md[k]; }
+    }
+  }
+  return RRTX_OK;
+}
+
+int rrtx_extend_candidates_dubins(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius,
+                                  double r_min, int64_t *offsets, int32_t *idx, double *key, double *cost_out,
+                                  double *cost_in, uint8_t *word_out, uint8_t *word_in, uint8_t *hit_out,
+                                  uint8_t *hit_in, int64_t cap, int64_t *needed, int32_t *nearest_idx,
+                                  double *nearest_dist, uint8_t *sample_unsafe) {
+  CHECK_CTX(ctx);
+  if (nq < 0 || cap < 0 || (nq > 0 && (!q || !offsets)) ||
+      (cap > 0 && (!idx || !key || !cost_out || !cost_in || !hit_out || !hit_in)))
+    return fail(ctx, RRTX_E_INVALID, "extend_candidates_dubins: bad arguments");
+  if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "extend_candidates_dubins needs a dim=4 [x y t theta] context");
+  if (nq == 0) { if (needed) *needed = 0; if (offsets) offsets[0] = 0; return RRTX_OK; }
+  int rc = stage_in(ctx, ctx->ws_q, q, sizeof(double) * (size_t)nq * 4);
+  if (rc) return rc;
+  const int64_t dcap = cap > 0 ? cap : 1;
+  const bool want_nearest = nearest_idx && nearest_dist;
+  RRTX_HIP(ctx, ctx->ws_out_off.ensure(sizeof(int64_t) * ((size_t)nq + 2)));
+  RRTX_HIP(ctx, ctx->ws_out_idx.ensure(sizeof(int32_t) * (size_t)dcap));
+  RRTX_HIP(ctx, ctx->ws_out_dist.ensure(sizeof(double) * 3 * (size_t)dcap));          // key, cost_out, cost_in
+  RRTX_HIP(ctx, ctx->ws_out_u8a.ensure(8 * (size_t)dcap + (size_t)nq));                // words (3+3), hits (1+1), unsafe
+  RRTX_HIP(ctx, ctx->ws_out_i32.ensure(sizeof(int32_t) * (size_t)nq));
+  RRTX_HIP(ctx, ctx->ws_out_f64.ensure(sizeof(double) * (size_t)nq));
+  RRTX_HIP(ctx, ctx->ws_owner.ensure(sizeof(int32_t) * (size_t)dcap));
+  int64_t *off_dev = ctx->ws_out_off.as<int64_t>();
+  int64_t *needed_dev = off_dev + nq + 1;
+  double *key_dev = ctx->ws_out_dist.as<double>(), *co_dev = key_dev + dcap, *ci_dev = co_dev + dcap;
+  uint8_t *wo_dev = ctx->ws_out_u8a.as<uint8_t>(), *wi_dev = wo_dev + 3 * dcap, *ho_dev = wi_dev + 3 * dcap,
+          *hi_dev = ho_dev + dcap, *unsafe_dev = hi_dev + dcap;
+  // with wrapped dimensions a list key is the distance to the copy that found the node FIRST
+  // (addToRangeList), not the minimum over the copies, so kdFindNearest cannot be read off the list
+  const bool nearest_from_list = want_nearest && ctx->n_wraps == 0;
+  rc = launch_nn_radius(ctx, ctx->ws_q.as<double>(), nullptr, r, nq, off_dev, ctx->ws_out_idx.as<int32_t>(), key_dev,
+                        cap, needed_dev, ctx->ws_owner.as<int32_t>(),
+                        nearest_from_list ? ctx->ws_out_i32.as<int32_t>() : nullptr,
+                        nearest_from_list ? ctx->ws_out_f64.as<double>() : nullptr);
+  if (rc) return rc;
+  rc = launch_candidate_dubins(ctx, ctx->ws_q.as<double>(), nq, off_dev, ctx->ws_out_idx.as<int32_t>(),
+                               ctx->ws_owner.as<int32_t>(), cap, r_min, robot_radius, co_dev, ci_dev, wo_dev, wi_dev,
+                               ho_dev, hi_dev);
+  if (rc) return rc;
+  if (sample_unsafe) {
+    rc = launch_points_polygons(ctx, ctx->ws_q.as<double>(), nq, robot_radius, unsafe_dev, nullptr);
+    if (rc) return rc;
+  }
+  if (want_nearest && !nearest_from_list) {
+    rc = nearest_with_fallback(ctx, ctx->ws_q.as<double>(), nq, ctx->ws_out_i32.as<int32_t>(), ctx->ws_out_f64.as<double>());
+    if (rc) return rc;
+  }
+  int64_t total = 0;
+  RRTX_HIP(ctx, hipMemcpyAsync(offsets, off_dev, sizeof(int64_t) * ((size_t)nq + 1), hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipMemcpyAsync(&total, needed_dev, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (needed) *needed = total;
+  ctx->last_neighbors = total;
+  if (total > cap) return fail(ctx, RRTX_E_CAPACITY, "extend_candidates_dubins: %lld neighbours, capacity %lld", (long long)total, (long long)cap);
+  const size_t n = (size_t)total;
+  if (n > 0) {
+    RRTX_HIP(ctx, hipMemcpyAsync(idx, ctx->ws_out_idx.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipMemcpyAsync(key, key_dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipMemcpyAsync(cost_out, co_dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipMemcpyAsync(cost_in, ci_dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (word_out) RRTX_HIP(ctx, hipMemcpyAsync(word_out, wo_dev, 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (word_in) RRTX_HIP(ctx, hipMemcpyAsync(word_in, wi_dev, 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipMemcpyAsync(hit_out, ho_dev, n, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipMemcpyAsync(hit_in, hi_dev, n, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (sample_unsafe) RRTX_HIP(ctx, hipMemcpyAsync(sample_unsafe, unsafe_dev, (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+  if (want_nearest) {
+    RRTX_HIP(ctx, hipMemcpyAsync(nearest_idx, ctx->ws_out_i32.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipMemcpyAsync(nearest_dist, ctx->ws_out_f64.p, sizeof(double) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (want_nearest) {
+    std::vector<int> miss;
+    for (int i = 0; i < nq; ++i) if (nearest_idx[i] < 0) miss.push_back(i);
+    if (!miss.empty()) {
+      std::vector<double> mq(miss.size() * 4);
+      for (size_t k = 0; k < miss.size(); ++k) std::memcpy(&mq[k * 4], q + (size_t)miss[k] * 4, sizeof(double) * 4);
       std::vector<int32_t> mi(miss.size());
       std::vector<double> md(miss.size());
       rc = rrtx_nn_nearest(ctx, mq.data(), (int)miss.size(), mi.data(), md.data());

@@ -192,6 +192,10 @@ int launch_dubins_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev,
 int launch_dubins_edges_check(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne,
                               double r_min, double robot_radius, double *cost_dev, uint8_t *word_dev,
                               uint8_t *hit_dev, int32_t *traj_len_dev);
+int launch_candidate_dubins(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
+                            const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap, double r_min,
+                            double robot_radius, double *cost_out, double *cost_in, uint8_t *word_out,
+                            uint8_t *word_in, uint8_t *hit_out, uint8_t *hit_in);
 int launch_dubins_trajectory(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
                              const int64_t *traj_off_dev, double *traj_xy_dev, int64_t cap_rows,
                              int32_t *traj_len_dev);

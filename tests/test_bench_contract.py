@@ -1,0 +1,34 @@
+"""CPU checks of the measurement contract: bench.py parses its flags without a GPU and the committed
+bench line (profiles/) carries every field the driver and the judge read."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_help_runs_without_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in r.stdout
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_bench.json")))
+    assert line["metric"] == baseline["metric"]
+    for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["vs_baseline"] is None and line["data"] == "synthetic" and line["dtype"] == "f64"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    rf = line["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["traffic"] is None or rf["traffic"] > 0
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
+    assert line["value"] > 50 * cb["value"]                 # north_star: >= 50x the CPU path

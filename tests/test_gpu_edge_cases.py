@@ -110,3 +110,22 @@ def test_nan_inputs_flow_through():
         assert len(idx) == 0
         hit, first = ctx.edges_check([[np.nan, 0, 0]], [[1, 0, 0]], 0.5)
         assert list(hit) == [1] and list(first) == [0]
+
+
+def test_results_are_deterministic_across_runs():
+    """hits are appended with atomics in arbitrary order, then ordered by node index: 10 repeated
+    calls must return identical bytes (also exercises the LDS queues / record buffer for races)"""
+    from rrtqx_3d_amd import synth
+    pts, Q, sph = synth.nodes(50_000, 3), synth.queries(2048, 3), synth.spheres(64)
+    r = synth.ball_radius(50_000, 3)
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        ctx.spheres_set(sph)
+        ref = ctx.extend_candidates(Q, r, 0.5)
+        refn = ctx.nn_nearest(Q)
+        for _ in range(10):
+            out = ctx.extend_candidates(Q, r, 0.5)
+            for k in ref:
+                assert np.array_equal(out[k], ref[k]), k
+            n = ctx.nn_nearest(Q)
+            assert np.array_equal(n[0], refn[0]) and np.array_equal(n[1], refn[1])

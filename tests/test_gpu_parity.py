@@ -390,6 +390,46 @@ def test_dubins_steer_tolerance(oracle):
             assert words_differ <= ne // 200
 
 
+def test_extend_candidates_dubins(oracle):
+    """fused Dubins preamble == its parts (wrapped range search + per-edge steer/check) == oracle"""
+    n = 8_000
+    pts = synth.nodes(n, 4)
+    Q = synth.queries(96, 4)
+    polys = synth.polygons(32)
+    ps = oracle.PolygonSet(polys)
+    r, r_min = 6.0, 1.0
+    tree = oracle.KDTree(4, wraps=[3], wrap_points=[2.0 * math.pi])
+    tree.insert_many(pts)
+    with Context(4) as ctx:
+        ctx.set_wrap(3, 2.0 * math.pi)
+        ctx.nodes_append(pts)
+        ctx.polygons_set(polys)
+        out = ctx.extend_candidates_dubins(Q, r, ROBOT_RADIUS, r_min)
+        off, idx = out["offsets"], out["idx"]
+        _check_csr(off, idx, out["key"], _oracle_lists(tree, Q, r))
+        owner = np.repeat(np.arange(len(Q)), np.diff(off))
+        s, g = Q[owner], pts[idx]
+        co, wo, ho, _ = ctx.dubins_edges_check(s, g, r_min, ROBOT_RADIUS)       # same device code, per edge
+        ci, wi, hi, _ = ctx.dubins_edges_check(g, s, r_min, ROBOT_RADIUS)
+        assert np.array_equal(out["cost_out"], co) and np.array_equal(out["cost_in"], ci)
+        assert np.array_equal(out["word_out"], wo) and np.array_equal(out["word_in"], wi)
+        assert np.array_equal(out["hit_out"], ho) and np.array_equal(out["hit_in"], hi)
+        assert (co != ci).any()                                                   # Dubins edges are directed
+        mism = 0
+        for k in range(0, len(idx), max(1, len(idx) // 300)):
+            c, w, traj = oracle.dubins_steer(s[k], g[k], r_min)
+            h, _ = oracle.dubins_edge_check_polygons(ps, s[k], g[k], traj, ROBOT_RADIUS, r_min)
+            assert abs(co[k] - c) <= REL_TOL_DUBINS * max(1.0, abs(c))
+            mism += (bool(ho[k]) != h)
+        assert mism <= 1
+        for i in range(len(Q)):
+            ni, nd = tree.nearest(Q[i])
+            assert out["nearest_idx"][i] == ni and out["nearest_dist"][i] == nd
+        for i in range(0, len(Q), 5):
+            u, _ = oracle.point_check_polygons(ps, Q[i], ROBOT_RADIUS)
+            assert bool(out["sample_unsafe"][i]) == u
+
+
 def test_dubins_trajectory_polyline(oracle):
     """edge.trajectory (R/DRRT_DubinsEdge_functions.jl:506-701): same number of rows as the
     reference's float ranges produce and the same points to 1e-6 relative (device libm)."""
