@@ -370,6 +370,30 @@ def test_radius_wrapped_theta_c3(oracle):
             assert idx[i] == ri and dist[i] == rd
 
 
+def test_radius_two_wrapped_dimensions(oracle):
+    """ghost iterator with two wrapped dimensions (3 ghosts per query, R/ghostPoint.jl:60-111):
+    binary visiting order, skip rule and first-discovery keys against the oracle's kd-tree"""
+    rng = np.random.default_rng(17)
+    n = 6000
+    pts = rng.uniform(0.0, 1.0, (n, 3))
+    pts[:, 1] *= 10.0                       # the middle dimension does not wrap
+    tree = oracle.KDTree(3, wraps=[0, 2], wrap_points=[1.0, 1.0])
+    tree.insert_many(pts)
+    Q = pts[rng.integers(0, n, 128)] + rng.normal(0, 0.01, (128, 3))
+    Q[:, [0, 2]] = np.clip(Q[:, [0, 2]], 0.0, 1.0)
+    with Context(3) as ctx:
+        ctx.set_wrap(0, 1.0)
+        ctx.set_wrap(2, 1.0)
+        ctx.nodes_append(pts)
+        for r in (0.08, 0.35, 0.7):         # 0.7 > period/2: the same node is seen by several copies
+            offsets, idx, dist = ctx.nn_radius(Q, r)
+            _check_csr(offsets, idx, dist, _oracle_lists(tree, Q, r))
+        idx, dist = ctx.nn_nearest(Q)
+        for i, q in enumerate(Q):
+            ri, rd = tree.nearest(q)
+            assert dist[i] == rd and (idx[i] == ri or np.array_equal(pts[idx[i]], pts[ri]))
+
+
 def test_dubins_steer_tolerance(oracle):
     rng = np.random.default_rng(5)
     ne = 4096
