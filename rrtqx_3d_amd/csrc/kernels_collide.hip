@@ -132,39 +132,68 @@ __global__ __launch_bounds__(256) void edges_spheres_kernel(const double *__rest
 __global__ __launch_bounds__(256) void candidate_edges_kernel(
     const double *__restrict__ q, int stride, const int64_t *__restrict__ offsets, int nq,
     const int32_t *__restrict__ idx, const int32_t *__restrict__ owner, const double *__restrict__ nx,
-    const double *__restrict__ ny, const double *__restrict__ nz, long long cap,
-    const SphRec *__restrict__ sph, const SphRec *__restrict__ reach, int m, uint8_t *__restrict__ hit_out,
-    uint8_t *__restrict__ hit_in) {
+    const double *__restrict__ ny, const double *__restrict__ nz, int n_nodes, long long cap,
+    const SphRec *__restrict__ sph, const float *__restrict__ reach_f, double ox, double oy, double oz, int m,
+    uint8_t *__restrict__ hit_out, uint8_t *__restrict__ hit_in) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long total = offsets[nq];
-  if (total > cap) total = cap;
-  const bool act = e < total;
+  const long long total = offsets[nq];
+  // capacity overflow: the CSR arrays are only partly written (the caller gets RRTX_E_CAPACITY and
+  // retries); nothing may be dereferenced through them
+  if (total > cap) return;
+  bool act = e < total;
   double sx = 0, sy = 0, sz = 0, tx = 0, ty = 0, tz = 0;
   if (act) {
     const int lo = owner[e];   // owning query (written by nn_order_kernel)
-    sx = q[(size_t)lo * stride + 0]; sy = q[(size_t)lo * stride + 1]; sz = q[(size_t)lo * stride + 2];
     const int n = idx[e];
-    tx = nx[n]; ty = ny[n]; tz = nz[n];
+    act = (unsigned)lo < (unsigned)nq && (unsigned)n < (unsigned)n_nodes;   // defensive: never index out of range
+    if (act) {
+      sx = q[(size_t)lo * stride + 0]; sy = q[(size_t)lo * stride + 1]; sz = q[(size_t)lo * stride + 2];
+      tx = nx[n]; ty = ny[n]; tz = nz[n];
+    }
   }
   // out: sample -> near ; in: near -> sample.  edgeLen is the same value either
   // way (squares of negated differences); the direction vector flips.
   const double bx = tx - sx, by = ty - sy, bz = tz - sz;
   const double cx = sx - tx, cy = sy - ty, cz = sz - tz;
   const double len = sqrt_rn(sq3(sx, sy, sz, tx, ty, tz));
-  const EdgeReach er = edge_reach(sx, sy, sz, tx, ty, tz, len);
   bool out_hit = false, in_hit = false;
   if (__ballot(act) == 0ull) return;   // the grid covers the caller's capacity, most waves are past the end
-  // groups of 8 obstacles: eight wave-uniform reach records per SMEM round trip, eight reach
-  // tests as straight-line VALU code, ONE wave-level branch per group (the per-obstacle
-  // exec-mask bookkeeping was twice the VALU work in SALU instructions)
+  // fp32 screen state of this lane's segment: midpoint relative to the context origin and the
+  // inflated half length  hls~ = RU[(L/2 + 3 eps |m|_1)(1 + 8 eps)]  (+inf disables the screen:
+  // zero-length edges collide with every active sphere, R/DRRT_Q.jl:1208; non-finite input)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  float mxf, myf, mzf, hlsf;
+  {
+    const double cmax = fmax(fmax(fmax(fabs(sx), fabs(sy)), fmax(fabs(sz), fabs(tx))), fmax(fabs(ty), fabs(tz)));
+    const bool usable = (len > 0.0) && (len < 1e30) && (cmax < 1e30) && (sx == sx) && (sy == sy) && (sz == sz) &&
+                        (tx == tx) && (ty == ty) && (tz == tz);
+    const double mx = 0.5 * (sx + tx) - ox, my = 0.5 * (sy + ty) - oy, mz = 0.5 * (sz + tz) - oz;
+    mxf = (float)mx; myf = (float)my; mzf = (float)mz;
+    const double eps = 5.9604644775390625e-08;
+    const double h = (0.5 * len * (1.0 + 1e-12) + 3.0 * eps * (fabs(mx) + fabs(my) + fabs(mz)) + 1e-30) * (1.0 + 8.0 * eps);
+    hlsf = usable ? __double2float_ru(h) : __builtin_inff();
+    if (!usable) { mxf = 0.f; myf = 0.f; mzf = 0.f; }
+  }
+  const f32x2 m2x = {mxf, mxf}, m2y = {myf, myf}, m2z = {mzf, mzf}, h2 = {hlsf, hlsf};
+  // groups of 8 obstacles: two s_load_dwordx16 bring four pair-interleaved records; each pair costs
+  // 8 packed fp32 instructions (3 sub, mul + 2 fma, add, mul) + 2 compares, ONE wave-level branch per group
   constexpr int G = 8;
   for (int j0 = 0; j0 < m; j0 += G) {
-    SphRec rb[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) rb[g] = reach[min(j0 + g, m - 1)];
+    const float *gp = reach_f + (size_t)(j0 / 8) * 32;
     unsigned touch = 0u;
 #pragma unroll
-    for (int g = 0; g < G; ++g) touch |= (may_touch(er, rb[g]) ? 1u : 0u) << g;
+    for (int pr = 0; pr < 4; ++pr) {
+      const f32x2 cx = {gp[8 * pr + 0], gp[8 * pr + 1]}, cy = {gp[8 * pr + 2], gp[8 * pr + 3]};
+      const f32x2 cz = {gp[8 * pr + 4], gp[8 * pr + 5]}, rr = {gp[8 * pr + 6], gp[8 * pr + 7]};
+      const f32x2 dx = cx - m2x, dy = cy - m2y, dz = cz - m2z;
+      f32x2 dm2 = dx * dx;
+      dm2 = __builtin_elementwise_fma(dy, dy, dm2);
+      dm2 = __builtin_elementwise_fma(dz, dz, dm2);
+      const f32x2 bound = rr + h2;
+      const f32x2 b2 = bound * bound;
+      touch |= (!(dm2.x > b2.x) ? 1u : 0u) << (2 * pr);
+      touch |= (!(dm2.y > b2.y) ? 1u : 0u) << (2 * pr + 1);
+    }
     if (j0 + G > m) touch &= (1u << (m - j0)) - 1u;
     if (!act) touch = 0u;
     if (__ballot(touch != 0u) == 0ull) continue;
@@ -472,7 +501,9 @@ void packed_range(const std::vector<int32_t> &orig, int begin, int end, int &pb,
 // ------------------------------------------------------------- host glue -----
 
 int sync_spheres(rrtx_ctx *ctx, double robot_radius) {
-  if (!ctx->sph_dirty && ctx->sph_packed_rr == robot_radius) return RRTX_OK;
+  const bool same_origin = ctx->sph_packed_origin[0] == ctx->origin[0] && ctx->sph_packed_origin[1] == ctx->origin[1] &&
+                           ctx->sph_packed_origin[2] == ctx->origin[2];
+  if (!ctx->sph_dirty && ctx->sph_packed_rr == robot_radius && same_origin) return RRTX_OK;
   const int m = (int)ctx->sph_active.size();
   std::vector<SphRec> rec, reach;
   std::vector<double> radius, thr_in;
@@ -506,6 +537,34 @@ int sync_spheres(rrtx_ctx *ctx, double robot_radius) {
     RRTX_HIP(ctx, hipMemcpy(ctx->d_sph.p, rec.data(), sizeof(SphRec) * na, hipMemcpyHostToDevice));
     RRTX_HIP(ctx, ctx->d_sph_reach.ensure(sizeof(SphRec) * na));
     RRTX_HIP(ctx, hipMemcpy(ctx->d_sph_reach.p, reach.data(), sizeof(SphRec) * na, hipMemcpyHostToDevice));
+    // fp32 reach table for the packed screen of candidate_edges_kernel: centres relative to the
+    // context origin, pair-interleaved {cxA,cxB, cyA,cyB, czA,czB, RA,RB}, padded to groups of 8
+    // obstacles with centres at +inf (never within reach).  R~ = RU[(R' + 3 eps |c|_1)(1 + 8 eps)].
+    {
+      const int ng = (na + 7) / 8;
+      std::vector<float> tf((size_t)ng * 32, std::numeric_limits<float>::infinity());
+      const double eps = 5.9604644775390625e-08;
+      for (int k = 0; k < na; ++k) {
+        const double cx = reach[k].cx - ctx->origin[0], cy = reach[k].cy - ctx->origin[1], cz = reach[k].cz - ctx->origin[2];
+        const double l1 = std::fabs(cx) + std::fabs(cy) + std::fabs(cz);
+        const double Rr = reach[k].thr;   // already inflated fp64 reach (or +inf)
+        double Rf = (Rr + 3.0 * eps * l1 + 1e-30) * (1.0 + 8.0 * eps);
+        float rf = (float)Rf;
+        if (!(rf >= Rf)) rf = std::nextafterf(rf, std::numeric_limits<float>::infinity());
+        if (!std::isfinite(Rf) || !(l1 < 1e30)) rf = std::numeric_limits<float>::infinity();
+        float *g = &tf[(size_t)(k / 8) * 32 + (size_t)((k % 8) / 2) * 8];
+        const int h = k & 1;
+        g[0 + h] = (float)cx; g[2 + h] = (float)cy; g[4 + h] = (float)cz; g[6 + h] = rf;
+        if (!std::isfinite(rf)) { g[0 + h] = 0.f; g[2 + h] = 0.f; g[4 + h] = 0.f; }   // reach +inf: always evaluated
+      }
+      // padding entries keep centre = +inf and R = +inf would pass; give them R = 0
+      for (int k = na; k < ng * 8; ++k) {
+        float *g = &tf[(size_t)(k / 8) * 32 + (size_t)((k % 8) / 2) * 8];
+        g[6 + (k & 1)] = 0.f;
+      }
+      RRTX_HIP(ctx, ctx->d_sph_reach_f.ensure(sizeof(float) * tf.size()));
+      RRTX_HIP(ctx, hipMemcpy(ctx->d_sph_reach_f.p, tf.data(), sizeof(float) * tf.size(), hipMemcpyHostToDevice));
+    }
     char *aux = ctx->d_sph_aux.as<char>();
     RRTX_HIP(ctx, hipMemcpy(aux, radius.data(), sizeof(double) * na, hipMemcpyHostToDevice));
     RRTX_HIP(ctx, hipMemcpy(aux + sizeof(double) * na, thr_in.data(), sizeof(double) * na,
@@ -515,6 +574,7 @@ int sync_spheres(rrtx_ctx *ctx, double robot_radius) {
   }
   ctx->sph_dirty = false;
   ctx->sph_packed_rr = robot_radius;
+  for (int k = 0; k < 3; ++k) ctx->sph_packed_origin[k] = ctx->origin[k];
   return RRTX_OK;
 }
 
@@ -620,8 +680,8 @@ int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int
   // the grid covers the caller's capacity; lanes past offsets[nq] idle
   hipLaunchKernelGGL(candidate_edges_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, q_dev,
                      ctx->dim, offsets_dev, nq, idx_dev, owner_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                     (long long)cap, ctx->d_sph.as<SphRec>(), ctx->d_sph_reach.as<SphRec>(), ctx->sph_n_active,
-                     hit_out_dev, hit_in_dev);
+                     (int)ctx->n_nodes, (long long)cap, ctx->d_sph.as<SphRec>(), ctx->d_sph_reach_f.as<float>(), ctx->origin[0],
+                     ctx->origin[1], ctx->origin[2], ctx->sph_n_active, hit_out_dev, hit_in_dev);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;

@@ -357,17 +357,18 @@ __device__ bool dubins_collides(const Steer &st, double sx, double sy, double gx
 __global__ __launch_bounds__(256) void candidate_dubins_kernel(
     const double *__restrict__ q, const int64_t *__restrict__ offsets, int nq, const int32_t *__restrict__ idx,
     const int32_t *__restrict__ owner, const double *__restrict__ nx, const double *__restrict__ ny,
-    const double *__restrict__ nz, const double *__restrict__ nw, long long cap, double r_min,
+    const double *__restrict__ nz, const double *__restrict__ nw, int n_nodes, long long cap, double r_min,
     double robot_radius, const double *__restrict__ meta, const int32_t *__restrict__ off,
     const double *__restrict__ vxy, int m, double *__restrict__ cost_out, double *__restrict__ cost_in,
     uint8_t *__restrict__ word_out, uint8_t *__restrict__ word_in, uint8_t *__restrict__ hit_out,
     uint8_t *__restrict__ hit_in) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long total = offsets[nq];
-  if (total > cap) total = cap;
+  const long long total = offsets[nq];
+  if (total > cap) return;      // capacity overflow: the CSR arrays are only partly written
   if (e >= total) return;
   const int qi = owner[e];
   const int n = idx[e];
+  if ((unsigned)qi >= (unsigned)nq || (unsigned)n >= (unsigned)n_nodes) return;   // defensive
   double s[4] = {q[4 * (size_t)qi], q[4 * (size_t)qi + 1], q[4 * (size_t)qi + 2], q[4 * (size_t)qi + 3]};
   double g[4] = {nx[n], ny[n], nz[n], nw[n]};
   Steer st;
@@ -438,7 +439,7 @@ int launch_candidate_dubins(rrtx_ctx *ctx, const double *q_dev, int nq, const in
   span_begin(ctx, KF_DUBINS);
   hipLaunchKernelGGL(candidate_dubins_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, q_dev,
                      offsets_dev, nq, idx_dev, owner_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[3],
-                     (long long)cap, r_min, robot_radius, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
+                     (int)ctx->n_nodes, (long long)cap, r_min, robot_radius, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
                      ctx->d_poly_vxy.as<double>(), ctx->poly_n_active, cost_out, cost_in, word_out, word_in, hit_out,
                      hit_in);
   span_end(ctx);

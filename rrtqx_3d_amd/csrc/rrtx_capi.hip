@@ -273,7 +273,7 @@ int rrtx_destroy(rrtx_ctx *ctx) {
     if (ctx->nodes_f[k]) (void)hipFree(ctx->nodes_f[k]);
   if (ctx->nodes_pp) (void)hipFree(ctx->nodes_pp);
   ctx->d_absmax.release();
-  DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_reach, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
+  DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_reach, &ctx->d_sph_reach_f, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
                     &ctx->d_poly_orig, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
                     &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_bsum, &ctx->ws_scalars, &ctx->ws_tmp_idx,
                     &ctx->ws_tmp_d2, &ctx->ws_owner, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,

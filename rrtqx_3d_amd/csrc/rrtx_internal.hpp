@@ -98,6 +98,8 @@ struct rrtx_ctx {
   int sph_n_active = 0;
   rrtx::DevBuf d_sph;               // SphRec[n_active]
   rrtx::DevBuf d_sph_reach;         // SphRec[n_active]: centre + inflated reach (conservative skip test)
+  rrtx::DevBuf d_sph_reach_f;       // fp32, origin-relative, pair-interleaved copy for the packed screen
+  double sph_packed_origin[3] = {0, 0, 0};
   rrtx::DevBuf d_sph_aux;           // double radius[n_active] then int32 orig[n_active]
 
   // polygon obstacles

@@ -81,6 +81,19 @@ def test_radius_capacity_two_call(small3):
     assert offsets[-1] == len(idx) > 8
 
 
+def test_extend_candidates_capacity_two_call(small3, oracle):
+    """a too-small capacity must come back as RRTX_E_CAPACITY without touching memory through the
+    partly written lists (regression: the candidate kernel once indexed nodes with unwritten entries)"""
+    pts, tree, ctx = small3
+    ctx.spheres_set(synth.spheres(16))
+    Q = synth.queries(128, 3)
+    out = ctx.extend_candidates(Q, 7.78, ROBOT_RADIUS, cap=8)
+    ref = ctx.extend_candidates(Q, 7.78, ROBOT_RADIUS, cap=1 << 16)
+    assert len(out["idx"]) == len(ref["idx"]) > 8
+    for k in ref:
+        assert np.array_equal(out[k], ref[k]), k
+
+
 def test_radius_per_query_radii_and_edge_cases(small3, oracle):
     pts, tree, ctx = small3
     rng = np.random.default_rng(3)
@@ -315,6 +328,31 @@ def test_extend_candidates_matches_parts(small3, oracle):
         assert out["nearest_idx"][i] == ri and out["nearest_dist"][i] == rd
     ru, _ = oracle.points_check_spheres(osph, m, Q, ROBOT_RADIUS, quick=True)
     assert np.array_equal(out["sample_unsafe"], ru)
+
+
+@pytest.mark.parametrize("root_at_cluster", [True, False])
+def test_candidate_edges_far_from_origin(oracle, root_at_cluster):
+    """the packed fp32 reach screen of the fused kernel works on coordinates relative to the first
+    node; put the whole scene 1e5 away (and, in the second case, leave the root at 0 so the shifted
+    coordinates are large and fp32 cancellation is at its worst) and require bit-exact flags"""
+    rng = np.random.default_rng(31)
+    off = np.array([1.0e5, -2.0e5, 3.0e5])
+    pts = rng.uniform(-20, 20, (4000, 3)) + off
+    if not root_at_cluster:
+        pts[0] = 0.0
+    sph = np.concatenate([rng.uniform(-20, 20, (48, 3)) + off, rng.uniform(1.0, 3.5, (48, 1))], 1)
+    Q = rng.uniform(-20, 20, (256, 3)) + off
+    Q[:8] = sph[:8, :3] + rng.normal(0, 1.0, (8, 3))          # samples right at obstacles
+    osph, m = oracle.make_spheres(sph)
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        ctx.spheres_set(sph)
+        out = ctx.extend_candidates(Q, 8.0, ROBOT_RADIUS)
+        p0, p1 = synth.candidate_edges(Q, pts, out["offsets"], out["idx"])
+        rh, _ = oracle.edges_check_spheres(osph, m, p0, p1, ROBOT_RADIUS)
+        n = len(out["idx"])
+        assert n > 1000 and 0 < rh.sum() < 2 * n
+        assert np.array_equal(out["hit_out"], rh[:n]) and np.array_equal(out["hit_in"], rh[n:])
 
 
 def test_polygons_edges_and_points(oracle):
