@@ -108,6 +108,8 @@ def lib() -> C.CDLL:
                                                  c_double_p, C.c_int, C.c_double, C.c_double, c_int32_p]
     L.orc_julia_range_len.restype = C.c_int64
     L.orc_julia_range_len.argtypes = [C.c_double] * 3
+    L.orc_kd_insert_many.restype = None
+    L.orc_kd_insert_many.argtypes = [C.c_void_p, c_double_p, C.c_int64]
     L.orc_extend_batch_spheres.restype = C.c_int64
     L.orc_extend_batch_spheres.argtypes = [C.c_void_p, C.POINTER(Sphere), C.c_int, c_double_p, C.c_int64,
                                            C.c_double, C.c_double, c_int64_p, c_int64_p, c_int64_p]
@@ -160,11 +162,8 @@ class KDTree:
 
     def insert_many(self, pts: np.ndarray):
         pts = np.ascontiguousarray(pts, dtype=np.float64)
-        f = lib().orc_kd_insert
-        base = pts.ctypes.data
-        stride = self.d * 8
-        for i in range(pts.shape[0]):
-            f(self._h, C.cast(base + i * stride, c_double_p))
+        assert pts.ndim == 2 and pts.shape[1] == self.d
+        lib().orc_kd_insert_many(self._h, _dp(pts), pts.shape[0])
 
     @property
     def size(self) -> int:

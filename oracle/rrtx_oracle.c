@@ -133,6 +133,10 @@ int64_t orc_kd_insert(orc_kd *t, const double *pos) {
   return me;
 }
 
+void orc_kd_insert_many(orc_kd *t, const double *pos, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) orc_kd_insert(t, pos + i * t->d);
+}
+
 static int64_t kd_depth_rec(const orc_kd *t, int64_t i) {
   /* iterative to survive degenerate trees */
   (void)i;

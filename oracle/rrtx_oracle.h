@@ -41,6 +41,7 @@ void orc_kd_destroy(orc_kd *t);
 /* wraps are 0-based dimension indices; wrap_points[i] is the period */
 void orc_kd_set_wraps(orc_kd *t, int nwraps, const int *wraps, const double *wrap_points);
 int64_t orc_kd_insert(orc_kd *t, const double *pos);  /* returns node index (insertion order) */
+void orc_kd_insert_many(orc_kd *t, const double *pos, int64_t n);  /* n rows of d doubles, in order */
 int64_t orc_kd_size(const orc_kd *t);
 int64_t orc_kd_depth(const orc_kd *t);
 const double *orc_kd_position(const orc_kd *t, int64_t idx);
