@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--scan-blocks", type=int, default=0, help="tuning: target workgroups of the range scan")
     ap.add_argument("--scan-items", type=int, default=0, help="tuning: target (tile, segment) work items")
     ap.add_argument("--tile-q", type=int, default=0, help="tuning: query copies per workgroup tile")
+    ap.add_argument("--nn-cull", type=int, default=1, help="slab culling of the range scan: 0 off, 1 auto, 2 always")
     args = ap.parse_args()
 
     import torch
@@ -153,6 +154,7 @@ def main():
         ctx.set_option(_capi.RRTX_OPT_SCAN_ITEMS, args.scan_items)
     if args.tile_q:
         ctx.set_option(_capi.RRTX_OPT_SCAN_TILE_Q, args.tile_q)
+    ctx.set_option(_capi.RRTX_OPT_NN_CULL, args.nn_cull)
 
     # ---- inputs resident in HBM before the timed region -----------------------
     d_pts = torch.from_numpy(pts).to(dev)
@@ -250,7 +252,9 @@ def main():
         scan_ms = st.ms_nn_scan / max(st.launches_nn_scan, 1)
         tile_q = int(st.last_tile_q)   # query copies sharing one streamed pass of the node arrays
         n_tiles = (B + tile_q - 1) // tile_q
-        bytes_streamed = n_tiles * N * 24 + B * 32 + k_total * 16      # node passes + queries + hit records
+        units = int(st.last_scan_units)  # slab-culled scan: (tile, 512-node chunk) pairs actually streamed
+        node_visits = units * 512 if units > 0 else n_tiles * N
+        bytes_streamed = node_visits * 24 + B * 32 + k_total * 16      # node passes + queries + hit records
         achieved = bytes_streamed / (scan_ms * 1e-3) / 1e9
         valu_ops = B * N * 9                                           # 3 sub, 3 mul, 2 add, 1 cmp per (query, node)
         # HBM-side bytes per launch of this kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE,
@@ -288,6 +292,8 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_streamed, "tile_q": tile_q,
+                "culled_units": units, "node_visits_per_launch": node_visits,
+                "node_visits_unculled": n_tiles * N,
                 "pairs_per_s": B * N / (scan_ms * 1e-3),
                 "valu_fp64_frac": (valu_ops / (scan_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS) if not args.nn_filter else None,
                 "note": "VALU-issue bound, node arrays are L2-resident (PMC traffic ~0.02 GB/launch); see DESIGN.md",

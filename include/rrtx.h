@@ -58,7 +58,8 @@ typedef struct {
   int64_t last_pairs;        /* (query copy, node) visits */
   int64_t last_neighbors;    /* sum of k */
   int32_t last_tile_q;       /* query copies that shared one streamed pass of the node arrays */
-  int32_t reserved;
+  int32_t last_scan_units;   /* slab-culled range scan: (64-copy tile, 512-node chunk) units the last call
+                              * visited; 0 when the last call streamed every node for every tile */
 } rrtx_stats_t;
 
 /* ---- lifetime ------------------------------------------------------------ */
@@ -89,6 +90,12 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
 #define RRTX_OPT_SCAN_BLOCKS 2
 #define RRTX_OPT_SCAN_TILE_Q 3
 #define RRTX_OPT_SCAN_ITEMS 4  /* target number of (tile, node segment) work items */
+/*   RRTX_OPT_NN_CULL (default 1): the range search keeps a second copy of the fp32 shadow
+ *   ordered by equal-width x slabs and sorts each call's query copies by x, so a tile of
+ *   copies only streams the node chunks whose x extent can reach it.  Purely a skip of
+ *   pairs that provably fail the exact test; results are identical.  0 = off (every tile
+ *   streams every node), 1 = on for trees of at least 8192 nodes, 2 = always on. */
+#define RRTX_OPT_NN_CULL 5
 int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value);
 
 /* Host-only helper (no GPU needed): the exact thresholds on SQUARED distances the kernels

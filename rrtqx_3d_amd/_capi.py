@@ -23,6 +23,7 @@ RRTX_OPT_NN_FILTER = 1
 RRTX_OPT_SCAN_BLOCKS = 2
 RRTX_OPT_SCAN_TILE_Q = 3
 RRTX_OPT_SCAN_ITEMS = 4
+RRTX_OPT_NN_CULL = 5
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -47,7 +48,7 @@ class Stats(C.Structure):
         ("ms_points", C.c_double), ("launches_points", C.c_int64),
         ("ms_dubins", C.c_double), ("launches_dubins", C.c_int64),
         ("last_pairs", C.c_int64), ("last_neighbors", C.c_int64),
-        ("last_tile_q", C.c_int32), ("reserved", C.c_int32),
+        ("last_tile_q", C.c_int32), ("last_scan_units", C.c_int32),
     ]
 
 

@@ -56,4 +56,33 @@ __device__ __forceinline__ double jl_clamp01(double v) {
 // f64 (checked on hardware by tests/test_gpu_parity.py::test_device_sqrt_div)
 __device__ __forceinline__ double sqrt_rn(double x) { return __builtin_sqrt(x); }
 
+// Order-preserving map double -> uint64 (for atomicMin / atomicMax on coordinates) and back.
+// An empty minimum is ~0 and an empty maximum is 0; both decode to NaN, which fails every
+// comparison, so an empty range never overlaps anything.
+__device__ __forceinline__ unsigned long long enc_ord(double d) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dec_ord(unsigned long long e) {
+  const unsigned long long u = (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e;
+  return __longlong_as_double((long long)u);
+}
+
+// Equal-width slab of coordinate x: monotone non-decreasing in x (every step is a monotone
+// rounded operation), NaN -> slab 0.  inv_w == 0 (degenerate or non-finite extent) puts
+// everything in slab 0.
+__device__ __forceinline__ int slab_of(double x, double x0, double inv_w, int K) {
+  const double v = (x - x0) * inv_w;
+  return (v >= 0.0) ? ((v < (double)K) ? (int)v : K - 1) : 0;
+}
+__device__ __forceinline__ void slab_map(unsigned long long lo_enc, unsigned long long hi_enc, int K, double *x0,
+                                         double *inv_w) {
+  const double lo = dec_ord(lo_enc), hi = dec_ord(hi_enc);
+  const double w = hi - lo;
+  double inv = (w > 0.0 && w < 1e300) ? (double)K / w : 0.0;
+  if (!(inv > 0.0 && inv < 1e300)) inv = 0.0;
+  *x0 = (lo == lo && lo > -1e300 && lo < 1e300) ? lo : 0.0;
+  *inv_w = inv;
+}
+
 }  // namespace rrtx

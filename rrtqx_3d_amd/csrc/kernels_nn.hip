@@ -31,7 +31,7 @@ constexpr int kChunk = 64 * kScanU;  // nodes per wave per chunk
 struct Scalars {
   unsigned long long total;        // records produced by scan + rootfix
   int n_copies;                    // valid query copies
-  int pad;
+  int n_units;                     // (tile, chunk) units of the culled range scan
   unsigned long long q_absmax;     // bit pattern of max |coordinate| over the query copies
 };
 
@@ -56,7 +56,7 @@ __global__ void nn_init_kernel(Scalars *__restrict__ sc, int n_copies_init, int 
                                int *__restrict__ fill_i32, int n_fill_i32, int v_i32) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int stride = gridDim.x * blockDim.x;
-  if (i == 0) { sc->total = 0ull; sc->n_copies = n_copies_init; sc->pad = 0; sc->q_absmax = 0ull; }
+  if (i == 0) { sc->total = 0ull; sc->n_copies = n_copies_init; sc->n_units = 0; sc->q_absmax = 0ull; }
   for (int k = i; k < n_i32; k += stride) zero_i32[k] = 0;
   for (int k = i; k < n_u64; k += stride) fill_u64[k] = v_u64;
   for (int k = i; k < n_fill_i32; k += stride) fill_i32[k] = v_i32;
@@ -69,9 +69,14 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
                                int n_wraps, int wd0, int wd1, int wd2, double wp0, double wp1, double wp2,
                                double ox, double oy, double oz, double ow,
                                SlotRec *__restrict__ slots, typename QRecT<D>::type *__restrict__ copies,
-                               int2 *__restrict__ meta, Scalars *__restrict__ sc) {
+                               int2 *__restrict__ meta, Scalars *__restrict__ sc,
+                               const unsigned long long *__restrict__ xrange, int n_buckets,
+                               int *__restrict__ qhist, int2 *__restrict__ cb) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
+  // culled scan: copies are bucketed by x over the extent of the node x coordinates
+  double bx0 = 0.0, binv = 0.0;
+  if (qhist) slab_map(xrange[0], xrange[1], n_buckets, &bx0, &binv);
   double p[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < D; ++k) p[k] = q[(size_t)i * D + k];
@@ -122,6 +127,10 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
       qr.thr = tlt;
       copies[pos] = qr;
       meta[pos] = make_int2(i, k);
+      if (qhist) {
+        const int b = slab_of(g[0], bx0, binv, n_buckets);
+        cb[pos] = make_int2(b, atomicAdd(&qhist[b], 1));
+      }
     }
   }
 }
@@ -253,27 +262,8 @@ __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
 //     t <= (R + 2 sqrt(D) eps C)^2 + K eps C^2 - |q~|^2  =: thr'   (rounded UP to fp32)
 // and "t > thr'" proves s >= thr.  Non-finite or huge C disables the screen.
 template <int D>
-__global__ void nn_filter_prep_kernel(const typename QRecT<D>::type *__restrict__ copies,
-                                      const Scalars *__restrict__ sc,
-                                      const unsigned long long *__restrict__ node_absmax, int n_copies_max,
-                                      double ox, double oy, double oz, double ow,
-                                      typename QRecFT<D>::type *__restrict__ copies_f) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n_copies = sc->n_copies;
-  if (i >= n_copies) {
-    // pad to a multiple of kQPI with records that never pass (the scan reads kQPI at a time)
-    if (i < ((n_copies + kQPI - 1) / kQPI) * kQPI) {
-      typename QRecFT<D>::type f;
-      f.x = 0.f; f.y = 0.f; f.z = 0.f;
-      if constexpr (D == 4) { f.w = 0.f; f.pad0 = 0.f; f.pad1 = 0.f; f.pad2 = 0.f; }
-      f.thr = -__builtin_inff();
-      copies_f[i] = f;
-    }
-    return;
-  }
-  const typename QRecT<D>::type c = copies[i];
-  unsigned long long cb = max(*node_absmax, sc->q_absmax);
-  const double C = __longlong_as_double((long long)cb);
+__device__ __forceinline__ typename QRecFT<D>::type make_qrecf(const typename QRecT<D>::type &c, double C, double ox,
+                                                               double oy, double oz, double ow) {
   const float qx = (float)(c.x - ox), qy = (float)(c.y - oy), qz = (float)(c.z - oz);
   float qw = 0.f;
   double qq = (double)qx * (double)qx + (double)qy * (double)qy + (double)qz * (double)qz;
@@ -297,60 +287,211 @@ __global__ void nn_filter_prep_kernel(const typename QRecT<D>::type *__restrict_
   f.x = -2.0f * qx; f.y = -2.0f * qy; f.z = -2.0f * qz;
   if constexpr (D == 4) { f.w = -2.0f * qw; f.pad0 = 0.f; f.pad1 = 0.f; f.pad2 = 0.f; }
   f.thr = thr_f;
-  copies_f[i] = f;
+  return f;
+}
+
+template <int D>
+__device__ __forceinline__ typename QRecFT<D>::type never_pass_qrecf() {
+  typename QRecFT<D>::type f;
+  f.x = 0.f; f.y = 0.f; f.z = 0.f;
+  if constexpr (D == 4) { f.w = 0.f; f.pad0 = 0.f; f.pad1 = 0.f; f.pad2 = 0.f; }
+  f.thr = -__builtin_inff();
+  return f;
+}
+
+template <int D>
+__global__ void nn_filter_prep_kernel(const typename QRecT<D>::type *__restrict__ copies,
+                                      const Scalars *__restrict__ sc,
+                                      const unsigned long long *__restrict__ node_absmax, int n_copies_max,
+                                      double ox, double oy, double oz, double ow,
+                                      typename QRecFT<D>::type *__restrict__ copies_f) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_copies = sc->n_copies;
+  if (i >= n_copies) {
+    // pad to a multiple of kQPI with records that never pass (the scan reads kQPI at a time)
+    if (i < ((n_copies + kQPI - 1) / kQPI) * kQPI) copies_f[i] = never_pass_qrecf<D>();
+    return;
+  }
+  unsigned long long cb = max(*node_absmax, sc->q_absmax);
+  copies_f[i] = make_qrecf<D>(copies[i], __longlong_as_double((long long)cb), ox, oy, oz, ow);
+}
+
+// Culled scan: the same records, written in x-bucket order (bucket start + the rank the pack
+// kernel drew), together with the fp64 copy and its (query, slot) tag.
+template <int D>
+__global__ void nn_place_kernel(const typename QRecT<D>::type *__restrict__ copies, const int2 *__restrict__ meta,
+                                const int2 *__restrict__ cb, const int *__restrict__ qstart,
+                                const Scalars *__restrict__ sc, const unsigned long long *__restrict__ node_absmax,
+                                double ox, double oy, double oz, double ow,
+                                typename QRecT<D>::type *__restrict__ copies_s, int2 *__restrict__ meta_s,
+                                typename QRecFT<D>::type *__restrict__ copies_f) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_copies = sc->n_copies;
+  if (i >= n_copies) {
+    if (i < ((n_copies + kQPI - 1) / kQPI) * kQPI) copies_f[i] = never_pass_qrecf<D>();
+    return;
+  }
+  const int2 b = cb[i];
+  const int dst = qstart[b.x] + b.y;
+  const typename QRecT<D>::type c = copies[i];
+  unsigned long long am = max(*node_absmax, sc->q_absmax);
+  copies_s[dst] = c;
+  meta_s[dst] = meta[i];
+  copies_f[dst] = make_qrecf<D>(c, __longlong_as_double((long long)am), ox, oy, oz, ow);
+}
+
+// One wave per tile of kTileQFilter bucket-ordered copies: the tile's x reach [lo, hi]
+// (every copy's x -+ its search radius, rounded outwards) against the exact x extent of every
+// node chunk.  A chunk outside the reach holds no node within range of any copy of the tile:
+// |x_q - x_n| > R implies fl(dx*dx) >= thr and the remaining squares only add (exact_math.hpp,
+// sq3).  The surviving (tile, chunk) pairs are the work units of nn_scan_f32_kernel<D, true>.
+template <int D>
+__global__ __launch_bounds__(256) void nn_units_kernel(const typename QRecT<D>::type *__restrict__ copies_s,
+                                                       Scalars *__restrict__ sc,
+                                                       const unsigned long long *__restrict__ chunk_lo,
+                                                       const unsigned long long *__restrict__ chunk_hi,
+                                                       int n_chunks, int tile_q, int2 *__restrict__ units,
+                                                       long long unit_cap) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int n_copies = sc->n_copies;
+  if ((long long)t * tile_q >= n_copies) return;
+  double lo = __builtin_inf(), hi = -__builtin_inf();
+  for (int j = lane; j < tile_q; j += 64) {
+    const int q = t * tile_q + j;
+    if (q >= n_copies) break;
+    const typename QRecT<D>::type c = copies_s[q];
+    const bool can_hit = (c.thr > 0.0) && (c.x - c.x == 0.0);      // thr NaN / <= 0, x NaN or +-inf: never
+    if (can_hit) {
+      const double R = sqrt_rn(c.thr) * (1.0 + 1e-15);             // thr = +inf -> R = +inf
+      double a = c.x - R, b = c.x + R;
+      a = a - (fabs(a) * 4.5e-16 + 1e-300);
+      b = b + (fabs(b) * 4.5e-16 + 1e-300);
+      lo = fmin(lo, a);
+      hi = fmax(hi, b);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, off));
+    hi = fmax(hi, __shfl_xor(hi, off));
+  }
+  if (!(lo <= hi)) return;
+  int cnt = 0;
+  for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+    const int c = c0 + lane;
+    const bool ok = c < n_chunks && dec_ord(chunk_hi[c]) >= lo && dec_ord(chunk_lo[c]) <= hi;
+    cnt += __popcll(__ballot(ok));
+  }
+  if (cnt == 0) return;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&sc->n_units, cnt);
+  base = __shfl(base, 0);
+  for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+    const int c = c0 + lane;
+    const bool ok = c < n_chunks && dec_ord(chunk_hi[c]) >= lo && dec_ord(chunk_lo[c]) <= hi;
+    const unsigned long long m = __ballot(ok);
+    if (ok) {
+      const long long pos = (long long)base + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < unit_cap) units[pos] = make_int2(t, c);
+    }
+    base += __popcll(m);
+  }
 }
 
 constexpr int kCandCap = 192;   // (copy, node) candidates queued in LDS per wave
 constexpr int kNearestWarm = 256;   // nodes sampled for the initial bound of the screened nearest scan
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Exact confirmation of a wave's queued candidates, 64 at a time with every lane
-// busy: unfused fp64 distance, the reference's strict compare, first-discovery
-// rule for ghosts; survivors go to the global record buffer with one atomic on
-// the shared counter per 64 candidates.
-template <int D>
-__device__ __forceinline__ void drain_candidates(const int2 *cand, int &wn, const double *__restrict__ nx,
-                                                 const double *__restrict__ ny, const double *__restrict__ nz,
-                                                 const double *__restrict__ nw,
-                                                 const typename QRecT<D>::type *__restrict__ copies,
-                                                 const int2 *__restrict__ meta, const SlotRec *__restrict__ slots,
-                                                 int n_slots, HitRec *__restrict__ recs, long long cap,
-                                                 Scalars *__restrict__ sc, int *__restrict__ count) {
+// Rare-path queue of the range scan, one per wave in LDS.
+//   event : "copy q was not screened out for the lanes in `mask` of the node chunk at `base`"
+//           (one record per flagged (copy, chunk) pair, pushed by a single lane)
+//   hit   : a confirmed neighbour, staged until one atomic on the shared counter appends a
+//           batch to the global record buffer
+// drain_events decides membership: eight lanes per event, lane u of the group re-tests node
+// base + 64 u + L for every flagged lane L with the exact unfused fp64 distance and the
+// reference's strict compare (first-discovery rule for ghosts).  Nothing of the fp32 screen
+// is reused, so the screen only has to be conservative.
+constexpr int kEvCap = 40;
+constexpr int kHitCap = 160;
+struct WaveQueue {
+  int4 ev[kEvCap];                   // q, base, node_end, unused
+  unsigned long long evm[kEvCap];
+  HitRec hit[kHitCap];
+};
+
+__device__ __forceinline__ void flush_hits(WaveQueue &wq, int &hn, HitRec *__restrict__ recs, long long cap,
+                                           Scalars *__restrict__ sc) {
+  if (hn == 0) return;
   const int lane = threadIdx.x & 63;
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(&sc->total, (unsigned long long)hn);
+  base = __shfl(base, 0);
   __builtin_amdgcn_wave_barrier();
-  for (int i0 = 0; i0 < wn; i0 += 64) {
-    const int i = i0 + lane;
-    bool hu = false;
-    double s = 0.0;
-    int owner = 0, id = 0;
-    if (i < wn) {
-      const int2 c = cand[i];
-      id = c.y;
-      const typename QRecT<D>::type ce = copies[c.x];
-      const int2 m = meta[c.x];
-      owner = m.x;
-      const double ex = nx[id], ey = ny[id], ez = nz[id];
-      double ew = 0.0;
-      if constexpr (D == 4) { ew = nw[id]; s = sq4(ce.x, ce.y, ce.z, ce.w, ex, ey, ez, ew); }
-      else s = sq3(ce.x, ce.y, ce.z, ex, ey, ez);
-      hu = s < ce.thr;
-      if (m.y > 0 && hu) hu = !seen_by_earlier_slot<D>(slots, n_slots, m.x, m.y, id, ex, ey, ez, ew);
+  for (int i = lane; i < hn; i += 64) {
+    const long long pos = (long long)base + i;
+    if (pos < cap) recs[pos] = wq.hit[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  hn = 0;
+}
+
+template <int D>
+__device__ __forceinline__ void drain_events(WaveQueue &wq, int &wn, int &hn, const double *__restrict__ nx,
+                                             const double *__restrict__ ny, const double *__restrict__ nz,
+                                             const double *__restrict__ nw,
+                                             const typename QRecT<D>::type *__restrict__ copies,
+                                             const int2 *__restrict__ meta, const SlotRec *__restrict__ slots,
+                                             int n_slots, HitRec *__restrict__ recs, long long cap,
+                                             Scalars *__restrict__ sc, int *__restrict__ count,
+                                             const int32_t *__restrict__ pos_id) {
+  // pos_id: node index of a shadow position (slab-ordered shadow), null = identity
+  const int lane = threadIdx.x & 63;
+  const int grp = lane >> 3, u = lane & 7;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  __builtin_amdgcn_wave_barrier();
+  for (int e0 = 0; e0 < wn; e0 += 8) {
+    const int e = e0 + grp;
+    unsigned long long mask = 0ull;
+    int4 ea = make_int4(0, 0, 0, 0);
+    typename QRecT<D>::type ce;
+    ce.x = 0.0; ce.y = 0.0; ce.z = 0.0; ce.thr = 0.0;
+    if constexpr (D == 4) ce.w = 0.0;
+    int2 m = make_int2(0, 0);
+    if (e < wn) {
+      ea = wq.ev[e];
+      mask = wq.evm[e];
+      ce = copies[ea.x];
+      m = meta[ea.x];
     }
-    const unsigned long long mask = __ballot(hu);
-    if (mask == 0ull) continue;
-    const int n = __popcll(mask);
-    const int leader = __ffsll((long long)mask) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(&sc->total, (unsigned long long)n);
-    base = __shfl(base, leader);
-    if (hu) {
-      const long long pos = (long long)base + __popcll(mask & ((1ull << lane) - 1ull));
-      if (pos < cap) {
-        HitRec r;
-        r.owner = owner; r.idx = id; r.d2 = s;
-        recs[pos] = r;
+    while (__ballot(mask != 0ull) != 0ull) {
+      const bool act = mask != 0ull;
+      const int L = act ? (__ffsll((long long)mask) - 1) : 0;
+      mask &= mask - 1ull;                 // 0 stays 0
+      const int pos = ea.y + u * 64 + L;
+      bool hu = false;
+      double s = 0.0;
+      int id = 0;
+      if (act && pos < ea.z) {
+        id = pos_id ? pos_id[pos] : pos;
+        const double ex = nx[id], ey = ny[id], ez = nz[id];
+        double ew = 0.0;
+        if constexpr (D == 4) { ew = nw[id]; s = sq4(ce.x, ce.y, ce.z, ce.w, ex, ey, ez, ew); }
+        else s = sq3(ce.x, ce.y, ce.z, ex, ey, ez);
+        hu = s < ce.thr;
+        if (m.y > 0 && hu) hu = !seen_by_earlier_slot<D>(slots, n_slots, m.x, m.y, id, ex, ey, ez, ew);
       }
-      atomicAdd(&count[owner], 1);
+      const unsigned long long hm = __ballot(hu);
+      if (hm == 0ull) continue;
+      const int n = __popcll(hm);
+      if (hn + n > kHitCap) flush_hits(wq, hn, recs, cap, sc);
+      if (hu) {
+        HitRec r;
+        r.owner = m.x; r.idx = id; r.d2 = s;
+        wq.hit[hn + __popcll(hm & lt_mask)] = r;
+        atomicAdd(&count[m.x], 1);
+      }
+      hn += n;
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -380,7 +521,7 @@ __device__ __forceinline__ void screen8(const typename QRecFT<D>::type &c, const
   }
 }
 
-template <int D>
+template <int D, bool CULL>
 __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
     const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
     const double *__restrict__ nw, const float *__restrict__ fx, const float *__restrict__ fy,
@@ -388,33 +529,26 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
     const typename QRecT<D>::type *__restrict__ copies, const typename QRecFT<D>::type *__restrict__ copies_f,
     const int2 *__restrict__ meta, const SlotRec *__restrict__ slots, int n_slots, int tile_q, int n_seg,
     int seg_len, HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
-    int *__restrict__ count) {
+    int *__restrict__ count, const int2 *__restrict__ units, const int32_t *__restrict__ pos_id) {
   // copies_f is padded to a multiple of kQPI records (thr = -inf) by the launcher.
-  // Persistent workgroups: block b walks work items b, b + gridDim.x, ... where
-  // item = tile * n_seg + seg.  gridDim.x and n_seg are multiples of 8, so a block keeps
-  // the same (item % 8) class: blocks b and b+8 share an XCD, hence each XCD's L2 keeps
-  // serving the same node segments.  Waves never synchronise; the candidate queue lives
-  // across items and is drained only when full and once at the end.
-  __shared__ int2 cand_all[kScanThreads / 64][kCandCap];
+  // Persistent workgroups.  Waves never synchronise; the candidate queue lives across work
+  // items and is drained only when full and once at the end.
+  //   CULL = false: block b walks items b, b + gridDim.x, ... where item = tile * n_seg + seg.
+  //     gridDim.x and n_seg are multiples of 8, so a block keeps the same (item % 8) class:
+  //     blocks b and b+8 share an XCD, hence each XCD's L2 keeps serving the same node segments.
+  //   CULL = true: wave w walks the (tile, chunk) unit list written by nn_units_kernel
+  //     (w, w + #waves, ...); fx.. are the slab-ordered shadow and pos_id maps a position
+  //     back to the node index.
+  __shared__ WaveQueue wq_all[kScanThreads / 64];
   const int n_copies = sc->n_copies;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  int2 *cand = cand_all[wave];
-  int wn = 0;                               // wave-uniform queue length
+  WaveQueue &wq = wq_all[wave];
+  int wn = 0, hn = 0;                       // wave-uniform: queued events, staged hits
   const float kInf = __builtin_inff();
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  const int n_tiles = (n_copies + tile_q - 1) / tile_q;
-  const int n_items = n_tiles * n_seg;
 
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-  const int seg = item % n_seg;
-  const int tile = item / n_seg;
-  const int q0 = tile * tile_q;
-  const int q1 = min(q0 + tile_q, n_copies);
-  const int node_begin = seg * seg_len;
-  const int node_end = min(n_nodes, node_begin + seg_len);
-
-  for (int base = node_begin + wave * kChunkF; base < node_end; base += (kScanThreads / 64) * kChunkF) {
+  // one chunk of kChunkF nodes (8 per lane, held in VGPRs) against the copies [q0, q1)
+  auto scan_chunk = [&](const int base, const int node_end, const int q0, const int q1) {
     float x[kScanFU], y[kScanFU], z[kScanFU], w[kScanFU], pp[kScanFU];
 #pragma unroll
     for (int u = 0; u < kScanFU; ++u) {
@@ -446,42 +580,49 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
         mk[k] = __ballot(!(tmin > c[k].thr));
         anym |= mk[k];
       }
-      if (__builtin_expect(anym != 0ull, 0)) {
-        // rare path: recompute the flagged copies, queue the surviving (copy, node) pairs;
-        // exactness is decided in drain_candidates
+      if (anym != 0ull) {
+        // some lane of some copy was not screened out: queue one event per flagged copy
+        if (wn + kQPI > kEvCap)
+          drain_events<D>(wq, wn, hn, nx, ny, nz, nw, copies, meta, slots, n_slots, recs, cap, sc, count, pos_id);
 #pragma unroll
         for (int k = 0; k < kQPI; ++k) {
           if (mk[k] == 0ull || q + k >= q1) continue;
-          const typename QRecFT<D>::type ck = copies_f[q + k];
-          float t[kScanFU];
-          screen8<D>(ck, x, y, z, w, pp, t);
-          // per-lane 8-bit survivor mask (VALU only), then one short scalar loop over the few
-          // lanes that have survivors; each such lane appends its own nodes to the queue
-          unsigned pm = 0u;
-#pragma unroll
-          for (int u = 0; u < kScanFU; ++u)
-            pm |= ((!(t[u] > ck.thr) && (base + u * 64 + lane) < node_end) ? 1u : 0u) << u;
-          unsigned long long lm = __ballot(pm != 0u);
-          while (lm != 0ull) {
-            const int L = __ffsll((long long)lm) - 1;
-            lm &= lm - 1ull;
-            const unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)pm, L);
-            const int n = __popc(bits);
-            if (wn + n > kCandCap)
-              drain_candidates<D>(cand, wn, nx, ny, nz, nw, copies, meta, slots, n_slots, recs, cap, sc, count);
-            if (lane == L) {
-              int wpos = wn;
-              for (int u = 0; u < kScanFU; ++u)
-                if ((bits >> u) & 1u) cand[wpos++] = make_int2(q + k, base + u * 64 + L);
-            }
-            wn += n;
+          if (lane == 0) {
+            wq.ev[wn] = make_int4(q + k, base, node_end, 0);
+            wq.evm[wn] = mk[k];
           }
+          wn += 1;
         }
       }
     }
+  };
+
+  if constexpr (CULL) {
+    const int n_units = sc->n_units;
+    const int n_waves = (int)gridDim.x * (kScanThreads / 64);
+    const int first = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kScanThreads / 64) + wave);
+    for (int u = first; u < n_units; u += n_waves) {
+      const int2 un = units[u];               // wave-uniform: scalar load
+      const int q0 = un.x * tile_q;
+      const int q1 = min(q0 + tile_q, n_copies);
+      scan_chunk(un.y * kChunkF, n_nodes, q0, q1);
+    }
+  } else {
+    const int n_tiles = (n_copies + tile_q - 1) / tile_q;
+    const int n_items = n_tiles * n_seg;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+      const int seg = item % n_seg;
+      const int tile = item / n_seg;
+      const int q0 = tile * tile_q;
+      const int q1 = min(q0 + tile_q, n_copies);
+      const int node_begin = seg * seg_len;
+      const int node_end = min(n_nodes, node_begin + seg_len);
+      for (int base = node_begin + wave * kChunkF; base < node_end; base += (kScanThreads / 64) * kChunkF)
+        scan_chunk(base, node_end, q0, q1);
+    }
   }
-  }  // items
-  drain_candidates<D>(cand, wn, nx, ny, nz, nw, copies, meta, slots, n_slots, recs, cap, sc, count);
+  drain_events<D>(wq, wn, hn, nx, ny, nz, nw, copies, meta, slots, n_slots, recs, cap, sc, count, pos_id);
+  flush_hits(wq, hn, recs, cap, sc);
 }
 
 // ------------------------------------------------------------- rootfix ------
@@ -987,7 +1128,143 @@ __global__ void nn_nearest_out_kernel(const unsigned long long *__restrict__ bes
   dist[i] = (b == ~0ull) ? __builtin_inf() : sqrt_rn(__longlong_as_double((long long)b));
 }
 
+// ------------------------------------------------------------ slab index ------
+// Rebuild of the slab-ordered shadow (rare: when enough nodes were appended since the last
+// one).  A counting sort of the nodes by equal-width x slab; the order inside a slab is the
+// order in which the atomics happened to land, which no result depends on.
+static_assert(kSlabChunk == kChunkF, "the culled scan visits one slab-index chunk per work unit");
+
+struct SlabParams { double x0, inv_w; int K; int pad; };
+
+__global__ void slab_params_kernel(const unsigned long long *__restrict__ xrange, int K,
+                                   SlabParams *__restrict__ sp, int *__restrict__ hist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    double x0, inv;
+    slab_map(xrange[0], xrange[1], K, &x0, &inv);
+    sp->x0 = x0; sp->inv_w = inv; sp->K = K; sp->pad = 0;
+  }
+  for (int k = i; k <= K; k += gridDim.x * blockDim.x) hist[k] = 0;
+}
+
+__global__ void slab_rank_kernel(const double *__restrict__ nx, int n, const SlabParams *__restrict__ sp,
+                                 int *__restrict__ hist, int2 *__restrict__ sr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = slab_of(nx[i], sp->x0, sp->inv_w, sp->K);
+  sr[i] = make_int2(b, atomicAdd(&hist[b], 1));
+}
+
+// exclusive scan of n ints by one workgroup of 1024; out[n] = total
+__global__ __launch_bounds__(1024) void excl_scan_kernel(const int *__restrict__ in, int *__restrict__ out, int n) {
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int per = (n + 1023) / 1024;
+  const int b = min(t * per, n), e = min(b + per, n);
+  int local = 0;
+  for (int i = b; i < e; ++i) local += in[i];
+  int v = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(v, off);
+    if (lane >= off) v += o;
+  }
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  int prefix = v - local;
+  for (int w = 0; w < wave; ++w) prefix += wsum[w];
+  for (int i = b; i < e; ++i) {
+    const int c = in[i];
+    out[i] = prefix;
+    prefix += c;
+  }
+  if (t == 1023) out[n] = prefix;
+}
+
+__global__ void slab_scatter_kernel(int n, const int2 *__restrict__ sr, const int *__restrict__ start,
+                                    const float *__restrict__ fx, const float *__restrict__ fy,
+                                    const float *__restrict__ fz, const float *__restrict__ fw,
+                                    const float *__restrict__ fpp, int dim, float *__restrict__ sx,
+                                    float *__restrict__ sy, float *__restrict__ sz, float *__restrict__ sw,
+                                    float *__restrict__ spp, int32_t *__restrict__ sid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int2 r = sr[i];
+  const int p = start[r.x] + r.y;
+  sx[p] = fx[i]; sy[p] = fy[i]; sz[p] = fz[i];
+  if (dim == 4) sw[p] = fw[i];
+  spp[p] = fpp[i];
+  sid[p] = i;
+}
+
+// exact fp64 x extent of every chunk of kSlabChunk positions (one wave per chunk)
+__global__ __launch_bounds__(256) void chunk_range_kernel(const double *__restrict__ nx,
+                                                          const int32_t *__restrict__ sid, int n, int n_chunks,
+                                                          unsigned long long *__restrict__ chunk_lo,
+                                                          unsigned long long *__restrict__ chunk_hi) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  unsigned long long lo = ~0ull, hi = 0ull;
+  for (int u = 0; u < kSlabChunk / 64; ++u) {
+    const int p = c * kSlabChunk + u * 64 + lane;
+    if (p < n) {
+      const double x = nx[sid[p]];
+      if (x == x) { const unsigned long long e = enc_ord(x); lo = min(lo, e); hi = max(hi, e); }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = min(lo, (unsigned long long)__shfl_xor(lo, off));
+    hi = max(hi, (unsigned long long)__shfl_xor(hi, off));
+  }
+  if (lane == 0) { chunk_lo[c] = lo; chunk_hi[c] = hi; }
+}
+
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+inline int pow2_ceil(long long v) {
+  int p = 1;
+  while (p < v && p < (1 << 30)) p <<= 1;
+  return p;
+}
+
+// bring the slab-ordered shadow up to date when the appended tail has grown too long
+int slab_refresh(rrtx_ctx *ctx) {
+  const int64_t n = ctx->n_nodes;
+  const int64_t tail = n - ctx->sl_n_sorted;
+  const int64_t limit = n / 128 > 1024 ? n / 128 : 1024;
+  if (tail <= limit) return RRTX_OK;
+  hipStream_t st = ctx->stream;
+  int K = pow2_ceil(n / 256);
+  if (K < 16) K = 16;
+  if (K > 16384) K = 16384;
+  RRTX_HIP(ctx, ctx->ws_slab_params.ensure(sizeof(SlabParams)));
+  RRTX_HIP(ctx, ctx->ws_slab_hist.ensure(sizeof(int) * (size_t)(K + 1)));
+  RRTX_HIP(ctx, ctx->ws_slab_start.ensure(sizeof(int) * (size_t)(K + 1)));
+  RRTX_HIP(ctx, ctx->ws_slab_sr.ensure(sizeof(int2) * (size_t)n));
+  SlabParams *sp = ctx->ws_slab_params.as<SlabParams>();
+  int *hist = ctx->ws_slab_hist.as<int>();
+  int *start = ctx->ws_slab_start.as<int>();
+  int2 *sr = ctx->ws_slab_sr.as<int2>();
+  const int nb = (int)((n + 255) / 256);
+  const int n_chunks = (int)((n + kSlabChunk - 1) / kSlabChunk);
+  span_begin(ctx, KF_NN_FINISH);
+  hipLaunchKernelGGL(slab_params_kernel, dim3((K + 256) / 256), dim3(256), 0, st,
+                     ctx->d_xrange.as<unsigned long long>(), K, sp, hist);
+  hipLaunchKernelGGL(slab_rank_kernel, dim3(nb), dim3(256), 0, st, ctx->nodes[0], (int)n, sp, hist, sr);
+  hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, st, hist, start, K);
+  hipLaunchKernelGGL(slab_scatter_kernel, dim3(nb), dim3(256), 0, st, (int)n, sr, start, ctx->nodes_f[0],
+                     ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->dim,
+                     ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp,
+                     ctx->sl_id);
+  hipLaunchKernelGGL(chunk_range_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, st, ctx->nodes[0], ctx->sl_id, (int)n,
+                     n_chunks, ctx->chunk_lo, ctx->chunk_hi);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  ctx->sl_n_sorted = n;
+  return RRTX_OK;
+}
 
 }  // namespace
 
@@ -1030,9 +1307,39 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   int *big_count = count + nq;          // zeroed together with count
   int *cursor = count + nq + 1;
   int *big_list = cursor + nq;
+
+  // ---- slab culling: on for large trees unless the worst-case unit list would be huge ----
+  const int n_nodes = (int)ctx->n_nodes;
+  const bool use_filter = ctx->opt_nn_filter != 0;
+  int tile_q = use_filter ? kTileQFilter : kTileQExact;
+  if (ctx->opt_tile_q > 0) tile_q = (ctx->opt_tile_q + kQPI - 1) / kQPI * kQPI;
+  const int n_tiles = (int)((n_copies_max + tile_q - 1) / tile_q);
+  const int n_chunks = (n_nodes + kSlabChunk - 1) / kSlabChunk;
+  const long long unit_cap = (long long)n_tiles * n_chunks;
+  const bool use_cull = use_filter && (ctx->opt_nn_cull == 2 || (ctx->opt_nn_cull == 1 && n_nodes >= 8192)) &&
+                        unit_cap * (long long)sizeof(int2) <= (1ll << 30);
+  ctx->last_culled = use_cull;
+  int n_buckets = 1;
+  int *qhist = nullptr, *qstart = nullptr;
+  int2 *cbk = nullptr;
+  if (use_cull) {
+    int rc = slab_refresh(ctx);
+    if (rc) return rc;
+    n_buckets = pow2_ceil((long long)(n_copies_max / 16));
+    if (n_buckets > 4096) n_buckets = 4096;
+    RRTX_HIP(ctx, ctx->ws_qhist.ensure(sizeof(int) * (size_t)(n_buckets + 1)));
+    RRTX_HIP(ctx, ctx->ws_qstart.ensure(sizeof(int) * (size_t)(n_buckets + 1)));
+    RRTX_HIP(ctx, ctx->ws_cb.ensure(sizeof(int2) * n_copies_max));
+    RRTX_HIP(ctx, ctx->ws_copies_s.ensure(n_copies_max * qrec_bytes));
+    RRTX_HIP(ctx, ctx->ws_meta_s.ensure(n_copies_max * sizeof(int2)));
+    RRTX_HIP(ctx, ctx->ws_units.ensure((size_t)(unit_cap > 0 ? unit_cap : 1) * sizeof(int2)));
+    qhist = ctx->ws_qhist.as<int>();
+    qstart = ctx->ws_qstart.as<int>();
+    cbk = ctx->ws_cb.as<int2>();
+  }
   hipLaunchKernelGGL(nn_init_kernel, dim3((nq + 1 + 255) / 256 < 64 ? (nq + 1 + 255) / 256 : 64), dim3(256), 0, st, sc,
                      (ctx->n_wraps == 0) ? nq : 0, count, nq + 1, (unsigned long long *)nullptr, 0, 0ull,
-                     (int *)nullptr, 0, 0);
+                     qhist, use_cull ? n_buckets + 1 : 0, 0);
 
   const double *thr_lt_arr = r_dev_thr_lt;
   const double *thr_gt_arr = r_dev_thr_lt ? r_dev_thr_lt + nq : nullptr;
@@ -1046,24 +1353,21 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
                          ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
                          ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
                          ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec4>(),
-                         ctx->ws_copy_meta.as<int2>(), sc);
+                         ctx->ws_copy_meta.as<int2>(), sc, ctx->d_xrange.as<unsigned long long>(), n_buckets, qhist,
+                         cbk);
     else
       hipLaunchKernelGGL(nn_pack_kernel<3>, grid, block, 0, st, q_dev, nq, thr_lt_arr, thr_gt_arr, tlt, tgt,
                          ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1], ctx->wrap_dim[2],
                          ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
                          ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
                          ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec3>(),
-                         ctx->ws_copy_meta.as<int2>(), sc);
+                         ctx->ws_copy_meta.as<int2>(), sc, ctx->d_xrange.as<unsigned long long>(), n_buckets, qhist,
+                         cbk);
   }
   span_end(ctx);
 
   // ---- scan geometry: tiles of copies x node segments (segment = XCD-affine) ----
-  const int n_nodes = (int)ctx->n_nodes;
-  const bool use_filter = ctx->opt_nn_filter != 0;
   const int chunk = use_filter ? kChunkF : kChunk;
-  int tile_q = use_filter ? kTileQFilter : kTileQExact;
-  if (ctx->opt_tile_q > 0) tile_q = (ctx->opt_tile_q + kQPI - 1) / kQPI * kQPI;
-  const int n_tiles = (int)((n_copies_max + tile_q - 1) / tile_q);
   const int wg_nodes = (kScanThreads / 64) * chunk;  // nodes one workgroup covers per pass
   int max_seg = (n_nodes + wg_nodes - 1) / wg_nodes;
   int want_seg = ((use_filter ? ctx->opt_scan_items : 4096) + n_tiles - 1) / n_tiles;
@@ -1079,14 +1383,34 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
     RRTX_HIP(ctx, ctx->ws_copies_f.ensure((n_copies_max + kQPI) * qf_bytes));
     span_begin(ctx, KF_NN_FINISH);
     dim3 grid((unsigned)((n_copies_max + kQPI + 255) / 256)), block(256);
-    if (D == 4)
-      hipLaunchKernelGGL(nn_filter_prep_kernel<4>, grid, block, 0, st, ctx->ws_copies.as<QRec4>(), sc,
-                         ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
-                         ctx->origin[2], ctx->origin[3], ctx->ws_copies_f.as<QRecF4>());
+    const unsigned long long *absmax = ctx->d_absmax.as<unsigned long long>();
+    if (use_cull) {
+      hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, st, qhist, qstart, n_buckets);
+      if (D == 4)
+        hipLaunchKernelGGL(nn_place_kernel<4>, grid, block, 0, st, ctx->ws_copies.as<QRec4>(),
+                           ctx->ws_copy_meta.as<int2>(), cbk, qstart, sc, absmax, ctx->origin[0], ctx->origin[1],
+                           ctx->origin[2], ctx->origin[3], ctx->ws_copies_s.as<QRec4>(), ctx->ws_meta_s.as<int2>(),
+                           ctx->ws_copies_f.as<QRecF4>());
+      else
+        hipLaunchKernelGGL(nn_place_kernel<3>, grid, block, 0, st, ctx->ws_copies.as<QRec3>(),
+                           ctx->ws_copy_meta.as<int2>(), cbk, qstart, sc, absmax, ctx->origin[0], ctx->origin[1],
+                           ctx->origin[2], ctx->origin[3], ctx->ws_copies_s.as<QRec3>(), ctx->ws_meta_s.as<int2>(),
+                           ctx->ws_copies_f.as<QRecF3>());
+      dim3 ugrid((unsigned)((n_tiles + 3) / 4));
+      if (D == 4)
+        hipLaunchKernelGGL(nn_units_kernel<4>, ugrid, block, 0, st, ctx->ws_copies_s.as<QRec4>(), sc, ctx->chunk_lo,
+                           ctx->chunk_hi, n_chunks, tile_q, ctx->ws_units.as<int2>(), unit_cap);
+      else
+        hipLaunchKernelGGL(nn_units_kernel<3>, ugrid, block, 0, st, ctx->ws_copies_s.as<QRec3>(), sc, ctx->chunk_lo,
+                           ctx->chunk_hi, n_chunks, tile_q, ctx->ws_units.as<int2>(), unit_cap);
+    } else if (D == 4)
+      hipLaunchKernelGGL(nn_filter_prep_kernel<4>, grid, block, 0, st, ctx->ws_copies.as<QRec4>(), sc, absmax,
+                         (int)n_copies_max, ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
+                         ctx->ws_copies_f.as<QRecF4>());
     else
-      hipLaunchKernelGGL(nn_filter_prep_kernel<3>, grid, block, 0, st, ctx->ws_copies.as<QRec3>(), sc,
-                         ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
-                         ctx->origin[2], ctx->origin[3], ctx->ws_copies_f.as<QRecF3>());
+      hipLaunchKernelGGL(nn_filter_prep_kernel<3>, grid, block, 0, st, ctx->ws_copies.as<QRec3>(), sc, absmax,
+                         (int)n_copies_max, ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
+                         ctx->ws_copies_f.as<QRecF3>());
     span_end(ctx);
   }
 
@@ -1098,18 +1422,36 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
       unsigned pg = (unsigned)ctx->opt_scan_blocks / 8u * 8u;
       if (pg < 8u) pg = 8u;
       if (pg < grid.x) grid.x = pg;
-      if (D == 4)
-        hipLaunchKernelGGL(nn_scan_f32_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                           ctx->nodes[3], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[3], ctx->nodes_pp, n_nodes,
-                           ctx->ws_copies.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(), ctx->ws_copy_meta.as<int2>(),
-                           ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len, ctx->ws_recs.as<HitRec>(),
-                           rec_cap, sc, count);
+      const int wi = D == 4 ? 3 : 2;
+      if (use_cull) {
+        grid.x = pg;
+        const int2 *units = ctx->ws_units.as<int2>();
+        if (D == 4)
+          hipLaunchKernelGGL((nn_scan_f32_kernel<4, true>), grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
+                             ctx->nodes[2], ctx->nodes[wi], ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[wi],
+                             ctx->sl_pp, n_nodes, ctx->ws_copies_s.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(),
+                             ctx->ws_meta_s.as<int2>(), ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len,
+                             ctx->ws_recs.as<HitRec>(), rec_cap, sc, count, units, ctx->sl_id);
+        else
+          hipLaunchKernelGGL((nn_scan_f32_kernel<3, true>), grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
+                             ctx->nodes[2], ctx->nodes[wi], ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[wi],
+                             ctx->sl_pp, n_nodes, ctx->ws_copies_s.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(),
+                             ctx->ws_meta_s.as<int2>(), ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len,
+                             ctx->ws_recs.as<HitRec>(), rec_cap, sc, count, units, ctx->sl_id);
+      } else if (D == 4)
+        hipLaunchKernelGGL((nn_scan_f32_kernel<4, false>), grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
+                           ctx->nodes[2], ctx->nodes[wi], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2],
+                           ctx->nodes_f[wi], ctx->nodes_pp, n_nodes, ctx->ws_copies.as<QRec4>(),
+                           ctx->ws_copies_f.as<QRecF4>(), ctx->ws_copy_meta.as<int2>(), ctx->ws_slots.as<SlotRec>(),
+                           n_slots, tile_q, n_seg, seg_len, ctx->ws_recs.as<HitRec>(), rec_cap, sc, count,
+                           (const int2 *)nullptr, (const int32_t *)nullptr);
       else
-        hipLaunchKernelGGL(nn_scan_f32_kernel<3>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                           ctx->nodes[2], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[2], ctx->nodes_pp, n_nodes,
-                           ctx->ws_copies.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(), ctx->ws_copy_meta.as<int2>(),
-                           ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len, ctx->ws_recs.as<HitRec>(),
-                           rec_cap, sc, count);
+        hipLaunchKernelGGL((nn_scan_f32_kernel<3, false>), grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
+                           ctx->nodes[2], ctx->nodes[wi], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2],
+                           ctx->nodes_f[wi], ctx->nodes_pp, n_nodes, ctx->ws_copies.as<QRec3>(),
+                           ctx->ws_copies_f.as<QRecF3>(), ctx->ws_copy_meta.as<int2>(), ctx->ws_slots.as<SlotRec>(),
+                           n_slots, tile_q, n_seg, seg_len, ctx->ws_recs.as<HitRec>(), rec_cap, sc, count,
+                           (const int2 *)nullptr, (const int32_t *)nullptr);
     } else if (D == 4)
       hipLaunchKernelGGL(nn_scan_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
                          ctx->nodes[3], n_nodes, ctx->ws_copies.as<QRec4>(), ctx->ws_copy_meta.as<int2>(),
@@ -1235,7 +1577,8 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
                          (const double *)nullptr, inf, nan, ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1],
                          ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
                          ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
-                         ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec4>(), ctx->ws_copy_meta.as<int2>(), sc);
+                         ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec4>(), ctx->ws_copy_meta.as<int2>(), sc,
+                         (const unsigned long long *)nullptr, 1, (int *)nullptr, (int2 *)nullptr);
       hipLaunchKernelGGL(nn_filter_prep_kernel<4>, pgrid, block, 0, st, ctx->ws_copies.as<QRec4>(), sc,
                          ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
                          ctx->origin[2], ctx->origin[3], ctx->ws_copies_f.as<QRecF4>());
@@ -1249,7 +1592,8 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
                          (const double *)nullptr, inf, nan, ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1],
                          ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
                          ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
-                         ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec3>(), ctx->ws_copy_meta.as<int2>(), sc);
+                         ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec3>(), ctx->ws_copy_meta.as<int2>(), sc,
+                         (const unsigned long long *)nullptr, 1, (int *)nullptr, (int2 *)nullptr);
       hipLaunchKernelGGL(nn_filter_prep_kernel<3>, pgrid, block, 0, st, ctx->ws_copies.as<QRec3>(), sc,
                          ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
                          ctx->origin[2], ctx->origin[3], ctx->ws_copies_f.as<QRecF3>());
@@ -1284,6 +1628,15 @@ int nearest_candidates(rrtx_ctx *ctx, long long *total) {
                                ctx->stream));
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *total = (long long)t;
+  return RRTX_OK;
+}
+
+int scan_units(rrtx_ctx *ctx, int *units) {
+  int u = 0;
+  RRTX_HIP(ctx, hipMemcpyAsync(&u, &ctx->ws_scalars.as<Scalars>()->n_units, sizeof(u), hipMemcpyDeviceToHost,
+                               ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *units = u;
   return RRTX_OK;
 }
 

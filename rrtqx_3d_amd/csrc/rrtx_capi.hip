@@ -123,15 +123,32 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
                                                          double *__restrict__ w, float *__restrict__ xf,
                                                          float *__restrict__ yf, float *__restrict__ zf,
                                                          float *__restrict__ wf, float *__restrict__ ppf,
-                                                         unsigned long long *__restrict__ absmax) {
+                                                         unsigned long long *__restrict__ absmax,
+                                                         float *__restrict__ sx, float *__restrict__ sy,
+                                                         float *__restrict__ sz, float *__restrict__ sw,
+                                                         float *__restrict__ spp, int32_t *__restrict__ sid,
+                                                         unsigned long long *__restrict__ chunk_lo,
+                                                         unsigned long long *__restrict__ chunk_hi,
+                                                         unsigned long long *__restrict__ xrange) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long m = 0ull;
+  unsigned long long xlo = ~0ull, xhi = 0ull;
   if (i < n) {
     const double a = pos[i * dim + 0], b = pos[i * dim + 1], c = pos[i * dim + 2];
     x[base + i] = a; y[base + i] = b; z[base + i] = c;
     const double sa = a - ox, sb = b - oy, sc = c - oz;
     const float fa = (float)sa, fb = (float)sb, fc = (float)sc;
     xf[base + i] = fa; yf[base + i] = fb; zf[base + i] = fc;
+    // slab index: a new node sits at position == index until the next rebuild; its chunk's
+    // x extent grows accordingly (a NaN x can never be within range of anything: not tracked)
+    sx[base + i] = fa; sy[base + i] = fb; sz[base + i] = fc;
+    sid[base + i] = (int32_t)(base + i);
+    if (a == a) {
+      xlo = xhi = enc_ord(a);
+      const long long ch = (base + i) / kSlabChunk;
+      atomicMin(&chunk_lo[ch], xlo);
+      atomicMax(&chunk_hi[ch], xhi);
+    }
     double pp = (double)fa * (double)fa + (double)fb * (double)fb + (double)fc * (double)fc;
     m = max(max((unsigned long long)__double_as_longlong(fabs(sa)), (unsigned long long)__double_as_longlong(fabs(sb))),
             (unsigned long long)__double_as_longlong(fabs(sc)));
@@ -141,16 +158,38 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
       const double sd = d - ow;
       const float fd = (float)sd;
       wf[base + i] = fd;
+      sw[base + i] = fd;
       pp += (double)fd * (double)fd;
       m = max(m, (unsigned long long)__double_as_longlong(fabs(sd)));
     }
     ppf[base + i] = (float)pp;
+    spp[base + i] = (float)pp;
   }
   for (int off = 32; off > 0; off >>= 1) {
     unsigned long long o = __shfl_xor(m, off);
     m = max(m, o);
+    o = __shfl_xor(xlo, off);
+    xlo = min(xlo, o);
+    o = __shfl_xor(xhi, off);
+    xhi = max(xhi, o);
   }
-  if ((threadIdx.x & 63) == 0 && m != 0ull) atomicMax(absmax, m);
+  if ((threadIdx.x & 63) == 0) {
+    if (m != 0ull) atomicMax(absmax, m);
+    if (xlo != ~0ull) { atomicMin(&xrange[0], xlo); atomicMax(&xrange[1], xhi); }
+  }
+}
+
+// reallocate one device array of the node store, keeping the first `keep` elements
+template <class T>
+int regrow(rrtx_ctx *ctx, T *&ptr, int64_t new_count, int64_t keep) {
+  T *nb = nullptr;
+  hipError_t e = hipMalloc(&nb, sizeof(T) * (size_t)new_count);
+  if (e != hipSuccess)
+    return fail(ctx, RRTX_E_NOMEM, "hipMalloc of %lld node slots failed: %s", (long long)new_count, hipGetErrorString(e));
+  if (keep > 0 && ptr) RRTX_HIP(ctx, hipMemcpy(nb, ptr, sizeof(T) * (size_t)keep, hipMemcpyDeviceToDevice));
+  if (ptr) RRTX_HIP(ctx, hipFree(ptr));
+  ptr = nb;
+  return RRTX_OK;
 }
 
 int grow_nodes(rrtx_ctx *ctx, int64_t need) {
@@ -159,34 +198,31 @@ int grow_nodes(rrtx_ctx *ctx, int64_t need) {
   while (nc < need) nc *= 2;
   if (nc > 0x7fffffffll) return fail(ctx, RRTX_E_CAPACITY, "node index space is int32 (%lld requested)", (long long)need);
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int rc;
   for (int k = 0; k < ctx->dim; ++k) {
-    double *nb = nullptr;
-    hipError_t e = hipMalloc(&nb, sizeof(double) * (size_t)nc);
-    if (e != hipSuccess) return fail(ctx, RRTX_E_NOMEM, "hipMalloc of %lld node slots failed: %s", (long long)nc, hipGetErrorString(e));
-    if (ctx->n_nodes > 0)
-      RRTX_HIP(ctx, hipMemcpy(nb, ctx->nodes[k], sizeof(double) * (size_t)ctx->n_nodes, hipMemcpyDeviceToDevice));
-    if (ctx->nodes[k]) RRTX_HIP(ctx, hipFree(ctx->nodes[k]));
-    ctx->nodes[k] = nb;
-    float *nf = nullptr;
-    e = hipMalloc(&nf, sizeof(float) * (size_t)nc);
-    if (e != hipSuccess) return fail(ctx, RRTX_E_NOMEM, "hipMalloc of %lld node slots failed: %s", (long long)nc, hipGetErrorString(e));
-    if (ctx->n_nodes > 0)
-      RRTX_HIP(ctx, hipMemcpy(nf, ctx->nodes_f[k], sizeof(float) * (size_t)ctx->n_nodes, hipMemcpyDeviceToDevice));
-    if (ctx->nodes_f[k]) RRTX_HIP(ctx, hipFree(ctx->nodes_f[k]));
-    ctx->nodes_f[k] = nf;
+    if ((rc = regrow(ctx, ctx->nodes[k], nc, ctx->n_nodes))) return rc;
+    if ((rc = regrow(ctx, ctx->nodes_f[k], nc, ctx->n_nodes))) return rc;
+    if ((rc = regrow(ctx, ctx->sl_f[k], nc, ctx->n_nodes))) return rc;
   }
+  if ((rc = regrow(ctx, ctx->nodes_pp, nc, ctx->n_nodes))) return rc;
+  if ((rc = regrow(ctx, ctx->sl_pp, nc, ctx->n_nodes))) return rc;
+  if ((rc = regrow(ctx, ctx->sl_id, nc, ctx->n_nodes))) return rc;
   {
-    float *nf = nullptr;
-    hipError_t e = hipMalloc(&nf, sizeof(float) * (size_t)nc);
-    if (e != hipSuccess) return fail(ctx, RRTX_E_NOMEM, "hipMalloc of %lld node slots failed: %s", (long long)nc, hipGetErrorString(e));
-    if (ctx->n_nodes > 0)
-      RRTX_HIP(ctx, hipMemcpy(nf, ctx->nodes_pp, sizeof(float) * (size_t)ctx->n_nodes, hipMemcpyDeviceToDevice));
-    if (ctx->nodes_pp) RRTX_HIP(ctx, hipFree(ctx->nodes_pp));
-    ctx->nodes_pp = nf;
+    // chunk extents: new chunks start empty (min = ~0, max = 0)
+    const int64_t nch = nc / kSlabChunk + 1;
+    const int64_t old = ctx->cap_chunks;
+    if ((rc = regrow(ctx, ctx->chunk_lo, nch, old))) return rc;
+    if ((rc = regrow(ctx, ctx->chunk_hi, nch, old))) return rc;
+    RRTX_HIP(ctx, hipMemset(ctx->chunk_lo + old, 0xff, sizeof(unsigned long long) * (size_t)(nch - old)));
+    RRTX_HIP(ctx, hipMemset(ctx->chunk_hi + old, 0x00, sizeof(unsigned long long) * (size_t)(nch - old)));
+    ctx->cap_chunks = nch;
   }
   if (!ctx->d_absmax.p) {
     RRTX_HIP(ctx, ctx->d_absmax.ensure(sizeof(unsigned long long)));
     RRTX_HIP(ctx, hipMemset(ctx->d_absmax.p, 0, sizeof(unsigned long long)));
+    RRTX_HIP(ctx, ctx->d_xrange.ensure(2 * sizeof(unsigned long long)));
+    RRTX_HIP(ctx, hipMemset(ctx->d_xrange.p, 0xff, sizeof(unsigned long long)));
+    RRTX_HIP(ctx, hipMemset(ctx->d_xrange.as<unsigned long long>() + 1, 0x00, sizeof(unsigned long long)));
   }
   ctx->cap_nodes = nc;
   return RRTX_OK;
@@ -272,12 +308,21 @@ int rrtx_destroy(rrtx_ctx *ctx) {
   for (int k = 0; k < 4; ++k)
     if (ctx->nodes_f[k]) (void)hipFree(ctx->nodes_f[k]);
   if (ctx->nodes_pp) (void)hipFree(ctx->nodes_pp);
+  for (int k = 0; k < 4; ++k)
+    if (ctx->sl_f[k]) (void)hipFree(ctx->sl_f[k]);
+  if (ctx->sl_pp) (void)hipFree(ctx->sl_pp);
+  if (ctx->sl_id) (void)hipFree(ctx->sl_id);
+  if (ctx->chunk_lo) (void)hipFree(ctx->chunk_lo);
+  if (ctx->chunk_hi) (void)hipFree(ctx->chunk_hi);
   ctx->d_absmax.release();
+  ctx->d_xrange.release();
   DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_reach, &ctx->d_sph_reach_f, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
                     &ctx->d_poly_orig, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
                     &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_bsum, &ctx->ws_scalars, &ctx->ws_tmp_idx,
                     &ctx->ws_tmp_d2, &ctx->ws_owner, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
-                    &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr, &ctx->ws_mask, &ctx->ws_i32a, &ctx->ws_i32b};
+                    &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr, &ctx->ws_mask, &ctx->ws_i32a, &ctx->ws_i32b,
+                    &ctx->ws_slab_hist, &ctx->ws_slab_start, &ctx->ws_slab_sr, &ctx->ws_slab_params, &ctx->ws_copies_s,
+                    &ctx->ws_meta_s, &ctx->ws_cb, &ctx->ws_qhist, &ctx->ws_qstart, &ctx->ws_units};
   for (auto b : bufs) b->release();
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -317,6 +362,7 @@ int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value) {
     case RRTX_OPT_SCAN_BLOCKS: ctx->opt_scan_blocks = value > 0 ? (int)value : 1280; return RRTX_OK;
     case RRTX_OPT_SCAN_ITEMS: ctx->opt_scan_items = value > 0 ? (int)value : 2048; return RRTX_OK;
     case RRTX_OPT_SCAN_TILE_Q: ctx->opt_tile_q = value > 0 ? (int)value : 0; return RRTX_OK;
+    case RRTX_OPT_NN_CULL: ctx->opt_nn_cull = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RRTX_OK;
     default: return fail(ctx, RRTX_E_INVALID, "set_option: unknown option %d", option);
   }
 }
@@ -339,7 +385,13 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out) {
   out->last_pairs = ctx->last_pairs;
   out->last_neighbors = ctx->last_neighbors;
   out->last_tile_q = ctx->last_tile_q;
-  out->reserved = 0;
+  out->last_scan_units = 0;
+  if (ctx->last_culled) {
+    int u = 0;
+    int rc = scan_units(ctx, &u);
+    if (rc) return rc;
+    out->last_scan_units = u;
+  }
   return RRTX_OK;
 }
 
@@ -364,7 +416,9 @@ int rrtx_nodes_append_dev(rrtx_ctx *ctx, const double *pos_dev, int64_t n) {
                      ctx->dim, (long long)n, (long long)ctx->n_nodes, ctx->origin[0], ctx->origin[1], ctx->origin[2],
                      ctx->origin[3], ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
                      ctx->nodes[ctx->dim == 4 ? 3 : 2], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2],
-                     ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->d_absmax.as<unsigned long long>());
+                     ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->d_absmax.as<unsigned long long>(),
+                     ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp, ctx->sl_id,
+                     ctx->chunk_lo, ctx->chunk_hi, ctx->d_xrange.as<unsigned long long>());
   RRTX_HIP(ctx, hipGetLastError());
   ctx->n_nodes += n;
   return RRTX_OK;

@@ -79,11 +79,25 @@ struct rrtx_ctx {
   int64_t n_nodes = 0, cap_nodes = 0;
   rrtx::DevBuf d_absmax;            // uint64: bit pattern of max |coordinate| over all nodes
 
+  // Slab-ordered copy of the fp32 shadow for the culled range scan (kernels_nn.hip, "slab
+  // index").  Positions [0, sl_n_sorted) hold nodes 0..sl_n_sorted-1 ordered by equal-width
+  // x slab; positions >= sl_n_sorted hold node p at position p (appended since the last
+  // rebuild).  chunk_lo/hi: exact fp64 x extent of every 512-position chunk (enc_ord).
+  float *sl_f[4] = {nullptr, nullptr, nullptr, nullptr};
+  float *sl_pp = nullptr;
+  int32_t *sl_id = nullptr;
+  unsigned long long *chunk_lo = nullptr, *chunk_hi = nullptr;
+  int64_t cap_chunks = 0;
+  int64_t sl_n_sorted = 0;
+  rrtx::DevBuf d_xrange;            // uint64[2]: enc_ord of min / max node x
+  rrtx::DevBuf ws_slab_hist, ws_slab_start, ws_slab_sr, ws_slab_params;
+
   // options (rrtx_set_option)
   int opt_nn_filter = 1;            // 1: fp32 prefilter + exact fp64 confirm, 0: exact fp64 scan
   int opt_scan_blocks = 1280;       // persistent workgroups of the range scan (256 CUs x 5 resident)
   int opt_scan_items = 2048;        // target number of (tile, segment) work items
   int opt_tile_q = 0;               // query copies per workgroup tile (0 = kernel default)
+  int opt_nn_cull = 1;              // 0 off, 1 auto (trees of >= 8192 nodes), 2 always
 
   // wrapped dimensions
   int n_wraps = 0;
@@ -119,6 +133,8 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_copies;   // QRec copies
   rrtx::DevBuf ws_copies_f; // fp32 prefilter copies
   rrtx::DevBuf ws_copy_meta;// int32 owner, slot per copy
+  rrtx::DevBuf ws_copies_s, ws_meta_s;  // copies / meta in x-bucket order (culled scan)
+  rrtx::DevBuf ws_cb, ws_qhist, ws_qstart, ws_units;
   rrtx::DevBuf ws_recs;     // HitRec
   rrtx::DevBuf ws_counts;   // int32 count[nq], cursor[nq]
   rrtx::DevBuf ws_bsum;     // int64 per-256-query sums of count (first level of the offsets scan)
@@ -143,6 +159,7 @@ struct rrtx_ctx {
   int64_t fam_launches[rrtx::KF_COUNT] = {0};
   int64_t last_pairs = 0, last_neighbors = 0;
   int last_tile_q = 0;
+  bool last_culled = false;         // the last range search used the slab-culled scan
   long long last_nearest_cap = 0;   // record capacity of the last screened nearest call (0: exact scan ran)
 };
 
@@ -176,6 +193,8 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_or_
 int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev,
                       bool exact = false);
 int nearest_candidates(rrtx_ctx *ctx, long long *total);
+int scan_units(rrtx_ctx *ctx, int *units);   // (tile, chunk) units of the last culled range scan
+constexpr int kSlabChunk = 512;              // node positions per chunk of the slab index
 int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
                          double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
                          uint8_t *hit_dev, int32_t *first_hit_dev, const int32_t *sidx_dev = nullptr,

@@ -1,0 +1,162 @@
+"""Slab-culled range scan (RRTX_OPT_NN_CULL): skipping node chunks by their x extent must not
+change a single neighbour index or stored distance.  Every case is checked against the CPU
+oracle's kd-tree (R/kdTree_general.jl semantics) and against the unculled scan."""
+import math
+
+import numpy as np
+import pytest
+
+from rrtqx_3d_amd import _capi, synth
+from rrtqx_3d_amd.context import Context
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_lists(tree, Q, r):
+    out = []
+    for i, q in enumerate(Q):
+        ri = r if np.isscalar(r) else r[i]
+        idx, key = tree.within_range(float(ri), q)
+        o = np.argsort(idx, kind="stable")
+        out.append((idx[o], key[o]))
+    return out
+
+
+def _check_csr(offsets, idx, dist, ref):
+    assert offsets[0] == 0 and offsets[-1] == len(idx)
+    for i, (ri, rk) in enumerate(ref):
+        a, b = offsets[i], offsets[i + 1]
+        assert np.array_equal(idx[a:b], ri), f"query {i}: neighbour set differs"
+        assert np.array_equal(dist[a:b], rk), f"query {i}: stored keys differ (bit-exact required)"
+
+
+def _both_modes(ctx, Q, r, ref):
+    units = {}
+    for mode in (2, 0):
+        ctx.set_option(_capi.RRTX_OPT_NN_CULL, mode)
+        offsets, idx, dist = ctx.nn_radius(Q, r)
+        _check_csr(offsets, idx, dist, ref)
+        units[mode] = ctx.stats().last_scan_units
+    ctx.set_option(_capi.RRTX_OPT_NN_CULL, 1)
+    assert units[0] == 0
+    return units[2]
+
+
+def test_cull_skips_most_chunks_and_matches(oracle):
+    n, nq = 60_000, 2048
+    pts = synth.nodes(n, 3)
+    Q = synth.queries(nq, 3)
+    r = synth.ball_radius(n, 3)
+    tree = oracle.KDTree(3)
+    tree.insert_many(pts)
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        units = _both_modes(ctx, Q, r, _oracle_lists(tree, Q, r))
+        n_tiles, n_chunks = (nq + 63) // 64, (n + 511) // 512
+        assert 0 < units < 0.35 * n_tiles * n_chunks     # x reach ~ (100/32 + 2 r) / 100 of the cloud
+
+
+def test_cull_tail_rebuild_and_capacity_growth(oracle):
+    """nodes appended after a rebuild live in an unsorted tail (chunk extents grow by atomics);
+    enough of them trigger the next rebuild; the node store is reallocated on the way"""
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-50, 50, (30_000, 3))
+    Q = rng.uniform(-55, 55, (700, 3))
+    r = 4.0
+    tree = oracle.KDTree(3)
+    with Context(3, node_capacity=1024) as ctx:
+        ctx.set_option(_capi.RRTX_OPT_NN_CULL, 2)
+        done = 0
+        for upto in (1, 5, 600, 9000, 9001, 9700, 12_000, 12_300, 30_000):
+            ctx.nodes_append(pts[done:upto])
+            tree.insert_many(pts[done:upto])
+            done = upto
+            offsets, idx, dist = ctx.nn_radius(Q, r)
+            _check_csr(offsets, idx, dist, _oracle_lists(tree, Q, r))
+
+
+def test_cull_wrapped_first_dimension_and_theta(oracle):
+    """ghost copies of a wrapped x move to another bucket / slab; theta wrap leaves x alone"""
+    rng = np.random.default_rng(17)
+    n = 6000
+    pts = rng.uniform(0.0, 1.0, (n, 3))
+    pts[:, 1] *= 10.0
+    tree = oracle.KDTree(3, wraps=[0, 2], wrap_points=[1.0, 1.0])
+    tree.insert_many(pts)
+    Q = pts[rng.integers(0, n, 128)] + rng.normal(0, 0.01, (128, 3))
+    Q[:, [0, 2]] = np.clip(Q[:, [0, 2]], 0.0, 1.0)
+    with Context(3) as ctx:
+        ctx.set_wrap(0, 1.0)
+        ctx.set_wrap(2, 1.0)
+        ctx.nodes_append(pts)
+        for r in (0.08, 0.35, 0.7):
+            _both_modes(ctx, Q, r, _oracle_lists(tree, Q, r))
+    n = 12_000
+    pts = synth.nodes(n, 4)
+    tree = oracle.KDTree(4, wraps=[3], wrap_points=[2.0 * math.pi])
+    tree.insert_many(pts)
+    Q = synth.queries(200, 4)
+    with Context(4) as ctx:
+        ctx.set_wrap(3, 2.0 * math.pi)
+        ctx.nodes_append(pts)
+        for r in (10.0, 2.5):
+            _both_modes(ctx, Q, r, _oracle_lists(tree, Q, r))
+
+
+def test_cull_degenerate_extents_and_nonfinite(oracle):
+    rng = np.random.default_rng(2)
+    cases = []
+    # every node on one x plane (zero-width extent: a single slab)
+    p = rng.uniform(-5, 5, (3000, 3)); p[:, 0] = 1.25
+    cases.append((p, rng.uniform(-5, 5, (100, 3)), 1.5))
+    # two far apart clusters: most slabs empty
+    p = np.concatenate([rng.normal(0, 1, (2000, 3)), rng.normal(0, 1, (2000, 3)) + [1e6, 0, 0]])
+    q = np.concatenate([rng.normal(0, 1, (50, 3)), rng.normal(0, 1, (50, 3)) + [1e6, 0, 0], [[5e5, 0, 0]]])
+    cases.append((p, q, 0.75))
+    # inf / NaN / huge coordinates among the nodes and the queries
+    p = rng.uniform(-5, 5, (1500, 3))
+    p[7] = [np.inf, 0, 0]; p[8] = [np.nan, 0, 0]; p[9] = [-np.inf, 1, 1]; p[10] = [1e300, 0, 0]; p[11] = [0, np.nan, 0]
+    q = rng.uniform(-5, 5, (40, 3))
+    q[0] = [np.nan, 0, 0]; q[1] = [np.inf, 0, 0]; q[2] = [1e300, 0.5, 0]; q[3] = [0, np.inf, 0]
+    cases.append((p, q, 2.0))
+    for pts, Q, r in cases:
+        tree = oracle.KDTree(3)
+        tree.insert_many(pts)
+        with Context(3) as ctx:
+            ctx.nodes_append(pts)
+            _both_modes(ctx, Q, r, _oracle_lists(tree, Q, r))
+
+
+def test_cull_per_query_radii_on_the_slab_boundary(oracle):
+    """radii from empty to everything, and nodes whose x distance equals the radius to the ulp
+    (the chunk test is on x alone, so these sit exactly on the edge of a tile's reach)"""
+    rng = np.random.default_rng(11)
+    n = 20_000
+    pts = rng.uniform(-50, 50, (n, 3))
+    Q = rng.uniform(-50, 50, (300, 3))
+    r = rng.uniform(0.0, 9.0, 300)
+    r[0] = 0.0; r[1] = 1e-300; r[2] = 500.0; r[3] = np.inf
+    for k in range(4, 120):          # node straight along x at distance r(1 + few ulps)
+        rel = rng.choice([0.0, 1e-16, -1e-16, 2e-16, -2e-16, 1e-15, -1e-15])
+        pts[k] = Q[k] + [r[k] * (1.0 + rel) * rng.choice([-1.0, 1.0]), 0.0, 0.0]
+    tree = oracle.KDTree(3)
+    tree.insert_many(pts)
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        _both_modes(ctx, Q, r, _oracle_lists(tree, Q, r))
+
+
+def test_cull_extend_candidates_same_as_unculled():
+    n, nq = 40_000, 1500
+    pts, Q, sph = synth.nodes(n, 3), synth.queries(nq, 3), synth.spheres(64)
+    r = synth.ball_radius(n, 3)
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        ctx.spheres_set(sph)
+        outs = []
+        for mode in (2, 0):
+            ctx.set_option(_capi.RRTX_OPT_NN_CULL, mode)
+            outs.append(ctx.extend_candidates(Q, r, 0.5))
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k], outs[1][k]), k
+        assert len(outs[0]["idx"]) > nq
