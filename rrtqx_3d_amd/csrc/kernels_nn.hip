@@ -35,6 +35,34 @@ struct Scalars {
   unsigned long long q_absmax;     // bit pattern of max |coordinate| over the query copies
 };
 
+// Where confirmed neighbours go.  count[q] hands out slots of query q's bucket (a returning
+// atomic per hit, but on one address per query, so they spread over the L2 channels; a single
+// shared counter sustains only ~88 returning atomics/us on MI355X).  A hit beyond the bucket
+// capacity goes to the shared overflow list, one atomic per wave.  count[q] ends as the exact
+// list length either way.
+struct HitSink {
+  int *count;
+  int32_t *bidx;        // [nq][bcap]
+  double *bd2;          // [nq][bcap]
+  int bcap;
+  int pad;
+  HitRec *recs;         // overflow list
+  long long cap;
+  Scalars *sc;          // ->total: entries of the overflow list
+};
+
+// arguments of the exact confirmation (see "Rare path of the range scan")
+struct ConfirmArgs {
+  const double *nx, *ny, *nz, *nw;   // node coordinates by shadow POSITION (fp64)
+  const void *copies;                // QRec3 / QRec4, in the order the scan indexes them
+  const int2 *meta;
+  const SlotRec *slots;
+  const int32_t *pos_id;             // node index of a shadow position, null = identity
+  int n_slots;
+  int pad;
+  HitSink hs;
+};
+
 // fp32 copy record for the prefilter: 16 B (D=3) / 32 B (D=4), one scalar load
 struct alignas(16) QRecF3 { float x, y, z, thr; };
 struct alignas(32) QRecF4 { float x, y, z, w, thr, pad0, pad1, pad2; };
@@ -53,10 +81,14 @@ constexpr int kChunkF = 64 * kScanFU;
 // three runtime kernels and ~20 us)
 __global__ void nn_init_kernel(Scalars *__restrict__ sc, int n_copies_init, int *__restrict__ zero_i32, int n_i32,
                                unsigned long long *__restrict__ fill_u64, int n_u64, unsigned long long v_u64,
-                               int *__restrict__ fill_i32, int n_fill_i32, int v_i32) {
+                               int *__restrict__ fill_i32, int n_fill_i32, int v_i32,
+                               ConfirmArgs *__restrict__ ca_dst, ConfirmArgs ca) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int stride = gridDim.x * blockDim.x;
-  if (i == 0) { sc->total = 0ull; sc->n_copies = n_copies_init; sc->n_units = 0; sc->q_absmax = 0ull; }
+  if (i == 0) {
+    sc->total = 0ull; sc->n_copies = n_copies_init; sc->n_units = 0; sc->q_absmax = 0ull;
+    if (ca_dst) *ca_dst = ca;
+  }
   for (int k = i; k < n_i32; k += stride) zero_i32[k] = 0;
   for (int k = i; k < n_u64; k += stride) fill_u64[k] = v_u64;
   for (int k = i; k < n_fill_i32; k += stride) fill_i32[k] = v_i32;
@@ -152,25 +184,33 @@ __device__ __noinline__ bool seen_by_earlier_slot(const SlotRec *__restrict__ sl
   return false;
 }
 
-constexpr int kStageCap = 128;   // hit records staged in LDS per wave before one global append
-
-// Flush a wave's staged records with ONE atomic on the global counter (a single
-// word sustains only ~88 returning atomics/us on MI355X, so per-hit atomics
-// would serialise the whole kernel).
-__device__ __forceinline__ void flush_stage(HitRec *stage, int &wn, HitRec *__restrict__ recs, long long cap,
-                                            Scalars *__restrict__ sc) {
-  if (wn == 0) return;
-  const int lane = threadIdx.x & 63;
-  unsigned long long base = 0;
-  if (lane == 0) base = atomicAdd(&sc->total, (unsigned long long)wn);
-  base = __shfl(base, 0);
-  __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < wn; i += 64) {
-    long long pos = (long long)base + i;
-    if (pos < cap) recs[pos] = stage[i];
+// every lane of the wave calls this together (the overflow branch uses a ballot)
+__device__ __forceinline__ void emit_hit(const HitSink &hs, bool hit, int owner, int id, double d2) {
+  int slot = 0;
+  if (hit) slot = atomicAdd(&hs.count[owner], 1);
+  const bool inb = hit && slot < hs.bcap;
+  if (inb) {
+    const size_t at = (size_t)owner * (size_t)hs.bcap + (size_t)slot;
+    hs.bidx[at] = id;
+    hs.bd2[at] = d2;
   }
-  __builtin_amdgcn_wave_barrier();
-  wn = 0;
+  const bool ov = hit && !inb;
+  const unsigned long long m = __ballot(ov);
+  if (m != 0ull) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(&hs.sc->total, (unsigned long long)__popcll(m));
+    base = __shfl(base, leader);
+    if (ov) {
+      const long long pos = (long long)base + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < hs.cap) {
+        HitRec r;
+        r.owner = owner; r.idx = id; r.d2 = d2;
+        hs.recs[pos] = r;
+      }
+    }
+  }
 }
 
 template <int D>
@@ -178,9 +218,7 @@ __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
     const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
     const double *__restrict__ nw, int n_nodes, const typename QRecT<D>::type *__restrict__ copies,
     const int2 *__restrict__ meta, const SlotRec *__restrict__ slots, int n_slots, int tile_q, int n_seg,
-    int seg_len, HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
-    int *__restrict__ count) {
-  __shared__ HitRec stage_all[kScanThreads / 64][kStageCap];
+    int seg_len, const Scalars *__restrict__ sc, HitSink hs) {
   // blocks b and b+8 share an XCD: the node segment is the fast-varying index so
   // each XCD's L2 keeps re-serving the same 1/8th of the node arrays.
   const int seg = blockIdx.x % n_seg;
@@ -191,8 +229,6 @@ __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
   const int q1 = min(q0 + tile_q, n_copies);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  HitRec *stage = stage_all[wave];
-  int wn = 0;   // wave-uniform number of staged records
   const int node_begin = seg * seg_len;
   const int node_end = min(n_nodes, node_begin + seg_len);
   const double kNaN = __builtin_nan("");
@@ -223,29 +259,19 @@ __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
         any = any || h[u];
       }
       if (__builtin_expect(__ballot(any) != 0ull, 0)) {
-        // rare path (k/N of the pairs): stage the hits of this wave in LDS
+        // rare path (k/N of the pairs)
         const int2 m = meta[q];
 #pragma unroll
         for (int u = 0; u < kScanU; ++u) {
           bool hu = h[u];
           if (m.y > 0 && hu)
             hu = !seen_by_earlier_slot<D>(slots, n_slots, m.x, m.y, id[u], x[u], y[u], z[u], w[u]);
-          const unsigned long long mask = __ballot(hu);
-          if (mask == 0ull) continue;
-          const int n = __popcll(mask);
-          if (wn + n > kStageCap) flush_stage(stage, wn, recs, cap, sc);
-          if (hu) {
-            HitRec r;
-            r.owner = m.x; r.idx = id[u]; r.d2 = s[u];
-            stage[wn + __popcll(mask & ((1ull << lane) - 1ull))] = r;
-          }
-          if (lane == 0) atomicAdd(&count[m.x], n);   // no-return atomic, one address per query
-          wn += n;
+          emit_hit(hs, hu, m.x, id[u], s[u]);
         }
       }
     }
   }
-  flush_stage(stage, wn, recs, cap, sc);
+  (void)lane;
 }
 
 // ------------------------------------------------------ fp32 prefilter ------
@@ -403,99 +429,104 @@ constexpr int kCandCap = 192;   // (copy, node) candidates queued in LDS per wav
 constexpr int kNearestWarm = 256;   // nodes sampled for the initial bound of the screened nearest scan
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Rare-path queue of the range scan, one per wave in LDS.
-//   event : "copy q was not screened out for the lanes in `mask` of the node chunk at `base`"
-//           (one record per flagged (copy, chunk) pair, pushed by a single lane)
-//   hit   : a confirmed neighbour, staged until one atomic on the shared counter appends a
-//           batch to the global record buffer
-// drain_events decides membership: eight lanes per event, lane u of the group re-tests node
-// base + 64 u + L for every flagged lane L with the exact unfused fp64 distance and the
-// reference's strict compare (first-discovery rule for ghosts).  Nothing of the fp32 screen
-// is reused, so the screen only has to be conservative.
-constexpr int kEvCap = 40;
-constexpr int kHitCap = 160;
-struct WaveQueue {
-  int4 ev[kEvCap];                   // q, base, node_end, unused
-  unsigned long long evm[kEvCap];
-  HitRec hit[kHitCap];
-};
+// Rare path of the range scan.  The screen ends, per (copy, node chunk), in a 64-bit mask of
+// the lanes whose eight nodes were not all screened out.  Each flagged lane records that as an
+// ENTRY (copy q, first position p0 of its eight nodes) in its wave's private slice of a global
+// buffer: no atomics, no recomputation, the position in the slice is a prefix count over the
+// mask.  nn_confirm_kernel then runs one lane per entry: it re-tests the eight nodes with the
+// exact unfused fp64 distance and the reference's strict compare (first-discovery rule for
+// ghosts).  Nothing of the fp32 screen is reused, so the screen only has to be conservative.
+// A slice has room for the worst case of one chunk (every lane of every copy of the tile) on
+// top of kEvSlack entries; a wave that cannot guarantee that before its next chunk confirms its
+// own entries on the spot (same routine), so nothing is ever dropped.
+constexpr int kEvSlack = 2048;
 
-__device__ __forceinline__ void flush_hits(WaveQueue &wq, int &hn, HitRec *__restrict__ recs, long long cap,
-                                           Scalars *__restrict__ sc) {
-  if (hn == 0) return;
-  const int lane = threadIdx.x & 63;
-  unsigned long long base = 0;
-  if (lane == 0) base = atomicAdd(&sc->total, (unsigned long long)hn);
-  base = __shfl(base, 0);
-  __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < hn; i += 64) {
-    const long long pos = (long long)base + i;
-    if (pos < cap) recs[pos] = wq.hit[i];
+// All lanes of the wave call this together; a lane without an entry passes has = false.
+// LM (lane-major chunk layout, slab-ordered shadow): the eight nodes sit at p0 + u, eight
+// consecutive doubles per coordinate array; otherwise at p0 + 64 u.
+template <int D, bool LM>
+__device__ __forceinline__ void confirm_entry(bool has, int2 en, int n_nodes, const ConfirmArgs &a) {
+  const typename QRecT<D>::type *__restrict__ copies = static_cast<const typename QRecT<D>::type *>(a.copies);
+  typename QRecT<D>::type ce;
+  ce.x = 0.0; ce.y = 0.0; ce.z = 0.0; ce.thr = 0.0;
+  if constexpr (D == 4) ce.w = 0.0;
+  int2 m = make_int2(0, 0);
+  const int p0 = has ? en.y : 0;
+  if (has) { ce = copies[en.x]; m = a.meta[en.x]; }
+  double ex[kScanFU], ey[kScanFU], ez[kScanFU], ew[kScanFU];
+  if constexpr (LM) {
+    // node arrays are allocated in whole chunks: the 64-byte rows are always readable
+    const double2 *rx = reinterpret_cast<const double2 *>(a.nx + p0);
+    const double2 *ry = reinterpret_cast<const double2 *>(a.ny + p0);
+    const double2 *rz = reinterpret_cast<const double2 *>(a.nz + p0);
+    const double2 *rw = reinterpret_cast<const double2 *>(a.nw + p0);
+#pragma unroll
+    for (int v = 0; v < kScanFU / 2; ++v) {
+      const double2 vx = rx[v], vy = ry[v], vz = rz[v];
+      ex[2 * v] = vx.x; ex[2 * v + 1] = vx.y;
+      ey[2 * v] = vy.x; ey[2 * v + 1] = vy.y;
+      ez[2 * v] = vz.x; ez[2 * v + 1] = vz.y;
+      if constexpr (D == 4) { const double2 vw = rw[v]; ew[2 * v] = vw.x; ew[2 * v + 1] = vw.y; }
+      else { ew[2 * v] = 0.0; ew[2 * v + 1] = 0.0; }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < kScanFU; ++u) {
+      const int pos = p0 + 64 * u;
+      const int pc = (pos < n_nodes) ? pos : 0;
+      ex[u] = a.nx[pc]; ey[u] = a.ny[pc]; ez[u] = a.nz[pc];
+      if constexpr (D == 4) ew[u] = a.nw[pc]; else ew[u] = 0.0;
+    }
   }
-  __builtin_amdgcn_wave_barrier();
-  hn = 0;
+  double s[kScanFU];
+  unsigned hm = 0u;
+#pragma unroll
+  for (int u = 0; u < kScanFU; ++u) {
+    const int pos = LM ? p0 + u : p0 + 64 * u;
+    if constexpr (D == 4) s[u] = sq4(ce.x, ce.y, ce.z, ce.w, ex[u], ey[u], ez[u], ew[u]);
+    else s[u] = sq3(ce.x, ce.y, ce.z, ex[u], ey[u], ez[u]);
+    bool hu = has && pos < n_nodes && (s[u] < ce.thr);
+    if (m.y > 0 && hu) {
+      const int id = a.pos_id ? a.pos_id[pos] : pos;
+      hu = !seen_by_earlier_slot<D>(a.slots, a.n_slots, m.x, m.y, id, ex[u], ey[u], ez[u], ew[u]);
+    }
+    hm |= (hu ? 1u : 0u) << u;
+  }
+  // normally one of the eight is a neighbour; emit them one per round
+  while (__ballot(hm != 0u) != 0ull) {
+    const bool h = hm != 0u;
+    const int uu = h ? (__ffs((int)hm) - 1) : 0;
+    hm &= hm - 1u;
+    double hs2 = s[0];
+#pragma unroll
+    for (int u = 1; u < kScanFU; ++u) hs2 = (uu == u) ? s[u] : hs2;
+    const int pos = LM ? p0 + uu : p0 + 64 * uu;
+    int hid = pos;
+    if (h && a.pos_id) hid = a.pos_id[pos];
+    emit_hit(a.hs, h, m.x, hid, hs2);
+  }
 }
 
-template <int D>
-__device__ __forceinline__ void drain_events(WaveQueue &wq, int &wn, int &hn, const double *__restrict__ nx,
-                                             const double *__restrict__ ny, const double *__restrict__ nz,
-                                             const double *__restrict__ nw,
-                                             const typename QRecT<D>::type *__restrict__ copies,
-                                             const int2 *__restrict__ meta, const SlotRec *__restrict__ slots,
-                                             int n_slots, HitRec *__restrict__ recs, long long cap,
-                                             Scalars *__restrict__ sc, int *__restrict__ count,
-                                             const int32_t *__restrict__ pos_id) {
-  // pos_id: node index of a shadow position (slab-ordered shadow), null = identity
+// One lane per entry.  kConfirmParts waves share a slice (rounds of 64 entries dealt round-robin)
+// so that the few slices holding several times the average do not set the kernel's duration.
+constexpr int kConfirmParts = 4;
+template <int D, bool LM>
+__global__ __launch_bounds__(256) void nn_confirm_kernel(ConfirmArgs a, const int2 *__restrict__ ev,
+                                                         const int *__restrict__ ev_cnt, int n_slices,
+                                                         int slice_cap, int n_nodes) {
   const int lane = threadIdx.x & 63;
-  const int grp = lane >> 3, u = lane & 7;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  __builtin_amdgcn_wave_barrier();
-  for (int e0 = 0; e0 < wn; e0 += 8) {
-    const int e = e0 + grp;
-    unsigned long long mask = 0ull;
-    int4 ea = make_int4(0, 0, 0, 0);
-    typename QRecT<D>::type ce;
-    ce.x = 0.0; ce.y = 0.0; ce.z = 0.0; ce.thr = 0.0;
-    if constexpr (D == 4) ce.w = 0.0;
-    int2 m = make_int2(0, 0);
-    if (e < wn) {
-      ea = wq.ev[e];
-      mask = wq.evm[e];
-      ce = copies[ea.x];
-      m = meta[ea.x];
-    }
-    while (__ballot(mask != 0ull) != 0ull) {
-      const bool act = mask != 0ull;
-      const int L = act ? (__ffsll((long long)mask) - 1) : 0;
-      mask &= mask - 1ull;                 // 0 stays 0
-      const int pos = ea.y + u * 64 + L;
-      bool hu = false;
-      double s = 0.0;
-      int id = 0;
-      if (act && pos < ea.z) {
-        id = pos_id ? pos_id[pos] : pos;
-        const double ex = nx[id], ey = ny[id], ez = nz[id];
-        double ew = 0.0;
-        if constexpr (D == 4) { ew = nw[id]; s = sq4(ce.x, ce.y, ce.z, ce.w, ex, ey, ez, ew); }
-        else s = sq3(ce.x, ce.y, ce.z, ex, ey, ez);
-        hu = s < ce.thr;
-        if (m.y > 0 && hu) hu = !seen_by_earlier_slot<D>(slots, n_slots, m.x, m.y, id, ex, ey, ez, ew);
-      }
-      const unsigned long long hm = __ballot(hu);
-      if (hm == 0ull) continue;
-      const int n = __popcll(hm);
-      if (hn + n > kHitCap) flush_hits(wq, hn, recs, cap, sc);
-      if (hu) {
-        HitRec r;
-        r.owner = m.x; r.idx = id; r.d2 = s;
-        wq.hit[hn + __popcll(hm & lt_mask)] = r;
-        atomicAdd(&count[m.x], 1);
-      }
-      hn += n;
-    }
+  const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
+  const int w = gw / kConfirmParts, part = gw % kConfirmParts;
+  if (w >= n_slices) return;
+  const int cnt = ev_cnt[w];
+  const int2 *__restrict__ mine = ev + (size_t)w * (size_t)slice_cap;
+  for (int e0 = 64 * part; e0 < cnt; e0 += 64 * kConfirmParts) {
+    const int e = e0 + lane;
+    const bool has = e < cnt;
+    int2 en = make_int2(0, 0);
+    if (has) en = mine[e];
+    confirm_entry<D, LM>(has, en, n_nodes, a);
   }
-  __builtin_amdgcn_wave_barrier();
-  wn = 0;
 }
 
 
@@ -523,44 +554,85 @@ __device__ __forceinline__ void screen8(const typename QRecFT<D>::type &c, const
 
 template <int D, bool CULL>
 __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
-    const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
-    const double *__restrict__ nw, const float *__restrict__ fx, const float *__restrict__ fy,
-    const float *__restrict__ fz, const float *__restrict__ fw, const float *__restrict__ fpp, int n_nodes,
-    const typename QRecT<D>::type *__restrict__ copies, const typename QRecFT<D>::type *__restrict__ copies_f,
-    const int2 *__restrict__ meta, const SlotRec *__restrict__ slots, int n_slots, int tile_q, int n_seg,
-    int seg_len, HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
-    int *__restrict__ count, const int2 *__restrict__ units, const int32_t *__restrict__ pos_id) {
+    const float *__restrict__ fx, const float *__restrict__ fy, const float *__restrict__ fz,
+    const float *__restrict__ fw, const float *__restrict__ fpp, int n_nodes,
+    const typename QRecFT<D>::type *__restrict__ copies_f, int tile_q, int n_seg, int seg_len,
+    const Scalars *__restrict__ sc, const int2 *__restrict__ units, int2 *__restrict__ ev,
+    int *__restrict__ ev_cnt, int slice_cap, const ConfirmArgs *__restrict__ ca) {
   // copies_f is padded to a multiple of kQPI records (thr = -inf) by the launcher.
-  // Persistent workgroups.  Waves never synchronise; the candidate queue lives across work
-  // items and is drained only when full and once at the end.
+  // Persistent workgroups; waves never synchronise.
   //   CULL = false: block b walks items b, b + gridDim.x, ... where item = tile * n_seg + seg.
   //     gridDim.x and n_seg are multiples of 8, so a block keeps the same (item % 8) class:
   //     blocks b and b+8 share an XCD, hence each XCD's L2 keeps serving the same node segments.
   //   CULL = true: wave w walks the (tile, chunk) unit list written by nn_units_kernel
-  //     (w, w + #waves, ...); fx.. are the slab-ordered shadow and pos_id maps a position
-  //     back to the node index.
-  __shared__ WaveQueue wq_all[kScanThreads / 64];
+  //     (w, w + #waves, ...); fx.. are the slab-ordered shadow.
+  // Flagged lanes become entries in this wave's slice of ev (see "Rare path of the range
+  // scan"); one chunk can raise at most 64 tile_q of them.
   const int n_copies = sc->n_copies;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  WaveQueue &wq = wq_all[wave];
-  int wn = 0, hn = 0;                       // wave-uniform: queued events, staged hits
+  const int slice = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kScanThreads / 64) + wave);
+  int2 *__restrict__ mine = ev + (size_t)slice * (size_t)slice_cap;
+  int wn = 0;                               // wave-uniform: entries in the slice
   const float kInf = __builtin_inff();
+
+  // slice (almost) full: confirm the queued entries here and now (same routine as nn_confirm_kernel)
+  auto drain_slice = [&]() {
+    __threadfence();                        // the wave's entry stores -> visible to its loads
+    const ConfirmArgs a = *ca;
+    for (int e0 = 0; e0 < wn; e0 += 64) {
+      const int e = e0 + lane;
+      const bool has = e < wn;
+      int2 en = make_int2(0, 0);
+      if (has) en = mine[e];
+      confirm_entry<D, CULL>(has, en, n_nodes, a);
+    }
+    wn = 0;
+  };
 
   // one chunk of kChunkF nodes (8 per lane, held in VGPRs) against the copies [q0, q1)
   auto scan_chunk = [&](const int base, const int node_end, const int q0, const int q1) {
     float x[kScanFU], y[kScanFU], z[kScanFU], w[kScanFU], pp[kScanFU];
+    if constexpr (CULL) {
+      // lane-major chunk: positions base + 8 lane .. + 7, two 16-byte loads per array (the arrays
+      // are allocated in whole chunks, so the rows of the last chunk are readable; what lies
+      // beyond node_end gets pp = +inf)
+      const unsigned p0 = (unsigned)(base + 8 * lane);
+      const float4 *rx = reinterpret_cast<const float4 *>(fx + p0);
+      const float4 *ry = reinterpret_cast<const float4 *>(fy + p0);
+      const float4 *rz = reinterpret_cast<const float4 *>(fz + p0);
+      const float4 *rw = reinterpret_cast<const float4 *>(fw + p0);
+      const float4 *rp = reinterpret_cast<const float4 *>(fpp + p0);
 #pragma unroll
-    for (int u = 0; u < kScanFU; ++u) {
-      const int id = base + u * 64 + lane;
-      const bool ok = id < node_end;
-      const unsigned idc = (unsigned)(ok ? id : node_end - 1);   // clamped (no divergent load), unsigned
-                                                                  // 32-bit index -> global_load saddr form
-      x[u] = fx[idc];
-      y[u] = fy[idc];
-      z[u] = fz[idc];
-      if constexpr (D == 4) w[u] = fw[idc]; else w[u] = 0.f;
-      pp[u] = ok ? fpp[idc] : kInf;        // +inf padding: t = +inf never survives a finite bound
+      for (int v = 0; v < 2; ++v) {
+        const float4 vx = rx[v], vy = ry[v], vz = rz[v], vp = rp[v];
+        x[4 * v] = vx.x; x[4 * v + 1] = vx.y; x[4 * v + 2] = vx.z; x[4 * v + 3] = vx.w;
+        y[4 * v] = vy.x; y[4 * v + 1] = vy.y; y[4 * v + 2] = vy.z; y[4 * v + 3] = vy.w;
+        z[4 * v] = vz.x; z[4 * v + 1] = vz.y; z[4 * v + 2] = vz.z; z[4 * v + 3] = vz.w;
+        pp[4 * v] = vp.x; pp[4 * v + 1] = vp.y; pp[4 * v + 2] = vp.z; pp[4 * v + 3] = vp.w;
+        if constexpr (D == 4) {
+          const float4 vw = rw[v];
+          w[4 * v] = vw.x; w[4 * v + 1] = vw.y; w[4 * v + 2] = vw.z; w[4 * v + 3] = vw.w;
+        } else {
+          w[4 * v] = 0.f; w[4 * v + 1] = 0.f; w[4 * v + 2] = 0.f; w[4 * v + 3] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kScanFU; ++u)
+        if ((int)p0 + u >= node_end) { x[u] = 0.f; y[u] = 0.f; z[u] = 0.f; w[u] = 0.f; pp[u] = kInf; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kScanFU; ++u) {
+        const int id = base + u * 64 + lane;
+        const bool ok = id < node_end;
+        const unsigned idc = (unsigned)(ok ? id : node_end - 1);   // clamped (no divergent load), unsigned
+                                                                    // 32-bit index -> global_load saddr form
+        x[u] = fx[idc];
+        y[u] = fy[idc];
+        z[u] = fz[idc];
+        if constexpr (D == 4) w[u] = fw[idc]; else w[u] = 0.f;
+        pp[u] = ok ? fpp[idc] : kInf;        // +inf padding: t = +inf never survives a finite bound
+      }
     }
     for (int q = q0; q < q1; q += kQPI) {
       // kQPI wave-uniform copy records per iteration (scalar loads); tile_q % kQPI == 0
@@ -581,17 +653,15 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
         anym |= mk[k];
       }
       if (anym != 0ull) {
-        // some lane of some copy was not screened out: queue one event per flagged copy
-        if (wn + kQPI > kEvCap)
-          drain_events<D>(wq, wn, hn, nx, ny, nz, nw, copies, meta, slots, n_slots, recs, cap, sc, count, pos_id);
+        // some lane of some copy was not screened out: every flagged lane files its own entry
 #pragma unroll
         for (int k = 0; k < kQPI; ++k) {
           if (mk[k] == 0ull || q + k >= q1) continue;
-          if (lane == 0) {
-            wq.ev[wn] = make_int4(q + k, base, node_end, 0);
-            wq.evm[wn] = mk[k];
-          }
-          wn += 1;
+          const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(mk[k] >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((unsigned)mk[k], 0u));
+          if ((mk[k] >> lane) & 1ull)
+            mine[wn + (int)before] = make_int2(q + k, CULL ? base + 8 * lane : base + lane);
+          wn += __popcll(mk[k]);
         }
       }
     }
@@ -605,6 +675,7 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
       const int2 un = units[u];               // wave-uniform: scalar load
       const int q0 = un.x * tile_q;
       const int q1 = min(q0 + tile_q, n_copies);
+      if (wn + 64 * tile_q > slice_cap) drain_slice();
       scan_chunk(un.y * kChunkF, n_nodes, q0, q1);
     }
   } else {
@@ -617,12 +688,13 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
       const int q1 = min(q0 + tile_q, n_copies);
       const int node_begin = seg * seg_len;
       const int node_end = min(n_nodes, node_begin + seg_len);
-      for (int base = node_begin + wave * kChunkF; base < node_end; base += (kScanThreads / 64) * kChunkF)
+      for (int base = node_begin + wave * kChunkF; base < node_end; base += (kScanThreads / 64) * kChunkF) {
+        if (wn + 64 * tile_q > slice_cap) drain_slice();
         scan_chunk(base, node_end, q0, q1);
+      }
     }
   }
-  drain_events<D>(wq, wn, hn, nx, ny, nz, nw, copies, meta, slots, n_slots, recs, cap, sc, count, pos_id);
-  flush_hits(wq, hn, recs, cap, sc);
+  if (lane == 0) ev_cnt[slice] = wn;
 }
 
 // ------------------------------------------------------------- rootfix ------
@@ -631,28 +703,22 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
 template <int D>
 __global__ __launch_bounds__(256) void nn_rootfix_kernel(const double *__restrict__ nx, const double *__restrict__ ny,
                                   const double *__restrict__ nz, const double *__restrict__ nw,
-                                  const SlotRec *__restrict__ slots, int n_slots, int nq,
-                                  HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
-                                  int *__restrict__ count, long long *__restrict__ block_sum) {
+                                  const SlotRec *__restrict__ slots, int n_slots, int nq, HitSink hs,
+                                  long long *__restrict__ block_sum) {
   __shared__ long long wsum[4];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int c = 0;
+  bool add = false;
+  double s = 0.0;
   if (i < nq) {
     SlotRec sr = slots[(size_t)i * n_slots];
-    double s = (D == 4) ? sq4(sr.x, sr.y, sr.z, sr.w, nx[0], ny[0], nz[0], nw[0])
-                        : sq3(sr.x, sr.y, sr.z, nx[0], ny[0], nz[0]);
-    c = count[i];               // final: the scan kernel has completed
-    if (s >= sr.thr_lt && s < sr.thr_gt) {
-      unsigned long long pos = atomicAdd(&sc->total, 1ull);
-      c += 1;
-      count[i] = c;
-      if ((long long)pos < cap) {
-        HitRec r;
-        r.owner = i; r.idx = 0; r.d2 = s;
-        recs[pos] = r;
-      }
-    }
+    s = (D == 4) ? sq4(sr.x, sr.y, sr.z, sr.w, nx[0], ny[0], nz[0], nw[0])
+                 : sq3(sr.x, sr.y, sr.z, nx[0], ny[0], nz[0]);
+    c = hs.count[i];            // final: scan and confirm kernels have completed
+    add = s >= sr.thr_lt && s < sr.thr_gt;
   }
+  emit_hit(hs, add, i, 0, s);   // whole wave together
+  if (add) c += 1;
   // per-block sum of the final counts: first level of the offsets scan
   long long v = c;
 #pragma unroll
@@ -697,21 +763,23 @@ __global__ __launch_bounds__(256) void nn_offsets_kernel(const int *__restrict__
   }
   if (i == nq - 1) {
     offsets[nq] = prefix + v;
-    if (needed) *needed = (int64_t)sc->total;
+    if (needed) *needed = (int64_t)(prefix + v);
   }
 }
 
 // ------------------------------------------------------------- scatter ------
+// Entry j of query q's list lives in its bucket for j < bcap and at tmp[offsets[q] + j]
+// otherwise; this kernel moves the overflow list (normally empty) to those places.
 __global__ void nn_scatter_kernel(const HitRec *__restrict__ recs, long long cap,
                                   const Scalars *__restrict__ sc, const int64_t *__restrict__ offsets,
-                                  int *__restrict__ cursor, int32_t *__restrict__ tmp_idx,
+                                  int *__restrict__ cursor, int bcap, int32_t *__restrict__ tmp_idx,
                                   double *__restrict__ tmp_d2, long long out_cap) {
   long long total = (long long)sc->total;
   if (total > cap) total = cap;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     HitRec r = recs[i];
-    long long dst = offsets[r.owner] + atomicAdd(&cursor[r.owner], 1);
+    long long dst = offsets[r.owner] + bcap + atomicAdd(&cursor[r.owner], 1);
     if (dst < out_cap) {
       tmp_idx[dst] = r.idx;
       tmp_d2[dst] = r.d2;
@@ -719,14 +787,28 @@ __global__ void nn_scatter_kernel(const HitRec *__restrict__ recs, long long cap
   }
 }
 
+// entry j of the (unordered) list of query q, see nn_scatter_kernel
+struct ListSrc {
+  const int32_t *bidx;
+  const double *bd2;
+  int bcap;
+  int pad;
+  const int32_t *tmp_idx;
+  const double *tmp_d2;
+  __device__ __forceinline__ int idx(int q, long long b, long long j) const {
+    return (j < bcap) ? bidx[(size_t)q * (size_t)bcap + (size_t)j] : tmp_idx[b + j];
+  }
+  __device__ __forceinline__ double d2(int q, long long b, long long j) const {
+    return (j < bcap) ? bd2[(size_t)q * (size_t)bcap + (size_t)j] : tmp_d2[b + j];
+  }
+};
+
 // --------------------------------------------------------------- order ------
 // one wave per query: rank each hit by node index, write idx ascending and
 // dist = sqrt(d2) (the key the reference stores, R/kdTree_general.jl:829-831).
 // Optionally also: owner[e] = query of CSR entry e, and the nearest node of the
 // list (lexicographic minimum of (d2, idx); -1 when the list is empty).
-__global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict__ offsets, int nq,
-                                                       const int32_t *__restrict__ tmp_idx,
-                                                       const double *__restrict__ tmp_d2,
+__global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict__ offsets, int nq, ListSrc src,
                                                        int32_t *__restrict__ idx,
                                                        double *__restrict__ dist, long long out_cap,
                                                        int32_t *__restrict__ owner,
@@ -743,8 +825,8 @@ __global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict
   double best = __builtin_inf();
   int best_i = 0x7fffffff;
   if (k > 0 && k <= 64) {
-    int my = (lane < k) ? tmp_idx[b + lane] : 0x7fffffff;
-    double d2 = (lane < k) ? tmp_d2[b + lane] : __builtin_inf();
+    int my = (lane < k) ? src.idx(q, b, lane) : 0x7fffffff;
+    double d2 = (lane < k) ? src.d2(q, b, lane) : __builtin_inf();
     int rank = 0;
     for (int j = 0; j < (int)k; ++j) {
       int other = __shfl(my, j);
@@ -779,9 +861,7 @@ __global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict
 // nn_order_kernel.  Up to kBigSort entries are sorted by node index with a bitonic network in
 // LDS; longer lists fall back to rank counting with all 256 threads.
 constexpr int kBigSort = 2048;
-__global__ __launch_bounds__(256) void nn_order_big_kernel(const int64_t *__restrict__ offsets,
-                                                           const int32_t *__restrict__ tmp_idx,
-                                                           const double *__restrict__ tmp_d2,
+__global__ __launch_bounds__(256) void nn_order_big_kernel(const int64_t *__restrict__ offsets, ListSrc src,
                                                            int32_t *__restrict__ idx, double *__restrict__ dist,
                                                            long long out_cap, int32_t *__restrict__ owner,
                                                            int32_t *__restrict__ nearest_idx,
@@ -806,8 +886,8 @@ __global__ __launch_bounds__(256) void nn_order_big_kernel(const int64_t *__rest
       int n2 = 64;
       while (n2 < k) n2 <<= 1;
       for (int i = t; i < n2; i += 256) {
-        s_idx[i] = (i < k) ? tmp_idx[b + i] : 0x7fffffff;
-        s_d2[i] = (i < k) ? tmp_d2[b + i] : __builtin_inf();
+        s_idx[i] = (i < k) ? src.idx(q, b, i) : 0x7fffffff;
+        s_d2[i] = (i < k) ? src.d2(q, b, i) : __builtin_inf();
       }
       __syncthreads();
       for (int size = 2; size <= n2; size <<= 1) {
@@ -837,10 +917,10 @@ __global__ __launch_bounds__(256) void nn_order_big_kernel(const int64_t *__rest
       }
     } else {
       for (int i = t; i < k; i += 256) {
-        const int my = tmp_idx[b + i];
-        const double d2 = tmp_d2[b + i];
+        const int my = src.idx(q, b, i);
+        const double d2 = src.d2(q, b, i);
         int rank = 0;
-        for (int j = 0; j < k; ++j) rank += (tmp_idx[b + j] < my) ? 1 : 0;
+        for (int j = 0; j < k; ++j) rank += (src.idx(q, b, j) < my) ? 1 : 0;
         idx[b + rank] = my;
         dist[b + rank] = sqrt_rn(d2);
         if (owner) owner[b + rank] = q;
@@ -1186,13 +1266,18 @@ __global__ void slab_scatter_kernel(int n, const int2 *__restrict__ sr, const in
                                     const float *__restrict__ fz, const float *__restrict__ fw,
                                     const float *__restrict__ fpp, int dim, float *__restrict__ sx,
                                     float *__restrict__ sy, float *__restrict__ sz, float *__restrict__ sw,
-                                    float *__restrict__ spp, int32_t *__restrict__ sid) {
+                                    float *__restrict__ spp, int32_t *__restrict__ sid,
+                                    const double *__restrict__ nx, const double *__restrict__ ny,
+                                    const double *__restrict__ nz, const double *__restrict__ nw,
+                                    double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ dz,
+                                    double *__restrict__ dw) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int2 r = sr[i];
   const int p = start[r.x] + r.y;
   sx[p] = fx[i]; sy[p] = fy[i]; sz[p] = fz[i];
-  if (dim == 4) sw[p] = fw[i];
+  dx[p] = nx[i]; dy[p] = ny[i]; dz[p] = nz[i];
+  if (dim == 4) { sw[p] = fw[i]; dw[p] = nw[i]; }
   spp[p] = fpp[i];
   sid[p] = i;
 }
@@ -1257,7 +1342,8 @@ int slab_refresh(rrtx_ctx *ctx) {
   hipLaunchKernelGGL(slab_scatter_kernel, dim3(nb), dim3(256), 0, st, (int)n, sr, start, ctx->nodes_f[0],
                      ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->dim,
                      ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp,
-                     ctx->sl_id);
+                     ctx->sl_id, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[ctx->dim == 4 ? 3 : 2],
+                     ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2], ctx->sl_d[ctx->dim == 4 ? 3 : 2]);
   hipLaunchKernelGGL(chunk_range_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, st, ctx->nodes[0], ctx->sl_id, (int)n,
                      n_chunks, ctx->chunk_lo, ctx->chunk_hi);
   span_end(ctx);
@@ -1313,6 +1399,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   const bool use_filter = ctx->opt_nn_filter != 0;
   int tile_q = use_filter ? kTileQFilter : kTileQExact;
   if (ctx->opt_tile_q > 0) tile_q = (ctx->opt_tile_q + kQPI - 1) / kQPI * kQPI;
+  if (use_filter && tile_q > 128) tile_q = 128;   // bounds the worst case of one chunk (64 tile_q entries)
   const int n_tiles = (int)((n_copies_max + tile_q - 1) / tile_q);
   const int n_chunks = (n_nodes + kSlabChunk - 1) / kSlabChunk;
   const long long unit_cap = (long long)n_tiles * n_chunks;
@@ -1337,9 +1424,38 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
     qstart = ctx->ws_qstart.as<int>();
     cbk = ctx->ws_cb.as<int2>();
   }
+  // ---- hit sink: per-query buckets (2x the average the caller made room for) + overflow list ----
+  long long bcap_ll = (rec_cap + nq - 1) / nq * 2;
+  bcap_ll = (bcap_ll + 7) / 8 * 8;
+  if (bcap_ll < 8) bcap_ll = 8;
+  if (bcap_ll > (1ll << 24)) bcap_ll = 1ll << 24;
+  const int bcap = (int)bcap_ll;
+  RRTX_HIP(ctx, ctx->ws_bkt_idx.ensure((size_t)nq * (size_t)bcap * sizeof(int32_t)));
+  RRTX_HIP(ctx, ctx->ws_bkt_d2.ensure((size_t)nq * (size_t)bcap * sizeof(double)));
+  HitSink hs;
+  hs.count = count;
+  hs.bidx = ctx->ws_bkt_idx.as<int32_t>();
+  hs.bd2 = ctx->ws_bkt_d2.as<double>();
+  hs.bcap = bcap;
+  hs.pad = 0;
+  hs.recs = ctx->ws_recs.as<HitRec>();
+  hs.cap = rec_cap;
+  hs.sc = sc;
+  ConfirmArgs ca;
+  double *const *pd = use_cull ? ctx->sl_d : ctx->nodes;
+  ca.nx = pd[0]; ca.ny = pd[1]; ca.nz = pd[2]; ca.nw = pd[D == 4 ? 3 : 2];
+  ca.copies = use_cull ? ctx->ws_copies_s.p : ctx->ws_copies.p;
+  ca.meta = use_cull ? ctx->ws_meta_s.as<int2>() : ctx->ws_copy_meta.as<int2>();
+  ca.slots = ctx->ws_slots.as<SlotRec>();
+  ca.pos_id = use_cull ? ctx->sl_id : nullptr;
+  ca.n_slots = n_slots;
+  ca.pad = 0;
+  ca.hs = hs;
+  RRTX_HIP(ctx, ctx->ws_confirm_args.ensure(sizeof(ConfirmArgs)));
+  ConfirmArgs *ca_dev = ctx->ws_confirm_args.as<ConfirmArgs>();
   hipLaunchKernelGGL(nn_init_kernel, dim3((nq + 1 + 255) / 256 < 64 ? (nq + 1 + 255) / 256 : 64), dim3(256), 0, st, sc,
                      (ctx->n_wraps == 0) ? nq : 0, count, nq + 1, (unsigned long long *)nullptr, 0, 0ull,
-                     qhist, use_cull ? n_buckets + 1 : 0, 0);
+                     qhist, use_cull ? n_buckets + 1 : 0, 0, ca_dev, ca);
 
   const double *thr_lt_arr = r_dev_thr_lt;
   const double *thr_gt_arr = r_dev_thr_lt ? r_dev_thr_lt + nq : nullptr;
@@ -1418,79 +1534,88 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   {
     dim3 grid((unsigned)n_tiles * (unsigned)n_seg), block(kScanThreads);
     if (use_filter) {
-      // persistent grid: opt_scan_blocks workgroups (multiple of 8) striding over the items
+      // persistent grid: opt_scan_blocks workgroups (multiple of 8) striding over the work
       unsigned pg = (unsigned)ctx->opt_scan_blocks / 8u * 8u;
       if (pg < 8u) pg = 8u;
-      if (pg < grid.x) grid.x = pg;
+      if (pg < grid.x || use_cull) grid.x = pg;
       const int wi = D == 4 ? 3 : 2;
-      if (use_cull) {
-        grid.x = pg;
-        const int2 *units = ctx->ws_units.as<int2>();
-        if (D == 4)
-          hipLaunchKernelGGL((nn_scan_f32_kernel<4, true>), grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
-                             ctx->nodes[2], ctx->nodes[wi], ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[wi],
-                             ctx->sl_pp, n_nodes, ctx->ws_copies_s.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(),
-                             ctx->ws_meta_s.as<int2>(), ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len,
-                             ctx->ws_recs.as<HitRec>(), rec_cap, sc, count, units, ctx->sl_id);
+      const int n_slices = (int)grid.x * (kScanThreads / 64);
+      const int slice_cap = 64 * tile_q + kEvSlack;
+      RRTX_HIP(ctx, ctx->ws_ev_a.ensure((size_t)n_slices * (size_t)slice_cap * sizeof(int2)));
+      RRTX_HIP(ctx, ctx->ws_ev_cnt.ensure((size_t)n_slices * sizeof(int)));
+      int2 *ev = ctx->ws_ev_a.as<int2>();
+      int *ev_cnt = ctx->ws_ev_cnt.as<int>();
+      const int2 *units = ctx->ws_units.as<int2>();
+      float *const *nf = use_cull ? ctx->sl_f : ctx->nodes_f;
+      const float *npp = use_cull ? ctx->sl_pp : ctx->nodes_pp;
+      if (D == 4) {
+        const QRecF4 *cf = ctx->ws_copies_f.as<QRecF4>();
+        if (use_cull)
+          hipLaunchKernelGGL((nn_scan_f32_kernel<4, true>), grid, block, 0, st, nf[0], nf[1], nf[2], nf[wi], npp,
+                             n_nodes, cf, tile_q, n_seg, seg_len, sc, units, ev, ev_cnt, slice_cap, ca_dev);
         else
-          hipLaunchKernelGGL((nn_scan_f32_kernel<3, true>), grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
-                             ctx->nodes[2], ctx->nodes[wi], ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[wi],
-                             ctx->sl_pp, n_nodes, ctx->ws_copies_s.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(),
-                             ctx->ws_meta_s.as<int2>(), ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len,
-                             ctx->ws_recs.as<HitRec>(), rec_cap, sc, count, units, ctx->sl_id);
-      } else if (D == 4)
-        hipLaunchKernelGGL((nn_scan_f32_kernel<4, false>), grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
-                           ctx->nodes[2], ctx->nodes[wi], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2],
-                           ctx->nodes_f[wi], ctx->nodes_pp, n_nodes, ctx->ws_copies.as<QRec4>(),
-                           ctx->ws_copies_f.as<QRecF4>(), ctx->ws_copy_meta.as<int2>(), ctx->ws_slots.as<SlotRec>(),
-                           n_slots, tile_q, n_seg, seg_len, ctx->ws_recs.as<HitRec>(), rec_cap, sc, count,
-                           (const int2 *)nullptr, (const int32_t *)nullptr);
+          hipLaunchKernelGGL((nn_scan_f32_kernel<4, false>), grid, block, 0, st, nf[0], nf[1], nf[2], nf[wi], npp,
+                             n_nodes, cf, tile_q, n_seg, seg_len, sc, units, ev, ev_cnt, slice_cap, ca_dev);
+      } else {
+        const QRecF3 *cf = ctx->ws_copies_f.as<QRecF3>();
+        if (use_cull)
+          hipLaunchKernelGGL((nn_scan_f32_kernel<3, true>), grid, block, 0, st, nf[0], nf[1], nf[2], nf[wi], npp,
+                             n_nodes, cf, tile_q, n_seg, seg_len, sc, units, ev, ev_cnt, slice_cap, ca_dev);
+        else
+          hipLaunchKernelGGL((nn_scan_f32_kernel<3, false>), grid, block, 0, st, nf[0], nf[1], nf[2], nf[wi], npp,
+                             n_nodes, cf, tile_q, n_seg, seg_len, sc, units, ev, ev_cnt, slice_cap, ca_dev);
+      }
+      // exact confirmation of the queued entries: one wave per slice, one lane per entry
+      dim3 cgrid((unsigned)(((long long)n_slices * kConfirmParts + 3) / 4));
+      if (D == 4 && use_cull)
+        hipLaunchKernelGGL((nn_confirm_kernel<4, true>), cgrid, dim3(256), 0, st, ca, ev, ev_cnt, n_slices, slice_cap,
+                           n_nodes);
+      else if (D == 4)
+        hipLaunchKernelGGL((nn_confirm_kernel<4, false>), cgrid, dim3(256), 0, st, ca, ev, ev_cnt, n_slices, slice_cap,
+                           n_nodes);
+      else if (use_cull)
+        hipLaunchKernelGGL((nn_confirm_kernel<3, true>), cgrid, dim3(256), 0, st, ca, ev, ev_cnt, n_slices, slice_cap,
+                           n_nodes);
       else
-        hipLaunchKernelGGL((nn_scan_f32_kernel<3, false>), grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
-                           ctx->nodes[2], ctx->nodes[wi], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2],
-                           ctx->nodes_f[wi], ctx->nodes_pp, n_nodes, ctx->ws_copies.as<QRec3>(),
-                           ctx->ws_copies_f.as<QRecF3>(), ctx->ws_copy_meta.as<int2>(), ctx->ws_slots.as<SlotRec>(),
-                           n_slots, tile_q, n_seg, seg_len, ctx->ws_recs.as<HitRec>(), rec_cap, sc, count,
-                           (const int2 *)nullptr, (const int32_t *)nullptr);
+        hipLaunchKernelGGL((nn_confirm_kernel<3, false>), cgrid, dim3(256), 0, st, ca, ev, ev_cnt, n_slices, slice_cap,
+                           n_nodes);
     } else if (D == 4)
       hipLaunchKernelGGL(nn_scan_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
                          ctx->nodes[3], n_nodes, ctx->ws_copies.as<QRec4>(), ctx->ws_copy_meta.as<int2>(),
-                         ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len,
-                         ctx->ws_recs.as<HitRec>(), rec_cap, sc, count);
+                         ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len, sc, hs);
     else
       hipLaunchKernelGGL(nn_scan_kernel<3>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
                          ctx->nodes[2], n_nodes, ctx->ws_copies.as<QRec3>(), ctx->ws_copy_meta.as<int2>(),
-                         ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len,
-                         ctx->ws_recs.as<HitRec>(), rec_cap, sc, count);
+                         ctx->ws_slots.as<SlotRec>(), n_slots, tile_q, n_seg, seg_len, sc, hs);
   }
   span_end(ctx);
   ctx->last_pairs = (int64_t)n_copies_max * n_nodes;
 
   RRTX_HIP(ctx, ctx->ws_bsum.ensure(sizeof(long long) * (size_t)((nq + 255) / 256)));
   long long *bsum = ctx->ws_bsum.as<long long>();
+  ListSrc src;
+  src.bidx = hs.bidx; src.bd2 = hs.bd2; src.bcap = bcap; src.pad = 0;
+  src.tmp_idx = ctx->ws_tmp_idx.as<int32_t>(); src.tmp_d2 = ctx->ws_tmp_d2.as<double>();
   span_begin(ctx, KF_NN_FINISH);
   {
     dim3 grid((nq + 255) / 256), block(256);
     if (D == 4)
       hipLaunchKernelGGL(nn_rootfix_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                         ctx->nodes[3], ctx->ws_slots.as<SlotRec>(), n_slots, nq, ctx->ws_recs.as<HitRec>(),
-                         rec_cap, sc, count, bsum);
+                         ctx->nodes[3], ctx->ws_slots.as<SlotRec>(), n_slots, nq, hs, bsum);
     else
       hipLaunchKernelGGL(nn_rootfix_kernel<3>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                         ctx->nodes[2], ctx->ws_slots.as<SlotRec>(), n_slots, nq, ctx->ws_recs.as<HitRec>(),
-                         rec_cap, sc, count, bsum);
+                         ctx->nodes[2], ctx->ws_slots.as<SlotRec>(), n_slots, nq, hs, bsum);
     hipLaunchKernelGGL(nn_offsets_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, count, nq, bsum, offsets_dev,
                        cursor, sc, needed_dev);
-    hipLaunchKernelGGL(nn_scatter_kernel, dim3(1024), dim3(256), 0, st, ctx->ws_recs.as<HitRec>(), rec_cap, sc,
-                       offsets_dev, cursor, ctx->ws_tmp_idx.as<int32_t>(), ctx->ws_tmp_d2.as<double>(),
+    // the overflow list is normally empty: a small grid finds that out quickly
+    hipLaunchKernelGGL(nn_scatter_kernel, dim3(64), dim3(256), 0, st, ctx->ws_recs.as<HitRec>(), rec_cap, sc,
+                       offsets_dev, cursor, bcap, ctx->ws_tmp_idx.as<int32_t>(), ctx->ws_tmp_d2.as<double>(),
                        (long long)cap);
-    hipLaunchKernelGGL(nn_order_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, offsets_dev, nq,
-                       ctx->ws_tmp_idx.as<int32_t>(), ctx->ws_tmp_d2.as<double>(), idx_dev, dist_dev,
+    hipLaunchKernelGGL(nn_order_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, offsets_dev, nq, src, idx_dev, dist_dev,
                        (long long)cap, owner_dev, nearest_idx_dev, nearest_dist_dev, big_list, big_count);
     // lists longer than one wave (queued by nn_order_kernel); exits at once when there are none
-    hipLaunchKernelGGL(nn_order_big_kernel, dim3(nq < 1024 ? nq : 1024), dim3(256), 0, st, offsets_dev,
-                       ctx->ws_tmp_idx.as<int32_t>(), ctx->ws_tmp_d2.as<double>(), idx_dev, dist_dev, (long long)cap,
-                       owner_dev, nearest_idx_dev, nearest_dist_dev, big_list, big_count);
+    hipLaunchKernelGGL(nn_order_big_kernel, dim3(nq < 1024 ? nq : 1024), dim3(256), 0, st, offsets_dev, src, idx_dev,
+                       dist_dev, (long long)cap, owner_dev, nearest_idx_dev, nearest_dist_dev, big_list, big_count);
   }
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
@@ -1553,7 +1678,8 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
   int *best_idx = reinterpret_cast<int *>(best_bits + nq);
   Scalars *sc = ctx->ws_scalars.as<Scalars>();
   hipLaunchKernelGGL(nn_init_kernel, dim3((nq + 255) / 256 < 64 ? (nq + 255) / 256 : 64), dim3(256), 0, st, sc,
-                     (ctx->n_wraps == 0) ? nq : 0, (int *)nullptr, 0, best_bits, nq, ~0ull, best_idx, nq, 0x7fffffff);
+                     (ctx->n_wraps == 0) ? nq : 0, (int *)nullptr, 0, best_bits, nq, ~0ull, best_idx, nq, 0x7fffffff,
+                     (ConfirmArgs *)nullptr, ConfirmArgs{});
   const double inf = std::numeric_limits<double>::infinity();
   const double nan = std::numeric_limits<double>::quiet_NaN();
 

@@ -127,6 +127,8 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
                                                          float *__restrict__ sx, float *__restrict__ sy,
                                                          float *__restrict__ sz, float *__restrict__ sw,
                                                          float *__restrict__ spp, int32_t *__restrict__ sid,
+                                                         double *__restrict__ dx, double *__restrict__ dy,
+                                                         double *__restrict__ dz, double *__restrict__ dw,
                                                          unsigned long long *__restrict__ chunk_lo,
                                                          unsigned long long *__restrict__ chunk_hi,
                                                          unsigned long long *__restrict__ xrange) {
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
     // slab index: a new node sits at position == index until the next rebuild; its chunk's
     // x extent grows accordingly (a NaN x can never be within range of anything: not tracked)
     sx[base + i] = fa; sy[base + i] = fb; sz[base + i] = fc;
+    dx[base + i] = a; dy[base + i] = b; dz[base + i] = c;
     sid[base + i] = (int32_t)(base + i);
     if (a == a) {
       xlo = xhi = enc_ord(a);
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
       const float fd = (float)sd;
       wf[base + i] = fd;
       sw[base + i] = fd;
+      dw[base + i] = d;
       pp += (double)fd * (double)fd;
       m = max(m, (unsigned long long)__double_as_longlong(fabs(sd)));
     }
@@ -203,6 +207,7 @@ int grow_nodes(rrtx_ctx *ctx, int64_t need) {
     if ((rc = regrow(ctx, ctx->nodes[k], nc, ctx->n_nodes))) return rc;
     if ((rc = regrow(ctx, ctx->nodes_f[k], nc, ctx->n_nodes))) return rc;
     if ((rc = regrow(ctx, ctx->sl_f[k], nc, ctx->n_nodes))) return rc;
+    if ((rc = regrow(ctx, ctx->sl_d[k], nc, ctx->n_nodes))) return rc;
   }
   if ((rc = regrow(ctx, ctx->nodes_pp, nc, ctx->n_nodes))) return rc;
   if ((rc = regrow(ctx, ctx->sl_pp, nc, ctx->n_nodes))) return rc;
@@ -310,6 +315,8 @@ int rrtx_destroy(rrtx_ctx *ctx) {
   if (ctx->nodes_pp) (void)hipFree(ctx->nodes_pp);
   for (int k = 0; k < 4; ++k)
     if (ctx->sl_f[k]) (void)hipFree(ctx->sl_f[k]);
+  for (int k = 0; k < 4; ++k)
+    if (ctx->sl_d[k]) (void)hipFree(ctx->sl_d[k]);
   if (ctx->sl_pp) (void)hipFree(ctx->sl_pp);
   if (ctx->sl_id) (void)hipFree(ctx->sl_id);
   if (ctx->chunk_lo) (void)hipFree(ctx->chunk_lo);
@@ -322,7 +329,8 @@ int rrtx_destroy(rrtx_ctx *ctx) {
                     &ctx->ws_tmp_d2, &ctx->ws_owner, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
                     &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr, &ctx->ws_mask, &ctx->ws_i32a, &ctx->ws_i32b,
                     &ctx->ws_slab_hist, &ctx->ws_slab_start, &ctx->ws_slab_sr, &ctx->ws_slab_params, &ctx->ws_copies_s,
-                    &ctx->ws_meta_s, &ctx->ws_cb, &ctx->ws_qhist, &ctx->ws_qstart, &ctx->ws_units};
+                    &ctx->ws_meta_s, &ctx->ws_cb, &ctx->ws_qhist, &ctx->ws_qstart, &ctx->ws_units, &ctx->ws_bkt_idx,
+                    &ctx->ws_bkt_d2, &ctx->ws_ev_a, &ctx->ws_ev_m, &ctx->ws_ev_cnt, &ctx->ws_confirm_args};
   for (auto b : bufs) b->release();
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -418,6 +426,7 @@ int rrtx_nodes_append_dev(rrtx_ctx *ctx, const double *pos_dev, int64_t n) {
                      ctx->nodes[ctx->dim == 4 ? 3 : 2], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2],
                      ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->d_absmax.as<unsigned long long>(),
                      ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp, ctx->sl_id,
+                     ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2], ctx->sl_d[ctx->dim == 4 ? 3 : 2],
                      ctx->chunk_lo, ctx->chunk_hi, ctx->d_xrange.as<unsigned long long>());
   RRTX_HIP(ctx, hipGetLastError());
   ctx->n_nodes += n;

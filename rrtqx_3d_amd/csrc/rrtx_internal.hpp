@@ -83,7 +83,11 @@ struct rrtx_ctx {
   // index").  Positions [0, sl_n_sorted) hold nodes 0..sl_n_sorted-1 ordered by equal-width
   // x slab; positions >= sl_n_sorted hold node p at position p (appended since the last
   // rebuild).  chunk_lo/hi: exact fp64 x extent of every 512-position chunk (enc_ord).
+  // Inside a chunk the positions are lane-major: scan lane L owns positions 8 L .. 8 L + 7, so
+  // its eight nodes are two 16-byte loads per array and the exact re-test of a flagged lane
+  // reads eight consecutive doubles (sl_d: the same order in fp64).
   float *sl_f[4] = {nullptr, nullptr, nullptr, nullptr};
+  double *sl_d[4] = {nullptr, nullptr, nullptr, nullptr};
   float *sl_pp = nullptr;
   int32_t *sl_id = nullptr;
   unsigned long long *chunk_lo = nullptr, *chunk_hi = nullptr;
@@ -135,6 +139,8 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_copy_meta;// int32 owner, slot per copy
   rrtx::DevBuf ws_copies_s, ws_meta_s;  // copies / meta in x-bucket order (culled scan)
   rrtx::DevBuf ws_cb, ws_qhist, ws_qstart, ws_units;
+  rrtx::DevBuf ws_bkt_idx, ws_bkt_d2;   // per-query hit buckets
+  rrtx::DevBuf ws_ev_a, ws_ev_m, ws_ev_cnt, ws_confirm_args;   // flagged (copy, chunk) events per scan wave
   rrtx::DevBuf ws_recs;     // HitRec
   rrtx::DevBuf ws_counts;   // int32 count[nq], cursor[nq]
   rrtx::DevBuf ws_bsum;     // int64 per-256-query sums of count (first level of the offsets scan)
