@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void candidate_edges_kernel(
     const int32_t *__restrict__ idx, const int32_t *__restrict__ owner, const double *__restrict__ nx,
     const double *__restrict__ ny, const double *__restrict__ nz, int n_nodes, long long cap,
     const SphRec *__restrict__ sph, const float *__restrict__ reach_f, double ox, double oy, double oz, int m,
+    const int32_t *__restrict__ lists, const int32_t *__restrict__ list_n, int list_cap, double r_bound,
     uint8_t *__restrict__ hit_out, uint8_t *__restrict__ hit_in) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = offsets[nq];
@@ -142,8 +143,9 @@ __global__ __launch_bounds__(256) void candidate_edges_kernel(
   if (total > cap) return;
   bool act = e < total;
   double sx = 0, sy = 0, sz = 0, tx = 0, ty = 0, tz = 0;
+  int lo = 0;
   if (act) {
-    const int lo = owner[e];   // owning query (written by nn_order_kernel)
+    lo = owner[e];             // owning query (written by nn_order_kernel)
     const int n = idx[e];
     act = (unsigned)lo < (unsigned)nq && (unsigned)n < (unsigned)n_nodes;   // defensive: never index out of range
     if (act) {
@@ -158,15 +160,39 @@ __global__ __launch_bounds__(256) void candidate_edges_kernel(
   const double len = sqrt_rn(sq3(sx, sy, sz, tx, ty, tz));
   bool out_hit = false, in_hit = false;
   if (__ballot(act) == 0ull) return;   // the grid covers the caller's capacity, most waves are past the end
-  // fp32 screen state of this lane's segment: midpoint relative to the context origin and the
-  // inflated half length  hls~ = RU[(L/2 + 3 eps |m|_1)(1 + 8 eps)]  (+inf disables the screen:
-  // zero-length edges collide with every active sphere, R/DRRT_Q.jl:1208; non-finite input)
+  // a segment the screens below may reason about: positive finite length, finite coordinates.
+  // (A zero-length edge collides with every active sphere: t = 0/0 = NaN, R/DRRT_Q.jl:1208.)
   typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const double cmax = fmax(fmax(fmax(fabs(sx), fabs(sy)), fmax(fabs(sz), fabs(tx))), fmax(fabs(ty), fabs(tz)));
+  const bool usable = (len > 0.0) && (len < 1e30) && (cmax < 1e30) && (sx == sx) && (sy == sy) && (sz == sz) &&
+                      (tx == tx) && (ty == ty) && (tz == tz);
+  // ---- fast path: only the spheres on the sample's list (sample_spheres_kernel) ----
+  bool need_full = act;
+  if (lists) {
+    int nl = 0;
+    if (act) {
+      nl = list_n[lo];
+      // the list only covers edges inside the ball it was built for
+      need_full = !usable || nl > list_cap || !(len <= r_bound);
+      if (need_full) nl = 0;
+    }
+    for (int c = 0; __ballot(c < nl) != 0ull; ++c) {
+      if (c < nl && !(out_hit && in_hit)) {
+        const SphRec ob = sph[lists[(size_t)lo * list_cap + c]];
+        if (!out_hit) out_hit = edge_hits_sphere(sx, sy, sz, bx, by, bz, len, ob);
+        if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len, ob);
+      }
+    }
+    if (__ballot(need_full) == 0ull) {
+      if (act) { hit_out[e] = out_hit ? 1 : 0; hit_in[e] = in_hit ? 1 : 0; }
+      return;
+    }
+  }
+  // ---- full obstacle loop for the lanes that need it ----
+  // fp32 screen state of this lane's segment: midpoint relative to the context origin and the
+  // inflated half length  hls~ = RU[(L/2 + 3 eps |m|_1)(1 + 8 eps)]  (+inf disables the screen)
   float mxf, myf, mzf, hlsf;
   {
-    const double cmax = fmax(fmax(fmax(fabs(sx), fabs(sy)), fmax(fabs(sz), fabs(tx))), fmax(fabs(ty), fabs(tz)));
-    const bool usable = (len > 0.0) && (len < 1e30) && (cmax < 1e30) && (sx == sx) && (sy == sy) && (sz == sz) &&
-                        (tx == tx) && (ty == ty) && (tz == tz);
     const double mx = 0.5 * (sx + tx) - ox, my = 0.5 * (sy + ty) - oy, mz = 0.5 * (sz + tz) - oz;
     mxf = (float)mx; myf = (float)my; mzf = (float)mz;
     const double eps = 5.9604644775390625e-08;
@@ -195,7 +221,7 @@ __global__ __launch_bounds__(256) void candidate_edges_kernel(
       touch |= (!(dm2.y > b2.y) ? 1u : 0u) << (2 * pr + 1);
     }
     if (j0 + G > m) touch &= (1u << (m - j0)) - 1u;
-    if (!act) touch = 0u;
+    if (!need_full) touch = 0u;
     if (__ballot(touch != 0u) == 0ull) continue;
     // rare: some lane is within reach of one of these spheres -> exact evaluation for that lane
     for (int g = 0; g < G; ++g) {
@@ -206,7 +232,7 @@ __global__ __launch_bounds__(256) void candidate_edges_kernel(
         if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len, ob);
       }
     }
-    if (__ballot(act && !(out_hit && in_hit)) == 0ull) break;
+    if (__ballot(need_full && !(out_hit && in_hit)) == 0ull) break;
   }
   if (act) {
     hit_out[e] = out_hit ? 1 : 0;
@@ -256,6 +282,64 @@ __global__ __launch_bounds__(256) void points_spheres_kernel(const double *__res
   if (act && sub == 0) {
     unsafe[i] = bad ? 1 : 0;
     if (clearance) clearance[i] = bad ? 0.0 : best;
+  }
+}
+
+// Samples of extend(): explicitPointCheck (as points_spheres_kernel, quick = 1) plus, per
+// sample, the short list of spheres that any candidate edge of that sample can possibly touch.
+// Every point the edge test looks at lies on the segment between the sample and a neighbour
+// within the search radius r (the reference's foot point p0 + t (p1 - p0), t in [0, 1],
+// R/DRRT_Q.jl:1208), hence within r of the sample; a sphere whose centre is farther than
+// r + robotRadius + radius (+ slack) from the sample cannot collide with any of those edges.
+// A list longer than kSphListCap is marked as overflowed (count = cap + 1) and the edges of
+// that sample take the full obstacle loop.  Never decides a result by itself.
+constexpr int kSphListCap = 8;
+__global__ __launch_bounds__(256) void sample_spheres_kernel(const double *__restrict__ p, int stride, long long np,
+                                                             const SphRec *__restrict__ sph,
+                                                             const SphRec *__restrict__ reach,
+                                                             const double *__restrict__ radius,
+                                                             const double *__restrict__ thr_in, int m,
+                                                             double robot_radius, double r_bound,
+                                                             uint8_t *__restrict__ unsafe,
+                                                             int32_t *__restrict__ lists, int32_t *__restrict__ list_n) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = gid / kPtLanes;
+  const int sub = (int)(gid % kPtLanes);
+  const int grp = (threadIdx.x & 63) / kPtLanes;
+  const bool act = i < np;
+  double px = 0, py = 0, pz = 0;
+  if (act) { px = p[i * stride + 0]; py = p[i * stride + 1]; pz = p[i * stride + 2]; }
+  const double pmax = fmax(fmax(fabs(px), fabs(py)), fabs(pz));
+  // slack for the rounding of the foot point and of this distance; NaN / inf sample: everything is a candidate
+  const double base_b = r_bound + 1e-12 * (pmax + 1.0);
+  bool bad = false;
+  int n_list = 0;
+  for (int j0 = 0; j0 < m; j0 += kPtLanes) {
+    const int j = j0 + sub;
+    const bool valid = j < m;
+    const int jc = valid ? j : m - 1;
+    const double s = sq3(sph[jc].cx, sph[jc].cy, sph[jc].cz, px, py, pz);
+    if (valid) {
+      if (!(s >= thr_in[jc])) bad = true;                                   // quickCheck, :1410
+      if ((sqrt_rn(s) - robot_radius) - radius[jc] < 0.0) bad = true;       // explicitPointCheck2D
+    }
+    const double B = base_b + reach[jc].thr;          // inflated robotRadius + radius (or +inf)
+    const bool cand = valid && act && !(s > B * B * (1.0 + 1e-12));
+    const unsigned gm = (unsigned)((__ballot(cand) >> (kPtLanes * grp)) & 0xffffull);
+    if (cand) {
+      const int at = n_list + __popc(gm & ((1u << sub) - 1u));
+      if (at < kSphListCap) lists[i * kSphListCap + at] = j;
+    }
+    n_list += __popc(gm);
+  }
+#pragma unroll
+  for (int off = kPtLanes / 2; off > 0; off >>= 1) {
+    const bool obad = __shfl_xor((int)bad, off) != 0;   // every lane takes part in the shuffle
+    bad = bad | obad;
+  }
+  if (act && sub == 0) {
+    if (unsafe) unsafe[i] = bad ? 1 : 0;
+    list_n[i] = n_list;
   }
 }
 
@@ -672,16 +756,39 @@ int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_d
 
 int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
                            const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap, double robot_radius,
-                           uint8_t *hit_out_dev, uint8_t *hit_in_dev) {
-  if (nq <= 0 || cap <= 0) return RRTX_OK;
+                           uint8_t *hit_out_dev, uint8_t *hit_in_dev, double r, uint8_t *sample_unsafe_dev) {
+  // r >= 0: radius of the ball the lists were built with -> per-sample sphere lists; r < 0: full loop
+  if (nq <= 0) return RRTX_OK;
   int rc = sync_spheres(ctx, robot_radius);
   if (rc) return rc;
+  const int m = ctx->sph_n_active;
+  const bool use_lists = r >= 0.0 && m > 0;
+  const double r_bound = r * (1.0 + 1e-12);
+  const int32_t *lists = nullptr, *list_n = nullptr;
+  if (use_lists || sample_unsafe_dev) {
+    RRTX_HIP(ctx, ctx->ws_sph_lists.ensure(sizeof(int32_t) * (size_t)nq * (kSphListCap + 1)));
+    int32_t *l = ctx->ws_sph_lists.as<int32_t>();
+    int32_t *ln = l + (size_t)nq * kSphListCap;
+    span_begin(ctx, KF_POINTS);
+    if (m > 0) {
+      const long long threads = (long long)nq * kPtLanes;
+      hipLaunchKernelGGL(sample_spheres_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
+                         q_dev, ctx->dim, (long long)nq, ctx->d_sph.as<SphRec>(), ctx->d_sph_reach.as<SphRec>(),
+                         sph_radius_dev(ctx), sph_thr_in_dev(ctx), m, robot_radius, use_lists ? r_bound : 0.0,
+                         sample_unsafe_dev, l, ln);
+    } else if (sample_unsafe_dev) {
+      RRTX_HIP(ctx, hipMemsetAsync(sample_unsafe_dev, 0, (size_t)nq, ctx->stream));
+    }
+    span_end(ctx);
+    if (use_lists) { lists = l; list_n = ln; }
+  }
+  if (cap <= 0) return RRTX_OK;
   span_begin(ctx, KF_EDGES);
   // the grid covers the caller's capacity; lanes past offsets[nq] idle
   hipLaunchKernelGGL(candidate_edges_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, q_dev,
                      ctx->dim, offsets_dev, nq, idx_dev, owner_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
                      (int)ctx->n_nodes, (long long)cap, ctx->d_sph.as<SphRec>(), ctx->d_sph_reach_f.as<float>(), ctx->origin[0],
-                     ctx->origin[1], ctx->origin[2], ctx->sph_n_active, hit_out_dev, hit_in_dev);
+                     ctx->origin[1], ctx->origin[2], m, lists, list_n, kSphListCap, r_bound, hit_out_dev, hit_in_dev);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;

@@ -330,7 +330,7 @@ int rrtx_destroy(rrtx_ctx *ctx) {
                     &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr, &ctx->ws_mask, &ctx->ws_i32a, &ctx->ws_i32b,
                     &ctx->ws_slab_hist, &ctx->ws_slab_start, &ctx->ws_slab_sr, &ctx->ws_slab_params, &ctx->ws_copies_s,
                     &ctx->ws_meta_s, &ctx->ws_cb, &ctx->ws_qhist, &ctx->ws_qstart, &ctx->ws_units, &ctx->ws_bkt_idx,
-                    &ctx->ws_bkt_d2, &ctx->ws_ev_a, &ctx->ws_ev_m, &ctx->ws_ev_cnt, &ctx->ws_confirm_args};
+                    &ctx->ws_bkt_d2, &ctx->ws_ev_a, &ctx->ws_ev_m, &ctx->ws_ev_cnt, &ctx->ws_confirm_args, &ctx->ws_sph_lists};
   for (auto b : bufs) b->release();
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -838,13 +838,10 @@ int rrtx_extend_candidates_dev(rrtx_ctx *ctx, const double *q, int nq, double r,
                             ctx->ws_owner.as<int32_t>(), want_nearest ? nearest_idx : nullptr,
                             want_nearest ? nearest_dist : nullptr);
   if (rc) return rc;
+  // one pass over the spheres per sample: explicitPointCheck + the sample's sphere list, then the edges
   rc = launch_candidate_edges(ctx, q, nq, offsets, idx, ctx->ws_owner.as<int32_t>(), cap, robot_radius, hit_out,
-                              hit_in);
+                              hit_in, (r >= 0.0) ? r : -1.0, sample_unsafe);
   if (rc) return rc;
-  if (sample_unsafe) {
-    rc = launch_points_spheres(ctx, q, nq, robot_radius, 1, sample_unsafe, nullptr);
-    if (rc) return rc;
-  }
   return RRTX_OK;
 }
 

@@ -152,6 +152,7 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_thr;      // per-query thresholds
   rrtx::DevBuf ws_mask;     // per-call obstacle mask (packed order)
   rrtx::DevBuf ws_i32a, ws_i32b;  // staged index arrays
+  rrtx::DevBuf ws_sph_lists;      // per sample: spheres its candidate edges can touch (+ counts)
 
   // radius -> threshold cache
   double thr_cache_r = -1.0, thr_cache_lt = 0.0, thr_cache_gt = 0.0;
@@ -229,7 +230,8 @@ int launch_dubins_trajectory(rrtx_ctx *ctx, const double *s_dev, const double *g
 // candidate edges of extend(): for every CSR entry both directed edges vs the sphere list
 int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
                            const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap, double robot_radius,
-                           uint8_t *hit_out_dev, uint8_t *hit_in_dev);
+                           uint8_t *hit_out_dev, uint8_t *hit_in_dev, double r = -1.0,
+                           uint8_t *sample_unsafe_dev = nullptr);
 int launch_nearest_from_lists(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
                               const int32_t *idx_dev, const double *dist_dev, int32_t *nearest_idx_dev,
                               double *nearest_dist_dev);

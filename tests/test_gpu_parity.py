@@ -355,6 +355,50 @@ def test_candidate_edges_far_from_origin(oracle, root_at_cluster):
         assert np.array_equal(out["hit_out"], rh[:n]) and np.array_equal(out["hit_in"], rh[n:])
 
 
+@pytest.mark.parametrize("case", ["dense", "huge_radius", "on_nodes", "inactive_mix"])
+def test_extend_candidates_sphere_lists(oracle, case):
+    """the candidate edges only look at the spheres on their sample's short list; lists that
+    overflow (dense or huge spheres, huge search radius), zero-length edges (a sample sitting on a
+    node collides with every active sphere, R/DRRT_Q.jl:1208) and inactive spheres must give the
+    reference's flags all the same"""
+    rng = np.random.default_rng({"dense": 1, "huge_radius": 2, "on_nodes": 3, "inactive_mix": 4}[case])
+    pts = rng.uniform(-20, 20, (6000, 3))
+    Q = rng.uniform(-20, 20, (300, 3))
+    r = 4.0
+    active = None
+    if case == "dense":
+        sph = np.concatenate([rng.uniform(-20, 20, (1500, 3)), rng.uniform(0.5, 6.0, (1500, 1))], 1)
+    elif case == "huge_radius":
+        sph = np.concatenate([rng.uniform(-20, 20, (40, 3)), rng.uniform(0.5, 3.0, (40, 1))], 1)
+        sph[3, 3] = 60.0          # one sphere swallows the world
+        r = 45.0
+        Q = Q[:24]
+    elif case == "on_nodes":
+        sph = np.concatenate([rng.uniform(-20, 20, (30, 3)), rng.uniform(0.5, 3.0, (30, 1))], 1)
+        Q[:100] = pts[rng.integers(0, len(pts), 100)]          # zero-length candidate edges
+        Q[100:110] = pts[0]                                    # ... to the root as well
+    else:
+        sph = np.concatenate([rng.uniform(-20, 20, (200, 3)), rng.uniform(0.5, 5.0, (200, 1))], 1)
+        active = (rng.uniform(size=200) < 0.5).astype(np.uint8)
+    osph, m = oracle.make_spheres(sph, active) if active is not None else oracle.make_spheres(sph)
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        ctx.spheres_set(sph, active) if active is not None else ctx.spheres_set(sph)
+        out = ctx.extend_candidates(Q, r, ROBOT_RADIUS)
+        p0, p1 = synth.candidate_edges(Q, pts, out["offsets"], out["idx"])
+        rh, _ = oracle.edges_check_spheres(osph, m, p0, p1, ROBOT_RADIUS)
+        n = len(out["idx"])
+        assert n > 500
+        assert np.array_equal(out["hit_out"], rh[:n]) and np.array_equal(out["hit_in"], rh[n:])
+        ru, _ = oracle.points_check_spheres(osph, m, Q, ROBOT_RADIUS, quick=True)
+        assert np.array_equal(out["sample_unsafe"], ru)
+        # the stand-alone edge kernel (full obstacle loop) agrees too
+        h2, _ = ctx.edges_check(p0, p1, ROBOT_RADIUS)
+        assert np.array_equal(h2, rh)
+        if case == "on_nodes":
+            assert rh[:n][out["cost"] == 0.0].all()            # every zero-length edge "collides"
+
+
 def test_polygons_edges_and_points(oracle):
     polys = synth.polygons(64)
     ps = oracle.PolygonSet(polys)
