@@ -184,10 +184,10 @@ __device__ __noinline__ bool seen_by_earlier_slot(const SlotRec *__restrict__ sl
   return false;
 }
 
-// every lane of the wave calls this together (the overflow branch uses a ballot)
-__device__ __forceinline__ void emit_hit(const HitSink &hs, bool hit, int owner, int id, double d2) {
-  int slot = 0;
-  if (hit) slot = atomicAdd(&hs.count[owner], 1);
+// Store a hit whose slot in its query's list is already known: bucket if the slot fits, shared
+// overflow list otherwise.  Every lane of the wave calls this together (the overflow branch
+// uses a ballot).
+__device__ __forceinline__ void place_hit(const HitSink &hs, bool hit, int owner, int slot, int id, double d2) {
   const bool inb = hit && slot < hs.bcap;
   if (inb) {
     const size_t at = (size_t)owner * (size_t)hs.bcap + (size_t)slot;
@@ -212,6 +212,21 @@ __device__ __forceinline__ void emit_hit(const HitSink &hs, bool hit, int owner,
     }
   }
 }
+
+// one hit per call: the slot comes from the query's counter.  Whole wave together.
+__device__ __forceinline__ void emit_hit(const HitSink &hs, bool hit, int owner, int id, double d2) {
+  int slot = 0;
+  if (hit) slot = atomicAdd(&hs.count[owner], 1);
+  place_hit(hs, hit, owner, slot, id, d2);
+}
+
+// emitters for confirm_entry: what to do with a confirmed neighbour
+struct GlobalEmit {
+  const HitSink &hs;
+  __device__ __forceinline__ void operator()(bool h, int /*q*/, int owner, int id, double d2) const {
+    emit_hit(hs, h, owner, id, d2);
+  }
+};
 
 template <int D>
 __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
@@ -366,65 +381,6 @@ __global__ void nn_place_kernel(const typename QRecT<D>::type *__restrict__ copi
   copies_f[dst] = make_qrecf<D>(c, __longlong_as_double((long long)am), ox, oy, oz, ow);
 }
 
-// One wave per tile of kTileQFilter bucket-ordered copies: the tile's x reach [lo, hi]
-// (every copy's x -+ its search radius, rounded outwards) against the exact x extent of every
-// node chunk.  A chunk outside the reach holds no node within range of any copy of the tile:
-// |x_q - x_n| > R implies fl(dx*dx) >= thr and the remaining squares only add (exact_math.hpp,
-// sq3).  The surviving (tile, chunk) pairs are the work units of nn_scan_f32_kernel<D, true>.
-template <int D>
-__global__ __launch_bounds__(256) void nn_units_kernel(const typename QRecT<D>::type *__restrict__ copies_s,
-                                                       Scalars *__restrict__ sc,
-                                                       const unsigned long long *__restrict__ chunk_lo,
-                                                       const unsigned long long *__restrict__ chunk_hi,
-                                                       int n_chunks, int tile_q, int2 *__restrict__ units,
-                                                       long long unit_cap) {
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int n_copies = sc->n_copies;
-  if ((long long)t * tile_q >= n_copies) return;
-  double lo = __builtin_inf(), hi = -__builtin_inf();
-  for (int j = lane; j < tile_q; j += 64) {
-    const int q = t * tile_q + j;
-    if (q >= n_copies) break;
-    const typename QRecT<D>::type c = copies_s[q];
-    const bool can_hit = (c.thr > 0.0) && (c.x - c.x == 0.0);      // thr NaN / <= 0, x NaN or +-inf: never
-    if (can_hit) {
-      const double R = sqrt_rn(c.thr) * (1.0 + 1e-15);             // thr = +inf -> R = +inf
-      double a = c.x - R, b = c.x + R;
-      a = a - (fabs(a) * 4.5e-16 + 1e-300);
-      b = b + (fabs(b) * 4.5e-16 + 1e-300);
-      lo = fmin(lo, a);
-      hi = fmax(hi, b);
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    lo = fmin(lo, __shfl_xor(lo, off));
-    hi = fmax(hi, __shfl_xor(hi, off));
-  }
-  if (!(lo <= hi)) return;
-  int cnt = 0;
-  for (int c0 = 0; c0 < n_chunks; c0 += 64) {
-    const int c = c0 + lane;
-    const bool ok = c < n_chunks && dec_ord(chunk_hi[c]) >= lo && dec_ord(chunk_lo[c]) <= hi;
-    cnt += __popcll(__ballot(ok));
-  }
-  if (cnt == 0) return;
-  int base = 0;
-  if (lane == 0) base = atomicAdd(&sc->n_units, cnt);
-  base = __shfl(base, 0);
-  for (int c0 = 0; c0 < n_chunks; c0 += 64) {
-    const int c = c0 + lane;
-    const bool ok = c < n_chunks && dec_ord(chunk_hi[c]) >= lo && dec_ord(chunk_lo[c]) <= hi;
-    const unsigned long long m = __ballot(ok);
-    if (ok) {
-      const long long pos = (long long)base + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < unit_cap) units[pos] = make_int2(t, c);
-    }
-    base += __popcll(m);
-  }
-}
-
 constexpr int kCandCap = 192;   // (copy, node) candidates queued in LDS per wave
 constexpr int kNearestWarm = 256;   // nodes sampled for the initial bound of the screened nearest scan
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -444,8 +400,8 @@ constexpr int kEvSlack = 2048;
 // All lanes of the wave call this together; a lane without an entry passes has = false.
 // LM (lane-major chunk layout, slab-ordered shadow): the eight nodes sit at p0 + u, eight
 // consecutive doubles per coordinate array; otherwise at p0 + 64 u.
-template <int D, bool LM>
-__device__ __forceinline__ void confirm_entry(bool has, int2 en, int n_nodes, const ConfirmArgs &a) {
+template <int D, bool LM, class Emit>
+__device__ __forceinline__ void confirm_entry(bool has, int2 en, int n_nodes, const ConfirmArgs &a, const Emit &emit) {
   const typename QRecT<D>::type *__restrict__ copies = static_cast<const typename QRecT<D>::type *>(a.copies);
   typename QRecT<D>::type ce;
   ce.x = 0.0; ce.y = 0.0; ce.z = 0.0; ce.thr = 0.0;
@@ -503,7 +459,7 @@ __device__ __forceinline__ void confirm_entry(bool has, int2 en, int n_nodes, co
     const int pos = LM ? p0 + uu : p0 + 64 * uu;
     int hid = pos;
     if (h && a.pos_id) hid = a.pos_id[pos];
-    emit_hit(a.hs, h, m.x, hid, hs2);
+    emit(h, en.x, m.x, hid, hs2);
   }
 }
 
@@ -525,7 +481,7 @@ __global__ __launch_bounds__(256) void nn_confirm_kernel(ConfirmArgs a, const in
     const bool has = e < cnt;
     int2 en = make_int2(0, 0);
     if (has) en = mine[e];
-    confirm_entry<D, LM>(has, en, n_nodes, a);
+    confirm_entry<D, LM>(has, en, n_nodes, a, GlobalEmit{a.hs});
   }
 }
 
@@ -552,149 +508,295 @@ __device__ __forceinline__ void screen8(const typename QRecFT<D>::type &c, const
   }
 }
 
-template <int D, bool CULL>
+// One chunk of kChunkF nodes (8 per lane, held in VGPRs) against the copies [q0, q1):
+// the hot loop of the range search.  LM selects the lane-major chunk layout of the slab-ordered
+// shadow.  Flagged lanes file (copy, first position) entries at mine[wn...] (see "Rare path").
+template <int D, bool LM>
+__device__ __forceinline__ void scan_chunk_f32(const float *__restrict__ fx, const float *__restrict__ fy,
+                                               const float *__restrict__ fz, const float *__restrict__ fw,
+                                               const float *__restrict__ fpp, const int base, const int node_end,
+                                               const typename QRecFT<D>::type *__restrict__ copies_f, const int q0,
+                                               const int q1, int2 *__restrict__ mine, int &wn) {
+  const int lane = threadIdx.x & 63;
+  const float kInf = __builtin_inff();
+  float x[kScanFU], y[kScanFU], z[kScanFU], w[kScanFU], pp[kScanFU];
+  if constexpr (LM) {
+    // lane-major chunk: positions base + 8 lane .. + 7, two 16-byte loads per array (the arrays
+    // are allocated in whole chunks, so the rows of the last chunk are readable; what lies
+    // beyond node_end gets pp = +inf)
+    const unsigned p0 = (unsigned)(base + 8 * lane);
+    const float4 *rx = reinterpret_cast<const float4 *>(fx + p0);
+    const float4 *ry = reinterpret_cast<const float4 *>(fy + p0);
+    const float4 *rz = reinterpret_cast<const float4 *>(fz + p0);
+    const float4 *rw = reinterpret_cast<const float4 *>(fw + p0);
+    const float4 *rp = reinterpret_cast<const float4 *>(fpp + p0);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const float4 vx = rx[v], vy = ry[v], vz = rz[v], vp = rp[v];
+      x[4 * v] = vx.x; x[4 * v + 1] = vx.y; x[4 * v + 2] = vx.z; x[4 * v + 3] = vx.w;
+      y[4 * v] = vy.x; y[4 * v + 1] = vy.y; y[4 * v + 2] = vy.z; y[4 * v + 3] = vy.w;
+      z[4 * v] = vz.x; z[4 * v + 1] = vz.y; z[4 * v + 2] = vz.z; z[4 * v + 3] = vz.w;
+      pp[4 * v] = vp.x; pp[4 * v + 1] = vp.y; pp[4 * v + 2] = vp.z; pp[4 * v + 3] = vp.w;
+      if constexpr (D == 4) {
+        const float4 vw = rw[v];
+        w[4 * v] = vw.x; w[4 * v + 1] = vw.y; w[4 * v + 2] = vw.z; w[4 * v + 3] = vw.w;
+      } else {
+        w[4 * v] = 0.f; w[4 * v + 1] = 0.f; w[4 * v + 2] = 0.f; w[4 * v + 3] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kScanFU; ++u)
+      if ((int)p0 + u >= node_end) { x[u] = 0.f; y[u] = 0.f; z[u] = 0.f; w[u] = 0.f; pp[u] = kInf; }
+  } else {
+#pragma unroll
+    for (int u = 0; u < kScanFU; ++u) {
+      const int id = base + u * 64 + lane;
+      const bool ok = id < node_end;
+      const unsigned idc = (unsigned)(ok ? id : node_end - 1);   // clamped (no divergent load), unsigned
+                                                                  // 32-bit index -> global_load saddr form
+      x[u] = fx[idc];
+      y[u] = fy[idc];
+      z[u] = fz[idc];
+      if constexpr (D == 4) w[u] = fw[idc]; else w[u] = 0.f;
+      pp[u] = ok ? fpp[idc] : kInf;        // +inf padding: t = +inf never survives a finite bound
+    }
+  }
+  for (int q = q0; q < q1; q += kQPI) {
+    // kQPI wave-uniform copy records per iteration (scalar loads); copies_f is padded to a
+    // multiple of kQPI records that never pass
+    typename QRecFT<D>::type c[kQPI];
+#pragma unroll
+    for (int k = 0; k < kQPI; ++k) c[k] = copies_f[q + k];
+    unsigned long long mk[kQPI];      // wave masks stay on the SALU (no short-circuit control flow)
+    unsigned long long anym = 0ull;
+#pragma unroll
+    for (int k = 0; k < kQPI; ++k) {
+      float t[kScanFU];
+      screen8<D>(c[k], x, y, z, w, pp, t);
+      const float m1 = fminf(fminf(t[0], t[1]), t[2]);          // v_min3_f32 x3 + v_min_f32
+      const float m2 = fminf(fminf(t[3], t[4]), t[5]);
+      const float m3 = fminf(fminf(t[6], t[7]), m1);
+      const float tmin = fminf(m2, m3);
+      mk[k] = __ballot(!(tmin > c[k].thr));
+      anym |= mk[k];
+    }
+    if (anym != 0ull) {
+      // some lane of some copy was not screened out: every flagged lane files its own entry
+#pragma unroll
+      for (int k = 0; k < kQPI; ++k) {
+        if (mk[k] == 0ull || q + k >= q1) continue;
+        const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(mk[k] >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((unsigned)mk[k], 0u));
+        if ((mk[k] >> lane) & 1ull)
+          mine[wn + (int)before] = make_int2(q + k, LM ? base + 8 * lane : base + lane);
+        wn += __popcll(mk[k]);
+      }
+    }
+  }
+}
+
+// a wave confirms the entries of its own slice (slice nearly full; same routine as nn_confirm_kernel)
+template <int D, bool LM>
+__device__ __forceinline__ void drain_slice(const int2 *__restrict__ mine, int &wn, int n_nodes,
+                                            const ConfirmArgs *__restrict__ ca) {
+  const int lane = threadIdx.x & 63;
+  // the wave's entry stores -> visible to its own loads (workgroup scope: no cache maintenance,
+  // an agent-scope fence would write back / invalidate L2 across the XCDs)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  const ConfirmArgs a = *ca;
+  for (int e0 = 0; e0 < wn; e0 += 64) {
+    const int e = e0 + lane;
+    const bool has = e < wn;
+    int2 en = make_int2(0, 0);
+    if (has) en = mine[e];
+    confirm_entry<D, LM>(has, en, n_nodes, a, GlobalEmit{a.hs});
+  }
+  wn = 0;
+}
+
+// Unculled range scan: every tile of copies streams every node.
+template <int D>
 __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
     const float *__restrict__ fx, const float *__restrict__ fy, const float *__restrict__ fz,
     const float *__restrict__ fw, const float *__restrict__ fpp, int n_nodes,
     const typename QRecFT<D>::type *__restrict__ copies_f, int tile_q, int n_seg, int seg_len,
-    const Scalars *__restrict__ sc, const int2 *__restrict__ units, int2 *__restrict__ ev,
-    int *__restrict__ ev_cnt, int slice_cap, const ConfirmArgs *__restrict__ ca) {
-  // copies_f is padded to a multiple of kQPI records (thr = -inf) by the launcher.
-  // Persistent workgroups; waves never synchronise.
-  //   CULL = false: block b walks items b, b + gridDim.x, ... where item = tile * n_seg + seg.
-  //     gridDim.x and n_seg are multiples of 8, so a block keeps the same (item % 8) class:
-  //     blocks b and b+8 share an XCD, hence each XCD's L2 keeps serving the same node segments.
-  //   CULL = true: wave w walks the (tile, chunk) unit list written by nn_units_kernel
-  //     (w, w + #waves, ...); fx.. are the slab-ordered shadow.
-  // Flagged lanes become entries in this wave's slice of ev (see "Rare path of the range
-  // scan"); one chunk can raise at most 64 tile_q of them.
+    const Scalars *__restrict__ sc, int2 *__restrict__ ev, int *__restrict__ ev_cnt, int slice_cap,
+    const ConfirmArgs *__restrict__ ca) {
+  // Persistent workgroups; waves never synchronise.  Block b walks items b, b + gridDim.x, ...
+  // where item = tile * n_seg + seg.  gridDim.x and n_seg are multiples of 8, so a block keeps
+  // the same (item % 8) class: blocks b and b+8 share an XCD, hence each XCD's L2 keeps serving
+  // the same node segments.  One chunk can raise at most 64 tile_q entries.
   const int n_copies = sc->n_copies;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int slice = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kScanThreads / 64) + wave);
   int2 *__restrict__ mine = ev + (size_t)slice * (size_t)slice_cap;
   int wn = 0;                               // wave-uniform: entries in the slice
-  const float kInf = __builtin_inff();
-
-  // slice (almost) full: confirm the queued entries here and now (same routine as nn_confirm_kernel)
-  auto drain_slice = [&]() {
-    __threadfence();                        // the wave's entry stores -> visible to its loads
-    const ConfirmArgs a = *ca;
-    for (int e0 = 0; e0 < wn; e0 += 64) {
-      const int e = e0 + lane;
-      const bool has = e < wn;
-      int2 en = make_int2(0, 0);
-      if (has) en = mine[e];
-      confirm_entry<D, CULL>(has, en, n_nodes, a);
-    }
-    wn = 0;
-  };
-
-  // one chunk of kChunkF nodes (8 per lane, held in VGPRs) against the copies [q0, q1)
-  auto scan_chunk = [&](const int base, const int node_end, const int q0, const int q1) {
-    float x[kScanFU], y[kScanFU], z[kScanFU], w[kScanFU], pp[kScanFU];
-    if constexpr (CULL) {
-      // lane-major chunk: positions base + 8 lane .. + 7, two 16-byte loads per array (the arrays
-      // are allocated in whole chunks, so the rows of the last chunk are readable; what lies
-      // beyond node_end gets pp = +inf)
-      const unsigned p0 = (unsigned)(base + 8 * lane);
-      const float4 *rx = reinterpret_cast<const float4 *>(fx + p0);
-      const float4 *ry = reinterpret_cast<const float4 *>(fy + p0);
-      const float4 *rz = reinterpret_cast<const float4 *>(fz + p0);
-      const float4 *rw = reinterpret_cast<const float4 *>(fw + p0);
-      const float4 *rp = reinterpret_cast<const float4 *>(fpp + p0);
-#pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        const float4 vx = rx[v], vy = ry[v], vz = rz[v], vp = rp[v];
-        x[4 * v] = vx.x; x[4 * v + 1] = vx.y; x[4 * v + 2] = vx.z; x[4 * v + 3] = vx.w;
-        y[4 * v] = vy.x; y[4 * v + 1] = vy.y; y[4 * v + 2] = vy.z; y[4 * v + 3] = vy.w;
-        z[4 * v] = vz.x; z[4 * v + 1] = vz.y; z[4 * v + 2] = vz.z; z[4 * v + 3] = vz.w;
-        pp[4 * v] = vp.x; pp[4 * v + 1] = vp.y; pp[4 * v + 2] = vp.z; pp[4 * v + 3] = vp.w;
-        if constexpr (D == 4) {
-          const float4 vw = rw[v];
-          w[4 * v] = vw.x; w[4 * v + 1] = vw.y; w[4 * v + 2] = vw.z; w[4 * v + 3] = vw.w;
-        } else {
-          w[4 * v] = 0.f; w[4 * v + 1] = 0.f; w[4 * v + 2] = 0.f; w[4 * v + 3] = 0.f;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kScanFU; ++u)
-        if ((int)p0 + u >= node_end) { x[u] = 0.f; y[u] = 0.f; z[u] = 0.f; w[u] = 0.f; pp[u] = kInf; }
-    } else {
-#pragma unroll
-      for (int u = 0; u < kScanFU; ++u) {
-        const int id = base + u * 64 + lane;
-        const bool ok = id < node_end;
-        const unsigned idc = (unsigned)(ok ? id : node_end - 1);   // clamped (no divergent load), unsigned
-                                                                    // 32-bit index -> global_load saddr form
-        x[u] = fx[idc];
-        y[u] = fy[idc];
-        z[u] = fz[idc];
-        if constexpr (D == 4) w[u] = fw[idc]; else w[u] = 0.f;
-        pp[u] = ok ? fpp[idc] : kInf;        // +inf padding: t = +inf never survives a finite bound
-      }
-    }
-    for (int q = q0; q < q1; q += kQPI) {
-      // kQPI wave-uniform copy records per iteration (scalar loads); tile_q % kQPI == 0
-      typename QRecFT<D>::type c[kQPI];
-#pragma unroll
-      for (int k = 0; k < kQPI; ++k) c[k] = copies_f[q + k];
-      unsigned long long mk[kQPI];      // wave masks stay on the SALU (no short-circuit control flow)
-      unsigned long long anym = 0ull;
-#pragma unroll
-      for (int k = 0; k < kQPI; ++k) {
-        float t[kScanFU];
-        screen8<D>(c[k], x, y, z, w, pp, t);
-        const float m1 = fminf(fminf(t[0], t[1]), t[2]);          // v_min3_f32 x3 + v_min_f32
-        const float m2 = fminf(fminf(t[3], t[4]), t[5]);
-        const float m3 = fminf(fminf(t[6], t[7]), m1);
-        const float tmin = fminf(m2, m3);
-        mk[k] = __ballot(!(tmin > c[k].thr));
-        anym |= mk[k];
-      }
-      if (anym != 0ull) {
-        // some lane of some copy was not screened out: every flagged lane files its own entry
-#pragma unroll
-        for (int k = 0; k < kQPI; ++k) {
-          if (mk[k] == 0ull || q + k >= q1) continue;
-          const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(mk[k] >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((unsigned)mk[k], 0u));
-          if ((mk[k] >> lane) & 1ull)
-            mine[wn + (int)before] = make_int2(q + k, CULL ? base + 8 * lane : base + lane);
-          wn += __popcll(mk[k]);
-        }
-      }
-    }
-  };
-
-  if constexpr (CULL) {
-    const int n_units = sc->n_units;
-    const int n_waves = (int)gridDim.x * (kScanThreads / 64);
-    const int first = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kScanThreads / 64) + wave);
-    for (int u = first; u < n_units; u += n_waves) {
-      const int2 un = units[u];               // wave-uniform: scalar load
-      const int q0 = un.x * tile_q;
-      const int q1 = min(q0 + tile_q, n_copies);
-      if (wn + 64 * tile_q > slice_cap) drain_slice();
-      scan_chunk(un.y * kChunkF, n_nodes, q0, q1);
-    }
-  } else {
-    const int n_tiles = (n_copies + tile_q - 1) / tile_q;
-    const int n_items = n_tiles * n_seg;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-      const int seg = item % n_seg;
-      const int tile = item / n_seg;
-      const int q0 = tile * tile_q;
-      const int q1 = min(q0 + tile_q, n_copies);
-      const int node_begin = seg * seg_len;
-      const int node_end = min(n_nodes, node_begin + seg_len);
-      for (int base = node_begin + wave * kChunkF; base < node_end; base += (kScanThreads / 64) * kChunkF) {
-        if (wn + 64 * tile_q > slice_cap) drain_slice();
-        scan_chunk(base, node_end, q0, q1);
-      }
+  const int n_tiles = (n_copies + tile_q - 1) / tile_q;
+  const int n_items = n_tiles * n_seg;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int seg = item % n_seg;
+    const int tile = item / n_seg;
+    const int q0 = tile * tile_q;
+    const int q1 = min(q0 + tile_q, n_copies);
+    const int node_begin = seg * seg_len;
+    const int node_end = min(n_nodes, node_begin + seg_len);
+    for (int base = node_begin + wave * kChunkF; base < node_end; base += (kScanThreads / 64) * kChunkF) {
+      if (wn + 64 * tile_q > slice_cap) drain_slice<D, false>(mine, wn, n_nodes, ca);
+      scan_chunk_f32<D, false>(fx, fy, fz, fw, fpp, base, node_end, copies_f, q0, q1, mine, wn);
     }
   }
   if (lane == 0) ev_cnt[slice] = wn;
+}
+
+// ---------------------------------------------------------- tile kernel ------
+// Culled range search, one workgroup per (tile of kTileB bucket-ordered copies, part):
+//   1. the tile's x reach [lo, hi]: every copy's x -+ its search radius, rounded outwards;
+//   2. the node chunks whose exact x extent overlaps the reach (a chunk outside it holds no node
+//      within range of any copy of the tile: |x_q - x_n| > R implies fl(dx*dx) >= thr and the
+//      remaining squares only add, exact_math.hpp sq3); part p of a tile takes chunks c = p mod n_parts;
+//   3. the screen of those chunks, one chunk per wave at a time (scan_chunk_f32), entries into the
+//      waves' slices;
+//   4. exact confirmation of the workgroup's entries, hits collected per copy in LDS;
+//   5. one counter update per copy, then the copy's hits go to its query's bucket in one piece.
+constexpr int kTileB = 16;            // copies per tile
+constexpr int kTbLcap = 96;           // hits per copy collected in LDS (more: straight to the bucket)
+constexpr int kTbList = 1024;         // chunk ids per pass of step 2
+constexpr int kTbSlack = 512;
+
+struct TileLds {
+  int list[kTbList];
+  int n_list;
+  int wcnt[kScanThreads / 64];
+  double lo, hi;
+  int lcnt[kTileB];
+  int hidx[kTileB][kTbLcap];
+  double hd2[kTileB][kTbLcap];
+};
+
+struct TileEmit {
+  TileLds &sm;
+  const HitSink &hs;
+  int q0;
+  __device__ __forceinline__ void operator()(bool h, int q, int owner, int id, double d2) const {
+    int slot = 0;
+    const int cl = q - q0;
+    if (h) slot = atomicAdd(&sm.lcnt[cl], 1);
+    const bool in_lds = h && slot < kTbLcap;
+    if (in_lds) { sm.hidx[cl][slot] = id; sm.hd2[cl][slot] = d2; }
+    const bool spill = h && !in_lds;
+    if (__ballot(spill) != 0ull) emit_hit(hs, spill, owner, id, d2);
+  }
+};
+
+template <int D>
+__global__ __launch_bounds__(kScanThreads, 5) void nn_tile_kernel(
+    const float *__restrict__ fx, const float *__restrict__ fy, const float *__restrict__ fz,
+    const float *__restrict__ fw, const float *__restrict__ fpp, int n_nodes, int n_chunks,
+    const unsigned long long *__restrict__ chunk_lo, const unsigned long long *__restrict__ chunk_hi,
+    const typename QRecT<D>::type *__restrict__ copies_s, const typename QRecFT<D>::type *__restrict__ copies_f,
+    const Scalars *__restrict__ sc, int n_parts, int2 *__restrict__ ev, int slice_cap,
+    const ConfirmArgs *__restrict__ ca, int *__restrict__ visits) {
+  __shared__ TileLds sm;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int part = blockIdx.x % n_parts;
+  const int n_copies = sc->n_copies;
+  const int n_tiles = (n_copies + kTileB - 1) / kTileB;
+  const int slice = (int)blockIdx.x * (kScanThreads / 64) + wave;
+  int2 *__restrict__ mine = ev + (size_t)slice * (size_t)slice_cap;
+  const int2 *__restrict__ blk = ev + (size_t)blockIdx.x * (kScanThreads / 64) * (size_t)slice_cap;
+  int visited = 0;                          // chunks this wave screened (statistics)
+
+  for (int tile = blockIdx.x / n_parts; tile < n_tiles; tile += gridDim.x / n_parts) {
+    const int q0 = tile * kTileB;
+    const int q1 = min(q0 + kTileB, n_copies);
+    int wn = 0;                             // wave-uniform: entries in the slice
+
+    // ---- 1. reach ----
+    if (t < kTileB) sm.lcnt[t] = 0;
+    if (wave == 0) {
+      double lo = __builtin_inf(), hi = -__builtin_inf();
+      if (q0 + lane < q1) {
+        const typename QRecT<D>::type c = copies_s[q0 + lane];
+        const bool can_hit = (c.thr > 0.0) && (c.x - c.x == 0.0);  // thr NaN / <= 0, x NaN or +-inf: never
+        if (can_hit) {
+          const double R = sqrt_rn(c.thr) * (1.0 + 1e-15);         // thr = +inf -> R = +inf
+          const double a = c.x - R, b = c.x + R;
+          lo = a - (fabs(a) * 4.5e-16 + 1e-300);
+          hi = b + (fabs(b) * 4.5e-16 + 1e-300);
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, off));
+        hi = fmax(hi, __shfl_xor(hi, off));
+      }
+      if (lane == 0) { sm.lo = lo; sm.hi = hi; }
+    }
+    __syncthreads();
+    const double lo = sm.lo, hi = sm.hi;
+    if (lo <= hi) {
+      for (int cb = 0; cb < n_chunks; cb += kTbList) {
+        // ---- 2. chunk list of this pass ----
+        if (t == 0) sm.n_list = 0;
+        __syncthreads();
+        const int ce = min(cb + kTbList, n_chunks);
+        // (the order inside the list is whatever the atomics give, so the parts of a tile
+        // split the chunks by chunk number, not by list position)
+        for (int c = cb + t; c < ce; c += kScanThreads)
+          if (c % n_parts == part && dec_ord(chunk_hi[c]) >= lo && dec_ord(chunk_lo[c]) <= hi)
+            sm.list[atomicAdd(&sm.n_list, 1)] = c;
+        __syncthreads();
+        const int nl = sm.n_list;
+        // ---- 3. screen ----
+        for (int i = wave; i < nl; i += kScanThreads / 64) {
+          const int chunk = __builtin_amdgcn_readfirstlane(sm.list[i]);
+          if (wn + 64 * kTileB > slice_cap) drain_slice<D, true>(mine, wn, n_nodes, ca);
+          scan_chunk_f32<D, true>(fx, fy, fz, fw, fpp, chunk * kChunkF, n_nodes, copies_f, q0, q1, mine, wn);
+          visited += 1;
+        }
+        __syncthreads();      // the list is rebuilt by the next pass
+      }
+    }
+    // ---- 4. confirm the workgroup's entries ----
+    if (lane == 0) sm.wcnt[wave] = wn;
+    // entries were written through to L2 by waves of this workgroup (same CU, same L1, which does
+    // not keep written lines): a workgroup-scope fence orders them before the barrier
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    const ConfirmArgs a = *ca;
+    const TileEmit emit{sm, a.hs, q0};
+    const int c0 = sm.wcnt[0], c1 = c0 + sm.wcnt[1], c2 = c1 + sm.wcnt[2], total = c2 + sm.wcnt[3];
+    for (int e0 = 0; e0 < total; e0 += kScanThreads) {
+      const int e = e0 + t;
+      const bool has = e < total;
+      int2 en = make_int2(0, 0);
+      if (has) {
+        const int w = (e >= c0) + (e >= c1) + (e >= c2);
+        const int local = e - (w == 0 ? 0 : (w == 1 ? c0 : (w == 2 ? c1 : c2)));
+        en = blk[(size_t)w * (size_t)slice_cap + local];
+      }
+      if (__ballot(has) != 0ull) confirm_entry<D, true>(has, en, n_nodes, a, emit);
+    }
+    __syncthreads();
+    // ---- 5. hand the collected hits to the buckets ----
+    for (int cl = wave; cl < q1 - q0; cl += kScanThreads / 64) {
+      const int n = min(sm.lcnt[cl], kTbLcap);
+      if (n == 0) continue;
+      const int owner = a.meta[q0 + cl].x;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&a.hs.count[owner], n);
+      base = __shfl(base, 0);
+      for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const bool h = j < n;
+        place_hit(a.hs, h, owner, base + j, h ? sm.hidx[cl][j] : 0, h ? sm.hd2[cl][j] : 0.0);
+      }
+    }
+    __syncthreads();          // LDS is reused by the next tile
+  }
+  if (lane == 0) visits[slice] = visited;
 }
 
 // ------------------------------------------------------------- rootfix ------
@@ -1402,9 +1504,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   if (use_filter && tile_q > 128) tile_q = 128;   // bounds the worst case of one chunk (64 tile_q entries)
   const int n_tiles = (int)((n_copies_max + tile_q - 1) / tile_q);
   const int n_chunks = (n_nodes + kSlabChunk - 1) / kSlabChunk;
-  const long long unit_cap = (long long)n_tiles * n_chunks;
-  const bool use_cull = use_filter && (ctx->opt_nn_cull == 2 || (ctx->opt_nn_cull == 1 && n_nodes >= 8192)) &&
-                        unit_cap * (long long)sizeof(int2) <= (1ll << 30);
+  const bool use_cull = use_filter && (ctx->opt_nn_cull == 2 || (ctx->opt_nn_cull == 1 && n_nodes >= 8192));
   ctx->last_culled = use_cull;
   int n_buckets = 1;
   int *qhist = nullptr, *qstart = nullptr;
@@ -1419,7 +1519,6 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
     RRTX_HIP(ctx, ctx->ws_cb.ensure(sizeof(int2) * n_copies_max));
     RRTX_HIP(ctx, ctx->ws_copies_s.ensure(n_copies_max * qrec_bytes));
     RRTX_HIP(ctx, ctx->ws_meta_s.ensure(n_copies_max * sizeof(int2)));
-    RRTX_HIP(ctx, ctx->ws_units.ensure((size_t)(unit_cap > 0 ? unit_cap : 1) * sizeof(int2)));
     qhist = ctx->ws_qhist.as<int>();
     qstart = ctx->ws_qstart.as<int>();
     cbk = ctx->ws_cb.as<int2>();
@@ -1492,7 +1591,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   if (n_seg >= 8) n_seg = n_seg / 8 * 8;  // segment index == blockIdx % 8 class == XCD
   int seg_len = round_up((n_nodes + n_seg - 1) / n_seg, chunk);
   n_seg = (n_nodes + seg_len - 1) / seg_len;
-  ctx->last_tile_q = tile_q;
+  ctx->last_tile_q = use_cull ? kTileB : tile_q;
 
   if (use_filter) {
     const size_t qf_bytes = (D == 4) ? sizeof(QRecF4) : sizeof(QRecF3);
@@ -1512,13 +1611,6 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
                            ctx->ws_copy_meta.as<int2>(), cbk, qstart, sc, absmax, ctx->origin[0], ctx->origin[1],
                            ctx->origin[2], ctx->origin[3], ctx->ws_copies_s.as<QRec3>(), ctx->ws_meta_s.as<int2>(),
                            ctx->ws_copies_f.as<QRecF3>());
-      dim3 ugrid((unsigned)((n_tiles + 3) / 4));
-      if (D == 4)
-        hipLaunchKernelGGL(nn_units_kernel<4>, ugrid, block, 0, st, ctx->ws_copies_s.as<QRec4>(), sc, ctx->chunk_lo,
-                           ctx->chunk_hi, n_chunks, tile_q, ctx->ws_units.as<int2>(), unit_cap);
-      else
-        hipLaunchKernelGGL(nn_units_kernel<3>, ugrid, block, 0, st, ctx->ws_copies_s.as<QRec3>(), sc, ctx->chunk_lo,
-                           ctx->chunk_hi, n_chunks, tile_q, ctx->ws_units.as<int2>(), unit_cap);
     } else if (D == 4)
       hipLaunchKernelGGL(nn_filter_prep_kernel<4>, grid, block, 0, st, ctx->ws_copies.as<QRec4>(), sc, absmax,
                          (int)n_copies_max, ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
@@ -1533,48 +1625,54 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   span_begin(ctx, KF_NN_SCAN);
   {
     dim3 grid((unsigned)n_tiles * (unsigned)n_seg), block(kScanThreads);
-    if (use_filter) {
+    const int wi = D == 4 ? 3 : 2;
+    if (use_cull) {
+      // one workgroup per (tile of kTileB copies, part); few tiles: several parts share a tile's chunks;
+      // many tiles: a bounded grid walks them
+      const int n_tiles_b = (int)((n_copies_max + kTileB - 1) / kTileB);
+      int n_parts = (1024 + n_tiles_b - 1) / n_tiles_b;
+      if (n_parts > 64) n_parts = 64;
+      long long nb = (long long)n_tiles_b * n_parts;
+      if (nb > 4096) nb = 4096;             // n_parts == 1 here
+      const int n_slices = (int)nb * (kScanThreads / 64);
+      const int slice_cap = 64 * kTileB + kTbSlack;
+      RRTX_HIP(ctx, ctx->ws_ev_a.ensure((size_t)n_slices * (size_t)slice_cap * sizeof(int2)));
+      RRTX_HIP(ctx, ctx->ws_ev_cnt.ensure((size_t)n_slices * sizeof(int)));
+      ctx->last_visit_slices = n_slices;
+      if (D == 4)
+        hipLaunchKernelGGL(nn_tile_kernel<4>, dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
+                           ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, ctx->chunk_lo, ctx->chunk_hi,
+                           ctx->ws_copies_s.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(), sc, n_parts,
+                           ctx->ws_ev_a.as<int2>(), slice_cap, ca_dev, ctx->ws_ev_cnt.as<int>());
+      else
+        hipLaunchKernelGGL(nn_tile_kernel<3>, dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
+                           ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, ctx->chunk_lo, ctx->chunk_hi,
+                           ctx->ws_copies_s.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(), sc, n_parts,
+                           ctx->ws_ev_a.as<int2>(), slice_cap, ca_dev, ctx->ws_ev_cnt.as<int>());
+    } else if (use_filter) {
       // persistent grid: opt_scan_blocks workgroups (multiple of 8) striding over the work
       unsigned pg = (unsigned)ctx->opt_scan_blocks / 8u * 8u;
       if (pg < 8u) pg = 8u;
-      if (pg < grid.x || use_cull) grid.x = pg;
-      const int wi = D == 4 ? 3 : 2;
+      if (pg < grid.x) grid.x = pg;
       const int n_slices = (int)grid.x * (kScanThreads / 64);
       const int slice_cap = 64 * tile_q + kEvSlack;
       RRTX_HIP(ctx, ctx->ws_ev_a.ensure((size_t)n_slices * (size_t)slice_cap * sizeof(int2)));
       RRTX_HIP(ctx, ctx->ws_ev_cnt.ensure((size_t)n_slices * sizeof(int)));
       int2 *ev = ctx->ws_ev_a.as<int2>();
       int *ev_cnt = ctx->ws_ev_cnt.as<int>();
-      const int2 *units = ctx->ws_units.as<int2>();
-      float *const *nf = use_cull ? ctx->sl_f : ctx->nodes_f;
-      const float *npp = use_cull ? ctx->sl_pp : ctx->nodes_pp;
-      if (D == 4) {
-        const QRecF4 *cf = ctx->ws_copies_f.as<QRecF4>();
-        if (use_cull)
-          hipLaunchKernelGGL((nn_scan_f32_kernel<4, true>), grid, block, 0, st, nf[0], nf[1], nf[2], nf[wi], npp,
-                             n_nodes, cf, tile_q, n_seg, seg_len, sc, units, ev, ev_cnt, slice_cap, ca_dev);
-        else
-          hipLaunchKernelGGL((nn_scan_f32_kernel<4, false>), grid, block, 0, st, nf[0], nf[1], nf[2], nf[wi], npp,
-                             n_nodes, cf, tile_q, n_seg, seg_len, sc, units, ev, ev_cnt, slice_cap, ca_dev);
-      } else {
-        const QRecF3 *cf = ctx->ws_copies_f.as<QRecF3>();
-        if (use_cull)
-          hipLaunchKernelGGL((nn_scan_f32_kernel<3, true>), grid, block, 0, st, nf[0], nf[1], nf[2], nf[wi], npp,
-                             n_nodes, cf, tile_q, n_seg, seg_len, sc, units, ev, ev_cnt, slice_cap, ca_dev);
-        else
-          hipLaunchKernelGGL((nn_scan_f32_kernel<3, false>), grid, block, 0, st, nf[0], nf[1], nf[2], nf[wi], npp,
-                             n_nodes, cf, tile_q, n_seg, seg_len, sc, units, ev, ev_cnt, slice_cap, ca_dev);
-      }
-      // exact confirmation of the queued entries: one wave per slice, one lane per entry
+      float *const *nf = ctx->nodes_f;
+      if (D == 4)
+        hipLaunchKernelGGL(nn_scan_f32_kernel<4>, grid, block, 0, st, nf[0], nf[1], nf[2], nf[wi], ctx->nodes_pp,
+                           n_nodes, ctx->ws_copies_f.as<QRecF4>(), tile_q, n_seg, seg_len, sc, ev, ev_cnt, slice_cap,
+                           ca_dev);
+      else
+        hipLaunchKernelGGL(nn_scan_f32_kernel<3>, grid, block, 0, st, nf[0], nf[1], nf[2], nf[wi], ctx->nodes_pp,
+                           n_nodes, ctx->ws_copies_f.as<QRecF3>(), tile_q, n_seg, seg_len, sc, ev, ev_cnt, slice_cap,
+                           ca_dev);
+      // exact confirmation of the queued entries: one lane per entry
       dim3 cgrid((unsigned)(((long long)n_slices * kConfirmParts + 3) / 4));
-      if (D == 4 && use_cull)
-        hipLaunchKernelGGL((nn_confirm_kernel<4, true>), cgrid, dim3(256), 0, st, ca, ev, ev_cnt, n_slices, slice_cap,
-                           n_nodes);
-      else if (D == 4)
+      if (D == 4)
         hipLaunchKernelGGL((nn_confirm_kernel<4, false>), cgrid, dim3(256), 0, st, ca, ev, ev_cnt, n_slices, slice_cap,
-                           n_nodes);
-      else if (use_cull)
-        hipLaunchKernelGGL((nn_confirm_kernel<3, true>), cgrid, dim3(256), 0, st, ca, ev, ev_cnt, n_slices, slice_cap,
                            n_nodes);
       else
         hipLaunchKernelGGL((nn_confirm_kernel<3, false>), cgrid, dim3(256), 0, st, ca, ev, ev_cnt, n_slices, slice_cap,
@@ -1758,11 +1856,15 @@ int nearest_candidates(rrtx_ctx *ctx, long long *total) {
 }
 
 int scan_units(rrtx_ctx *ctx, int *units) {
-  int u = 0;
-  RRTX_HIP(ctx, hipMemcpyAsync(&u, &ctx->ws_scalars.as<Scalars>()->n_units, sizeof(u), hipMemcpyDeviceToHost,
-                               ctx->stream));
-  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  *units = u;
+  // node chunks screened by the last culled range search: per-wave counts written by nn_tile_kernel
+  std::vector<int> v((size_t)ctx->last_visit_slices);
+  if (!v.empty()) {
+    RRTX_HIP(ctx, hipMemcpyAsync(v.data(), ctx->ws_ev_cnt.p, sizeof(int) * v.size(), hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  long long tot = 0;
+  for (int x : v) tot += x;
+  *units = (int)(tot > 0x7fffffffll ? 0x7fffffffll : tot);
   return RRTX_OK;
 }
 

@@ -37,6 +37,8 @@ def _both_modes(ctx, Q, r, ref):
         offsets, idx, dist = ctx.nn_radius(Q, r)
         _check_csr(offsets, idx, dist, ref)
         units[mode] = ctx.stats().last_scan_units
+    ctx.set_option(_capi.RRTX_OPT_NN_CULL, 2)
+    ctx.nn_radius(Q[:1], r if np.isscalar(r) else r[:1])     # so that stats() describe a culled call
     ctx.set_option(_capi.RRTX_OPT_NN_CULL, 1)
     assert units[0] == 0
     return units[2]
@@ -52,8 +54,9 @@ def test_cull_skips_most_chunks_and_matches(oracle):
     with Context(3) as ctx:
         ctx.nodes_append(pts)
         units = _both_modes(ctx, Q, r, _oracle_lists(tree, Q, r))
-        n_tiles, n_chunks = (nq + 63) // 64, (n + 511) // 512
-        assert 0 < units < 0.35 * n_tiles * n_chunks     # x reach ~ (100/32 + 2 r) / 100 of the cloud
+        tile = ctx.stats().last_tile_q
+        n_tiles, n_chunks = (nq + tile - 1) // tile, (n + 511) // 512
+        assert 0 < units < 0.35 * n_tiles * n_chunks     # x reach ~ (tile extent + 2 r) / 100 of the cloud
 
 
 def test_cull_tail_rebuild_and_capacity_growth(oracle):
