@@ -294,52 +294,53 @@ __global__ __launch_bounds__(256) void points_spheres_kernel(const double *__res
 // A list longer than kSphListCap is marked as overflowed (count = cap + 1) and the edges of
 // that sample take the full obstacle loop.  Never decides a result by itself.
 constexpr int kSphListCap = 8;
-__global__ __launch_bounds__(256) void sample_spheres_kernel(const double *__restrict__ p, int stride, long long np,
-                                                             const SphRec *__restrict__ sph,
-                                                             const SphRec *__restrict__ reach,
-                                                             const double *__restrict__ radius,
-                                                             const double *__restrict__ thr_in, int m,
-                                                             double robot_radius, double r_bound,
-                                                             uint8_t *__restrict__ unsafe,
-                                                             int32_t *__restrict__ lists, int32_t *__restrict__ list_n) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long i = gid / kPtLanes;
-  const int sub = (int)(gid % kPtLanes);
-  const int grp = (threadIdx.x & 63) / kPtLanes;
+// everything the sample pass needs about one sphere, one 64-byte record:
+//   thr_in  : quickCheck, inside the sphere            <=> !(s >= thr_in)   (R/DRRT_Q.jl:1410)
+//   thr_pt  : (sqrt(s) - robotRadius) - radius < 0     <=>  s < thr_pt      (thr_point_clear)
+//   reach   : inflated robotRadius + radius (or +inf)
+struct alignas(64) SampleSph { double cx, cy, cz, thr_in, thr_pt, reach, pad0, pad1; };
+
+// lane = sample; the kSampleWaves waves of a workgroup share the same 64 samples and split the
+// sphere table between them, so every sphere record is a wave-uniform (scalar) load; the partial
+// answers meet in LDS.
+constexpr int kSampleWaves = 16;
+__global__ __launch_bounds__(64 * kSampleWaves) void sample_spheres_kernel(
+    const double *__restrict__ p, int stride, long long np, const SampleSph *__restrict__ tab, int m,
+    double r_bound, uint8_t *__restrict__ unsafe, int32_t *__restrict__ lists, int32_t *__restrict__ list_n) {
+  __shared__ int s_bad[64];
+  __shared__ int s_n[64];
+  __shared__ int s_list[64][kSphListCap];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long i = (long long)blockIdx.x * 64 + lane;
   const bool act = i < np;
+  if (wave == 0) { s_bad[lane] = 0; s_n[lane] = 0; }
+  __syncthreads();
   double px = 0, py = 0, pz = 0;
   if (act) { px = p[i * stride + 0]; py = p[i * stride + 1]; pz = p[i * stride + 2]; }
   const double pmax = fmax(fmax(fabs(px), fabs(py)), fabs(pz));
   // slack for the rounding of the foot point and of this distance; NaN / inf sample: everything is a candidate
   const double base_b = r_bound + 1e-12 * (pmax + 1.0);
+  const int per = (m + kSampleWaves - 1) / kSampleWaves;
+  const int j0 = wave * per, j1 = min(j0 + per, m);
   bool bad = false;
-  int n_list = 0;
-  for (int j0 = 0; j0 < m; j0 += kPtLanes) {
-    const int j = j0 + sub;
-    const bool valid = j < m;
-    const int jc = valid ? j : m - 1;
-    const double s = sq3(sph[jc].cx, sph[jc].cy, sph[jc].cz, px, py, pz);
-    if (valid) {
-      if (!(s >= thr_in[jc])) bad = true;                                   // quickCheck, :1410
-      if ((sqrt_rn(s) - robot_radius) - radius[jc] < 0.0) bad = true;       // explicitPointCheck2D
+  for (int j = j0; j < j1; ++j) {
+    const SampleSph sp = tab[j];
+    const double s = sq3(sp.cx, sp.cy, sp.cz, px, py, pz);
+    bad = bad | !(s >= sp.thr_in) | (s < sp.thr_pt);
+    const double B = base_b + sp.reach;
+    if (act && !(s > B * B * (1.0 + 1e-12))) {
+      const int at = atomicAdd(&s_n[lane], 1);
+      if (at < kSphListCap) s_list[lane][at] = j;
     }
-    const double B = base_b + reach[jc].thr;          // inflated robotRadius + radius (or +inf)
-    const bool cand = valid && act && !(s > B * B * (1.0 + 1e-12));
-    const unsigned gm = (unsigned)((__ballot(cand) >> (kPtLanes * grp)) & 0xffffull);
-    if (cand) {
-      const int at = n_list + __popc(gm & ((1u << sub) - 1u));
-      if (at < kSphListCap) lists[i * kSphListCap + at] = j;
-    }
-    n_list += __popc(gm);
   }
-#pragma unroll
-  for (int off = kPtLanes / 2; off > 0; off >>= 1) {
-    const bool obad = __shfl_xor((int)bad, off) != 0;   // every lane takes part in the shuffle
-    bad = bad | obad;
-  }
-  if (act && sub == 0) {
-    if (unsafe) unsafe[i] = bad ? 1 : 0;
-    list_n[i] = n_list;
+  if (bad) atomicOr(&s_bad[lane], 1);
+  __syncthreads();
+  if (wave == 0 && act) {
+    if (unsafe) unsafe[i] = s_bad[lane] ? 1 : 0;
+    const int n = s_n[lane];
+    list_n[i] = n;
+    for (int c = 0; c < min(n, kSphListCap); ++c) lists[i * kSphListCap + c] = s_list[lane][c];
   }
 }
 
@@ -649,6 +650,18 @@ int sync_spheres(rrtx_ctx *ctx, double robot_radius) {
       RRTX_HIP(ctx, ctx->d_sph_reach_f.ensure(sizeof(float) * tf.size()));
       RRTX_HIP(ctx, hipMemcpy(ctx->d_sph_reach_f.p, tf.data(), sizeof(float) * tf.size(), hipMemcpyHostToDevice));
     }
+    {
+      std::vector<SampleSph> st((size_t)na);
+      for (int k = 0; k < na; ++k) {
+        st[k].cx = rec[k].cx; st[k].cy = rec[k].cy; st[k].cz = rec[k].cz;
+        st[k].thr_in = thr_in[k];
+        st[k].thr_pt = thr_point_clear(robot_radius, radius[k]);
+        st[k].reach = reach[k].thr;
+        st[k].pad0 = 0.0; st[k].pad1 = 0.0;
+      }
+      RRTX_HIP(ctx, ctx->d_sph_sample.ensure(sizeof(SampleSph) * na));
+      RRTX_HIP(ctx, hipMemcpy(ctx->d_sph_sample.p, st.data(), sizeof(SampleSph) * na, hipMemcpyHostToDevice));
+    }
     char *aux = ctx->d_sph_aux.as<char>();
     RRTX_HIP(ctx, hipMemcpy(aux, radius.data(), sizeof(double) * na, hipMemcpyHostToDevice));
     RRTX_HIP(ctx, hipMemcpy(aux + sizeof(double) * na, thr_in.data(), sizeof(double) * na,
@@ -771,11 +784,9 @@ int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int
     int32_t *ln = l + (size_t)nq * kSphListCap;
     span_begin(ctx, KF_POINTS);
     if (m > 0) {
-      const long long threads = (long long)nq * kPtLanes;
-      hipLaunchKernelGGL(sample_spheres_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
-                         q_dev, ctx->dim, (long long)nq, ctx->d_sph.as<SphRec>(), ctx->d_sph_reach.as<SphRec>(),
-                         sph_radius_dev(ctx), sph_thr_in_dev(ctx), m, robot_radius, use_lists ? r_bound : 0.0,
-                         sample_unsafe_dev, l, ln);
+      hipLaunchKernelGGL(sample_spheres_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64 * kSampleWaves), 0, ctx->stream,
+                         q_dev, ctx->dim, (long long)nq, ctx->d_sph_sample.as<SampleSph>(), m,
+                         use_lists ? r_bound : 0.0, sample_unsafe_dev, l, ln);
     } else if (sample_unsafe_dev) {
       RRTX_HIP(ctx, hipMemsetAsync(sample_unsafe_dev, 0, (size_t)nq, ctx->stream));
     }

@@ -95,6 +95,20 @@ __global__ void nn_init_kernel(Scalars *__restrict__ sc, int n_copies_init, int 
 }
 
 // ---------------------------------------------------------------- pack ------
+// What the radius search folds into the pack pass (all null / zero for the nearest search):
+//   * per-call state: count[i] (with the root rule below), the long-list counter, the device
+//     copy of the confirmation arguments, and the reset of the scalars the NEXT call will use
+//     (the calls alternate between two Scalars records, so no separate init launch is needed);
+//   * the root rule: kdFindWithinRange adds the root when distToRoot <= range
+//     (R/kdTree_general.jl:896) while every other node needs < range (:830): the scan finds the
+//     root only when <, so a root at exactly the range is entered here as the first list entry.
+struct PackFused {
+  int *count;                      // [nq] list lengths, [nq] = long-list counter
+  Scalars *sc_next;
+  ConfirmArgs *ca_dst;
+  const double *nx, *ny, *nz, *nw; // node arrays (the root is node 0)
+};
+
 template <int D>
 __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const double *__restrict__ thr_lt_arr,
                                const double *__restrict__ thr_gt_arr, double thr_lt_s, double thr_gt_s,
@@ -103,68 +117,92 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
                                SlotRec *__restrict__ slots, typename QRecT<D>::type *__restrict__ copies,
                                int2 *__restrict__ meta, Scalars *__restrict__ sc,
                                const unsigned long long *__restrict__ xrange, int n_buckets,
-                               int *__restrict__ qhist, int2 *__restrict__ cb) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nq) return;
-  // culled scan: copies are bucketed by x over the extent of the node x coordinates
-  double bx0 = 0.0, binv = 0.0;
-  if (qhist) slab_map(xrange[0], xrange[1], n_buckets, &bx0, &binv);
-  double p[4] = {0.0, 0.0, 0.0, 0.0};
+                               int *__restrict__ qhist, int2 *__restrict__ cb, PackFused pf, ConfirmArgs ca) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = i < nq;
+  if (i == 0 && pf.count) {
+    pf.count[nq] = 0;
+    *pf.ca_dst = ca;
+    Scalars *nx_sc = pf.sc_next;
+    nx_sc->total = 0ull; nx_sc->n_copies = 0; nx_sc->n_units = 0; nx_sc->q_absmax = 0ull;
+    if (n_wraps == 0) sc->n_copies = nq;       // nobody counts copies then: one per query
+  }
+  unsigned long long am = 0ull;                // max |copy - origin| feeds the prefilter's rounding bound
+  if (act) {
+    // culled scan: copies are bucketed by x over the extent of the node x coordinates
+    double bx0 = 0.0, binv = 0.0;
+    if (qhist) slab_map(xrange[0], xrange[1], n_buckets, &bx0, &binv);
+    double p[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int k = 0; k < D; ++k) p[k] = q[(size_t)i * D + k];
-  const double tlt = thr_lt_arr ? thr_lt_arr[i] : thr_lt_s;
-  const double tgt = thr_gt_arr ? thr_gt_arr[i] : thr_gt_s;
-  const int n_slots = 1 << n_wraps;
-  const int wd[3] = {wd0, wd1, wd2};
-  const double wp[3] = {wp0, wp1, wp2};
-  for (int k = 0; k < n_slots; ++k) {
-    // ghost k: bit pattern of k, the LAST wrapped dimension is the least
-    // significant bit (iteration order of getNextGhostPoint)
-    double g[4] = {p[0], p[1], p[2], p[3]};
-    double c[4] = {p[0], p[1], p[2], p[3]};
-    for (int w = 0; w < n_wraps; ++w) {
-      int bit = (k >> (n_wraps - 1 - w)) & 1;
-      if (!bit) continue;
-      int dimi = wd[w];
-      double dim_val = p[dimi];
-      double dim_closest = 0.0;
-      if (p[dimi] < wp[w] / 2.0) { dim_val += wp[w]; dim_closest += wp[w]; }
-      else { dim_val -= wp[w]; }
-      g[dimi] = dim_val;
-      c[dimi] = dim_closest;
+    for (int k = 0; k < D; ++k) p[k] = q[(size_t)i * D + k];
+    const double tlt = thr_lt_arr ? thr_lt_arr[i] : thr_lt_s;
+    const double tgt = thr_gt_arr ? thr_gt_arr[i] : thr_gt_s;
+    const int n_slots = 1 << n_wraps;
+    const int wd[3] = {wd0, wd1, wd2};
+    const double wp[3] = {wp0, wp1, wp2};
+    if (pf.count) {
+      const double s = (D == 4) ? sq4(p[0], p[1], p[2], p[3], pf.nx[0], pf.ny[0], pf.nz[0], pf.nw[0])
+                                : sq3(p[0], p[1], p[2], pf.nx[0], pf.ny[0], pf.nz[0]);
+      const bool add = s >= tlt && s < tgt;
+      pf.count[i] = add ? 1 : 0;
+      if (add) {                               // bcap >= 8: entry 0 of the bucket always exists
+        ca.hs.bidx[(size_t)i * (size_t)ca.hs.bcap] = 0;
+        ca.hs.bd2[(size_t)i * (size_t)ca.hs.bcap] = s;
+      }
     }
-    bool valid = true;
-    if (k > 0) {
-      // skip when dist(closestUnwrappedPoint, ghost) > range  (R/ghostPoint.jl:104)
-      double s = (D == 4) ? sq4(c[0], c[1], c[2], c[3], g[0], g[1], g[2], g[3])
-                          : sq3(c[0], c[1], c[2], g[0], g[1], g[2]);
-      valid = !(s >= tgt);
-    }
-    SlotRec sr;
-    sr.x = g[0]; sr.y = g[1]; sr.z = g[2]; sr.w = g[3];
-    sr.thr_lt = valid ? tlt : -1.0;
-    sr.thr_gt = tgt;
-    sr.pad0 = 0.0; sr.pad1 = 0.0;
-    slots[(size_t)i * n_slots + k] = sr;
-    if (valid) {
-      // max |copy - origin| feeds the prefilter's rounding bound
-      const double og[4] = {ox, oy, oz, ow};
-      unsigned long long am = 0ull;
-      for (int c2 = 0; c2 < D; ++c2) am = max(am, (unsigned long long)__double_as_longlong(fabs(g[c2] - og[c2])));
-      atomicMax(&sc->q_absmax, am);
-      int pos = (n_wraps == 0) ? i : atomicAdd(&sc->n_copies, 1);
-      typename QRecT<D>::type qr;
-      qr.x = g[0]; qr.y = g[1]; qr.z = g[2];
-      if constexpr (D == 4) { qr.w = g[3]; qr.pad0 = 0.0; qr.pad1 = 0.0; qr.pad2 = 0.0; }
-      qr.thr = tlt;
-      copies[pos] = qr;
-      meta[pos] = make_int2(i, k);
-      if (qhist) {
-        const int b = slab_of(g[0], bx0, binv, n_buckets);
-        cb[pos] = make_int2(b, atomicAdd(&qhist[b], 1));
+    for (int k = 0; k < n_slots; ++k) {
+      // ghost k: bit pattern of k, the LAST wrapped dimension is the least
+      // significant bit (iteration order of getNextGhostPoint)
+      double g[4] = {p[0], p[1], p[2], p[3]};
+      double c[4] = {p[0], p[1], p[2], p[3]};
+      for (int w = 0; w < n_wraps; ++w) {
+        int bit = (k >> (n_wraps - 1 - w)) & 1;
+        if (!bit) continue;
+        int dimi = wd[w];
+        double dim_val = p[dimi];
+        double dim_closest = 0.0;
+        if (p[dimi] < wp[w] / 2.0) { dim_val += wp[w]; dim_closest += wp[w]; }
+        else { dim_val -= wp[w]; }
+        g[dimi] = dim_val;
+        c[dimi] = dim_closest;
+      }
+      bool valid = true;
+      if (k > 0) {
+        // skip when dist(closestUnwrappedPoint, ghost) > range  (R/ghostPoint.jl:104)
+        double s = (D == 4) ? sq4(c[0], c[1], c[2], c[3], g[0], g[1], g[2], g[3])
+                            : sq3(c[0], c[1], c[2], g[0], g[1], g[2]);
+        valid = !(s >= tgt);
+      }
+      SlotRec sr;
+      sr.x = g[0]; sr.y = g[1]; sr.z = g[2]; sr.w = g[3];
+      sr.thr_lt = valid ? tlt : -1.0;
+      sr.thr_gt = tgt;
+      sr.pad0 = 0.0; sr.pad1 = 0.0;
+      slots[(size_t)i * n_slots + k] = sr;
+      if (valid) {
+        const double og[4] = {ox, oy, oz, ow};
+        for (int c2 = 0; c2 < D; ++c2) am = max(am, (unsigned long long)__double_as_longlong(fabs(g[c2] - og[c2])));
+        int pos = (n_wraps == 0) ? i : atomicAdd(&sc->n_copies, 1);
+        typename QRecT<D>::type qr;
+        qr.x = g[0]; qr.y = g[1]; qr.z = g[2];
+        if constexpr (D == 4) { qr.w = g[3]; qr.pad0 = 0.0; qr.pad1 = 0.0; qr.pad2 = 0.0; }
+        qr.thr = tlt;
+        copies[pos] = qr;
+        meta[pos] = make_int2(i, k);
+        if (qhist) {
+          const int b = slab_of(g[0], bx0, binv, n_buckets);
+          cb[pos] = make_int2(b, atomicAdd(&qhist[b], 1));
+        }
       }
     }
   }
+  // one atomic per wave on the shared maximum
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(am, off);
+    am = max(am, o);
+  }
+  if ((threadIdx.x & 63) == 0 && am != 0ull) atomicMax(&sc->q_absmax, am);
 }
 
 // ---------------------------------------------------------------- scan ------
@@ -358,14 +396,37 @@ __global__ void nn_filter_prep_kernel(const typename QRecT<D>::type *__restrict_
 }
 
 // Culled scan: the same records, written in x-bucket order (bucket start + the rank the pack
-// kernel drew), together with the fp64 copy and its (query, slot) tag.
+// kernel drew), together with the fp64 copy and its (query, slot) tag.  Every workgroup first
+// scans the whole bucket histogram (<= 4096 counters) into LDS; that is cheaper than a launch.
+constexpr int kMaxQBuckets = 4096;
 template <int D>
-__global__ void nn_place_kernel(const typename QRecT<D>::type *__restrict__ copies, const int2 *__restrict__ meta,
-                                const int2 *__restrict__ cb, const int *__restrict__ qstart,
-                                const Scalars *__restrict__ sc, const unsigned long long *__restrict__ node_absmax,
-                                double ox, double oy, double oz, double ow,
-                                typename QRecT<D>::type *__restrict__ copies_s, int2 *__restrict__ meta_s,
-                                typename QRecFT<D>::type *__restrict__ copies_f) {
+__global__ __launch_bounds__(256) void nn_place_kernel(
+    const typename QRecT<D>::type *__restrict__ copies, const int2 *__restrict__ meta, const int2 *__restrict__ cb,
+    const int *__restrict__ qhist, int n_buckets, const Scalars *__restrict__ sc,
+    const unsigned long long *__restrict__ node_absmax, double ox, double oy, double oz, double ow,
+    typename QRecT<D>::type *__restrict__ copies_s, int2 *__restrict__ meta_s,
+    typename QRecFT<D>::type *__restrict__ copies_f) {
+  __shared__ int start[kMaxQBuckets];
+  __shared__ int wsum[4];
+  {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (n_buckets + 255) / 256;
+    const int b0 = min(t * per, n_buckets), b1 = min(b0 + per, n_buckets);
+    int local = 0;
+    for (int k = b0; k < b1; ++k) local += qhist[k];
+    int v = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(v, off);
+      if (lane >= off) v += o;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int prefix = v - local;
+    for (int w = 0; w < wave; ++w) prefix += wsum[w];
+    for (int k = b0; k < b1; ++k) { start[k] = prefix; prefix += qhist[k]; }
+    __syncthreads();
+  }
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n_copies = sc->n_copies;
   if (i >= n_copies) {
@@ -373,7 +434,8 @@ __global__ void nn_place_kernel(const typename QRecT<D>::type *__restrict__ copi
     return;
   }
   const int2 b = cb[i];
-  const int dst = qstart[b.x] + b.y;
+  const int dst = start[b.x] + b.y;
+  if ((unsigned)dst >= (unsigned)n_copies) return;   // cannot happen with a consistent histogram; never write outside
   const typename QRecT<D>::type c = copies[i];
   unsigned long long am = max(*node_absmax, sc->q_absmax);
   copies_s[dst] = c;
@@ -799,30 +861,16 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_tile_kernel(
   if (lane == 0) visits[slice] = visited;
 }
 
-// ------------------------------------------------------------- rootfix ------
-// kdFindWithinRange adds the root when distToRoot <= range (R/kdTree_general.jl:896);
-// the scan found it only when < range.
-template <int D>
-__global__ __launch_bounds__(256) void nn_rootfix_kernel(const double *__restrict__ nx, const double *__restrict__ ny,
-                                  const double *__restrict__ nz, const double *__restrict__ nw,
-                                  const SlotRec *__restrict__ slots, int n_slots, int nq, HitSink hs,
-                                  long long *__restrict__ block_sum) {
+// ------------------------------------------------------------- offsets ------
+// Exclusive scan of the list lengths.  block_sum (per-256 sums, nn_blocksum_kernel) is used for
+// very large batches; otherwise workgroup b adds up the counts of the workgroups before it
+// itself, which is cheaper than another launch.  Also re-zeroes the bucket histogram of the
+// culled scan for the next call.
+__global__ __launch_bounds__(256) void nn_blocksum_kernel(const int *__restrict__ count, int nq,
+                                                          long long *__restrict__ block_sum) {
   __shared__ long long wsum[4];
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int c = 0;
-  bool add = false;
-  double s = 0.0;
-  if (i < nq) {
-    SlotRec sr = slots[(size_t)i * n_slots];
-    s = (D == 4) ? sq4(sr.x, sr.y, sr.z, sr.w, nx[0], ny[0], nz[0], nw[0])
-                 : sq3(sr.x, sr.y, sr.z, nx[0], ny[0], nz[0]);
-    c = hs.count[i];            // final: scan and confirm kernels have completed
-    add = s >= sr.thr_lt && s < sr.thr_gt;
-  }
-  emit_hit(hs, add, i, 0, s);   // whole wave together
-  if (add) c += 1;
-  // per-block sum of the final counts: first level of the offsets scan
-  long long v = c;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  long long v = (i < nq) ? (long long)count[i] : 0ll;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
@@ -830,20 +878,29 @@ __global__ __launch_bounds__(256) void nn_rootfix_kernel(const double *__restric
   if (threadIdx.x == 0) block_sum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// ------------------------------------------------------------- offsets ------
 __global__ __launch_bounds__(256) void nn_offsets_kernel(const int *__restrict__ count, int nq,
                                                          const long long *__restrict__ block_sum,
                                                          int64_t *__restrict__ offsets,
                                                          int *__restrict__ cursor,
-                                                         const Scalars *__restrict__ sc,
-                                                         int64_t *__restrict__ needed) {
-  // block b covers counts [256 b, 256 b + 256): prefix = sum of the preceding block sums
-  // (written by nn_rootfix_kernel), then a shuffle scan inside the block.  No inter-block sync.
+                                                         int64_t *__restrict__ needed, int *__restrict__ qhist,
+                                                         int n_qhist) {
   __shared__ long long red[4];
   __shared__ long long wave_tot[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int k = blockIdx.x * 256 + t; k < n_qhist; k += gridDim.x * 256) qhist[k] = 0;
   long long p = 0;
-  for (int j = t; j < (int)blockIdx.x; j += 256) p += block_sum[j];
+  if (block_sum) {
+    for (int j = t; j < (int)blockIdx.x; j += 256) p += block_sum[j];
+  } else {
+    // 256 b counts precede workgroup b: 16-byte loads, four in flight per thread
+    const int4 *c4 = reinterpret_cast<const int4 *>(count);
+    const int n4 = (int)blockIdx.x * 64;
+#pragma unroll 4
+    for (int j = t; j < n4; j += 256) {
+      const int4 v = c4[j];
+      p += (long long)v.x + v.y + v.z + v.w;
+    }
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
   if (lane == 0) red[wave] = p;
@@ -906,10 +963,10 @@ struct ListSrc {
 };
 
 // --------------------------------------------------------------- order ------
-// one wave per query: rank each hit by node index, write idx ascending and
-// dist = sqrt(d2) (the key the reference stores, R/kdTree_general.jl:829-831).
-// Optionally also: owner[e] = query of CSR entry e, and the nearest node of the
-// list (lexicographic minimum of (d2, idx); -1 when the list is empty).
+// Half a wave per query (lists of up to 64 entries, two per lane): rank each hit by node index,
+// write idx ascending and dist = sqrt(d2) (the key the reference stores,
+// R/kdTree_general.jl:829-831).  Optionally also: owner[e] = query of CSR entry e, and the
+// nearest node of the list (lexicographic minimum of (d2, idx); -1 when the list is empty).
 __global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict__ offsets, int nq, ListSrc src,
                                                        int32_t *__restrict__ idx,
                                                        double *__restrict__ dist, long long out_cap,
@@ -917,44 +974,60 @@ __global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict
                                                        int32_t *__restrict__ nearest_idx,
                                                        double *__restrict__ nearest_dist,
                                                        int *__restrict__ big_list, int *__restrict__ big_count) {
-  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (q >= nq) return;
-  const int lane = threadIdx.x & 63;
-  const long long b = offsets[q];
-  long long e = offsets[q + 1];
-  if (e > out_cap) e = out_cap;
-  const long long k = e - b;
-  double best = __builtin_inf();
-  int best_i = 0x7fffffff;
-  if (k > 0 && k <= 64) {
-    int my = (lane < k) ? src.idx(q, b, lane) : 0x7fffffff;
-    double d2 = (lane < k) ? src.d2(q, b, lane) : __builtin_inf();
-    int rank = 0;
-    for (int j = 0; j < (int)k; ++j) {
-      int other = __shfl(my, j);
-      rank += (other < my) ? 1 : 0;
-    }
-    if (lane < k) {
-      idx[b + rank] = my;
-      dist[b + rank] = sqrt_rn(d2);
-      if (owner) owner[b + rank] = q;
-    }
-    best = d2; best_i = my;
-  } else if (k > 64) {
-    // long list (obstacle sweeps, Dubins balls): queued for nn_order_big_kernel
-    if (lane == 0) big_list[atomicAdd(big_count, 1)] = q;
-    return;
+  const int hl = threadIdx.x & 31;
+  const int q = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5);
+  const bool qv = q < nq;
+  long long b = 0, k = 0;
+  if (qv) {
+    b = offsets[q];
+    long long e = offsets[q + 1];
+    if (e > out_cap) e = out_cap;
+    k = e - b;
+  }
+  const bool small = k <= 64;
+  // long list (obstacle sweeps, Dubins balls): queued for nn_order_big_kernel
+  if (qv && !small && hl == 0) big_list[atomicAdd(big_count, 1)] = q;
+  const int kk = (qv && small) ? (int)k : 0;
+  const int kInt = 0x7fffffff;
+  const int m0 = (hl < kk) ? src.idx(q, b, hl) : kInt;
+  const int m1 = (hl + 32 < kk) ? src.idx(q, b, hl + 32) : kInt;
+  const double d0 = (hl < kk) ? src.d2(q, b, hl) : __builtin_inf();
+  const double d1 = (hl + 32 < kk) ? src.d2(q, b, hl + 32) : __builtin_inf();
+  const int kmax = max(kk, __shfl_xor(kk, 32));      // the two halves of a wave run the same loops
+  int r0 = 0, r1 = 0;
+  for (int j = 0; j < min(kmax, 32); ++j) {
+    const int o = __shfl(m0, j, 32);
+    r0 += (o < m0) ? 1 : 0;
+    r1 += (o < m1) ? 1 : 0;
+  }
+  for (int j = 32; j < kmax; ++j) {
+    const int o = __shfl(m1, j - 32, 32);
+    r0 += (o < m0) ? 1 : 0;
+    r1 += (o < m1) ? 1 : 0;
+  }
+  if (hl < kk) {
+    idx[b + r0] = m0;
+    dist[b + r0] = sqrt_rn(d0);
+    if (owner) owner[b + r0] = q;
+  }
+  if (hl + 32 < kk) {
+    idx[b + r1] = m1;
+    dist[b + r1] = sqrt_rn(d1);
+    if (owner) owner[b + r1] = q;
   }
   if (nearest_idx) {
+    double best = d0;
+    int best_i = m0;
+    if ((d1 < best) || (d1 == best && m1 < best_i)) { best = d1; best_i = m1; }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      double ob = __shfl_xor(best, off);
-      int oi = __shfl_xor(best_i, off);
+    for (int off = 16; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off);
+      const int oi = __shfl_xor(best_i, off);
       if ((ob < best) || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
     }
-    if (lane == 0) {
-      nearest_idx[q] = (k > 0) ? best_i : -1;
-      nearest_dist[q] = (k > 0) ? sqrt_rn(best) : __builtin_inf();
+    if (qv && small && hl == 0) {
+      nearest_idx[q] = (kk > 0) ? best_i : -1;
+      nearest_dist[q] = (kk > 0) ? sqrt_rn(best) : __builtin_inf();
     }
   }
 }
@@ -1484,15 +1557,21 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   RRTX_HIP(ctx, ctx->ws_copies.ensure(n_copies_max * qrec_bytes));
   RRTX_HIP(ctx, ctx->ws_copy_meta.ensure(n_copies_max * sizeof(int2)));
   RRTX_HIP(ctx, ctx->ws_counts.ensure(((size_t)nq * 3 + 2) * sizeof(int)));
-  RRTX_HIP(ctx, ctx->ws_scalars.ensure(sizeof(Scalars)));
+  // two Scalars records used alternately: each call's pack kernel resets the other one
+  if (!ctx->ws_scalars.p) {
+    RRTX_HIP(ctx, ctx->ws_scalars.ensure(2 * sizeof(Scalars)));
+    RRTX_HIP(ctx, hipMemsetAsync(ctx->ws_scalars.p, 0, 2 * sizeof(Scalars), st));
+  }
   const long long rec_cap = (long long)(cap > 0 ? cap : 1);
   RRTX_HIP(ctx, ctx->ws_recs.ensure((size_t)rec_cap * sizeof(HitRec)));
   RRTX_HIP(ctx, ctx->ws_tmp_idx.ensure((size_t)rec_cap * sizeof(int32_t)));
   RRTX_HIP(ctx, ctx->ws_tmp_d2.ensure((size_t)rec_cap * sizeof(double)));
 
-  Scalars *sc = ctx->ws_scalars.as<Scalars>();
+  ctx->scalars_flip ^= 1;
+  Scalars *sc = ctx->ws_scalars.as<Scalars>() + ctx->scalars_flip;
+  Scalars *sc_next = ctx->ws_scalars.as<Scalars>() + (ctx->scalars_flip ^ 1);
   int *count = ctx->ws_counts.as<int>();
-  int *big_count = count + nq;          // zeroed together with count
+  int *big_count = count + nq;          // zeroed by the pack kernel
   int *cursor = count + nq + 1;
   int *big_list = cursor + nq;
 
@@ -1507,20 +1586,21 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   const bool use_cull = use_filter && (ctx->opt_nn_cull == 2 || (ctx->opt_nn_cull == 1 && n_nodes >= 8192));
   ctx->last_culled = use_cull;
   int n_buckets = 1;
-  int *qhist = nullptr, *qstart = nullptr;
+  int *qhist = nullptr;
   int2 *cbk = nullptr;
   if (use_cull) {
     int rc = slab_refresh(ctx);
     if (rc) return rc;
     n_buckets = pow2_ceil((long long)(n_copies_max / 16));
-    if (n_buckets > 4096) n_buckets = 4096;
-    RRTX_HIP(ctx, ctx->ws_qhist.ensure(sizeof(int) * (size_t)(n_buckets + 1)));
-    RRTX_HIP(ctx, ctx->ws_qstart.ensure(sizeof(int) * (size_t)(n_buckets + 1)));
+    if (n_buckets > kMaxQBuckets) n_buckets = kMaxQBuckets;
+    if (!ctx->ws_qhist.p) {               // stays all zero between calls (nn_offsets_kernel re-zeroes it)
+      RRTX_HIP(ctx, ctx->ws_qhist.ensure(sizeof(int) * (size_t)(kMaxQBuckets + 1)));
+      RRTX_HIP(ctx, hipMemsetAsync(ctx->ws_qhist.p, 0, sizeof(int) * (size_t)(kMaxQBuckets + 1), st));
+    }
     RRTX_HIP(ctx, ctx->ws_cb.ensure(sizeof(int2) * n_copies_max));
     RRTX_HIP(ctx, ctx->ws_copies_s.ensure(n_copies_max * qrec_bytes));
     RRTX_HIP(ctx, ctx->ws_meta_s.ensure(n_copies_max * sizeof(int2)));
     qhist = ctx->ws_qhist.as<int>();
-    qstart = ctx->ws_qstart.as<int>();
     cbk = ctx->ws_cb.as<int2>();
   }
   // ---- hit sink: per-query buckets (2x the average the caller made room for) + overflow list ----
@@ -1552,9 +1632,11 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   ca.hs = hs;
   RRTX_HIP(ctx, ctx->ws_confirm_args.ensure(sizeof(ConfirmArgs)));
   ConfirmArgs *ca_dev = ctx->ws_confirm_args.as<ConfirmArgs>();
-  hipLaunchKernelGGL(nn_init_kernel, dim3((nq + 1 + 255) / 256 < 64 ? (nq + 1 + 255) / 256 : 64), dim3(256), 0, st, sc,
-                     (ctx->n_wraps == 0) ? nq : 0, count, nq + 1, (unsigned long long *)nullptr, 0, 0ull,
-                     qhist, use_cull ? n_buckets + 1 : 0, 0, ca_dev, ca);
+  PackFused pf;
+  pf.count = count;
+  pf.sc_next = sc_next;
+  pf.ca_dst = ca_dev;
+  pf.nx = ctx->nodes[0]; pf.ny = ctx->nodes[1]; pf.nz = ctx->nodes[2]; pf.nw = ctx->nodes[D == 4 ? 3 : 2];
 
   const double *thr_lt_arr = r_dev_thr_lt;
   const double *thr_gt_arr = r_dev_thr_lt ? r_dev_thr_lt + nq : nullptr;
@@ -1569,7 +1651,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
                          ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
                          ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec4>(),
                          ctx->ws_copy_meta.as<int2>(), sc, ctx->d_xrange.as<unsigned long long>(), n_buckets, qhist,
-                         cbk);
+                         cbk, pf, ca);
     else
       hipLaunchKernelGGL(nn_pack_kernel<3>, grid, block, 0, st, q_dev, nq, thr_lt_arr, thr_gt_arr, tlt, tgt,
                          ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1], ctx->wrap_dim[2],
@@ -1577,7 +1659,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
                          ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
                          ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec3>(),
                          ctx->ws_copy_meta.as<int2>(), sc, ctx->d_xrange.as<unsigned long long>(), n_buckets, qhist,
-                         cbk);
+                         cbk, pf, ca);
   }
   span_end(ctx);
 
@@ -1600,17 +1682,16 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
     dim3 grid((unsigned)((n_copies_max + kQPI + 255) / 256)), block(256);
     const unsigned long long *absmax = ctx->d_absmax.as<unsigned long long>();
     if (use_cull) {
-      hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, st, qhist, qstart, n_buckets);
       if (D == 4)
         hipLaunchKernelGGL(nn_place_kernel<4>, grid, block, 0, st, ctx->ws_copies.as<QRec4>(),
-                           ctx->ws_copy_meta.as<int2>(), cbk, qstart, sc, absmax, ctx->origin[0], ctx->origin[1],
-                           ctx->origin[2], ctx->origin[3], ctx->ws_copies_s.as<QRec4>(), ctx->ws_meta_s.as<int2>(),
-                           ctx->ws_copies_f.as<QRecF4>());
+                           ctx->ws_copy_meta.as<int2>(), cbk, qhist, n_buckets, sc, absmax, ctx->origin[0],
+                           ctx->origin[1], ctx->origin[2], ctx->origin[3], ctx->ws_copies_s.as<QRec4>(),
+                           ctx->ws_meta_s.as<int2>(), ctx->ws_copies_f.as<QRecF4>());
       else
         hipLaunchKernelGGL(nn_place_kernel<3>, grid, block, 0, st, ctx->ws_copies.as<QRec3>(),
-                           ctx->ws_copy_meta.as<int2>(), cbk, qstart, sc, absmax, ctx->origin[0], ctx->origin[1],
-                           ctx->origin[2], ctx->origin[3], ctx->ws_copies_s.as<QRec3>(), ctx->ws_meta_s.as<int2>(),
-                           ctx->ws_copies_f.as<QRecF3>());
+                           ctx->ws_copy_meta.as<int2>(), cbk, qhist, n_buckets, sc, absmax, ctx->origin[0],
+                           ctx->origin[1], ctx->origin[2], ctx->origin[3], ctx->ws_copies_s.as<QRec3>(),
+                           ctx->ws_meta_s.as<int2>(), ctx->ws_copies_f.as<QRecF3>());
     } else if (D == 4)
       hipLaunchKernelGGL(nn_filter_prep_kernel<4>, grid, block, 0, st, ctx->ws_copies.as<QRec4>(), sc, absmax,
                          (int)n_copies_max, ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
@@ -1696,20 +1777,19 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   src.tmp_idx = ctx->ws_tmp_idx.as<int32_t>(); src.tmp_d2 = ctx->ws_tmp_d2.as<double>();
   span_begin(ctx, KF_NN_FINISH);
   {
-    dim3 grid((nq + 255) / 256), block(256);
-    if (D == 4)
-      hipLaunchKernelGGL(nn_rootfix_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                         ctx->nodes[3], ctx->ws_slots.as<SlotRec>(), n_slots, nq, hs, bsum);
-    else
-      hipLaunchKernelGGL(nn_rootfix_kernel<3>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                         ctx->nodes[2], ctx->ws_slots.as<SlotRec>(), n_slots, nq, hs, bsum);
-    hipLaunchKernelGGL(nn_offsets_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, count, nq, bsum, offsets_dev,
-                       cursor, sc, needed_dev);
+    const int nblk = (nq + 255) / 256;
+    const long long *bsum_arg = nullptr;
+    if (nq > 65536) {                     // large batch: per-256 sums first
+      hipLaunchKernelGGL(nn_blocksum_kernel, dim3(nblk), dim3(256), 0, st, count, nq, bsum);
+      bsum_arg = bsum;
+    }
+    hipLaunchKernelGGL(nn_offsets_kernel, dim3(nblk), dim3(256), 0, st, count, nq, bsum_arg, offsets_dev, cursor,
+                       needed_dev, qhist, use_cull ? n_buckets + 1 : 0);
     // the overflow list is normally empty: a small grid finds that out quickly
     hipLaunchKernelGGL(nn_scatter_kernel, dim3(64), dim3(256), 0, st, ctx->ws_recs.as<HitRec>(), rec_cap, sc,
                        offsets_dev, cursor, bcap, ctx->ws_tmp_idx.as<int32_t>(), ctx->ws_tmp_d2.as<double>(),
                        (long long)cap);
-    hipLaunchKernelGGL(nn_order_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, offsets_dev, nq, src, idx_dev, dist_dev,
+    hipLaunchKernelGGL(nn_order_kernel, dim3((nq + 7) / 8), dim3(256), 0, st, offsets_dev, nq, src, idx_dev, dist_dev,
                        (long long)cap, owner_dev, nearest_idx_dev, nearest_dist_dev, big_list, big_count);
     // lists longer than one wave (queued by nn_order_kernel); exits at once when there are none
     hipLaunchKernelGGL(nn_order_big_kernel, dim3(nq < 1024 ? nq : 1024), dim3(256), 0, st, offsets_dev, src, idx_dev,
@@ -1769,12 +1849,12 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
   RRTX_HIP(ctx, ctx->ws_copies.ensure(n_copies_max * qrec_bytes));
   RRTX_HIP(ctx, ctx->ws_copies_f.ensure((n_copies_max + kQPI) * qf_bytes));
   RRTX_HIP(ctx, ctx->ws_copy_meta.ensure(n_copies_max * sizeof(int2)));
-  RRTX_HIP(ctx, ctx->ws_scalars.ensure(sizeof(Scalars)));
+  RRTX_HIP(ctx, ctx->ws_scalars_nn.ensure(sizeof(Scalars)));
   RRTX_HIP(ctx, ctx->ws_recs.ensure((size_t)rec_cap * sizeof(HitRec)));
   RRTX_HIP(ctx, ctx->ws_partial.ensure((size_t)nq * (sizeof(unsigned long long) + sizeof(int))));
   unsigned long long *best_bits = ctx->ws_partial.as<unsigned long long>();
   int *best_idx = reinterpret_cast<int *>(best_bits + nq);
-  Scalars *sc = ctx->ws_scalars.as<Scalars>();
+  Scalars *sc = ctx->ws_scalars_nn.as<Scalars>();
   hipLaunchKernelGGL(nn_init_kernel, dim3((nq + 255) / 256 < 64 ? (nq + 255) / 256 : 64), dim3(256), 0, st, sc,
                      (ctx->n_wraps == 0) ? nq : 0, (int *)nullptr, 0, best_bits, nq, ~0ull, best_idx, nq, 0x7fffffff,
                      (ConfirmArgs *)nullptr, ConfirmArgs{});
@@ -1802,7 +1882,8 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
                          ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
                          ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
                          ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec4>(), ctx->ws_copy_meta.as<int2>(), sc,
-                         (const unsigned long long *)nullptr, 1, (int *)nullptr, (int2 *)nullptr);
+                         (const unsigned long long *)nullptr, 1, (int *)nullptr, (int2 *)nullptr, PackFused{},
+                         ConfirmArgs{});
       hipLaunchKernelGGL(nn_filter_prep_kernel<4>, pgrid, block, 0, st, ctx->ws_copies.as<QRec4>(), sc,
                          ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
                          ctx->origin[2], ctx->origin[3], ctx->ws_copies_f.as<QRecF4>());
@@ -1817,7 +1898,8 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
                          ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
                          ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
                          ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec3>(), ctx->ws_copy_meta.as<int2>(), sc,
-                         (const unsigned long long *)nullptr, 1, (int *)nullptr, (int2 *)nullptr);
+                         (const unsigned long long *)nullptr, 1, (int *)nullptr, (int2 *)nullptr, PackFused{},
+                         ConfirmArgs{});
       hipLaunchKernelGGL(nn_filter_prep_kernel<3>, pgrid, block, 0, st, ctx->ws_copies.as<QRec3>(), sc,
                          ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
                          ctx->origin[2], ctx->origin[3], ctx->ws_copies_f.as<QRecF3>());
@@ -1848,7 +1930,7 @@ int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_d
 // number of candidate records the last screened nearest call produced (device scalar)
 int nearest_candidates(rrtx_ctx *ctx, long long *total) {
   unsigned long long t = 0;
-  RRTX_HIP(ctx, hipMemcpyAsync(&t, &ctx->ws_scalars.as<Scalars>()->total, sizeof(t), hipMemcpyDeviceToHost,
+  RRTX_HIP(ctx, hipMemcpyAsync(&t, &ctx->ws_scalars_nn.as<Scalars>()->total, sizeof(t), hipMemcpyDeviceToHost,
                                ctx->stream));
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *total = (long long)t;

@@ -67,6 +67,15 @@ double thr_first_gt(double r) {
   return first_true(r * r, [r](double s) { return std::sqrt(s) > r; });
 }
 
+// first s with !((sqrt(s) - robotRadius) - radius < 0): explicitPointCheck's per-sphere test
+// (R/DRRT_Q.jl:1555-1570) as a threshold on the squared distance, "collision <=> s < thr".
+// The expression is monotone in s (every step is a monotone rounded operation).
+double thr_point_clear(double robot_radius, double radius) {
+  const double g = robot_radius + radius;
+  double t = first_true(g * g, [=](double s) { return !((std::sqrt(s) - robot_radius) - radius < 0.0); });
+  return std::isnan(t) ? INFINITY : t;      // never clear (e.g. infinite radius): s < +inf
+}
+
 // ---- profiling spans -------------------------------------------------------------
 static hipEvent_t take_event(rrtx_ctx *ctx) {
   if (!ctx->event_pool.empty()) {
@@ -325,12 +334,12 @@ int rrtx_destroy(rrtx_ctx *ctx) {
   ctx->d_xrange.release();
   DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_reach, &ctx->d_sph_reach_f, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
                     &ctx->d_poly_orig, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
-                    &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_bsum, &ctx->ws_scalars, &ctx->ws_tmp_idx,
+                    &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_bsum, &ctx->ws_scalars, &ctx->ws_scalars_nn, &ctx->ws_tmp_idx,
                     &ctx->ws_tmp_d2, &ctx->ws_owner, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
                     &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr, &ctx->ws_mask, &ctx->ws_i32a, &ctx->ws_i32b,
                     &ctx->ws_slab_hist, &ctx->ws_slab_start, &ctx->ws_slab_sr, &ctx->ws_slab_params, &ctx->ws_copies_s,
                     &ctx->ws_meta_s, &ctx->ws_cb, &ctx->ws_qhist, &ctx->ws_qstart, &ctx->ws_units, &ctx->ws_bkt_idx,
-                    &ctx->ws_bkt_d2, &ctx->ws_ev_a, &ctx->ws_ev_m, &ctx->ws_ev_cnt, &ctx->ws_confirm_args, &ctx->ws_sph_lists};
+                    &ctx->ws_bkt_d2, &ctx->ws_ev_a, &ctx->ws_ev_m, &ctx->ws_ev_cnt, &ctx->ws_confirm_args, &ctx->ws_sph_lists, &ctx->d_sph_sample};
   for (auto b : bufs) b->release();
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

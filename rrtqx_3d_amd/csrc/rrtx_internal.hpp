@@ -119,6 +119,7 @@ struct rrtx_ctx {
   rrtx::DevBuf d_sph_reach_f;       // fp32, origin-relative, pair-interleaved copy for the packed screen
   double sph_packed_origin[3] = {0, 0, 0};
   rrtx::DevBuf d_sph_aux;           // double radius[n_active] then int32 orig[n_active]
+  rrtx::DevBuf d_sph_sample;        // SampleSph[n_active]: one record per sphere for sample_spheres_kernel
 
   // polygon obstacles
   std::vector<int32_t> poly_off;    // m+1
@@ -144,7 +145,9 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_recs;     // HitRec
   rrtx::DevBuf ws_counts;   // int32 count[nq], cursor[nq]
   rrtx::DevBuf ws_bsum;     // int64 per-256-query sums of count (first level of the offsets scan)
-  rrtx::DevBuf ws_scalars;  // device scalars: total, n_copies, ...
+  rrtx::DevBuf ws_scalars;  // device scalars of the range search: two records used alternately
+  rrtx::DevBuf ws_scalars_nn;  // ... of the nearest search
+  int scalars_flip = 0;
   rrtx::DevBuf ws_tmp_idx, ws_tmp_d2;
   rrtx::DevBuf ws_owner;    // int32 owner query of every CSR entry (extend_candidates)
   rrtx::DevBuf ws_out_off, ws_out_idx, ws_out_dist, ws_out_u8a, ws_out_u8b, ws_out_i32, ws_out_f64;
@@ -192,6 +195,7 @@ void span_end(rrtx_ctx *ctx);
 //   first_gt(r): smallest s >= 0 with sqrt(s) >  r   (sqrt(s) <= r  <=>  s <  first_gt(r))
 double thr_first_ge(double r);
 double thr_first_gt(double r);
+double thr_point_clear(double robot_radius, double radius);
 
 // ---- launchers (device pointers, enqueue on ctx->stream) ----------------------
 int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_or_null, double r_scalar,
