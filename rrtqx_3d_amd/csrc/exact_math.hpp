@@ -75,6 +75,18 @@ __device__ __forceinline__ int slab_of(double x, double x0, double inv_w, int K)
   const double v = (x - x0) * inv_w;
   return (v >= 0.0) ? ((v < (double)K) ? (int)v : K - 1) : 0;
 }
+// x and y extent of a group of nodes (enc_ord values; empty: lo = ~0, hi = 0)
+struct ChunkExt { unsigned long long xlo, xhi, ylo, yhi; };
+
+// Cell of (x, y) in a Kx x Ky grid laid over [x0, ..] x [y0, ..], numbered row by row in
+// boustrophedon order (odd rows run backwards) so that consecutive cells are neighbours.
+// Only used to ORDER nodes and query copies; no result depends on it.
+__device__ __forceinline__ int cell_of(double x, double y, double x0, double inv_wx, int Kx, double y0,
+                                       double inv_wy, int Ky) {
+  const int cx = slab_of(x, x0, inv_wx, Kx), cy = slab_of(y, y0, inv_wy, Ky);
+  return cy * Kx + ((cy & 1) ? (Kx - 1 - cx) : cx);
+}
+
 __device__ __forceinline__ void slab_map(unsigned long long lo_enc, unsigned long long hi_enc, int K, double *x0,
                                          double *inv_w) {
   const double lo = dec_ord(lo_enc), hi = dec_ord(hi_enc);

@@ -129,9 +129,15 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
   }
   unsigned long long am = 0ull;                // max |copy - origin| feeds the prefilter's rounding bound
   if (act) {
-    // culled scan: copies are bucketed by x over the extent of the node x coordinates
-    double bx0 = 0.0, binv = 0.0;
-    if (qhist) slab_map(xrange[0], xrange[1], n_buckets, &bx0, &binv);
+    // culled scan: copies are bucketed by (x, y) cell over the extent of the node coordinates,
+    // n_buckets = side * side
+    double bx0 = 0.0, bxi = 0.0, by0 = 0.0, byi = 0.0;
+    int side = 1;
+    if (qhist) {
+      while (side * side < n_buckets) side <<= 1;
+      slab_map(xrange[0], xrange[1], side, &bx0, &bxi);
+      slab_map(xrange[2], xrange[3], side, &by0, &byi);
+    }
     double p[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < D; ++k) p[k] = q[(size_t)i * D + k];
@@ -190,7 +196,7 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
         copies[pos] = qr;
         meta[pos] = make_int2(i, k);
         if (qhist) {
-          const int b = slab_of(g[0], bx0, binv, n_buckets);
+          const int b = cell_of(g[0], g[1], bx0, bxi, side, by0, byi, side);
           cb[pos] = make_int2(b, atomicAdd(&qhist[b], 1));
         }
       }
@@ -713,10 +719,11 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
 
 // ---------------------------------------------------------- tile kernel ------
 // Culled range search, one workgroup per (tile of kTileB bucket-ordered copies, part):
-//   1. the tile's x reach [lo, hi]: every copy's x -+ its search radius, rounded outwards;
-//   2. the node chunks whose exact x extent overlaps the reach (a chunk outside it holds no node
-//      within range of any copy of the tile: |x_q - x_n| > R implies fl(dx*dx) >= thr and the
-//      remaining squares only add, exact_math.hpp sq3); part p of a tile takes chunks c = p mod n_parts;
+//   1. the tile's reach in x and in y: every copy's coordinate -+ its search radius, rounded outwards;
+//   2. the node chunks whose exact x and y extents both overlap the reach (a chunk outside it
+//      holds no node within range of any copy of the tile: |x_q - x_n| > R, or the same in y,
+//      implies that square alone is >= thr after rounding, and the other squares only add,
+//      exact_math.hpp sq3); part p of a tile takes chunks c = p mod n_parts;
 //   3. the screen of those chunks, one chunk per wave at a time (scan_chunk_f32), entries into the
 //      waves' slices;
 //   4. exact confirmation of the workgroup's entries, hits collected per copy in LDS;
@@ -730,7 +737,7 @@ struct TileLds {
   int list[kTbList];
   int n_list;
   int wcnt[kScanThreads / 64];
-  double lo, hi;
+  double lo, hi, ylo, yhi;
   int lcnt[kTileB];
   int hidx[kTileB][kTbLcap];
   double hd2[kTileB][kTbLcap];
@@ -755,8 +762,7 @@ template <int D>
 __global__ __launch_bounds__(kScanThreads, 5) void nn_tile_kernel(
     const float *__restrict__ fx, const float *__restrict__ fy, const float *__restrict__ fz,
     const float *__restrict__ fw, const float *__restrict__ fpp, int n_nodes, int n_chunks,
-    const unsigned long long *__restrict__ chunk_lo, const unsigned long long *__restrict__ chunk_hi,
-    const typename QRecT<D>::type *__restrict__ copies_s, const typename QRecFT<D>::type *__restrict__ copies_f,
+    const ChunkExt *__restrict__ chunk_ext, const typename QRecT<D>::type *__restrict__ copies_s, const typename QRecFT<D>::type *__restrict__ copies_f,
     const Scalars *__restrict__ sc, int n_parts, int2 *__restrict__ ev, int slice_cap,
     const ConfirmArgs *__restrict__ ca, int *__restrict__ visits) {
   __shared__ TileLds sm;
@@ -778,26 +784,31 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_tile_kernel(
     // ---- 1. reach ----
     if (t < kTileB) sm.lcnt[t] = 0;
     if (wave == 0) {
-      double lo = __builtin_inf(), hi = -__builtin_inf();
+      double lo = __builtin_inf(), hi = -__builtin_inf(), ylo = __builtin_inf(), yhi = -__builtin_inf();
       if (q0 + lane < q1) {
         const typename QRecT<D>::type c = copies_s[q0 + lane];
-        const bool can_hit = (c.thr > 0.0) && (c.x - c.x == 0.0);  // thr NaN / <= 0, x NaN or +-inf: never
+        // thr NaN / <= 0, x or y NaN or +-inf: the copy can never have a neighbour
+        const bool can_hit = (c.thr > 0.0) && (c.x - c.x == 0.0) && (c.y - c.y == 0.0);
         if (can_hit) {
           const double R = sqrt_rn(c.thr) * (1.0 + 1e-15);         // thr = +inf -> R = +inf
-          const double a = c.x - R, b = c.x + R;
+          const double a = c.x - R, b = c.x + R, ya = c.y - R, yb = c.y + R;
           lo = a - (fabs(a) * 4.5e-16 + 1e-300);
           hi = b + (fabs(b) * 4.5e-16 + 1e-300);
+          ylo = ya - (fabs(ya) * 4.5e-16 + 1e-300);
+          yhi = yb + (fabs(yb) * 4.5e-16 + 1e-300);
         }
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
         lo = fmin(lo, __shfl_xor(lo, off));
         hi = fmax(hi, __shfl_xor(hi, off));
+        ylo = fmin(ylo, __shfl_xor(ylo, off));
+        yhi = fmax(yhi, __shfl_xor(yhi, off));
       }
-      if (lane == 0) { sm.lo = lo; sm.hi = hi; }
+      if (lane == 0) { sm.lo = lo; sm.hi = hi; sm.ylo = ylo; sm.yhi = yhi; }
     }
     __syncthreads();
-    const double lo = sm.lo, hi = sm.hi;
+    const double lo = sm.lo, hi = sm.hi, ylo = sm.ylo, yhi = sm.yhi;
     if (lo <= hi) {
       for (int cb = 0; cb < n_chunks; cb += kTbList) {
         // ---- 2. chunk list of this pass ----
@@ -807,8 +818,11 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_tile_kernel(
         // (the order inside the list is whatever the atomics give, so the parts of a tile
         // split the chunks by chunk number, not by list position)
         for (int c = cb + t; c < ce; c += kScanThreads)
-          if (c % n_parts == part && dec_ord(chunk_hi[c]) >= lo && dec_ord(chunk_lo[c]) <= hi)
-            sm.list[atomicAdd(&sm.n_list, 1)] = c;
+          if (c % n_parts == part) {
+            const ChunkExt ce = chunk_ext[c];
+            if (dec_ord(ce.xhi) >= lo && dec_ord(ce.xlo) <= hi && dec_ord(ce.yhi) >= ylo && dec_ord(ce.ylo) <= yhi)
+              sm.list[atomicAdd(&sm.n_list, 1)] = c;
+          }
         __syncthreads();
         const int nl = sm.n_list;
         // ---- 3. screen ----
@@ -1389,24 +1403,25 @@ __global__ void nn_nearest_out_kernel(const unsigned long long *__restrict__ bes
 // order in which the atomics happened to land, which no result depends on.
 static_assert(kSlabChunk == kChunkF, "the culled scan visits one slab-index chunk per work unit");
 
-struct SlabParams { double x0, inv_w; int K; int pad; };
+struct SlabParams { double x0, inv_wx, y0, inv_wy; int Kx, Ky; };
 
-__global__ void slab_params_kernel(const unsigned long long *__restrict__ xrange, int K,
+__global__ void slab_params_kernel(const unsigned long long *__restrict__ xrange, int Kx, int Ky,
                                    SlabParams *__restrict__ sp, int *__restrict__ hist) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) {
-    double x0, inv;
-    slab_map(xrange[0], xrange[1], K, &x0, &inv);
-    sp->x0 = x0; sp->inv_w = inv; sp->K = K; sp->pad = 0;
+    double x0, ix, y0, iy;
+    slab_map(xrange[0], xrange[1], Kx, &x0, &ix);
+    slab_map(xrange[2], xrange[3], Ky, &y0, &iy);
+    sp->x0 = x0; sp->inv_wx = ix; sp->y0 = y0; sp->inv_wy = iy; sp->Kx = Kx; sp->Ky = Ky;
   }
-  for (int k = i; k <= K; k += gridDim.x * blockDim.x) hist[k] = 0;
+  for (int k = i; k <= Kx * Ky; k += gridDim.x * blockDim.x) hist[k] = 0;
 }
 
-__global__ void slab_rank_kernel(const double *__restrict__ nx, int n, const SlabParams *__restrict__ sp,
-                                 int *__restrict__ hist, int2 *__restrict__ sr) {
+__global__ void slab_rank_kernel(const double *__restrict__ nx, const double *__restrict__ ny, int n,
+                                 const SlabParams *__restrict__ sp, int *__restrict__ hist, int2 *__restrict__ sr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int b = slab_of(nx[i], sp->x0, sp->inv_w, sp->K);
+  const int b = cell_of(nx[i], ny[i], sp->x0, sp->inv_wx, sp->Kx, sp->y0, sp->inv_wy, sp->Ky);
   sr[i] = make_int2(b, atomicAdd(&hist[b], 1));
 }
 
@@ -1457,28 +1472,35 @@ __global__ void slab_scatter_kernel(int n, const int2 *__restrict__ sr, const in
   sid[p] = i;
 }
 
-// exact fp64 x extent of every chunk of kSlabChunk positions (one wave per chunk)
-__global__ __launch_bounds__(256) void chunk_range_kernel(const double *__restrict__ nx,
+// exact fp64 x and y extent of every chunk of kSlabChunk positions (one wave per chunk)
+__global__ __launch_bounds__(256) void chunk_range_kernel(const double *__restrict__ nx, const double *__restrict__ ny,
                                                           const int32_t *__restrict__ sid, int n, int n_chunks,
-                                                          unsigned long long *__restrict__ chunk_lo,
-                                                          unsigned long long *__restrict__ chunk_hi) {
+                                                          ChunkExt *__restrict__ chunk_ext) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= n_chunks) return;
-  unsigned long long lo = ~0ull, hi = 0ull;
+  unsigned long long lo = ~0ull, hi = 0ull, ylo = ~0ull, yhi = 0ull;
   for (int u = 0; u < kSlabChunk / 64; ++u) {
     const int p = c * kSlabChunk + u * 64 + lane;
     if (p < n) {
-      const double x = nx[sid[p]];
+      const int id = sid[p];
+      const double x = nx[id], y = ny[id];
       if (x == x) { const unsigned long long e = enc_ord(x); lo = min(lo, e); hi = max(hi, e); }
+      if (y == y) { const unsigned long long e = enc_ord(y); ylo = min(ylo, e); yhi = max(yhi, e); }
     }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     lo = min(lo, (unsigned long long)__shfl_xor(lo, off));
     hi = max(hi, (unsigned long long)__shfl_xor(hi, off));
+    ylo = min(ylo, (unsigned long long)__shfl_xor(ylo, off));
+    yhi = max(yhi, (unsigned long long)__shfl_xor(yhi, off));
   }
-  if (lane == 0) { chunk_lo[c] = lo; chunk_hi[c] = hi; }
+  if (lane == 0) {
+    ChunkExt ce;
+    ce.xlo = lo; ce.xhi = hi; ce.ylo = ylo; ce.yhi = yhi;
+    chunk_ext[c] = ce;
+  }
 }
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -1496,9 +1518,11 @@ int slab_refresh(rrtx_ctx *ctx) {
   const int64_t limit = n / 128 > 1024 ? n / 128 : 1024;
   if (tail <= limit) return RRTX_OK;
   hipStream_t st = ctx->stream;
-  int K = pow2_ceil(n / 256);
-  if (K < 16) K = 16;
-  if (K > 16384) K = 16384;
+  // about one cell per chunk: cells of ~512 nodes, laid out as a square grid over (x, y)
+  int side = (int)std::sqrt((double)n / (double)kSlabChunk);
+  if (side < 2) side = 2;
+  if (side > 256) side = 256;
+  const int K = side * side;
   RRTX_HIP(ctx, ctx->ws_slab_params.ensure(sizeof(SlabParams)));
   RRTX_HIP(ctx, ctx->ws_slab_hist.ensure(sizeof(int) * (size_t)(K + 1)));
   RRTX_HIP(ctx, ctx->ws_slab_start.ensure(sizeof(int) * (size_t)(K + 1)));
@@ -1511,16 +1535,16 @@ int slab_refresh(rrtx_ctx *ctx) {
   const int n_chunks = (int)((n + kSlabChunk - 1) / kSlabChunk);
   span_begin(ctx, KF_NN_FINISH);
   hipLaunchKernelGGL(slab_params_kernel, dim3((K + 256) / 256), dim3(256), 0, st,
-                     ctx->d_xrange.as<unsigned long long>(), K, sp, hist);
-  hipLaunchKernelGGL(slab_rank_kernel, dim3(nb), dim3(256), 0, st, ctx->nodes[0], (int)n, sp, hist, sr);
+                     ctx->d_xrange.as<unsigned long long>(), side, side, sp, hist);
+  hipLaunchKernelGGL(slab_rank_kernel, dim3(nb), dim3(256), 0, st, ctx->nodes[0], ctx->nodes[1], (int)n, sp, hist, sr);
   hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, st, hist, start, K);
   hipLaunchKernelGGL(slab_scatter_kernel, dim3(nb), dim3(256), 0, st, (int)n, sr, start, ctx->nodes_f[0],
                      ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->dim,
                      ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp,
                      ctx->sl_id, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[ctx->dim == 4 ? 3 : 2],
                      ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2], ctx->sl_d[ctx->dim == 4 ? 3 : 2]);
-  hipLaunchKernelGGL(chunk_range_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, st, ctx->nodes[0], ctx->sl_id, (int)n,
-                     n_chunks, ctx->chunk_lo, ctx->chunk_hi);
+  hipLaunchKernelGGL(chunk_range_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, st, ctx->nodes[0], ctx->nodes[1],
+                     ctx->sl_id, (int)n, n_chunks, reinterpret_cast<ChunkExt *>(ctx->chunk_ext));
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   ctx->sl_n_sorted = n;
@@ -1591,8 +1615,8 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   if (use_cull) {
     int rc = slab_refresh(ctx);
     if (rc) return rc;
-    n_buckets = pow2_ceil((long long)(n_copies_max / 16));
-    if (n_buckets > kMaxQBuckets) n_buckets = kMaxQBuckets;
+    n_buckets = 1;                          // side * side cells, about 16 copies each
+    while (n_buckets < (long long)(n_copies_max / 16) && n_buckets < kMaxQBuckets) n_buckets *= 4;
     if (!ctx->ws_qhist.p) {               // stays all zero between calls (nn_offsets_kernel re-zeroes it)
       RRTX_HIP(ctx, ctx->ws_qhist.ensure(sizeof(int) * (size_t)(kMaxQBuckets + 1)));
       RRTX_HIP(ctx, hipMemsetAsync(ctx->ws_qhist.p, 0, sizeof(int) * (size_t)(kMaxQBuckets + 1), st));
@@ -1722,12 +1746,12 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
       ctx->last_visit_slices = n_slices;
       if (D == 4)
         hipLaunchKernelGGL(nn_tile_kernel<4>, dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
-                           ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, ctx->chunk_lo, ctx->chunk_hi,
+                           ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, reinterpret_cast<const ChunkExt *>(ctx->chunk_ext),
                            ctx->ws_copies_s.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(), sc, n_parts,
                            ctx->ws_ev_a.as<int2>(), slice_cap, ca_dev, ctx->ws_ev_cnt.as<int>());
       else
         hipLaunchKernelGGL(nn_tile_kernel<3>, dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
-                           ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, ctx->chunk_lo, ctx->chunk_hi,
+                           ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, reinterpret_cast<const ChunkExt *>(ctx->chunk_ext),
                            ctx->ws_copies_s.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(), sc, n_parts,
                            ctx->ws_ev_a.as<int2>(), slice_cap, ca_dev, ctx->ws_ev_cnt.as<int>());
     } else if (use_filter) {

@@ -138,12 +138,11 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
                                                          float *__restrict__ spp, int32_t *__restrict__ sid,
                                                          double *__restrict__ dx, double *__restrict__ dy,
                                                          double *__restrict__ dz, double *__restrict__ dw,
-                                                         unsigned long long *__restrict__ chunk_lo,
-                                                         unsigned long long *__restrict__ chunk_hi,
+                                                         ChunkExt *__restrict__ chunk_ext,
                                                          unsigned long long *__restrict__ xrange) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long m = 0ull;
-  unsigned long long xlo = ~0ull, xhi = 0ull;
+  unsigned long long xlo = ~0ull, xhi = 0ull, ylo = ~0ull, yhi = 0ull;
   if (i < n) {
     const double a = pos[i * dim + 0], b = pos[i * dim + 1], c = pos[i * dim + 2];
     x[base + i] = a; y[base + i] = b; z[base + i] = c;
@@ -155,11 +154,16 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
     sx[base + i] = fa; sy[base + i] = fb; sz[base + i] = fc;
     dx[base + i] = a; dy[base + i] = b; dz[base + i] = c;
     sid[base + i] = (int32_t)(base + i);
+    const long long ch = (base + i) / kSlabChunk;
     if (a == a) {
       xlo = xhi = enc_ord(a);
-      const long long ch = (base + i) / kSlabChunk;
-      atomicMin(&chunk_lo[ch], xlo);
-      atomicMax(&chunk_hi[ch], xhi);
+      atomicMin(&chunk_ext[ch].xlo, xlo);
+      atomicMax(&chunk_ext[ch].xhi, xhi);
+    }
+    if (b == b) {
+      ylo = yhi = enc_ord(b);
+      atomicMin(&chunk_ext[ch].ylo, ylo);
+      atomicMax(&chunk_ext[ch].yhi, yhi);
     }
     double pp = (double)fa * (double)fa + (double)fb * (double)fb + (double)fc * (double)fc;
     m = max(max((unsigned long long)__double_as_longlong(fabs(sa)), (unsigned long long)__double_as_longlong(fabs(sb))),
@@ -185,10 +189,15 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
     xlo = min(xlo, o);
     o = __shfl_xor(xhi, off);
     xhi = max(xhi, o);
+    o = __shfl_xor(ylo, off);
+    ylo = min(ylo, o);
+    o = __shfl_xor(yhi, off);
+    yhi = max(yhi, o);
   }
   if ((threadIdx.x & 63) == 0) {
     if (m != 0ull) atomicMax(absmax, m);
     if (xlo != ~0ull) { atomicMin(&xrange[0], xlo); atomicMax(&xrange[1], xhi); }
+    if (ylo != ~0ull) { atomicMin(&xrange[2], ylo); atomicMax(&xrange[3], yhi); }
   }
 }
 
@@ -225,18 +234,17 @@ int grow_nodes(rrtx_ctx *ctx, int64_t need) {
     // chunk extents: new chunks start empty (min = ~0, max = 0)
     const int64_t nch = nc / kSlabChunk + 1;
     const int64_t old = ctx->cap_chunks;
-    if ((rc = regrow(ctx, ctx->chunk_lo, nch, old))) return rc;
-    if ((rc = regrow(ctx, ctx->chunk_hi, nch, old))) return rc;
-    RRTX_HIP(ctx, hipMemset(ctx->chunk_lo + old, 0xff, sizeof(unsigned long long) * (size_t)(nch - old)));
-    RRTX_HIP(ctx, hipMemset(ctx->chunk_hi + old, 0x00, sizeof(unsigned long long) * (size_t)(nch - old)));
+    if ((rc = regrow(ctx, ctx->chunk_ext, nch, old))) return rc;
+    std::vector<ChunkExtHost> empty((size_t)(nch - old), ChunkExtHost{~0ull, 0ull, ~0ull, 0ull});
+    RRTX_HIP(ctx, hipMemcpy(ctx->chunk_ext + old, empty.data(), sizeof(ChunkExtHost) * empty.size(), hipMemcpyHostToDevice));
     ctx->cap_chunks = nch;
   }
   if (!ctx->d_absmax.p) {
     RRTX_HIP(ctx, ctx->d_absmax.ensure(sizeof(unsigned long long)));
     RRTX_HIP(ctx, hipMemset(ctx->d_absmax.p, 0, sizeof(unsigned long long)));
-    RRTX_HIP(ctx, ctx->d_xrange.ensure(2 * sizeof(unsigned long long)));
-    RRTX_HIP(ctx, hipMemset(ctx->d_xrange.p, 0xff, sizeof(unsigned long long)));
-    RRTX_HIP(ctx, hipMemset(ctx->d_xrange.as<unsigned long long>() + 1, 0x00, sizeof(unsigned long long)));
+    const unsigned long long none[4] = {~0ull, 0ull, ~0ull, 0ull};
+    RRTX_HIP(ctx, ctx->d_xrange.ensure(sizeof(none)));
+    RRTX_HIP(ctx, hipMemcpy(ctx->d_xrange.p, none, sizeof(none), hipMemcpyHostToDevice));
   }
   ctx->cap_nodes = nc;
   return RRTX_OK;
@@ -328,8 +336,7 @@ int rrtx_destroy(rrtx_ctx *ctx) {
     if (ctx->sl_d[k]) (void)hipFree(ctx->sl_d[k]);
   if (ctx->sl_pp) (void)hipFree(ctx->sl_pp);
   if (ctx->sl_id) (void)hipFree(ctx->sl_id);
-  if (ctx->chunk_lo) (void)hipFree(ctx->chunk_lo);
-  if (ctx->chunk_hi) (void)hipFree(ctx->chunk_hi);
+  if (ctx->chunk_ext) (void)hipFree(ctx->chunk_ext);
   ctx->d_absmax.release();
   ctx->d_xrange.release();
   DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_reach, &ctx->d_sph_reach_f, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
@@ -436,7 +443,7 @@ int rrtx_nodes_append_dev(rrtx_ctx *ctx, const double *pos_dev, int64_t n) {
                      ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->d_absmax.as<unsigned long long>(),
                      ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp, ctx->sl_id,
                      ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2], ctx->sl_d[ctx->dim == 4 ? 3 : 2],
-                     ctx->chunk_lo, ctx->chunk_hi, ctx->d_xrange.as<unsigned long long>());
+                     reinterpret_cast<ChunkExt *>(ctx->chunk_ext), ctx->d_xrange.as<unsigned long long>());
   RRTX_HIP(ctx, hipGetLastError());
   ctx->n_nodes += n;
   return RRTX_OK;

@@ -39,6 +39,9 @@ struct alignas(16) HitRec { int32_t owner; int32_t idx; double d2; };
 // distance (hit <=> !(s >= thr), thr = first s with sqrt(s) > robotRadius+radius).
 struct alignas(32) SphRec { double cx, cy, cz, thr; };
 
+// host-side mirror of exact_math.hpp's ChunkExt (this header is also read by plain C++)
+struct ChunkExtHost { unsigned long long xlo, xhi, ylo, yhi; };
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
@@ -81,8 +84,8 @@ struct rrtx_ctx {
 
   // Slab-ordered copy of the fp32 shadow for the culled range scan (kernels_nn.hip, "slab
   // index").  Positions [0, sl_n_sorted) hold nodes 0..sl_n_sorted-1 ordered by equal-width
-  // x slab; positions >= sl_n_sorted hold node p at position p (appended since the last
-  // rebuild).  chunk_lo/hi: exact fp64 x extent of every 512-position chunk (enc_ord).
+  // (x, y) grid cell; positions >= sl_n_sorted hold node p at position p (appended since the
+  // last rebuild).  chunk_ext: exact fp64 x and y extent of every 512-position chunk (enc_ord).
   // Inside a chunk the positions are lane-major: scan lane L owns positions 8 L .. 8 L + 7, so
   // its eight nodes are two 16-byte loads per array and the exact re-test of a flagged lane
   // reads eight consecutive doubles (sl_d: the same order in fp64).
@@ -90,10 +93,10 @@ struct rrtx_ctx {
   double *sl_d[4] = {nullptr, nullptr, nullptr, nullptr};
   float *sl_pp = nullptr;
   int32_t *sl_id = nullptr;
-  unsigned long long *chunk_lo = nullptr, *chunk_hi = nullptr;
+  rrtx::ChunkExtHost *chunk_ext = nullptr;   // x / y extent of every chunk (enc_ord), see exact_math.hpp ChunkExt
   int64_t cap_chunks = 0;
   int64_t sl_n_sorted = 0;
-  rrtx::DevBuf d_xrange;            // uint64[2]: enc_ord of min / max node x
+  rrtx::DevBuf d_xrange;            // uint64[4]: enc_ord of min / max node x, min / max node y
   rrtx::DevBuf ws_slab_hist, ws_slab_start, ws_slab_sr, ws_slab_params;
 
   // options (rrtx_set_option)
