@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void edges_spheres_kernel(const double *__rest
 // directions share the segment, so one reach test serves both.
 __global__ __launch_bounds__(256) void candidate_edges_kernel(
     const double *__restrict__ q, int stride, const int64_t *__restrict__ offsets, int nq,
-    const int32_t *__restrict__ idx, const int32_t *__restrict__ owner, const double *__restrict__ nx,
-    const double *__restrict__ ny, const double *__restrict__ nz, int n_nodes, long long cap,
+    const int32_t *__restrict__ idx, const int32_t *__restrict__ owner, const double4 *__restrict__ naos,
+    int n_nodes, long long cap,
     const SphRec *__restrict__ sph, const float *__restrict__ reach_f, double ox, double oy, double oz, int m,
     const int32_t *__restrict__ lists, const int32_t *__restrict__ list_n, int list_cap, double r_bound,
     uint8_t *__restrict__ hit_out, uint8_t *__restrict__ hit_in) {
@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void candidate_edges_kernel(
     act = (unsigned)lo < (unsigned)nq && (unsigned)n < (unsigned)n_nodes;   // defensive: never index out of range
     if (act) {
       sx = q[(size_t)lo * stride + 0]; sy = q[(size_t)lo * stride + 1]; sz = q[(size_t)lo * stride + 2];
-      tx = nx[n]; ty = ny[n]; tz = nz[n];
+      const double4 nd = naos[n];          // one 32-byte record instead of three scattered reads
+      tx = nd.x; ty = nd.y; tz = nd.z;
     }
   }
   // out: sample -> near ; in: near -> sample.  edgeLen is the same value either
@@ -797,7 +798,7 @@ int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int
   span_begin(ctx, KF_EDGES);
   // the grid covers the caller's capacity; lanes past offsets[nq] idle
   hipLaunchKernelGGL(candidate_edges_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, q_dev,
-                     ctx->dim, offsets_dev, nq, idx_dev, owner_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                     ctx->dim, offsets_dev, nq, idx_dev, owner_dev, reinterpret_cast<const double4 *>(ctx->nodes_aos),
                      (int)ctx->n_nodes, (long long)cap, ctx->d_sph.as<SphRec>(), ctx->d_sph_reach_f.as<float>(), ctx->origin[0],
                      ctx->origin[1], ctx->origin[2], m, lists, list_n, kSphListCap, r_bound, hit_out_dev, hit_in_dev);
   span_end(ctx);

@@ -184,7 +184,7 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
       sr.thr_lt = valid ? tlt : -1.0;
       sr.thr_gt = tgt;
       sr.pad0 = 0.0; sr.pad1 = 0.0;
-      slots[(size_t)i * n_slots + k] = sr;
+      if (n_wraps > 0) slots[(size_t)i * n_slots + k] = sr;   // only the ghost rules read the table
       if (valid) {
         const double og[4] = {ox, oy, oz, ow};
         for (int c2 = 0; c2 < D; ++c2) am = max(am, (unsigned long long)__double_as_longlong(fabs(g[c2] - og[c2])));

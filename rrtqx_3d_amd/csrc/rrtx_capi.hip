@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
                                                          float *__restrict__ spp, int32_t *__restrict__ sid,
                                                          double *__restrict__ dx, double *__restrict__ dy,
                                                          double *__restrict__ dz, double *__restrict__ dw,
+                                                         double *__restrict__ aos,
                                                          ChunkExt *__restrict__ chunk_ext,
                                                          unsigned long long *__restrict__ xrange) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
     }
     ppf[base + i] = (float)pp;
     spp[base + i] = (float)pp;
+    reinterpret_cast<double4 *>(aos)[base + i] = make_double4(a, b, c, dim == 4 ? pos[i * dim + 3] : 0.0);
   }
   for (int off = 32; off > 0; off >>= 1) {
     unsigned long long o = __shfl_xor(m, off);
@@ -228,6 +230,16 @@ int grow_nodes(rrtx_ctx *ctx, int64_t need) {
     if ((rc = regrow(ctx, ctx->sl_d[k], nc, ctx->n_nodes))) return rc;
   }
   if ((rc = regrow(ctx, ctx->nodes_pp, nc, ctx->n_nodes))) return rc;
+  {
+    double *old_aos = ctx->nodes_aos;
+    double *nb = nullptr;
+    hipError_t e = hipMalloc(&nb, sizeof(double) * 4 * (size_t)nc);
+    if (e != hipSuccess) return fail(ctx, RRTX_E_NOMEM, "hipMalloc of %lld node slots failed: %s", (long long)nc, hipGetErrorString(e));
+    if (ctx->n_nodes > 0 && old_aos)
+      RRTX_HIP(ctx, hipMemcpy(nb, old_aos, sizeof(double) * 4 * (size_t)ctx->n_nodes, hipMemcpyDeviceToDevice));
+    if (old_aos) RRTX_HIP(ctx, hipFree(old_aos));
+    ctx->nodes_aos = nb;
+  }
   if ((rc = regrow(ctx, ctx->sl_pp, nc, ctx->n_nodes))) return rc;
   if ((rc = regrow(ctx, ctx->sl_id, nc, ctx->n_nodes))) return rc;
   {
@@ -330,6 +342,7 @@ int rrtx_destroy(rrtx_ctx *ctx) {
   for (int k = 0; k < 4; ++k)
     if (ctx->nodes_f[k]) (void)hipFree(ctx->nodes_f[k]);
   if (ctx->nodes_pp) (void)hipFree(ctx->nodes_pp);
+  if (ctx->nodes_aos) (void)hipFree(ctx->nodes_aos);
   for (int k = 0; k < 4; ++k)
     if (ctx->sl_f[k]) (void)hipFree(ctx->sl_f[k]);
   for (int k = 0; k < 4; ++k)
@@ -442,7 +455,7 @@ int rrtx_nodes_append_dev(rrtx_ctx *ctx, const double *pos_dev, int64_t n) {
                      ctx->nodes[ctx->dim == 4 ? 3 : 2], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2],
                      ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->d_absmax.as<unsigned long long>(),
                      ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp, ctx->sl_id,
-                     ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2], ctx->sl_d[ctx->dim == 4 ? 3 : 2],
+                     ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2], ctx->sl_d[ctx->dim == 4 ? 3 : 2], ctx->nodes_aos,
                      reinterpret_cast<ChunkExt *>(ctx->chunk_ext), ctx->d_xrange.as<unsigned long long>());
   RRTX_HIP(ctx, hipGetLastError());
   ctx->n_nodes += n;

@@ -73,6 +73,8 @@ struct rrtx_ctx {
 
   // node SoA (fp64), one array per coordinate
   double *nodes[4] = {nullptr, nullptr, nullptr, nullptr};
+  // the same coordinates, four doubles per node (x y z w): one 32-byte read per random node access
+  double *nodes_aos = nullptr;
   // fp32 shadow of the node SoA for the conservative range prefilter
   // (kernels_nn.hip, nn_scan_f32_kernel); never used to decide a result
   float *nodes_f[4] = {nullptr, nullptr, nullptr, nullptr};
