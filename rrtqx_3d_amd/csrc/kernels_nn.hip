@@ -264,6 +264,24 @@ __device__ __forceinline__ void emit_hit(const HitSink &hs, bool hit, int owner,
   place_hit(hs, hit, owner, slot, id, d2);
 }
 
+// Many hits of few queries in one wave (dense balls): one counter update per distinct query.
+// Whole wave together.
+__device__ __forceinline__ void emit_hits_grouped(const HitSink &hs, bool hit, int owner, int id, double d2) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long rem = __ballot(hit);
+  while (rem != 0ull) {
+    const int L = __ffsll((long long)rem) - 1;
+    const int o = __builtin_amdgcn_readlane(owner, L);
+    const bool mine = hit && owner == o;
+    const unsigned long long m = __ballot(mine);
+    int base = 0;
+    if (lane == L) base = atomicAdd(&hs.count[o], __popcll(m));
+    base = __builtin_amdgcn_readlane(base, L);
+    place_hit(hs, mine, o, base + __popcll(m & ((1ull << lane) - 1ull)), id, d2);
+    rem &= ~m;
+  }
+}
+
 // emitters for confirm_entry: what to do with a confirmed neighbour
 struct GlobalEmit {
   const HitSink &hs;
@@ -754,7 +772,7 @@ struct TileEmit {
     const bool in_lds = h && slot < kTbLcap;
     if (in_lds) { sm.hidx[cl][slot] = id; sm.hd2[cl][slot] = d2; }
     const bool spill = h && !in_lds;
-    if (__ballot(spill) != 0ull) emit_hit(hs, spill, owner, id, d2);
+    if (__ballot(spill) != 0ull) emit_hits_grouped(hs, spill, owner, id, d2);   // at most kTileB queries per wave
   }
 };
 
