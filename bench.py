@@ -241,6 +241,22 @@ def main():
         compute()
     fence()
     st_all = ctx.stats()
+    # the brute-force form of the search (every tile of 64 copies streams every node, north_star's
+    # kernel) is measured beside the default culled form: a short pass with culling switched off
+    bf = None
+    if args.nn_filter and args.nn_cull and st.last_scan_units > 0:
+        ctx.set_option(_capi.RRTX_OPT_NN_CULL, 0)
+        compute()
+        fence()
+        ctx.profile(1)
+        for i in range(5):
+            compute()
+        fence()
+        st_bf = ctx.stats()
+        bf = {"scan_ms": st_bf.ms_nn_scan / max(st_bf.launches_nn_scan, 1), "tile_q": int(st_bf.last_tile_q)}
+        ctx.set_option(_capi.RRTX_OPT_NN_CULL, args.nn_cull)
+        compute()
+        fence()
     ctx.profile(0)
 
     # ---- aggregate over ranks ----------------------------------------------------
@@ -259,11 +275,24 @@ def main():
         valu_ops = B * N * 9                                           # 3 sub, 3 mul, 2 add, 1 cmp per (query, node)
         # HBM-side bytes per launch of this kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE,
         # rocprofv3 --pmc, scripts_gpu_pmc.sh); PMC counters cannot be read inside this process.
+        culled = units > 0
+        kernel = ("nn_tile_kernel<3>" if culled else "nn_scan_f32_kernel<3> + nn_confirm_kernel<3>") if args.nn_filter \
+            else "nn_scan_kernel<3>"
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if args.config == "C4" and args.nn_filter and os.path.exists(tpath):
             tj = json.load(open(tpath))
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 PMC passes)"
+            if tj.get("kernel") == kernel:
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 PMC passes)"
+        roof_bf = None
+        if bf:
+            nt = (B + bf["tile_q"] - 1) // bf["tile_q"]
+            by = nt * N * 24 + B * 32 + k_total * 16
+            ach = by / (bf["scan_ms"] * 1e-3) / 1e9
+            roof_bf = {"kernel": "nn_scan_f32_kernel<3> + nn_confirm_kernel<3> (RRTX_OPT_NN_CULL=0)", "bound": "hbm",
+                       "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                       "algorithmic_bytes_per_launch": by, "tile_q": bf["tile_q"], "ms": bf["scan_ms"],
+                       "pairs_per_s": B * N / (bf["scan_ms"] * 1e-3)}
         out = {
             "metric": "collision-checked edges/sec + radius-NN queries/sec at N=200k nodes, 256 obs",
             "value": e_sum * args.steps / t_max,
@@ -288,7 +317,7 @@ def main():
                 "points": st_all.ms_points / 5,
             },
             "roofline": {
-                "kernel": "nn_scan_f32_kernel<3>" if args.nn_filter else "nn_scan_kernel<3>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_streamed, "tile_q": tile_q,
@@ -296,8 +325,12 @@ def main():
                 "node_visits_unculled": n_tiles * N,
                 "pairs_per_s": B * N / (scan_ms * 1e-3),
                 "valu_fp64_frac": (valu_ops / (scan_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS) if not args.nn_filter else None,
-                "note": "VALU-issue bound, node arrays are L2-resident (PMC traffic ~0.02 GB/launch); see DESIGN.md",
+                "note": ("culled search: bytes = chunks actually streamed x 512 nodes x 24 B (SURVEY 8d figure per node "
+                         "visit, T_q = tile_q); the kernel is latency / issue bound and its working set is L2-resident, "
+                         "see DESIGN.md 4.1") if culled else
+                        "VALU-issue bound, node arrays are L2-resident; see DESIGN.md",
             },
+            "roofline_bruteforce": roof_bf,
         }
         if world == 1:
             # the same step through the host-pointer entry point (what a ccall from Julia pays):

@@ -155,17 +155,8 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
     sx[base + i] = fa; sy[base + i] = fb; sz[base + i] = fc;
     dx[base + i] = a; dy[base + i] = b; dz[base + i] = c;
     sid[base + i] = (int32_t)(base + i);
-    const long long ch = (base + i) / kSlabChunk;
-    if (a == a) {
-      xlo = xhi = enc_ord(a);
-      atomicMin(&chunk_ext[ch].xlo, xlo);
-      atomicMax(&chunk_ext[ch].xhi, xhi);
-    }
-    if (b == b) {
-      ylo = yhi = enc_ord(b);
-      atomicMin(&chunk_ext[ch].ylo, ylo);
-      atomicMax(&chunk_ext[ch].yhi, yhi);
-    }
+    if (a == a) xlo = xhi = enc_ord(a);
+    if (b == b) ylo = yhi = enc_ord(b);
     double pp = (double)fa * (double)fa + (double)fb * (double)fb + (double)fc * (double)fc;
     m = max(max((unsigned long long)__double_as_longlong(fabs(sa)), (unsigned long long)__double_as_longlong(fabs(sb))),
             (unsigned long long)__double_as_longlong(fabs(sc)));
@@ -184,6 +175,15 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
     spp[base + i] = (float)pp;
     reinterpret_cast<double4 *>(aos)[base + i] = make_double4(a, b, c, dim == 4 ? pos[i * dim + 3] : 0.0);
   }
+  // chunk extents: the 64 positions of a wave lie in one chunk unless they straddle a chunk
+  // boundary; then one lane updates the chunk with the wave's extent, otherwise every lane its own
+  const long long ch = (base + i) / kSlabChunk;
+  const long long ch_first = (base + ((long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63))) / kSlabChunk;
+  const bool one_chunk = __ballot(i < n && ch != ch_first) == 0ull;
+  if (!one_chunk && i < n) {
+    if (xlo != ~0ull) { atomicMin(&chunk_ext[ch].xlo, xlo); atomicMax(&chunk_ext[ch].xhi, xhi); }
+    if (ylo != ~0ull) { atomicMin(&chunk_ext[ch].ylo, ylo); atomicMax(&chunk_ext[ch].yhi, yhi); }
+  }
   for (int off = 32; off > 0; off >>= 1) {
     unsigned long long o = __shfl_xor(m, off);
     m = max(m, o);
@@ -197,6 +197,10 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
     yhi = max(yhi, o);
   }
   if ((threadIdx.x & 63) == 0) {
+    if (one_chunk) {
+      if (xlo != ~0ull) { atomicMin(&chunk_ext[ch_first].xlo, xlo); atomicMax(&chunk_ext[ch_first].xhi, xhi); }
+      if (ylo != ~0ull) { atomicMin(&chunk_ext[ch_first].ylo, ylo); atomicMax(&chunk_ext[ch_first].yhi, yhi); }
+    }
     if (m != 0ull) atomicMax(absmax, m);
     if (xlo != ~0ull) { atomicMin(&xrange[0], xlo); atomicMax(&xrange[1], xhi); }
     if (ylo != ~0ull) { atomicMin(&xrange[2], ylo); atomicMax(&xrange[3], yhi); }

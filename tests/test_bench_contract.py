@@ -18,7 +18,7 @@ def test_bench_help_runs_without_gpu():
 
 def test_committed_bench_line_has_the_contract_fields():
     baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_bench.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_v5_bench.json")))
     assert line["metric"] == baseline["metric"]
     for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
