@@ -1,19 +1,22 @@
-// kernels_nn.hip -- batched brute-force nearest / radius search over the node SoA.
+// kernels_nn.hip -- batched nearest / radius search over the node SoA.
 // Replaces kdFindNearest / kdFindWithinRange (R/kdTree_general.jl:254-385,
 // 800-955) and the ghost-point handling for wrapped dimensions
 // (R/ghostPoint.jl:60-111).  gfx950 only: 64-lane waves, scalar (SMEM) query
-// stream, wave-ballot hit compaction.
+// stream, packed fp32 screen, exact fp64 confirmation.
 //
-// Radius search pipeline (all on ctx->stream, no host sync):
-//   pack    : queries -> slot table (query + ghosts) and the compact copy list
-//   scan    : every (copy, node) pair; lane = node (U nodes per lane held in
-//             VGPRs), the copy tile is streamed through SGPRs; rare hits are
-//             appended to a record buffer with one atomic per wave
-//   rootfix : the reference includes the root with <= instead of <
-//             (R/kdTree_general.jl:896 vs :830)
+// Radius search pipeline (all on ctx->stream, no host sync; DESIGN.md 4.1):
+//   pack    : queries -> slot table (query + ghosts), copy records, (x, y) bucket and rank of
+//             every copy, the root rule (<= instead of <, R/kdTree_general.jl:896 vs :830),
+//             per-call state
+//   place   : copies in bucket order + their fp32 screen records      (culled search)
+//   tile    : per tile of 16 copies: chunks within reach -> fp32 screen -> exact confirmation
+//             -> hits into the queries' buckets                          (culled search)
+//   [ prep, scan, confirm : the same three steps for the brute-force search, every tile of 64
+//             copies streams every node ]
 //   offsets : exclusive scan of the per-query counts
-//   scatter : records -> per-query segments
-//   order   : per query: sort by node index, dist = sqrt(d2)
+//   scatter : overflow list -> behind the buckets (normally nothing to do)
+//   order   : per query: sort by node index, dist = sqrt(d2), owner, nearest
+//   order_big: the same for lists longer than 64
 #include "exact_math.hpp"
 #include "rrtx_internal.hpp"
 

@@ -144,9 +144,9 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_copies_f; // fp32 prefilter copies
   rrtx::DevBuf ws_copy_meta;// int32 owner, slot per copy
   rrtx::DevBuf ws_copies_s, ws_meta_s;  // copies / meta in x-bucket order (culled scan)
-  rrtx::DevBuf ws_cb, ws_qhist, ws_qstart, ws_units;
+  rrtx::DevBuf ws_cb, ws_qhist;         // (bucket, rank) per copy; bucket histogram
   rrtx::DevBuf ws_bkt_idx, ws_bkt_d2;   // per-query hit buckets
-  rrtx::DevBuf ws_ev_a, ws_ev_m, ws_ev_cnt, ws_confirm_args;   // flagged (copy, chunk) events per scan wave
+  rrtx::DevBuf ws_ev_a, ws_ev_cnt, ws_confirm_args;   // per-wave entry slices, their counts, confirm arguments
   rrtx::DevBuf ws_recs;     // HitRec
   rrtx::DevBuf ws_counts;   // int32 count[nq], cursor[nq]
   rrtx::DevBuf ws_bsum;     // int64 per-256-query sums of count (first level of the offsets scan)
