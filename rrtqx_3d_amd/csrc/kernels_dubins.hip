@@ -331,19 +331,35 @@ __device__ bool seg_hits_polygon(double ax, double ay, double bx, double by, dou
   return false;
 }
 
-// two-stage test of one steered edge against the polygon list (:750-774)
+// two-stage test of one steered edge against the polygon list (:750-774).  The reference walks
+// the obstacle list and, for an obstacle whose inflated chord test (stage 1) fails to clear it,
+// every polyline piece (stage 2); the answer is the OR over all (obstacle, piece) tests, so the
+// loops may be swapped: stage 1 marks up to 64 obstacles in a bit mask, then the polyline is
+// generated ONCE (two transcendentals per point) and every piece is tested against the marked
+// obstacles.  Same set of tests, same arithmetic in each.
 __device__ bool dubins_collides(const Steer &st, double sx, double sy, double gx, double gy, double r_min,
                                 double robot_radius, const double *__restrict__ meta,
                                 const int32_t *__restrict__ off, const double *__restrict__ vxy, int m) {
-  for (int j = 0; j < m; ++j) {
-    if (!seg_hits_polygon(sx, sy, gx, gy, robot_radius + 2 * r_min, meta, off, vxy, j)) continue;
+  for (int j0 = 0; j0 < m; j0 += 64) {
+    const int j1 = (j0 + 64 < m) ? j0 + 64 : m;
+    unsigned long long mask = 0ull;
+    for (int j = j0; j < j1; ++j)
+      if (seg_hits_polygon(sx, sy, gx, gy, robot_radius + 2 * r_min, meta, off, vxy, j)) mask |= 1ull << (j - j0);
+    if (mask == 0ull) continue;
     double px = 0, py = 0;
     int row = 0;
     for (int pi = 0; pi < 3; ++pi) {
       for (int k = 0; k < st.pc[pi].len; ++k, ++row) {
         double x, y;
         piece_point(st.pc[pi], k, r_min, x, y);
-        if (row > 0 && seg_hits_polygon(px, py, x, y, robot_radius, meta, off, vxy, j)) return true;
+        if (row > 0) {
+          unsigned long long mm = mask;
+          while (mm != 0ull) {
+            const int j = j0 + __ffsll((long long)mm) - 1;
+            mm &= mm - 1ull;
+            if (seg_hits_polygon(px, py, x, y, robot_radius, meta, off, vxy, j)) return true;
+          }
+        }
         px = x; py = y;
       }
     }
