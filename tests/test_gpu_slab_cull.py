@@ -212,3 +212,46 @@ def test_cull_large_batch_walks_tiles_and_block_sums():
                 want = np.concatenate([[0], want])
             assert np.array_equal(idx[off[i]:off[i + 1]], want)
             assert np.array_equal(dist[off[i]:off[i + 1]], np.sqrt(s[want]))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_cull_randomised_scenarios(oracle, seed):
+    """random trees (uniform / clustered / duplicated points / lattice), appended in random pieces
+    with searches in between, random per-query radii, with and without a wrapped dimension:
+    culled == brute force == oracle after every piece"""
+    rng = np.random.default_rng(1000 + seed)
+    d = 3 if seed % 2 == 0 else 4
+    n = int(rng.integers(2_000, 14_000))
+    kind = seed % 4
+    if kind == 0:
+        pts = rng.uniform(-30, 30, (n, d))
+    elif kind == 1:                                   # a few tight clusters + background
+        c = rng.uniform(-30, 30, (5, d))
+        pts = c[rng.integers(0, 5, n)] + rng.normal(0, 0.7, (n, d))
+        pts[: n // 10] = rng.uniform(-30, 30, (n // 10, d))
+    elif kind == 2:                                   # many exact duplicates
+        base = rng.uniform(-30, 30, (n // 8 + 1, d))
+        pts = base[rng.integers(0, len(base), n)]
+    else:                                             # integer lattice: ties in x and y everywhere
+        pts = rng.integers(-12, 13, (n, d)).astype(np.float64)
+    wraps, wrap_points = (None, None)
+    if d == 4:
+        pts[:, 3] = rng.uniform(0, 2 * math.pi, n)
+        pts[:, 2] = 0.0
+        wraps, wrap_points = [3], [2 * math.pi]
+    nq = int(rng.integers(1, 400))
+    Q = pts[rng.integers(0, n, nq)] + rng.normal(0, 1.5, (nq, d))
+    if d == 4:
+        Q[:, 3] = np.mod(Q[:, 3], 2 * math.pi)
+    r = rng.uniform(0.0, 6.0, nq)
+    tree = oracle.KDTree(d, wraps=wraps, wrap_points=wrap_points)
+    with Context(d, node_capacity=1024) as ctx:
+        if d == 4:
+            ctx.set_wrap(3, 2 * math.pi)
+        cuts = sorted(set([n] + [int(x) for x in rng.integers(1, n, 3)]))
+        done = 0
+        for upto in cuts:
+            ctx.nodes_append(pts[done:upto])
+            tree.insert_many(pts[done:upto])
+            done = upto
+            _both_modes(ctx, Q, r, _oracle_lists(tree, Q, r))
