@@ -96,6 +96,10 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
  *   pairs that provably fail the exact test; results are identical.  0 = off (every tile
  *   streams every node), 1 = on for trees of at least 8192 nodes, 2 = always on. */
 #define RRTX_OPT_NN_CULL 5
+/*   RRTX_OPT_PROFILE_EVERY (default 1): with rrtx_profile level 1, only every n-th launch of the
+ *   range-search kernel is bracketed by HIP events (an event record between two kernels drains the
+ *   pipeline for several microseconds); rrtx_stats then reports the timed launches only. */
+#define RRTX_OPT_PROFILE_EVERY 6
 int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value);
 
 /* Host-only helper (no GPU needed): the exact thresholds on SQUARED distances the kernels

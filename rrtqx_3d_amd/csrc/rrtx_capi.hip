@@ -92,8 +92,13 @@ void span_begin(rrtx_ctx *ctx, int family) {
   ctx->fam_launches[family] += 1;
   // level 1 times only the dominant kernel family: every event record costs ~10 us of pipeline
   // drain between two kernels that would otherwise run back to back
-  ctx->span_open = ctx->profiling == 2 || (ctx->profiling == 1 && family == KF_NN_SCAN);
-  if (!ctx->span_open) return;
+  ctx->span_open = ctx->profiling == 2;
+  if (ctx->profiling == 1 && family == KF_NN_SCAN) {
+    // level 1 may sample: only every opt_profile_every-th launch of the family carries events
+    ctx->span_tick += 1;
+    ctx->span_open = ctx->span_tick % ctx->opt_profile_every == 0;
+  }
+  if (!ctx->span_open) { ctx->fam_launches[family] -= 1; return; }   // launches = timed launches
   TimedSpan s;
   s.a = take_event(ctx);
   s.b = take_event(ctx);
@@ -404,6 +409,7 @@ int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value) {
     case RRTX_OPT_SCAN_ITEMS: ctx->opt_scan_items = value > 0 ? (int)value : 2048; return RRTX_OK;
     case RRTX_OPT_SCAN_TILE_Q: ctx->opt_tile_q = value > 0 ? (int)value : 0; return RRTX_OK;
     case RRTX_OPT_NN_CULL: ctx->opt_nn_cull = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RRTX_OK;
+    case RRTX_OPT_PROFILE_EVERY: ctx->opt_profile_every = value > 1 ? (int)value : 1; return RRTX_OK;
     default: return fail(ctx, RRTX_E_INVALID, "set_option: unknown option %d", option);
   }
 }

@@ -107,6 +107,8 @@ struct rrtx_ctx {
   int opt_scan_items = 2048;        // target number of (tile, segment) work items
   int opt_tile_q = 0;               // query copies per workgroup tile (0 = kernel default)
   int opt_nn_cull = 1;              // 0 off, 1 auto (trees of >= 8192 nodes), 2 always
+  int opt_profile_every = 1;        // profiling level 1 times every n-th launch of the search kernel
+  long long span_tick = 0;
 
   // wrapped dimensions
   int n_wraps = 0;
