@@ -33,6 +33,15 @@ def test_radius_full_size_properties(oracle, cfg_name):
         off0, idx0, dist0 = ctx.nn_radius(Q, r)
         ctx.set_option(_capi.RRTX_OPT_NN_FILTER, 1)
         assert np.array_equal(off, off0) and np.array_equal(idx, idx0) and np.array_equal(dist, dist0)
+        # (2b) and so does the brute-force screened search (every tile streams every node); the
+        # default call above took the culled path, and says so in its statistics
+        assert ctx.stats().last_scan_units == 0
+        ctx.set_option(_capi.RRTX_OPT_NN_CULL, 0)
+        off1, idx1, dist1 = ctx.nn_radius(Q, r)
+        ctx.set_option(_capi.RRTX_OPT_NN_CULL, 1)
+        assert np.array_equal(off, off1) and np.array_equal(idx, idx1) and np.array_equal(dist, dist1)
+        ctx.nn_radius(Q[:64], r)
+        assert ctx.stats().last_scan_units > 0
         # (1a) every list is strictly ascending in node index, every key is < r and equals the metric
         owner = np.repeat(np.arange(B), np.diff(off))
         assert (dist < r).all()
