@@ -1,0 +1,424 @@
+// kernels_nearest.hip -- batched kdFindNearest (R/kdTree_general.jl:254-385) over the node SoA:
+// exact fp64 scan and the screened fast path.  gfx950 only.
+#include "nn_device.hpp"
+
+#include <limits>
+
+namespace rrtx {
+
+namespace {
+
+// -------------------------------------------------------------- nearest -----
+// lane = query; nodes are streamed through SGPRs (wave-uniform loads).  Each
+// block handles 256 queries against one node segment and writes the segment's
+// best (d2, idx); nn_nearest_reduce picks the lexicographic minimum.
+template <int D>
+__global__ __launch_bounds__(256) void nn_nearest_partial_kernel(
+    const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
+    const double *__restrict__ nw, int n_nodes, const double *__restrict__ q, int nq, int n_wraps, int wd0,
+    int wd1, int wd2, double wp0, double wp1, double wp2, int seg_len, double *__restrict__ part_d2,
+    int32_t *__restrict__ part_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int seg = blockIdx.y;
+  const int node_begin = seg * seg_len;
+  const int node_end = min(n_nodes, node_begin + seg_len);
+  double p[4] = {0.0, 0.0, 0.0, 0.0};
+  if (i < nq) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) p[k] = q[(size_t)i * D + k];
+  }
+  const int wd[3] = {wd0, wd1, wd2};
+  const double wp[3] = {wp0, wp1, wp2};
+  double best = __builtin_inf();
+  int best_i = 0x7fffffff;
+  const int n_slots = 1 << n_wraps;
+  for (int k = 0; k < n_slots; ++k) {
+    double g[4] = {p[0], p[1], p[2], p[3]};
+    for (int w = 0; w < n_wraps; ++w) {
+      if (!((k >> (n_wraps - 1 - w)) & 1)) continue;
+      int dimi = wd[w];
+      g[dimi] = (p[dimi] < wp[w] / 2.0) ? (p[dimi] + wp[w]) : (p[dimi] - wp[w]);
+    }
+#pragma unroll 4
+    for (int n = node_begin; n < node_end; ++n) {
+      double s;
+      if constexpr (D == 4) s = sq4(g[0], g[1], g[2], g[3], nx[n], ny[n], nz[n], nw[n]);
+      else s = sq3(g[0], g[1], g[2], nx[n], ny[n], nz[n]);
+      bool better = (s < best) || (s == best && n < best_i);
+      best = better ? s : best;
+      best_i = better ? n : best_i;
+    }
+  }
+  if (i < nq) {
+    part_d2[(size_t)seg * nq + i] = best;
+    part_idx[(size_t)seg * nq + i] = best_i;
+  }
+}
+
+__global__ void nn_nearest_reduce_kernel(const double *__restrict__ part_d2,
+                                         const int32_t *__restrict__ part_idx, int nq, int n_seg,
+                                         int32_t *__restrict__ idx, double *__restrict__ dist) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  double best = __builtin_inf();
+  int best_i = 0x7fffffff;
+  for (int s = 0; s < n_seg; ++s) {
+    double d2 = part_d2[(size_t)s * nq + i];
+    int id = part_idx[(size_t)s * nq + i];
+    bool better = (d2 < best) || (d2 == best && id < best_i);
+    best = better ? d2 : best;
+    best_i = better ? id : best_i;
+  }
+  idx[i] = best_i;
+  dist[i] = sqrt_rn(best);
+}
+
+// nearest from the radius lists (valid when the list is non-empty): the first
+// minimum of the stored keys, ties to the lowest index (lists are index-sorted)
+__global__ void nn_nearest_from_lists_kernel(const int64_t *__restrict__ offsets, const int32_t *__restrict__ idx,
+                                             const double *__restrict__ dist, int nq,
+                                             int32_t *__restrict__ nearest_idx,
+                                             double *__restrict__ nearest_dist) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  double best = __builtin_inf();
+  int best_i = -1;
+  for (int64_t k = offsets[i]; k < offsets[i + 1]; ++k) {
+    double d = dist[k];
+    if (d < best) { best = d; best_i = idx[k]; }
+  }
+  nearest_idx[i] = best_i;   // -1: empty list, caller falls back to the full scan
+  nearest_dist[i] = best;
+}
+
+// ------------------------------------------------ nearest, screened (fast path) ------
+// kdFindNearest for a batch: lane = query copy, nodes streamed through SGPRs 8 at a time.
+// Each lane keeps the running minimum of the fp32 screen value t (see "fp32 prefilter");
+// for two nodes i, j of the same copy, "i is at least as close as j" in exact arithmetic
+// implies  t_i <= t_j + M  with  M = (2K + 16 D + 4) eps C^2  (both roundings of t, plus the
+// effect of the fp32 conversions on the two distances).  So every node that can be the exact
+// nearest satisfies t <= running_min + M when it is visited; those few nodes (about ln(n) per
+// segment) are queued and confirmed with the exact unfused fp64 distance:
+//   atomicMin on the bit pattern of d2 (monotone for non-negative doubles), then the lowest
+//   index among the records that attain it (nn_nearest_tie_kernel).
+template <int D>
+__device__ __forceinline__ void drain_nearest(const int2 *cand, int &wn, const double *__restrict__ nx,
+                                              const double *__restrict__ ny, const double *__restrict__ nz,
+                                              const double *__restrict__ nw,
+                                              const typename QRecT<D>::type *__restrict__ copies,
+                                              const int2 *__restrict__ meta, HitRec *__restrict__ recs,
+                                              long long cap, Scalars *__restrict__ sc,
+                                              unsigned long long *__restrict__ best_bits) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_wave_barrier();
+  for (int i0 = 0; i0 < wn; i0 += 64) {
+    const int i = i0 + lane;
+    const bool v = i < wn;
+    double s = 0.0;
+    int owner = 0, id = 0;
+    if (v) {
+      const int2 c = cand[i];
+      id = c.y;
+      const typename QRecT<D>::type ce = copies[c.x];
+      owner = meta[c.x].x;
+      if constexpr (D == 4) s = sq4(ce.x, ce.y, ce.z, ce.w, nx[id], ny[id], nz[id], nw[id]);
+      else s = sq3(ce.x, ce.y, ce.z, nx[id], ny[id], nz[id]);
+      atomicMin(&best_bits[owner], (unsigned long long)__double_as_longlong(s));
+    }
+    const unsigned long long mask = __ballot(v);
+    const int n = __popcll(mask);
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&sc->total, (unsigned long long)n);
+    base = __shfl(base, 0);
+    if (v) {
+      const long long pos = (long long)base + lane;
+      if (pos < cap) {
+        HitRec r;
+        r.owner = owner; r.idx = id; r.d2 = s;
+        recs[pos] = r;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  wn = 0;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void nn_nearest_f32_kernel(
+    const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
+    const double *__restrict__ nw, const float *__restrict__ fx, const float *__restrict__ fy,
+    const float *__restrict__ fz, const float *__restrict__ fw, const float *__restrict__ fpp, int n_nodes,
+    const typename QRecT<D>::type *__restrict__ copies, const typename QRecFT<D>::type *__restrict__ copies_f,
+    const int2 *__restrict__ meta, const unsigned long long *__restrict__ node_absmax, int n_seg, int seg_len,
+    HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
+    unsigned long long *__restrict__ best_bits) {
+  __shared__ int2 cand_all[4][kCandCap];
+  const int seg = blockIdx.x % n_seg;        // XCD-affine node segment
+  const int cb = blockIdx.x / n_seg;
+  const int n_copies = sc->n_copies;
+  if (cb * 256 >= n_copies) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  int2 *cand = cand_all[wave];
+  int wn = 0;
+  const int copy = cb * 256 + threadIdx.x;
+  typename QRecFT<D>::type c;
+  c.x = 0.f; c.y = 0.f; c.z = 0.f;
+  if constexpr (D == 4) c.w = 0.f;
+  bool valid = copy < n_copies;
+  if (valid) c = copies_f[copy];
+  // a NaN copy can never be ordered: it produces no candidates (result: idx INT_MAX, dist inf)
+  valid = valid && (c.x == c.x) && (c.y == c.y) && (c.z == c.z);
+  if constexpr (D == 4) valid = valid && (c.w == c.w);
+  unsigned long long cbits = max(*node_absmax, sc->q_absmax);
+  const double C = __longlong_as_double((long long)cbits);
+  const double eps = 5.9604644775390625e-08;
+  const double Kc = (D == 4) ? (2.0 * 42.0 + 16.0 * 4.0 + 4.0) : (2.0 * 26.0 + 16.0 * 3.0 + 4.0);
+  const float M = (C <= 1e15) ? __double2float_ru(Kc * eps * C * C + 1e-30) : __builtin_inff();
+  const f32x2 cx2 = {c.x, c.x}, cy2 = {c.y, c.y}, cz2 = {c.z, c.z};
+  float runmin = __builtin_inff();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int node_begin = seg * seg_len;
+  const int node_end = min(n_nodes, node_begin + seg_len);
+
+  // t of eight wave-uniform nodes starting at j (unconditional scalar loads, straight-line VALU):
+  // t = fma(cx, px, fma(cy, py, cz * pz)) + pp  (same rounding budget K as the range screen)
+  auto screen_group = [&](int j, float *t) -> float {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int a = j + 2 * v;
+      const f32x2 pz = {fz[a], fz[a + 1]}, py = {fy[a], fy[a + 1]}, px = {fx[a], fx[a + 1]};
+      const f32x2 pp = {fpp[a], fpp[a + 1]};
+      f32x2 acc = cz2 * pz;
+      if constexpr (D == 4) {
+        const f32x2 cw2 = {c.w, c.w}, pw = {fw[a], fw[a + 1]};
+        acc = __builtin_elementwise_fma(cw2, pw, acc);
+      }
+      acc = __builtin_elementwise_fma(cy2, py, acc);
+      acc = __builtin_elementwise_fma(cx2, px, acc);
+      acc = acc + pp;
+      t[2 * v] = acc.x; t[2 * v + 1] = acc.y;
+    }
+    const float m1 = fminf(fminf(t[0], t[1]), t[2]);
+    const float m2 = fminf(fminf(t[3], t[4]), t[5]);
+    const float m3 = fminf(fminf(t[6], t[7]), m1);
+    return fminf(m2, m3);
+  };
+  // warm start: the running minimum over the first nodes of the tree (no candidates are taken
+  // here; these nodes are visited again by the segment that owns them).  Starting from the best
+  // of m samples cuts the expected number of running-minimum updates per segment from ln(n) to
+  // ln((n + m) / m).
+  {
+    const int warm = min(kNearestWarm, n_nodes / 8 * 8);
+    for (int j = 0; j < warm; j += 8) {
+      float t[8];
+      runmin = fminf(runmin, screen_group(j, t));
+    }
+  }
+  const int full_end = node_begin + (node_end - node_begin) / 8 * 8;
+  for (int j = node_begin; j < full_end; j += 8) {
+    float t[8];
+    const float tmin = screen_group(j, t);
+    const float bound = runmin + M;
+    if (__builtin_expect(__ballot(valid && !(tmin > bound)) != 0ull, 0)) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned long long m = __ballot(valid && !(t[u] > bound));
+        if (m == 0ull) continue;
+        const int n = __popcll(m);
+        if (wn + n > kCandCap) drain_nearest<D>(cand, wn, nx, ny, nz, nw, copies, meta, recs, cap, sc, best_bits);
+        if ((m >> lane) & 1ull) cand[wn + __popcll(m & lt_mask)] = make_int2(copy, j + u);
+        wn += n;
+      }
+    }
+    runmin = fminf(runmin, tmin);
+  }
+  // ragged tail (< 8 nodes, only the last segment has one): every node is a candidate
+  for (int j = full_end; j < node_end; ++j) {
+    const unsigned long long m = __ballot(valid);
+    if (m == 0ull) break;
+    const int n = __popcll(m);
+    if (wn + n > kCandCap) drain_nearest<D>(cand, wn, nx, ny, nz, nw, copies, meta, recs, cap, sc, best_bits);
+    if (valid) cand[wn + __popcll(m & lt_mask)] = make_int2(copy, j);
+    wn += n;
+  }
+  drain_nearest<D>(cand, wn, nx, ny, nz, nw, copies, meta, recs, cap, sc, best_bits);
+}
+
+// lowest node index among the confirmed candidates that attain the minimum d2
+__global__ void nn_nearest_tie_kernel(const HitRec *__restrict__ recs, long long cap,
+                                      const Scalars *__restrict__ sc,
+                                      const unsigned long long *__restrict__ best_bits,
+                                      int *__restrict__ best_idx) {
+  long long total = (long long)sc->total;
+  if (total > cap) total = cap;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const HitRec r = recs[i];
+    if ((unsigned long long)__double_as_longlong(r.d2) == best_bits[r.owner]) atomicMin(&best_idx[r.owner], r.idx);
+  }
+}
+
+__global__ void nn_nearest_out_kernel(const unsigned long long *__restrict__ best_bits,
+                                      const int *__restrict__ best_idx, int nq, int32_t *__restrict__ idx,
+                                      double *__restrict__ dist) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const unsigned long long b = best_bits[i];
+  idx[i] = (b == ~0ull) ? 0x7fffffff : best_idx[i];     // no candidate (NaN query): same as the exact scan
+  dist[i] = (b == ~0ull) ? __builtin_inf() : sqrt_rn(__longlong_as_double((long long)b));
+}
+
+}  // namespace
+
+static int launch_nn_nearest_exact(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev) {
+  const int n_nodes = (int)ctx->n_nodes;
+  const int qblocks = (nq + 255) / 256;
+  int want_seg = (2048 + qblocks - 1) / qblocks;
+  int max_seg = (n_nodes + 255) / 256;
+  int n_seg = want_seg < max_seg ? want_seg : max_seg;
+  if (n_seg < 1) n_seg = 1;
+  int seg_len = (n_nodes + n_seg - 1) / n_seg;
+  n_seg = (n_nodes + seg_len - 1) / seg_len;
+  RRTX_HIP(ctx, ctx->ws_partial.ensure((size_t)n_seg * nq * (sizeof(double) + sizeof(int32_t))));
+  double *pd2 = ctx->ws_partial.as<double>();
+  int32_t *pidx = reinterpret_cast<int32_t *>(pd2 + (size_t)n_seg * nq);
+  hipStream_t st = ctx->stream;
+  span_begin(ctx, KF_NN_NEAREST);
+  dim3 grid(qblocks, n_seg), block(256);
+  if (ctx->dim == 4)
+    hipLaunchKernelGGL(nn_nearest_partial_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
+                       ctx->nodes[2], ctx->nodes[3], n_nodes, q_dev, nq, ctx->n_wraps, ctx->wrap_dim[0],
+                       ctx->wrap_dim[1], ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1],
+                       ctx->wrap_period[2], seg_len, pd2, pidx);
+  else
+    hipLaunchKernelGGL(nn_nearest_partial_kernel<3>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
+                       ctx->nodes[2], ctx->nodes[2], n_nodes, q_dev, nq, ctx->n_wraps, ctx->wrap_dim[0],
+                       ctx->wrap_dim[1], ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1],
+                       ctx->wrap_period[2], seg_len, pd2, pidx);
+  hipLaunchKernelGGL(nn_nearest_reduce_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, pd2, pidx, nq, n_seg,
+                     idx_dev, dist_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+// Screened nearest (see nn_nearest_f32_kernel).  *overflow_cap receives the record capacity used;
+// the caller compares it with Scalars.total (rrtx_capi.hip) and falls back to the exact scan when
+// an adversarial visiting order produced more candidates than fit.
+static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev,
+                                      double *dist_dev) {
+  const int D = ctx->dim;
+  const int n_slots = 1 << ctx->n_wraps;
+  const int n_nodes = (int)ctx->n_nodes;
+  hipStream_t st = ctx->stream;
+  const size_t n_copies_max = (size_t)nq * n_slots;
+  const size_t qrec_bytes = (D == 4) ? sizeof(QRec4) : sizeof(QRec3);
+  const size_t qf_bytes = (D == 4) ? sizeof(QRecF4) : sizeof(QRecF3);
+  const long long rec_cap = (long long)n_copies_max * 1024 + 4096;
+  RRTX_HIP(ctx, ctx->ws_slots.ensure(n_copies_max * sizeof(SlotRec)));
+  RRTX_HIP(ctx, ctx->ws_copies.ensure(n_copies_max * qrec_bytes));
+  RRTX_HIP(ctx, ctx->ws_copies_f.ensure((n_copies_max + kQPI) * qf_bytes));
+  RRTX_HIP(ctx, ctx->ws_copy_meta.ensure(n_copies_max * sizeof(int2)));
+  RRTX_HIP(ctx, ctx->ws_scalars_nn.ensure(sizeof(Scalars)));
+  RRTX_HIP(ctx, ctx->ws_recs.ensure((size_t)rec_cap * sizeof(HitRec)));
+  RRTX_HIP(ctx, ctx->ws_partial.ensure((size_t)nq * (sizeof(unsigned long long) + sizeof(int))));
+  unsigned long long *best_bits = ctx->ws_partial.as<unsigned long long>();
+  int *best_idx = reinterpret_cast<int *>(best_bits + nq);
+  Scalars *sc = ctx->ws_scalars_nn.as<Scalars>();
+  hipLaunchKernelGGL(nn_init_kernel, dim3((nq + 255) / 256 < 64 ? (nq + 255) / 256 : 64), dim3(256), 0, st, sc,
+                     (ctx->n_wraps == 0) ? nq : 0, (int *)nullptr, 0, best_bits, nq, ~0ull, best_idx, nq, 0x7fffffff,
+                     (ConfirmArgs *)nullptr, ConfirmArgs{});
+  const double inf = std::numeric_limits<double>::infinity();
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+
+  // launch geometry: blocks of 256 copies x node segments (segment fast-varying -> XCD affine)
+  const int cblocks = (int)((n_copies_max + 255) / 256);
+  int want_seg = (2048 + cblocks - 1) / cblocks;
+  int max_seg = (n_nodes + 1023) / 1024;
+  int n_seg = want_seg < max_seg ? want_seg : max_seg;
+  if (n_seg < 1) n_seg = 1;
+  if (n_seg >= 8) n_seg = n_seg / 8 * 8;
+  int seg_len = round_up((n_nodes + n_seg - 1) / n_seg, 8);
+  n_seg = (n_nodes + seg_len - 1) / seg_len;
+
+  span_begin(ctx, KF_NN_NEAREST);
+  {
+    dim3 grid((nq + 255) / 256), block(256);
+    dim3 pgrid((unsigned)((n_copies_max + kQPI + 255) / 256));
+    dim3 sgrid((unsigned)cblocks * (unsigned)n_seg);
+    if (D == 4) {
+      hipLaunchKernelGGL(nn_pack_kernel<4>, grid, block, 0, st, q_dev, nq, (const double *)nullptr,
+                         (const double *)nullptr, inf, nan, ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1],
+                         ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
+                         ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
+                         ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec4>(), ctx->ws_copy_meta.as<int2>(), sc,
+                         (const unsigned long long *)nullptr, 1, (int *)nullptr, (int2 *)nullptr, PackFused{},
+                         ConfirmArgs{});
+      hipLaunchKernelGGL(nn_filter_prep_kernel<4>, pgrid, block, 0, st, ctx->ws_copies.as<QRec4>(), sc,
+                         ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
+                         ctx->origin[2], ctx->origin[3], ctx->ws_copies_f.as<QRecF4>());
+      hipLaunchKernelGGL(nn_nearest_f32_kernel<4>, sgrid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                         ctx->nodes[3], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[3],
+                         ctx->nodes_pp, n_nodes, ctx->ws_copies.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(),
+                         ctx->ws_copy_meta.as<int2>(), ctx->d_absmax.as<unsigned long long>(), n_seg, seg_len,
+                         ctx->ws_recs.as<HitRec>(), rec_cap, sc, best_bits);
+    } else {
+      hipLaunchKernelGGL(nn_pack_kernel<3>, grid, block, 0, st, q_dev, nq, (const double *)nullptr,
+                         (const double *)nullptr, inf, nan, ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1],
+                         ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
+                         ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
+                         ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec3>(), ctx->ws_copy_meta.as<int2>(), sc,
+                         (const unsigned long long *)nullptr, 1, (int *)nullptr, (int2 *)nullptr, PackFused{},
+                         ConfirmArgs{});
+      hipLaunchKernelGGL(nn_filter_prep_kernel<3>, pgrid, block, 0, st, ctx->ws_copies.as<QRec3>(), sc,
+                         ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
+                         ctx->origin[2], ctx->origin[3], ctx->ws_copies_f.as<QRecF3>());
+      hipLaunchKernelGGL(nn_nearest_f32_kernel<3>, sgrid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
+                         ctx->nodes[2], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[2],
+                         ctx->nodes_pp, n_nodes, ctx->ws_copies.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(),
+                         ctx->ws_copy_meta.as<int2>(), ctx->d_absmax.as<unsigned long long>(), n_seg, seg_len,
+                         ctx->ws_recs.as<HitRec>(), rec_cap, sc, best_bits);
+    }
+    hipLaunchKernelGGL(nn_nearest_tie_kernel, dim3(1024), dim3(256), 0, st, ctx->ws_recs.as<HitRec>(), rec_cap, sc,
+                       best_bits, best_idx);
+    hipLaunchKernelGGL(nn_nearest_out_kernel, grid, block, 0, st, best_bits, best_idx, nq, idx_dev, dist_dev);
+  }
+  span_end(ctx);
+  ctx->last_nearest_cap = rec_cap;
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev, bool exact) {
+  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "nearest search on an empty tree");
+  if (nq <= 0) return RRTX_OK;
+  ctx->last_nearest_cap = 0;
+  if (exact || !ctx->opt_nn_filter) return launch_nn_nearest_exact(ctx, q_dev, nq, idx_dev, dist_dev);
+  return launch_nn_nearest_screened(ctx, q_dev, nq, idx_dev, dist_dev);
+}
+
+// number of candidate records the last screened nearest call produced (device scalar)
+int nearest_candidates(rrtx_ctx *ctx, long long *total) {
+  unsigned long long t = 0;
+  RRTX_HIP(ctx, hipMemcpyAsync(&t, &ctx->ws_scalars_nn.as<Scalars>()->total, sizeof(t), hipMemcpyDeviceToHost,
+                               ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *total = (long long)t;
+  return RRTX_OK;
+}
+
+int launch_nearest_from_lists(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
+                              const int32_t *idx_dev, const double *dist_dev, int32_t *nearest_idx_dev,
+                              double *nearest_dist_dev) {
+  (void)q_dev;
+  if (nq <= 0) return RRTX_OK;
+  span_begin(ctx, KF_NN_FINISH);
+  hipLaunchKernelGGL(nn_nearest_from_lists_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream,
+                     offsets_dev, idx_dev, dist_dev, nq, nearest_idx_dev, nearest_dist_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+}  // namespace rrtx

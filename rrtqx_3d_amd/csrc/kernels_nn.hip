@@ -1,8 +1,9 @@
-// kernels_nn.hip -- batched nearest / radius search over the node SoA.
-// Replaces kdFindNearest / kdFindWithinRange (R/kdTree_general.jl:254-385,
-// 800-955) and the ghost-point handling for wrapped dimensions
-// (R/ghostPoint.jl:60-111).  gfx950 only: 64-lane waves, scalar (SMEM) query
-// stream, packed fp32 screen, exact fp64 confirmation.
+// kernels_nn.hip -- batched radius search over the node SoA.
+// Replaces kdFindWithinRange (R/kdTree_general.jl:800-955) and the ghost-point
+// handling for wrapped dimensions (R/ghostPoint.jl:60-111); kdFindNearest lives in
+// kernels_nearest.hip, the slab index in kernels_slab.hip, shared device code in
+// nn_device.hpp.  gfx950 only: 64-lane waves, scalar (SMEM) query stream, packed
+// fp32 screen, exact fp64 confirmation.
 //
 // Radius search pipeline (all on ctx->stream, no host sync):
 //   pack    : queries -> slot table (query + ghosts), copy records, (x, y) bucket and rank of
@@ -17,8 +18,7 @@
 //   scatter : overflow list -> behind the buckets (normally nothing to do)
 //   order   : per query: sort by node index, dist = sqrt(d2), owner, nearest
 //   order_big: the same for lists longer than 64
-#include "exact_math.hpp"
-#include "rrtx_internal.hpp"
+#include "nn_device.hpp"
 
 #include <limits>
 
@@ -26,273 +26,8 @@ namespace rrtx {
 
 namespace {
 
-constexpr int kScanU = 4;        // nodes per lane
-constexpr int kScanThreads = 256;
-constexpr int kChunk = 64 * kScanU;  // nodes per wave per chunk
-
-// device scalars in ws_scalars
-struct Scalars {
-  unsigned long long total;        // records produced by scan + rootfix
-  int n_copies;                    // valid query copies
-  int n_units;                     // (tile, chunk) units of the culled range scan
-  unsigned long long q_absmax;     // bit pattern of max |coordinate| over the query copies
-};
-
-// Where confirmed neighbours go.  count[q] hands out slots of query q's bucket (a returning
-// atomic per hit, but on one address per query, so they spread over the L2 channels; a single
-// shared counter sustains only ~88 returning atomics/us on MI355X).  A hit beyond the bucket
-// capacity goes to the shared overflow list, one atomic per wave.  count[q] ends as the exact
-// list length either way.
-struct HitSink {
-  int *count;
-  int32_t *bidx;        // [nq][bcap]
-  double *bd2;          // [nq][bcap]
-  int bcap;
-  int pad;
-  HitRec *recs;         // overflow list
-  long long cap;
-  Scalars *sc;          // ->total: entries of the overflow list
-};
-
-// arguments of the exact confirmation (see "Rare path of the range scan")
-struct ConfirmArgs {
-  const double *nx, *ny, *nz, *nw;   // node coordinates by shadow POSITION (fp64)
-  const void *copies;                // QRec3 / QRec4, in the order the scan indexes them
-  const int2 *meta;
-  const SlotRec *slots;
-  const int32_t *pos_id;             // node index of a shadow position, null = identity
-  int n_slots;
-  int pad;
-  HitSink hs;
-};
-
-// fp32 copy record for the prefilter: 16 B (D=3) / 32 B (D=4), one scalar load
-struct alignas(16) QRecF3 { float x, y, z, thr; };
-struct alignas(32) QRecF4 { float x, y, z, w, thr, pad0, pad1, pad2; };
-template <int D> struct QRecFT;
-template <> struct QRecFT<3> { using type = QRecF3; };
-template <> struct QRecFT<4> { using type = QRecF4; };
-
-constexpr int kTileQExact = 32;            // query copies per workgroup tile, exact fp64 scan
-constexpr int kTileQFilter = 64;           // ... fp32-prefilter scan
-constexpr int kScanFU = 8;                 // nodes per lane in the fp32-prefilter scan
-constexpr int kQPI = 4;                    // query copies per inner iteration (amortises loop/branch/SMEM overhead)
-constexpr int kChunkF = 64 * kScanFU;
-
-// ---------------------------------------------------------------- init ------
-// per-call device state in one launch (a 24-byte H2D copy from pageable memory plus a memset were
-// three runtime kernels and ~20 us)
-__global__ void nn_init_kernel(Scalars *__restrict__ sc, int n_copies_init, int *__restrict__ zero_i32, int n_i32,
-                               unsigned long long *__restrict__ fill_u64, int n_u64, unsigned long long v_u64,
-                               int *__restrict__ fill_i32, int n_fill_i32, int v_i32,
-                               ConfirmArgs *__restrict__ ca_dst, ConfirmArgs ca) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int stride = gridDim.x * blockDim.x;
-  if (i == 0) {
-    sc->total = 0ull; sc->n_copies = n_copies_init; sc->n_units = 0; sc->q_absmax = 0ull;
-    if (ca_dst) *ca_dst = ca;
-  }
-  for (int k = i; k < n_i32; k += stride) zero_i32[k] = 0;
-  for (int k = i; k < n_u64; k += stride) fill_u64[k] = v_u64;
-  for (int k = i; k < n_fill_i32; k += stride) fill_i32[k] = v_i32;
-}
-
-// ---------------------------------------------------------------- pack ------
-// What the radius search folds into the pack pass (all null / zero for the nearest search):
-//   * per-call state: count[i] (with the root rule below), the long-list counter, the device
-//     copy of the confirmation arguments, and the reset of the scalars the NEXT call will use
-//     (the calls alternate between two Scalars records, so no separate init launch is needed);
-//   * the root rule: kdFindWithinRange adds the root when distToRoot <= range
-//     (R/kdTree_general.jl:896) while every other node needs < range (:830): the scan finds the
-//     root only when <, so a root at exactly the range is entered here as the first list entry.
-struct PackFused {
-  int *count;                      // [nq] list lengths, [nq] = long-list counter
-  Scalars *sc_next;
-  ConfirmArgs *ca_dst;
-  const double *nx, *ny, *nz, *nw; // node arrays (the root is node 0)
-};
-
-template <int D>
-__global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const double *__restrict__ thr_lt_arr,
-                               const double *__restrict__ thr_gt_arr, double thr_lt_s, double thr_gt_s,
-                               int n_wraps, int wd0, int wd1, int wd2, double wp0, double wp1, double wp2,
-                               double ox, double oy, double oz, double ow,
-                               SlotRec *__restrict__ slots, typename QRecT<D>::type *__restrict__ copies,
-                               int2 *__restrict__ meta, Scalars *__restrict__ sc,
-                               const unsigned long long *__restrict__ xrange, int n_buckets,
-                               int *__restrict__ qhist, int2 *__restrict__ cb, PackFused pf, ConfirmArgs ca) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool act = i < nq;
-  if (i == 0 && pf.count) {
-    pf.count[nq] = 0;
-    *pf.ca_dst = ca;
-    Scalars *nx_sc = pf.sc_next;
-    nx_sc->total = 0ull; nx_sc->n_copies = 0; nx_sc->n_units = 0; nx_sc->q_absmax = 0ull;
-    if (n_wraps == 0) sc->n_copies = nq;       // nobody counts copies then: one per query
-  }
-  unsigned long long am = 0ull;                // max |copy - origin| feeds the prefilter's rounding bound
-  if (act) {
-    // culled scan: copies are bucketed by (x, y) cell over the extent of the node coordinates,
-    // n_buckets = side * side
-    double bx0 = 0.0, bxi = 0.0, by0 = 0.0, byi = 0.0;
-    int side = 1;
-    if (qhist) {
-      while (side * side < n_buckets) side <<= 1;
-      slab_map(xrange[0], xrange[1], side, &bx0, &bxi);
-      slab_map(xrange[2], xrange[3], side, &by0, &byi);
-    }
-    double p[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < D; ++k) p[k] = q[(size_t)i * D + k];
-    const double tlt = thr_lt_arr ? thr_lt_arr[i] : thr_lt_s;
-    const double tgt = thr_gt_arr ? thr_gt_arr[i] : thr_gt_s;
-    const int n_slots = 1 << n_wraps;
-    const int wd[3] = {wd0, wd1, wd2};
-    const double wp[3] = {wp0, wp1, wp2};
-    if (pf.count) {
-      const double s = (D == 4) ? sq4(p[0], p[1], p[2], p[3], pf.nx[0], pf.ny[0], pf.nz[0], pf.nw[0])
-                                : sq3(p[0], p[1], p[2], pf.nx[0], pf.ny[0], pf.nz[0]);
-      const bool add = s >= tlt && s < tgt;
-      pf.count[i] = add ? 1 : 0;
-      if (add) {                               // bcap >= 8: entry 0 of the bucket always exists
-        ca.hs.bidx[(size_t)i * (size_t)ca.hs.bcap] = 0;
-        ca.hs.bd2[(size_t)i * (size_t)ca.hs.bcap] = s;
-      }
-    }
-    for (int k = 0; k < n_slots; ++k) {
-      // ghost k: bit pattern of k, the LAST wrapped dimension is the least
-      // significant bit (iteration order of getNextGhostPoint)
-      double g[4] = {p[0], p[1], p[2], p[3]};
-      double c[4] = {p[0], p[1], p[2], p[3]};
-      for (int w = 0; w < n_wraps; ++w) {
-        int bit = (k >> (n_wraps - 1 - w)) & 1;
-        if (!bit) continue;
-        int dimi = wd[w];
-        double dim_val = p[dimi];
-        double dim_closest = 0.0;
-        if (p[dimi] < wp[w] / 2.0) { dim_val += wp[w]; dim_closest += wp[w]; }
-        else { dim_val -= wp[w]; }
-        g[dimi] = dim_val;
-        c[dimi] = dim_closest;
-      }
-      bool valid = true;
-      if (k > 0) {
-        // skip when dist(closestUnwrappedPoint, ghost) > range  (R/ghostPoint.jl:104)
-        double s = (D == 4) ? sq4(c[0], c[1], c[2], c[3], g[0], g[1], g[2], g[3])
-                            : sq3(c[0], c[1], c[2], g[0], g[1], g[2]);
-        valid = !(s >= tgt);
-      }
-      SlotRec sr;
-      sr.x = g[0]; sr.y = g[1]; sr.z = g[2]; sr.w = g[3];
-      sr.thr_lt = valid ? tlt : -1.0;
-      sr.thr_gt = tgt;
-      sr.pad0 = 0.0; sr.pad1 = 0.0;
-      if (n_wraps > 0) slots[(size_t)i * n_slots + k] = sr;   // only the ghost rules read the table
-      if (valid) {
-        const double og[4] = {ox, oy, oz, ow};
-        for (int c2 = 0; c2 < D; ++c2) am = max(am, (unsigned long long)__double_as_longlong(fabs(g[c2] - og[c2])));
-        int pos = (n_wraps == 0) ? i : atomicAdd(&sc->n_copies, 1);
-        typename QRecT<D>::type qr;
-        qr.x = g[0]; qr.y = g[1]; qr.z = g[2];
-        if constexpr (D == 4) { qr.w = g[3]; qr.pad0 = 0.0; qr.pad1 = 0.0; qr.pad2 = 0.0; }
-        qr.thr = tlt;
-        copies[pos] = qr;
-        meta[pos] = make_int2(i, k);
-        if (qhist) {
-          const int b = cell_of(g[0], g[1], bx0, bxi, side, by0, byi, side);
-          cb[pos] = make_int2(b, atomicAdd(&qhist[b], 1));
-        }
-      }
-    }
-  }
-  // one atomic per wave on the shared maximum
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned long long o = __shfl_xor(am, off);
-    am = max(am, o);
-  }
-  if ((threadIdx.x & 63) == 0 && am != 0ull) atomicMax(&sc->q_absmax, am);
-}
-
-// ---------------------------------------------------------------- scan ------
-// was this node already discovered by an earlier copy (slot < my slot) of the
-// same query?  (addToRangeList keeps the first discovery, R/kdTree_general.jl:765)
-template <int D>
-__device__ __noinline__ bool seen_by_earlier_slot(const SlotRec *__restrict__ slots, int n_slots, int owner,
-                                                  int slot, int node_idx, double x, double y, double z,
-                                                  double w) {
-  for (int j = 0; j < slot; ++j) {
-    SlotRec sr = slots[(size_t)owner * n_slots + j];
-    if (sr.thr_lt < 0.0) continue;
-    double s = (D == 4) ? sq4(sr.x, sr.y, sr.z, sr.w, x, y, z, w) : sq3(sr.x, sr.y, sr.z, x, y, z);
-    double thr = (j == 0 && node_idx == 0) ? sr.thr_gt : sr.thr_lt;  // root uses <=
-    if (s < thr) return true;
-  }
-  return false;
-}
-
-// Store a hit whose slot in its query's list is already known: bucket if the slot fits, shared
-// overflow list otherwise.  Every lane of the wave calls this together (the overflow branch
-// uses a ballot).
-__device__ __forceinline__ void place_hit(const HitSink &hs, bool hit, int owner, int slot, int id, double d2) {
-  const bool inb = hit && slot < hs.bcap;
-  if (inb) {
-    const size_t at = (size_t)owner * (size_t)hs.bcap + (size_t)slot;
-    hs.bidx[at] = id;
-    hs.bd2[at] = d2;
-  }
-  const bool ov = hit && !inb;
-  const unsigned long long m = __ballot(ov);
-  if (m != 0ull) {
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(&hs.sc->total, (unsigned long long)__popcll(m));
-    base = __shfl(base, leader);
-    if (ov) {
-      const long long pos = (long long)base + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < hs.cap) {
-        HitRec r;
-        r.owner = owner; r.idx = id; r.d2 = d2;
-        hs.recs[pos] = r;
-      }
-    }
-  }
-}
-
-// one hit per call: the slot comes from the query's counter.  Whole wave together.
-__device__ __forceinline__ void emit_hit(const HitSink &hs, bool hit, int owner, int id, double d2) {
-  int slot = 0;
-  if (hit) slot = atomicAdd(&hs.count[owner], 1);
-  place_hit(hs, hit, owner, slot, id, d2);
-}
-
-// Many hits of few queries in one wave (dense balls): one counter update per distinct query.
-// Whole wave together.
-__device__ __forceinline__ void emit_hits_grouped(const HitSink &hs, bool hit, int owner, int id, double d2) {
-  const int lane = threadIdx.x & 63;
-  unsigned long long rem = __ballot(hit);
-  while (rem != 0ull) {
-    const int L = __ffsll((long long)rem) - 1;
-    const int o = __builtin_amdgcn_readlane(owner, L);
-    const bool mine = hit && owner == o;
-    const unsigned long long m = __ballot(mine);
-    int base = 0;
-    if (lane == L) base = atomicAdd(&hs.count[o], __popcll(m));
-    base = __builtin_amdgcn_readlane(base, L);
-    place_hit(hs, mine, o, base + __popcll(m & ((1ull << lane) - 1ull)), id, d2);
-    rem &= ~m;
-  }
-}
-
-// emitters for confirm_entry: what to do with a confirmed neighbour
-struct GlobalEmit {
-  const HitSink &hs;
-  __device__ __forceinline__ void operator()(bool h, int /*q*/, int owner, int id, double d2) const {
-    emit_hit(hs, h, owner, id, d2);
-  }
-};
-
+// ------------------------------------------------------- exact fp64 scan ------
+// RRTX_OPT_NN_FILTER = 0: every (copy, node) pair with the reference's arithmetic
 template <int D>
 __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
     const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
@@ -354,74 +89,6 @@ __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
   (void)lane;
 }
 
-// ------------------------------------------------------ fp32 prefilter ------
-// Conservative screen: a pair may only be DROPPED when it provably fails the
-// exact test; pairs that survive are re-tested with the exact unfused fp64
-// arithmetic, which alone decides membership ("fp32 prefilter").
-//
-// Norm expansion on coordinates shifted by the context origin o (P = p - o,
-// Q = q - o, p~ = fl32(P), q~ = fl32(Q), eps = 2^-24, C >= max |P_i|, |Q_i|):
-//     t = fma(ax, p~x, fma(ay, p~y, fma(az, p~z, pp))),  a = -2 q~,  pp = fl32(|p~|^2)
-//   |t - (|p~|^2 - 2 q~.p~)| <= K eps C^2      K = D + sum_{k<=D} (D + 2k)  (24 / 40), used: 26 / 42
-//   |q~ - p~| <= |Q - P| + 2 sqrt(D) eps C
-// so whenever the exact fp64 s < thr (=> |Q - P| <= R = sqrt(thr)(1 + 1e-15)):
-//     t <= (R + 2 sqrt(D) eps C)^2 + K eps C^2 - |q~|^2  =: thr'   (rounded UP to fp32)
-// and "t > thr'" proves s >= thr.  Non-finite or huge C disables the screen.
-template <int D>
-__device__ __forceinline__ typename QRecFT<D>::type make_qrecf(const typename QRecT<D>::type &c, double C, double ox,
-                                                               double oy, double oz, double ow) {
-  const float qx = (float)(c.x - ox), qy = (float)(c.y - oy), qz = (float)(c.z - oz);
-  float qw = 0.f;
-  double qq = (double)qx * (double)qx + (double)qy * (double)qy + (double)qz * (double)qz;
-  if constexpr (D == 4) { qw = (float)(c.w - ow); qq += (double)qw * (double)qw; }
-  float thr_f;
-  if (!(C <= 1e15)) {
-    thr_f = __builtin_inff();              // non-finite or huge coordinates: screen nothing
-  } else if (!(c.thr > 0.0)) {
-    thr_f = -__builtin_inff();              // exact test can never pass (s >= 0 >= thr, or thr NaN)
-  } else {
-    const double eps = 5.9604644775390625e-08;   // 2^-24
-    const double K = (D == 4) ? 42.0 : 26.0;
-    const double two_sqrt_d = (D == 4) ? 4.0 : 3.4641016151377544;
-    const double R = sqrt_rn(c.thr) * (1.0 + 1e-15);
-    const double b = R + two_sqrt_d * eps * C * (1.0 + 1e-6);
-    const double T = b * b * (1.0 + 1e-12) + K * eps * C * C + 1e-30 - qq * (1.0 - 1e-14);
-    thr_f = __double2float_ru(T);
-    if (thr_f != thr_f) thr_f = __builtin_inff();
-  }
-  typename QRecFT<D>::type f;
-  f.x = -2.0f * qx; f.y = -2.0f * qy; f.z = -2.0f * qz;
-  if constexpr (D == 4) { f.w = -2.0f * qw; f.pad0 = 0.f; f.pad1 = 0.f; f.pad2 = 0.f; }
-  f.thr = thr_f;
-  return f;
-}
-
-template <int D>
-__device__ __forceinline__ typename QRecFT<D>::type never_pass_qrecf() {
-  typename QRecFT<D>::type f;
-  f.x = 0.f; f.y = 0.f; f.z = 0.f;
-  if constexpr (D == 4) { f.w = 0.f; f.pad0 = 0.f; f.pad1 = 0.f; f.pad2 = 0.f; }
-  f.thr = -__builtin_inff();
-  return f;
-}
-
-template <int D>
-__global__ void nn_filter_prep_kernel(const typename QRecT<D>::type *__restrict__ copies,
-                                      const Scalars *__restrict__ sc,
-                                      const unsigned long long *__restrict__ node_absmax, int n_copies_max,
-                                      double ox, double oy, double oz, double ow,
-                                      typename QRecFT<D>::type *__restrict__ copies_f) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n_copies = sc->n_copies;
-  if (i >= n_copies) {
-    // pad to a multiple of kQPI with records that never pass (the scan reads kQPI at a time)
-    if (i < ((n_copies + kQPI - 1) / kQPI) * kQPI) copies_f[i] = never_pass_qrecf<D>();
-    return;
-  }
-  unsigned long long cb = max(*node_absmax, sc->q_absmax);
-  copies_f[i] = make_qrecf<D>(copies[i], __longlong_as_double((long long)cb), ox, oy, oz, ow);
-}
-
 // Culled scan: the same records, written in x-bucket order (bucket start + the rank the pack
 // kernel drew), together with the fp64 copy and its (query, slot) tag.  Every workgroup first
 // scans the whole bucket histogram (<= 4096 counters) into LDS; that is cheaper than a launch.
@@ -469,10 +136,6 @@ __global__ __launch_bounds__(256) void nn_place_kernel(
   meta_s[dst] = meta[i];
   copies_f[dst] = make_qrecf<D>(c, __longlong_as_double((long long)am), ox, oy, oz, ow);
 }
-
-constexpr int kCandCap = 192;   // (copy, node) candidates queued in LDS per wave
-constexpr int kNearestWarm = 256;   // nodes sampled for the initial bound of the screened nearest scan
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Rare path of the range scan.  The screen ends, per (copy, node chunk), in a 64-bit mask of
 // the lanes whose eight nodes were not all screened out.  Each flagged lane records that as an
@@ -574,28 +237,6 @@ __global__ __launch_bounds__(256) void nn_confirm_kernel(ConfirmArgs a, const in
   }
 }
 
-
-// t values of one copy against the lane's 8 nodes: D packed fp32 FMAs per PAIR of
-// nodes (v_pk_fma_f32).  Plain v_fma_f32 issues once per 4 cycles per SIMD like
-// the fp64 ops; only the packed form reaches the fp32 vector rate.
-template <int D>
-__device__ __forceinline__ void screen8(const typename QRecFT<D>::type &c, const float *x, const float *y,
-                                        const float *z, const float *w, const float *pp, float *t) {
-  const f32x2 cx2 = {c.x, c.x}, cy2 = {c.y, c.y}, cz2 = {c.z, c.z};
-#pragma unroll
-  for (int v = 0; v < kScanFU / 2; ++v) {
-    f32x2 a = {pp[2 * v], pp[2 * v + 1]};
-    const f32x2 xz = {z[2 * v], z[2 * v + 1]}, xy = {y[2 * v], y[2 * v + 1]}, xx = {x[2 * v], x[2 * v + 1]};
-    a = __builtin_elementwise_fma(cz2, xz, a);
-    if constexpr (D == 4) {
-      const f32x2 cw2 = {c.w, c.w}, xw = {w[2 * v], w[2 * v + 1]};
-      a = __builtin_elementwise_fma(cw2, xw, a);
-    }
-    a = __builtin_elementwise_fma(cy2, xy, a);
-    a = __builtin_elementwise_fma(cx2, xx, a);
-    t[2 * v] = a.x; t[2 * v + 1] = a.y;
-  }
-}
 
 // One chunk of kChunkF nodes (8 per lane, held in VGPRs) against the copies [q0, q1):
 // the hot loop of the range search.  LM selects the lane-major chunk layout of the slab-ordered
@@ -1157,421 +798,6 @@ __global__ __launch_bounds__(256) void nn_order_big_kernel(const int64_t *__rest
   }
 }
 
-// -------------------------------------------------------------- nearest -----
-// lane = query; nodes are streamed through SGPRs (wave-uniform loads).  Each
-// block handles 256 queries against one node segment and writes the segment's
-// best (d2, idx); nn_nearest_reduce picks the lexicographic minimum.
-template <int D>
-__global__ __launch_bounds__(256) void nn_nearest_partial_kernel(
-    const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
-    const double *__restrict__ nw, int n_nodes, const double *__restrict__ q, int nq, int n_wraps, int wd0,
-    int wd1, int wd2, double wp0, double wp1, double wp2, int seg_len, double *__restrict__ part_d2,
-    int32_t *__restrict__ part_idx) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int seg = blockIdx.y;
-  const int node_begin = seg * seg_len;
-  const int node_end = min(n_nodes, node_begin + seg_len);
-  double p[4] = {0.0, 0.0, 0.0, 0.0};
-  if (i < nq) {
-#pragma unroll
-    for (int k = 0; k < D; ++k) p[k] = q[(size_t)i * D + k];
-  }
-  const int wd[3] = {wd0, wd1, wd2};
-  const double wp[3] = {wp0, wp1, wp2};
-  double best = __builtin_inf();
-  int best_i = 0x7fffffff;
-  const int n_slots = 1 << n_wraps;
-  for (int k = 0; k < n_slots; ++k) {
-    double g[4] = {p[0], p[1], p[2], p[3]};
-    for (int w = 0; w < n_wraps; ++w) {
-      if (!((k >> (n_wraps - 1 - w)) & 1)) continue;
-      int dimi = wd[w];
-      g[dimi] = (p[dimi] < wp[w] / 2.0) ? (p[dimi] + wp[w]) : (p[dimi] - wp[w]);
-    }
-#pragma unroll 4
-    for (int n = node_begin; n < node_end; ++n) {
-      double s;
-      if constexpr (D == 4) s = sq4(g[0], g[1], g[2], g[3], nx[n], ny[n], nz[n], nw[n]);
-      else s = sq3(g[0], g[1], g[2], nx[n], ny[n], nz[n]);
-      bool better = (s < best) || (s == best && n < best_i);
-      best = better ? s : best;
-      best_i = better ? n : best_i;
-    }
-  }
-  if (i < nq) {
-    part_d2[(size_t)seg * nq + i] = best;
-    part_idx[(size_t)seg * nq + i] = best_i;
-  }
-}
-
-__global__ void nn_nearest_reduce_kernel(const double *__restrict__ part_d2,
-                                         const int32_t *__restrict__ part_idx, int nq, int n_seg,
-                                         int32_t *__restrict__ idx, double *__restrict__ dist) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nq) return;
-  double best = __builtin_inf();
-  int best_i = 0x7fffffff;
-  for (int s = 0; s < n_seg; ++s) {
-    double d2 = part_d2[(size_t)s * nq + i];
-    int id = part_idx[(size_t)s * nq + i];
-    bool better = (d2 < best) || (d2 == best && id < best_i);
-    best = better ? d2 : best;
-    best_i = better ? id : best_i;
-  }
-  idx[i] = best_i;
-  dist[i] = sqrt_rn(best);
-}
-
-// nearest from the radius lists (valid when the list is non-empty): the first
-// minimum of the stored keys, ties to the lowest index (lists are index-sorted)
-__global__ void nn_nearest_from_lists_kernel(const int64_t *__restrict__ offsets, const int32_t *__restrict__ idx,
-                                             const double *__restrict__ dist, int nq,
-                                             int32_t *__restrict__ nearest_idx,
-                                             double *__restrict__ nearest_dist) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nq) return;
-  double best = __builtin_inf();
-  int best_i = -1;
-  for (int64_t k = offsets[i]; k < offsets[i + 1]; ++k) {
-    double d = dist[k];
-    if (d < best) { best = d; best_i = idx[k]; }
-  }
-  nearest_idx[i] = best_i;   // -1: empty list, caller falls back to the full scan
-  nearest_dist[i] = best;
-}
-
-// ------------------------------------------------ nearest, screened (fast path) ------
-// kdFindNearest for a batch: lane = query copy, nodes streamed through SGPRs 8 at a time.
-// Each lane keeps the running minimum of the fp32 screen value t (see "fp32 prefilter");
-// for two nodes i, j of the same copy, "i is at least as close as j" in exact arithmetic
-// implies  t_i <= t_j + M  with  M = (2K + 16 D + 4) eps C^2  (both roundings of t, plus the
-// effect of the fp32 conversions on the two distances).  So every node that can be the exact
-// nearest satisfies t <= running_min + M when it is visited; those few nodes (about ln(n) per
-// segment) are queued and confirmed with the exact unfused fp64 distance:
-//   atomicMin on the bit pattern of d2 (monotone for non-negative doubles), then the lowest
-//   index among the records that attain it (nn_nearest_tie_kernel).
-template <int D>
-__device__ __forceinline__ void drain_nearest(const int2 *cand, int &wn, const double *__restrict__ nx,
-                                              const double *__restrict__ ny, const double *__restrict__ nz,
-                                              const double *__restrict__ nw,
-                                              const typename QRecT<D>::type *__restrict__ copies,
-                                              const int2 *__restrict__ meta, HitRec *__restrict__ recs,
-                                              long long cap, Scalars *__restrict__ sc,
-                                              unsigned long long *__restrict__ best_bits) {
-  const int lane = threadIdx.x & 63;
-  __builtin_amdgcn_wave_barrier();
-  for (int i0 = 0; i0 < wn; i0 += 64) {
-    const int i = i0 + lane;
-    const bool v = i < wn;
-    double s = 0.0;
-    int owner = 0, id = 0;
-    if (v) {
-      const int2 c = cand[i];
-      id = c.y;
-      const typename QRecT<D>::type ce = copies[c.x];
-      owner = meta[c.x].x;
-      if constexpr (D == 4) s = sq4(ce.x, ce.y, ce.z, ce.w, nx[id], ny[id], nz[id], nw[id]);
-      else s = sq3(ce.x, ce.y, ce.z, nx[id], ny[id], nz[id]);
-      atomicMin(&best_bits[owner], (unsigned long long)__double_as_longlong(s));
-    }
-    const unsigned long long mask = __ballot(v);
-    const int n = __popcll(mask);
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&sc->total, (unsigned long long)n);
-    base = __shfl(base, 0);
-    if (v) {
-      const long long pos = (long long)base + lane;
-      if (pos < cap) {
-        HitRec r;
-        r.owner = owner; r.idx = id; r.d2 = s;
-        recs[pos] = r;
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  wn = 0;
-}
-
-template <int D>
-__global__ __launch_bounds__(256) void nn_nearest_f32_kernel(
-    const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
-    const double *__restrict__ nw, const float *__restrict__ fx, const float *__restrict__ fy,
-    const float *__restrict__ fz, const float *__restrict__ fw, const float *__restrict__ fpp, int n_nodes,
-    const typename QRecT<D>::type *__restrict__ copies, const typename QRecFT<D>::type *__restrict__ copies_f,
-    const int2 *__restrict__ meta, const unsigned long long *__restrict__ node_absmax, int n_seg, int seg_len,
-    HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
-    unsigned long long *__restrict__ best_bits) {
-  __shared__ int2 cand_all[4][kCandCap];
-  const int seg = blockIdx.x % n_seg;        // XCD-affine node segment
-  const int cb = blockIdx.x / n_seg;
-  const int n_copies = sc->n_copies;
-  if (cb * 256 >= n_copies) return;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  int2 *cand = cand_all[wave];
-  int wn = 0;
-  const int copy = cb * 256 + threadIdx.x;
-  typename QRecFT<D>::type c;
-  c.x = 0.f; c.y = 0.f; c.z = 0.f;
-  if constexpr (D == 4) c.w = 0.f;
-  bool valid = copy < n_copies;
-  if (valid) c = copies_f[copy];
-  // a NaN copy can never be ordered: it produces no candidates (result: idx INT_MAX, dist inf)
-  valid = valid && (c.x == c.x) && (c.y == c.y) && (c.z == c.z);
-  if constexpr (D == 4) valid = valid && (c.w == c.w);
-  unsigned long long cbits = max(*node_absmax, sc->q_absmax);
-  const double C = __longlong_as_double((long long)cbits);
-  const double eps = 5.9604644775390625e-08;
-  const double Kc = (D == 4) ? (2.0 * 42.0 + 16.0 * 4.0 + 4.0) : (2.0 * 26.0 + 16.0 * 3.0 + 4.0);
-  const float M = (C <= 1e15) ? __double2float_ru(Kc * eps * C * C + 1e-30) : __builtin_inff();
-  const f32x2 cx2 = {c.x, c.x}, cy2 = {c.y, c.y}, cz2 = {c.z, c.z};
-  float runmin = __builtin_inff();
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  const int node_begin = seg * seg_len;
-  const int node_end = min(n_nodes, node_begin + seg_len);
-
-  // t of eight wave-uniform nodes starting at j (unconditional scalar loads, straight-line VALU):
-  // t = fma(cx, px, fma(cy, py, cz * pz)) + pp  (same rounding budget K as the range screen)
-  auto screen_group = [&](int j, float *t) -> float {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int a = j + 2 * v;
-      const f32x2 pz = {fz[a], fz[a + 1]}, py = {fy[a], fy[a + 1]}, px = {fx[a], fx[a + 1]};
-      const f32x2 pp = {fpp[a], fpp[a + 1]};
-      f32x2 acc = cz2 * pz;
-      if constexpr (D == 4) {
-        const f32x2 cw2 = {c.w, c.w}, pw = {fw[a], fw[a + 1]};
-        acc = __builtin_elementwise_fma(cw2, pw, acc);
-      }
-      acc = __builtin_elementwise_fma(cy2, py, acc);
-      acc = __builtin_elementwise_fma(cx2, px, acc);
-      acc = acc + pp;
-      t[2 * v] = acc.x; t[2 * v + 1] = acc.y;
-    }
-    const float m1 = fminf(fminf(t[0], t[1]), t[2]);
-    const float m2 = fminf(fminf(t[3], t[4]), t[5]);
-    const float m3 = fminf(fminf(t[6], t[7]), m1);
-    return fminf(m2, m3);
-  };
-  // warm start: the running minimum over the first nodes of the tree (no candidates are taken
-  // here; these nodes are visited again by the segment that owns them).  Starting from the best
-  // of m samples cuts the expected number of running-minimum updates per segment from ln(n) to
-  // ln((n + m) / m).
-  {
-    const int warm = min(kNearestWarm, n_nodes / 8 * 8);
-    for (int j = 0; j < warm; j += 8) {
-      float t[8];
-      runmin = fminf(runmin, screen_group(j, t));
-    }
-  }
-  const int full_end = node_begin + (node_end - node_begin) / 8 * 8;
-  for (int j = node_begin; j < full_end; j += 8) {
-    float t[8];
-    const float tmin = screen_group(j, t);
-    const float bound = runmin + M;
-    if (__builtin_expect(__ballot(valid && !(tmin > bound)) != 0ull, 0)) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const unsigned long long m = __ballot(valid && !(t[u] > bound));
-        if (m == 0ull) continue;
-        const int n = __popcll(m);
-        if (wn + n > kCandCap) drain_nearest<D>(cand, wn, nx, ny, nz, nw, copies, meta, recs, cap, sc, best_bits);
-        if ((m >> lane) & 1ull) cand[wn + __popcll(m & lt_mask)] = make_int2(copy, j + u);
-        wn += n;
-      }
-    }
-    runmin = fminf(runmin, tmin);
-  }
-  // ragged tail (< 8 nodes, only the last segment has one): every node is a candidate
-  for (int j = full_end; j < node_end; ++j) {
-    const unsigned long long m = __ballot(valid);
-    if (m == 0ull) break;
-    const int n = __popcll(m);
-    if (wn + n > kCandCap) drain_nearest<D>(cand, wn, nx, ny, nz, nw, copies, meta, recs, cap, sc, best_bits);
-    if (valid) cand[wn + __popcll(m & lt_mask)] = make_int2(copy, j);
-    wn += n;
-  }
-  drain_nearest<D>(cand, wn, nx, ny, nz, nw, copies, meta, recs, cap, sc, best_bits);
-}
-
-// lowest node index among the confirmed candidates that attain the minimum d2
-__global__ void nn_nearest_tie_kernel(const HitRec *__restrict__ recs, long long cap,
-                                      const Scalars *__restrict__ sc,
-                                      const unsigned long long *__restrict__ best_bits,
-                                      int *__restrict__ best_idx) {
-  long long total = (long long)sc->total;
-  if (total > cap) total = cap;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const HitRec r = recs[i];
-    if ((unsigned long long)__double_as_longlong(r.d2) == best_bits[r.owner]) atomicMin(&best_idx[r.owner], r.idx);
-  }
-}
-
-__global__ void nn_nearest_out_kernel(const unsigned long long *__restrict__ best_bits,
-                                      const int *__restrict__ best_idx, int nq, int32_t *__restrict__ idx,
-                                      double *__restrict__ dist) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nq) return;
-  const unsigned long long b = best_bits[i];
-  idx[i] = (b == ~0ull) ? 0x7fffffff : best_idx[i];     // no candidate (NaN query): same as the exact scan
-  dist[i] = (b == ~0ull) ? __builtin_inf() : sqrt_rn(__longlong_as_double((long long)b));
-}
-
-// ------------------------------------------------------------ slab index ------
-// Rebuild of the slab-ordered shadow (rare: when enough nodes were appended since the last
-// one).  A counting sort of the nodes by equal-width x slab; the order inside a slab is the
-// order in which the atomics happened to land, which no result depends on.
-static_assert(kSlabChunk == kChunkF, "the culled scan visits one slab-index chunk per work unit");
-
-struct SlabParams { double x0, inv_wx, y0, inv_wy; int Kx, Ky; };
-
-__global__ void slab_params_kernel(const unsigned long long *__restrict__ xrange, int Kx, int Ky,
-                                   SlabParams *__restrict__ sp, int *__restrict__ hist) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) {
-    double x0, ix, y0, iy;
-    slab_map(xrange[0], xrange[1], Kx, &x0, &ix);
-    slab_map(xrange[2], xrange[3], Ky, &y0, &iy);
-    sp->x0 = x0; sp->inv_wx = ix; sp->y0 = y0; sp->inv_wy = iy; sp->Kx = Kx; sp->Ky = Ky;
-  }
-  for (int k = i; k <= Kx * Ky; k += gridDim.x * blockDim.x) hist[k] = 0;
-}
-
-__global__ void slab_rank_kernel(const double *__restrict__ nx, const double *__restrict__ ny, int n,
-                                 const SlabParams *__restrict__ sp, int *__restrict__ hist, int2 *__restrict__ sr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int b = cell_of(nx[i], ny[i], sp->x0, sp->inv_wx, sp->Kx, sp->y0, sp->inv_wy, sp->Ky);
-  sr[i] = make_int2(b, atomicAdd(&hist[b], 1));
-}
-
-// exclusive scan of n ints by one workgroup of 1024; out[n] = total
-__global__ __launch_bounds__(1024) void excl_scan_kernel(const int *__restrict__ in, int *__restrict__ out, int n) {
-  __shared__ int wsum[16];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int per = (n + 1023) / 1024;
-  const int b = min(t * per, n), e = min(b + per, n);
-  int local = 0;
-  for (int i = b; i < e; ++i) local += in[i];
-  int v = local;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(v, off);
-    if (lane >= off) v += o;
-  }
-  if (lane == 63) wsum[wave] = v;
-  __syncthreads();
-  int prefix = v - local;
-  for (int w = 0; w < wave; ++w) prefix += wsum[w];
-  for (int i = b; i < e; ++i) {
-    const int c = in[i];
-    out[i] = prefix;
-    prefix += c;
-  }
-  if (t == 1023) out[n] = prefix;
-}
-
-__global__ void slab_scatter_kernel(int n, const int2 *__restrict__ sr, const int *__restrict__ start,
-                                    const float *__restrict__ fx, const float *__restrict__ fy,
-                                    const float *__restrict__ fz, const float *__restrict__ fw,
-                                    const float *__restrict__ fpp, int dim, float *__restrict__ sx,
-                                    float *__restrict__ sy, float *__restrict__ sz, float *__restrict__ sw,
-                                    float *__restrict__ spp, int32_t *__restrict__ sid,
-                                    const double *__restrict__ nx, const double *__restrict__ ny,
-                                    const double *__restrict__ nz, const double *__restrict__ nw,
-                                    double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ dz,
-                                    double *__restrict__ dw) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int2 r = sr[i];
-  const int p = start[r.x] + r.y;
-  sx[p] = fx[i]; sy[p] = fy[i]; sz[p] = fz[i];
-  dx[p] = nx[i]; dy[p] = ny[i]; dz[p] = nz[i];
-  if (dim == 4) { sw[p] = fw[i]; dw[p] = nw[i]; }
-  spp[p] = fpp[i];
-  sid[p] = i;
-}
-
-// exact fp64 x and y extent of every chunk of kSlabChunk positions (one wave per chunk)
-__global__ __launch_bounds__(256) void chunk_range_kernel(const double *__restrict__ nx, const double *__restrict__ ny,
-                                                          const int32_t *__restrict__ sid, int n, int n_chunks,
-                                                          ChunkExt *__restrict__ chunk_ext) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (c >= n_chunks) return;
-  unsigned long long lo = ~0ull, hi = 0ull, ylo = ~0ull, yhi = 0ull;
-  for (int u = 0; u < kSlabChunk / 64; ++u) {
-    const int p = c * kSlabChunk + u * 64 + lane;
-    if (p < n) {
-      const int id = sid[p];
-      const double x = nx[id], y = ny[id];
-      if (x == x) { const unsigned long long e = enc_ord(x); lo = min(lo, e); hi = max(hi, e); }
-      if (y == y) { const unsigned long long e = enc_ord(y); ylo = min(ylo, e); yhi = max(yhi, e); }
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    lo = min(lo, (unsigned long long)__shfl_xor(lo, off));
-    hi = max(hi, (unsigned long long)__shfl_xor(hi, off));
-    ylo = min(ylo, (unsigned long long)__shfl_xor(ylo, off));
-    yhi = max(yhi, (unsigned long long)__shfl_xor(yhi, off));
-  }
-  if (lane == 0) {
-    ChunkExt ce;
-    ce.xlo = lo; ce.xhi = hi; ce.ylo = ylo; ce.yhi = yhi;
-    chunk_ext[c] = ce;
-  }
-}
-
-inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
-
-inline int pow2_ceil(long long v) {
-  int p = 1;
-  while (p < v && p < (1 << 30)) p <<= 1;
-  return p;
-}
-
-// bring the slab-ordered shadow up to date when the appended tail has grown too long
-int slab_refresh(rrtx_ctx *ctx) {
-  const int64_t n = ctx->n_nodes;
-  const int64_t tail = n - ctx->sl_n_sorted;
-  const int64_t limit = n / 128 > 1024 ? n / 128 : 1024;
-  if (tail <= limit) return RRTX_OK;
-  hipStream_t st = ctx->stream;
-  // about one cell per chunk: cells of ~512 nodes, laid out as a square grid over (x, y)
-  int side = (int)std::sqrt((double)n / (double)kSlabChunk);
-  if (side < 2) side = 2;
-  if (side > 256) side = 256;
-  const int K = side * side;
-  RRTX_HIP(ctx, ctx->ws_slab_params.ensure(sizeof(SlabParams)));
-  RRTX_HIP(ctx, ctx->ws_slab_hist.ensure(sizeof(int) * (size_t)(K + 1)));
-  RRTX_HIP(ctx, ctx->ws_slab_start.ensure(sizeof(int) * (size_t)(K + 1)));
-  RRTX_HIP(ctx, ctx->ws_slab_sr.ensure(sizeof(int2) * (size_t)n));
-  SlabParams *sp = ctx->ws_slab_params.as<SlabParams>();
-  int *hist = ctx->ws_slab_hist.as<int>();
-  int *start = ctx->ws_slab_start.as<int>();
-  int2 *sr = ctx->ws_slab_sr.as<int2>();
-  const int nb = (int)((n + 255) / 256);
-  const int n_chunks = (int)((n + kSlabChunk - 1) / kSlabChunk);
-  span_begin(ctx, KF_NN_FINISH);
-  hipLaunchKernelGGL(slab_params_kernel, dim3((K + 256) / 256), dim3(256), 0, st,
-                     ctx->d_xrange.as<unsigned long long>(), side, side, sp, hist);
-  hipLaunchKernelGGL(slab_rank_kernel, dim3(nb), dim3(256), 0, st, ctx->nodes[0], ctx->nodes[1], (int)n, sp, hist, sr);
-  hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, st, hist, start, K);
-  hipLaunchKernelGGL(slab_scatter_kernel, dim3(nb), dim3(256), 0, st, (int)n, sr, start, ctx->nodes_f[0],
-                     ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->dim,
-                     ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp,
-                     ctx->sl_id, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[ctx->dim == 4 ? 3 : 2],
-                     ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2], ctx->sl_d[ctx->dim == 4 ? 3 : 2]);
-  hipLaunchKernelGGL(chunk_range_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, st, ctx->nodes[0], ctx->nodes[1],
-                     ctx->sl_id, (int)n, n_chunks, reinterpret_cast<ChunkExt *>(ctx->chunk_ext));
-  span_end(ctx);
-  RRTX_HIP(ctx, hipGetLastError());
-  ctx->sl_n_sorted = n;
-  return RRTX_OK;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------- launchers ----
@@ -1845,143 +1071,6 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   return RRTX_OK;
 }
 
-static int launch_nn_nearest_exact(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev) {
-  const int n_nodes = (int)ctx->n_nodes;
-  const int qblocks = (nq + 255) / 256;
-  int want_seg = (2048 + qblocks - 1) / qblocks;
-  int max_seg = (n_nodes + 255) / 256;
-  int n_seg = want_seg < max_seg ? want_seg : max_seg;
-  if (n_seg < 1) n_seg = 1;
-  int seg_len = (n_nodes + n_seg - 1) / n_seg;
-  n_seg = (n_nodes + seg_len - 1) / seg_len;
-  RRTX_HIP(ctx, ctx->ws_partial.ensure((size_t)n_seg * nq * (sizeof(double) + sizeof(int32_t))));
-  double *pd2 = ctx->ws_partial.as<double>();
-  int32_t *pidx = reinterpret_cast<int32_t *>(pd2 + (size_t)n_seg * nq);
-  hipStream_t st = ctx->stream;
-  span_begin(ctx, KF_NN_NEAREST);
-  dim3 grid(qblocks, n_seg), block(256);
-  if (ctx->dim == 4)
-    hipLaunchKernelGGL(nn_nearest_partial_kernel<4>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
-                       ctx->nodes[2], ctx->nodes[3], n_nodes, q_dev, nq, ctx->n_wraps, ctx->wrap_dim[0],
-                       ctx->wrap_dim[1], ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1],
-                       ctx->wrap_period[2], seg_len, pd2, pidx);
-  else
-    hipLaunchKernelGGL(nn_nearest_partial_kernel<3>, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1],
-                       ctx->nodes[2], ctx->nodes[2], n_nodes, q_dev, nq, ctx->n_wraps, ctx->wrap_dim[0],
-                       ctx->wrap_dim[1], ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1],
-                       ctx->wrap_period[2], seg_len, pd2, pidx);
-  hipLaunchKernelGGL(nn_nearest_reduce_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, pd2, pidx, nq, n_seg,
-                     idx_dev, dist_dev);
-  span_end(ctx);
-  RRTX_HIP(ctx, hipGetLastError());
-  return RRTX_OK;
-}
-
-// Screened nearest (see nn_nearest_f32_kernel).  *overflow_cap receives the record capacity used;
-// the caller compares it with Scalars.total (rrtx_capi.hip) and falls back to the exact scan when
-// an adversarial visiting order produced more candidates than fit.
-static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev,
-                                      double *dist_dev) {
-  const int D = ctx->dim;
-  const int n_slots = 1 << ctx->n_wraps;
-  const int n_nodes = (int)ctx->n_nodes;
-  hipStream_t st = ctx->stream;
-  const size_t n_copies_max = (size_t)nq * n_slots;
-  const size_t qrec_bytes = (D == 4) ? sizeof(QRec4) : sizeof(QRec3);
-  const size_t qf_bytes = (D == 4) ? sizeof(QRecF4) : sizeof(QRecF3);
-  const long long rec_cap = (long long)n_copies_max * 1024 + 4096;
-  RRTX_HIP(ctx, ctx->ws_slots.ensure(n_copies_max * sizeof(SlotRec)));
-  RRTX_HIP(ctx, ctx->ws_copies.ensure(n_copies_max * qrec_bytes));
-  RRTX_HIP(ctx, ctx->ws_copies_f.ensure((n_copies_max + kQPI) * qf_bytes));
-  RRTX_HIP(ctx, ctx->ws_copy_meta.ensure(n_copies_max * sizeof(int2)));
-  RRTX_HIP(ctx, ctx->ws_scalars_nn.ensure(sizeof(Scalars)));
-  RRTX_HIP(ctx, ctx->ws_recs.ensure((size_t)rec_cap * sizeof(HitRec)));
-  RRTX_HIP(ctx, ctx->ws_partial.ensure((size_t)nq * (sizeof(unsigned long long) + sizeof(int))));
-  unsigned long long *best_bits = ctx->ws_partial.as<unsigned long long>();
-  int *best_idx = reinterpret_cast<int *>(best_bits + nq);
-  Scalars *sc = ctx->ws_scalars_nn.as<Scalars>();
-  hipLaunchKernelGGL(nn_init_kernel, dim3((nq + 255) / 256 < 64 ? (nq + 255) / 256 : 64), dim3(256), 0, st, sc,
-                     (ctx->n_wraps == 0) ? nq : 0, (int *)nullptr, 0, best_bits, nq, ~0ull, best_idx, nq, 0x7fffffff,
-                     (ConfirmArgs *)nullptr, ConfirmArgs{});
-  const double inf = std::numeric_limits<double>::infinity();
-  const double nan = std::numeric_limits<double>::quiet_NaN();
-
-  // launch geometry: blocks of 256 copies x node segments (segment fast-varying -> XCD affine)
-  const int cblocks = (int)((n_copies_max + 255) / 256);
-  int want_seg = (2048 + cblocks - 1) / cblocks;
-  int max_seg = (n_nodes + 1023) / 1024;
-  int n_seg = want_seg < max_seg ? want_seg : max_seg;
-  if (n_seg < 1) n_seg = 1;
-  if (n_seg >= 8) n_seg = n_seg / 8 * 8;
-  int seg_len = round_up((n_nodes + n_seg - 1) / n_seg, 8);
-  n_seg = (n_nodes + seg_len - 1) / seg_len;
-
-  span_begin(ctx, KF_NN_NEAREST);
-  {
-    dim3 grid((nq + 255) / 256), block(256);
-    dim3 pgrid((unsigned)((n_copies_max + kQPI + 255) / 256));
-    dim3 sgrid((unsigned)cblocks * (unsigned)n_seg);
-    if (D == 4) {
-      hipLaunchKernelGGL(nn_pack_kernel<4>, grid, block, 0, st, q_dev, nq, (const double *)nullptr,
-                         (const double *)nullptr, inf, nan, ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1],
-                         ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
-                         ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
-                         ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec4>(), ctx->ws_copy_meta.as<int2>(), sc,
-                         (const unsigned long long *)nullptr, 1, (int *)nullptr, (int2 *)nullptr, PackFused{},
-                         ConfirmArgs{});
-      hipLaunchKernelGGL(nn_filter_prep_kernel<4>, pgrid, block, 0, st, ctx->ws_copies.as<QRec4>(), sc,
-                         ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
-                         ctx->origin[2], ctx->origin[3], ctx->ws_copies_f.as<QRecF4>());
-      hipLaunchKernelGGL(nn_nearest_f32_kernel<4>, sgrid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                         ctx->nodes[3], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[3],
-                         ctx->nodes_pp, n_nodes, ctx->ws_copies.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(),
-                         ctx->ws_copy_meta.as<int2>(), ctx->d_absmax.as<unsigned long long>(), n_seg, seg_len,
-                         ctx->ws_recs.as<HitRec>(), rec_cap, sc, best_bits);
-    } else {
-      hipLaunchKernelGGL(nn_pack_kernel<3>, grid, block, 0, st, q_dev, nq, (const double *)nullptr,
-                         (const double *)nullptr, inf, nan, ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1],
-                         ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
-                         ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
-                         ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec3>(), ctx->ws_copy_meta.as<int2>(), sc,
-                         (const unsigned long long *)nullptr, 1, (int *)nullptr, (int2 *)nullptr, PackFused{},
-                         ConfirmArgs{});
-      hipLaunchKernelGGL(nn_filter_prep_kernel<3>, pgrid, block, 0, st, ctx->ws_copies.as<QRec3>(), sc,
-                         ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
-                         ctx->origin[2], ctx->origin[3], ctx->ws_copies_f.as<QRecF3>());
-      hipLaunchKernelGGL(nn_nearest_f32_kernel<3>, sgrid, block, 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
-                         ctx->nodes[2], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[2],
-                         ctx->nodes_pp, n_nodes, ctx->ws_copies.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(),
-                         ctx->ws_copy_meta.as<int2>(), ctx->d_absmax.as<unsigned long long>(), n_seg, seg_len,
-                         ctx->ws_recs.as<HitRec>(), rec_cap, sc, best_bits);
-    }
-    hipLaunchKernelGGL(nn_nearest_tie_kernel, dim3(1024), dim3(256), 0, st, ctx->ws_recs.as<HitRec>(), rec_cap, sc,
-                       best_bits, best_idx);
-    hipLaunchKernelGGL(nn_nearest_out_kernel, grid, block, 0, st, best_bits, best_idx, nq, idx_dev, dist_dev);
-  }
-  span_end(ctx);
-  ctx->last_nearest_cap = rec_cap;
-  RRTX_HIP(ctx, hipGetLastError());
-  return RRTX_OK;
-}
-
-int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev, bool exact) {
-  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "nearest search on an empty tree");
-  if (nq <= 0) return RRTX_OK;
-  ctx->last_nearest_cap = 0;
-  if (exact || !ctx->opt_nn_filter) return launch_nn_nearest_exact(ctx, q_dev, nq, idx_dev, dist_dev);
-  return launch_nn_nearest_screened(ctx, q_dev, nq, idx_dev, dist_dev);
-}
-
-// number of candidate records the last screened nearest call produced (device scalar)
-int nearest_candidates(rrtx_ctx *ctx, long long *total) {
-  unsigned long long t = 0;
-  RRTX_HIP(ctx, hipMemcpyAsync(&t, &ctx->ws_scalars_nn.as<Scalars>()->total, sizeof(t), hipMemcpyDeviceToHost,
-                               ctx->stream));
-  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  *total = (long long)t;
-  return RRTX_OK;
-}
-
 int scan_units(rrtx_ctx *ctx, int *units) {
   // node chunks screened by the last culled range search: per-wave counts written by nn_tile_kernel
   std::vector<int> v((size_t)ctx->last_visit_slices);
@@ -1992,19 +1081,6 @@ int scan_units(rrtx_ctx *ctx, int *units) {
   long long tot = 0;
   for (int x : v) tot += x;
   *units = (int)(tot > 0x7fffffffll ? 0x7fffffffll : tot);
-  return RRTX_OK;
-}
-
-int launch_nearest_from_lists(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
-                              const int32_t *idx_dev, const double *dist_dev, int32_t *nearest_idx_dev,
-                              double *nearest_dist_dev) {
-  (void)q_dev;
-  if (nq <= 0) return RRTX_OK;
-  span_begin(ctx, KF_NN_FINISH);
-  hipLaunchKernelGGL(nn_nearest_from_lists_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream,
-                     offsets_dev, idx_dev, dist_dev, nq, nearest_idx_dev, nearest_dist_dev);
-  span_end(ctx);
-  RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
 }
 

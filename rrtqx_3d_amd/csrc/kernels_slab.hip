@@ -1,0 +1,157 @@
+// kernels_slab.hip -- the slab index of the culled range search: a copy of the
+// screen arrays ordered by (x, y) grid cell with per-chunk extents, rebuilt on the stream when
+// enough nodes have been appended.  gfx950 only.
+#include "nn_device.hpp"
+
+namespace rrtx {
+
+namespace {
+
+// ------------------------------------------------------------ slab index ------
+// Rebuild of the slab-ordered shadow (rare: when enough nodes were appended since the last
+// one).  A counting sort of the nodes by equal-width x slab; the order inside a slab is the
+// order in which the atomics happened to land, which no result depends on.
+static_assert(kSlabChunk == kChunkF, "the culled scan visits one slab-index chunk per work unit");
+
+struct SlabParams { double x0, inv_wx, y0, inv_wy; int Kx, Ky; };
+
+__global__ void slab_params_kernel(const unsigned long long *__restrict__ xrange, int Kx, int Ky,
+                                   SlabParams *__restrict__ sp, int *__restrict__ hist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    double x0, ix, y0, iy;
+    slab_map(xrange[0], xrange[1], Kx, &x0, &ix);
+    slab_map(xrange[2], xrange[3], Ky, &y0, &iy);
+    sp->x0 = x0; sp->inv_wx = ix; sp->y0 = y0; sp->inv_wy = iy; sp->Kx = Kx; sp->Ky = Ky;
+  }
+  for (int k = i; k <= Kx * Ky; k += gridDim.x * blockDim.x) hist[k] = 0;
+}
+
+__global__ void slab_rank_kernel(const double *__restrict__ nx, const double *__restrict__ ny, int n,
+                                 const SlabParams *__restrict__ sp, int *__restrict__ hist, int2 *__restrict__ sr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = cell_of(nx[i], ny[i], sp->x0, sp->inv_wx, sp->Kx, sp->y0, sp->inv_wy, sp->Ky);
+  sr[i] = make_int2(b, atomicAdd(&hist[b], 1));
+}
+
+// exclusive scan of n ints by one workgroup of 1024; out[n] = total
+__global__ __launch_bounds__(1024) void excl_scan_kernel(const int *__restrict__ in, int *__restrict__ out, int n) {
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int per = (n + 1023) / 1024;
+  const int b = min(t * per, n), e = min(b + per, n);
+  int local = 0;
+  for (int i = b; i < e; ++i) local += in[i];
+  int v = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(v, off);
+    if (lane >= off) v += o;
+  }
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  int prefix = v - local;
+  for (int w = 0; w < wave; ++w) prefix += wsum[w];
+  for (int i = b; i < e; ++i) {
+    const int c = in[i];
+    out[i] = prefix;
+    prefix += c;
+  }
+  if (t == 1023) out[n] = prefix;
+}
+
+__global__ void slab_scatter_kernel(int n, const int2 *__restrict__ sr, const int *__restrict__ start,
+                                    const float *__restrict__ fx, const float *__restrict__ fy,
+                                    const float *__restrict__ fz, const float *__restrict__ fw,
+                                    const float *__restrict__ fpp, int dim, float *__restrict__ sx,
+                                    float *__restrict__ sy, float *__restrict__ sz, float *__restrict__ sw,
+                                    float *__restrict__ spp, int32_t *__restrict__ sid,
+                                    const double *__restrict__ nx, const double *__restrict__ ny,
+                                    const double *__restrict__ nz, const double *__restrict__ nw,
+                                    double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ dz,
+                                    double *__restrict__ dw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int2 r = sr[i];
+  const int p = start[r.x] + r.y;
+  sx[p] = fx[i]; sy[p] = fy[i]; sz[p] = fz[i];
+  dx[p] = nx[i]; dy[p] = ny[i]; dz[p] = nz[i];
+  if (dim == 4) { sw[p] = fw[i]; dw[p] = nw[i]; }
+  spp[p] = fpp[i];
+  sid[p] = i;
+}
+
+// exact fp64 x and y extent of every chunk of kSlabChunk positions (one wave per chunk)
+__global__ __launch_bounds__(256) void chunk_range_kernel(const double *__restrict__ nx, const double *__restrict__ ny,
+                                                          const int32_t *__restrict__ sid, int n, int n_chunks,
+                                                          ChunkExt *__restrict__ chunk_ext) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  unsigned long long lo = ~0ull, hi = 0ull, ylo = ~0ull, yhi = 0ull;
+  for (int u = 0; u < kSlabChunk / 64; ++u) {
+    const int p = c * kSlabChunk + u * 64 + lane;
+    if (p < n) {
+      const int id = sid[p];
+      const double x = nx[id], y = ny[id];
+      if (x == x) { const unsigned long long e = enc_ord(x); lo = min(lo, e); hi = max(hi, e); }
+      if (y == y) { const unsigned long long e = enc_ord(y); ylo = min(ylo, e); yhi = max(yhi, e); }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = min(lo, (unsigned long long)__shfl_xor(lo, off));
+    hi = max(hi, (unsigned long long)__shfl_xor(hi, off));
+    ylo = min(ylo, (unsigned long long)__shfl_xor(ylo, off));
+    yhi = max(yhi, (unsigned long long)__shfl_xor(yhi, off));
+  }
+  if (lane == 0) {
+    ChunkExt ce;
+    ce.xlo = lo; ce.xhi = hi; ce.ylo = ylo; ce.yhi = yhi;
+    chunk_ext[c] = ce;
+  }
+}
+
+}  // namespace
+
+int slab_refresh(rrtx_ctx *ctx) {
+  const int64_t n = ctx->n_nodes;
+  const int64_t tail = n - ctx->sl_n_sorted;
+  const int64_t limit = n / 128 > 1024 ? n / 128 : 1024;
+  if (tail <= limit) return RRTX_OK;
+  hipStream_t st = ctx->stream;
+  // about one cell per chunk: cells of ~512 nodes, laid out as a square grid over (x, y)
+  int side = (int)std::sqrt((double)n / (double)kSlabChunk);
+  if (side < 2) side = 2;
+  if (side > 256) side = 256;
+  const int K = side * side;
+  RRTX_HIP(ctx, ctx->ws_slab_params.ensure(sizeof(SlabParams)));
+  RRTX_HIP(ctx, ctx->ws_slab_hist.ensure(sizeof(int) * (size_t)(K + 1)));
+  RRTX_HIP(ctx, ctx->ws_slab_start.ensure(sizeof(int) * (size_t)(K + 1)));
+  RRTX_HIP(ctx, ctx->ws_slab_sr.ensure(sizeof(int2) * (size_t)n));
+  SlabParams *sp = ctx->ws_slab_params.as<SlabParams>();
+  int *hist = ctx->ws_slab_hist.as<int>();
+  int *start = ctx->ws_slab_start.as<int>();
+  int2 *sr = ctx->ws_slab_sr.as<int2>();
+  const int nb = (int)((n + 255) / 256);
+  const int n_chunks = (int)((n + kSlabChunk - 1) / kSlabChunk);
+  span_begin(ctx, KF_NN_FINISH);
+  hipLaunchKernelGGL(slab_params_kernel, dim3((K + 256) / 256), dim3(256), 0, st,
+                     ctx->d_xrange.as<unsigned long long>(), side, side, sp, hist);
+  hipLaunchKernelGGL(slab_rank_kernel, dim3(nb), dim3(256), 0, st, ctx->nodes[0], ctx->nodes[1], (int)n, sp, hist, sr);
+  hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, st, hist, start, K);
+  hipLaunchKernelGGL(slab_scatter_kernel, dim3(nb), dim3(256), 0, st, (int)n, sr, start, ctx->nodes_f[0],
+                     ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->dim,
+                     ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp,
+                     ctx->sl_id, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[ctx->dim == 4 ? 3 : 2],
+                     ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2], ctx->sl_d[ctx->dim == 4 ? 3 : 2]);
+  hipLaunchKernelGGL(chunk_range_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, st, ctx->nodes[0], ctx->nodes[1],
+                     ctx->sl_id, (int)n, n_chunks, reinterpret_cast<ChunkExt *>(ctx->chunk_ext));
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  ctx->sl_n_sorted = n;
+  return RRTX_OK;
+}
+
+}  // namespace rrtx

@@ -213,6 +213,7 @@ int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_d
                       bool exact = false);
 int nearest_candidates(rrtx_ctx *ctx, long long *total);
 int scan_units(rrtx_ctx *ctx, int *units);   // (tile, chunk) units of the last culled range scan
+int slab_refresh(rrtx_ctx *ctx);             // bring the slab index up to date (kernels_slab.hip)
 constexpr int kSlabChunk = 512;              // node positions per chunk of the slab index
 int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
                          double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
