@@ -331,40 +331,84 @@ __device__ bool seg_hits_polygon(double ax, double ay, double bx, double by, dou
   return false;
 }
 
-// two-stage test of one steered edge against the polygon list (:750-774).  The reference walks
-// the obstacle list and, for an obstacle whose inflated chord test (stage 1) fails to clear it,
-// every polyline piece (stage 2); the answer is the OR over all (obstacle, piece) tests, so the
-// loops may be swapped: stage 1 marks up to 64 obstacles in a bit mask, then the polyline is
-// generated ONCE (two transcendentals per point) and every piece is tested against the marked
-// obstacles.  Same set of tests, same arithmetic in each.
-__device__ bool dubins_collides(const Steer &st, double sx, double sy, double gx, double gy, double r_min,
-                                double robot_radius, const double *__restrict__ meta,
-                                const int32_t *__restrict__ off, const double *__restrict__ vxy, int m) {
+// Two-stage test of the steered edges of one wave against the polygon list (:750-774).  The
+// reference walks the obstacle list and, for an obstacle whose inflated chord test (stage 1) does
+// not clear it, every polyline piece (stage 2); the answer is the OR over all (obstacle, piece)
+// tests, so the work may be dealt differently:
+//   stage 1, lane = edge: marks of up to 64 obstacles in a bit mask;
+//   stage 2, lane = (edge, polyline piece): the pieces of all 64 edges of the wave are numbered
+//     through (prefix sum of the row counts) and handed out 64 at a time, so lanes stay busy
+//     whatever the lengths of the individual polylines are; an edge that has collided drops
+//     its remaining pieces.
+// Same set of tests, same arithmetic in each.  Every lane of the wave calls this together.
+struct WaveDubins {
+  Piece pc[64][3];
+  unsigned long long mask[64];
+  int pstart[65];
+  int done[64];
+};
+
+__device__ __forceinline__ void polyline_point(const Piece *pc, int row, double r_min, double &x, double &y) {
+  int pi = 0;
+  if (row >= pc[0].len) { row -= pc[0].len; pi = 1; }
+  if (pi == 1 && row >= pc[1].len) { row -= pc[1].len; pi = 2; }
+  piece_point(pc[pi], row, r_min, x, y);
+}
+
+__device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st, double sx, double sy, double gx,
+                                     double gy, double r_min, double robot_radius, const double *__restrict__ meta,
+                                     const int32_t *__restrict__ off, const double *__restrict__ vxy, int m) {
+  const int lane = threadIdx.x & 63;
+  w.pc[lane][0] = st.pc[0]; w.pc[lane][1] = st.pc[1]; w.pc[lane][2] = st.pc[2];
+  w.done[lane] = 0;
+  const int rows = st.pc[0].len + st.pc[1].len + st.pc[2].len;
   for (int j0 = 0; j0 < m; j0 += 64) {
     const int j1 = (j0 + 64 < m) ? j0 + 64 : m;
+    // ---- stage 1 (lane = edge) ----
     unsigned long long mask = 0ull;
-    for (int j = j0; j < j1; ++j)
-      if (seg_hits_polygon(sx, sy, gx, gy, robot_radius + 2 * r_min, meta, off, vxy, j)) mask |= 1ull << (j - j0);
-    if (mask == 0ull) continue;
-    double px = 0, py = 0;
-    int row = 0;
-    for (int pi = 0; pi < 3; ++pi) {
-      for (int k = 0; k < st.pc[pi].len; ++k, ++row) {
-        double x, y;
-        piece_point(st.pc[pi], k, r_min, x, y);
-        if (row > 0) {
-          unsigned long long mm = mask;
+    if (valid && !w.done[lane])
+      for (int j = j0; j < j1; ++j)
+        if (seg_hits_polygon(sx, sy, gx, gy, robot_radius + 2 * r_min, meta, off, vxy, j)) mask |= 1ull << (j - j0);
+    w.mask[lane] = mask;
+    const int segs = (mask != 0ull && rows > 1) ? rows - 1 : 0;
+    int incl = segs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    w.pstart[lane + 1] = incl;
+    if (lane == 0) w.pstart[0] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int total = __shfl(incl, 63);
+    // ---- stage 2 (lane = one polyline piece of one edge) ----
+    for (int i0 = 0; i0 < total; i0 += 64) {
+      const int i = i0 + lane;
+      if (i < total) {
+        int lo = 0, hi = 64;                       // edge e with pstart[e] <= i < pstart[e + 1]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (w.pstart[mid] <= i) lo = mid; else hi = mid;
+        }
+        const int e = lo;
+        if (!w.done[e]) {
+          const int row = i - w.pstart[e] + 1;
+          double px, py, x, y;
+          polyline_point(w.pc[e], row - 1, r_min, px, py);
+          polyline_point(w.pc[e], row, r_min, x, y);
+          unsigned long long mm = w.mask[e];
           while (mm != 0ull) {
             const int j = j0 + __ffsll((long long)mm) - 1;
             mm &= mm - 1ull;
-            if (seg_hits_polygon(px, py, x, y, robot_radius, meta, off, vxy, j)) return true;
+            if (seg_hits_polygon(px, py, x, y, robot_radius, meta, off, vxy, j)) { w.done[e] = 1; break; }
           }
         }
-        px = x; py = y;
       }
+      __builtin_amdgcn_wave_barrier();
     }
+    __builtin_amdgcn_wave_barrier();
   }
-  return false;
+  return valid && w.done[lane] != 0;
 }
 
 // Candidate Dubins edges of extend(): CSR entry e = (sample qi, node idx[e]); both directed edges
@@ -378,24 +422,39 @@ __global__ __launch_bounds__(256) void candidate_dubins_kernel(
     const double *__restrict__ vxy, int m, double *__restrict__ cost_out, double *__restrict__ cost_in,
     uint8_t *__restrict__ word_out, uint8_t *__restrict__ word_in, uint8_t *__restrict__ hit_out,
     uint8_t *__restrict__ hit_in) {
+  __shared__ WaveDubins wd[4];
+  WaveDubins &w = wd[threadIdx.x >> 6];
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = offsets[nq];
   if (total > cap) return;      // capacity overflow: the CSR arrays are only partly written
-  if (e >= total) return;
-  const int qi = owner[e];
-  const int n = idx[e];
-  if ((unsigned)qi >= (unsigned)nq || (unsigned)n >= (unsigned)n_nodes) return;   // defensive
-  double s[4] = {q[4 * (size_t)qi], q[4 * (size_t)qi + 1], q[4 * (size_t)qi + 2], q[4 * (size_t)qi + 3]};
-  double g[4] = {nx[n], ny[n], nz[n], nw[n]};
+  bool valid = e < total;
+  int qi = 0, n = 0;
+  if (valid) {
+    qi = owner[e];
+    n = idx[e];
+    valid = (unsigned)qi < (unsigned)nq && (unsigned)n < (unsigned)n_nodes;   // defensive
+  }
+  if (__ballot(valid) == 0ull) return;   // the grid covers the caller's capacity
+  double s[4] = {0, 0, 0, 0}, g[4] = {1, 0, 0, 0};
+  if (valid) {
+    for (int k = 0; k < 4; ++k) s[k] = q[4 * (size_t)qi + k];
+    g[0] = nx[n]; g[1] = ny[n]; g[2] = nz[n]; g[3] = nw[n];
+  }
   Steer st;
   dubins_steer<true>(s, g, r_min, st);
-  cost_out[e] = st.cost;
-  if (word_out) write_word(word_out, e, st.word);
-  hit_out[e] = dubins_collides(st, s[0], s[1], g[0], g[1], r_min, robot_radius, meta, off, vxy, m) ? 1 : 0;
+  if (valid) {
+    cost_out[e] = st.cost;
+    if (word_out) write_word(word_out, e, st.word);
+  }
+  const bool ho = wave_dubins_collides(w, valid, st, s[0], s[1], g[0], g[1], r_min, robot_radius, meta, off, vxy, m);
+  if (valid) hit_out[e] = ho ? 1 : 0;
   dubins_steer<true>(g, s, r_min, st);
-  cost_in[e] = st.cost;
-  if (word_in) write_word(word_in, e, st.word);
-  hit_in[e] = dubins_collides(st, g[0], g[1], s[0], s[1], r_min, robot_radius, meta, off, vxy, m) ? 1 : 0;
+  if (valid) {
+    cost_in[e] = st.cost;
+    if (word_in) write_word(word_in, e, st.word);
+  }
+  const bool hi = wave_dubins_collides(w, valid, st, g[0], g[1], s[0], s[1], r_min, robot_radius, meta, off, vxy, m);
+  if (valid) hit_in[e] = hi ? 1 : 0;
 }
 
 // explicitEdgeCheck(S, ::DubinsEdge, ob) over the polygon list (:750-774):
@@ -406,17 +465,22 @@ __global__ __launch_bounds__(256) void dubins_edges_check_kernel(
     double robot_radius, const double *__restrict__ meta, const int32_t *__restrict__ off,
     const double *__restrict__ vxy, int m, double *__restrict__ cost, uint8_t *__restrict__ word,
     uint8_t *__restrict__ hit, int32_t *__restrict__ traj_len) {
+  __shared__ WaveDubins wd[4];
+  WaveDubins &w = wd[threadIdx.x >> 6];
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ne) return;
+  const bool valid = i < ne;
+  const long long ic = valid ? i : ne - 1;        // inactive lanes repeat the last edge (ne > 0)
   Steer st;
-  dubins_steer<true>(s + 4 * i, g + 4 * i, r_min, st);
-  if (cost) cost[i] = st.cost;
-  if (word) write_word(word, i, st.word);
+  dubins_steer<true>(s + 4 * ic, g + 4 * ic, r_min, st);
   const int P = st.pc[0].len + st.pc[1].len + st.pc[2].len;
-  if (traj_len) traj_len[i] = P;
-  const double sx = s[4 * i], sy = s[4 * i + 1], gx = g[4 * i], gy = g[4 * i + 1];
-  const bool h = dubins_collides(st, sx, sy, gx, gy, r_min, robot_radius, meta, off, vxy, m);
-  hit[i] = h ? 1 : 0;
+  if (valid) {
+    if (cost) cost[i] = st.cost;
+    if (word) write_word(word, i, st.word);
+    if (traj_len) traj_len[i] = P;
+  }
+  const double sx = s[4 * ic], sy = s[4 * ic + 1], gx = g[4 * ic], gy = g[4 * ic + 1];
+  const bool h = wave_dubins_collides(w, valid, st, sx, sy, gx, gy, r_min, robot_radius, meta, off, vxy, m);
+  if (valid) hit[i] = h ? 1 : 0;
 }
 
 // edge.trajectory (R/DRRT_DubinsEdge_functions.jl:699-701): the P x 2 polyline of every edge,
