@@ -63,6 +63,11 @@ def main():
         print(json.dumps({"case": "C3 dubins_steer", "edges": ne, "wall_ms": round(wall, 3), "kernel_ms": k}))
         _, wall, k = timed(ctx, lambda: ctx.dubins_edges_check(s, g, 1.0, 0.5), reps=3)
         print(json.dumps({"case": "C3 dubins_edges_check (64 polygons)", "edges": ne, "wall_ms": round(wall, 3), "kernel_ms": k}))
+        # the whole fused Dubins preamble at config scale: wrapped range search + both directed edges
+        # of every neighbour steered and checked against the polygons
+        out, wall, k = timed(ctx, lambda: ctx.extend_candidates_dubins(Q, r, 0.5, 1.0, cap=6_000_000), reps=2)
+        print(json.dumps({"case": "C3 extend_candidates_dubins (host buffers)", "B": cfg.batch, "neighbors": int(len(out["idx"])),
+                          "directed_edges": 2 * int(len(out["idx"])), "wall_ms": round(wall, 3), "kernel_ms": k}))
 
 
 if __name__ == "__main__":
