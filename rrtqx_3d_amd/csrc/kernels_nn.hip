@@ -838,9 +838,11 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   RRTX_HIP(ctx, ctx->ws_tmp_idx.ensure((size_t)rec_cap * sizeof(int32_t)));
   RRTX_HIP(ctx, ctx->ws_tmp_d2.ensure((size_t)rec_cap * sizeof(double)));
 
-  ctx->scalars_flip ^= 1;
-  Scalars *sc = ctx->ws_scalars.as<Scalars>() + ctx->scalars_flip;
-  Scalars *sc_next = ctx->ws_scalars.as<Scalars>() + (ctx->scalars_flip ^ 1);
+  // (the switch is committed once the pack kernel, which resets the other record, is enqueued:
+  // an error return before that leaves the pristine record for the next call)
+  const int flip = ctx->scalars_flip ^ 1;
+  Scalars *sc = ctx->ws_scalars.as<Scalars>() + flip;
+  Scalars *sc_next = ctx->ws_scalars.as<Scalars>() + (flip ^ 1);
   int *count = ctx->ws_counts.as<int>();
   int *big_count = count + nq;          // zeroed by the pack kernel
   int *cursor = count + nq + 1;
@@ -933,6 +935,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
                          cbk, pf, ca);
   }
   span_end(ctx);
+  ctx->scalars_flip = flip;
 
   // ---- scan geometry: tiles of copies x node segments (segment = XCD-affine) ----
   const int chunk = use_filter ? kChunkF : kChunk;
