@@ -170,6 +170,22 @@ int rrtx_edges_check(rrtx_ctx *ctx, int kind, const double *p0, const double *p1
 int rrtx_edges_check_idx(rrtx_ctx *ctx, const int32_t *start_idx, const int32_t *end_idx, int64_t ne,
                          double robot_radius, int obstacle_or_minus1, const uint8_t *obstacle_mask,
                          uint8_t *hit, int32_t *first_hit);
+/* Obstacle sweep against a device mirror of the planner's directed edges.
+ * rrtx_graph_edges_append registers edges start -> end (node indices; what RRTNodeNeighborIterator
+ * walks: the out-neighbour edges and the parent edge of every node) and returns the id of the first
+ * one; ids are consecutive.  The mirror may be a superset of the live graph (edges the planner has
+ * dropped are simply ignored by the caller).  rrtx_obstacle_sweep is the edge loop of addNewObstacle
+ * (R/DRRT_Q.jl:3195-3290): nodes within search_range (= robotRadius + delta + ob.radius) of sphere
+ * `obstacle`'s centre -- kdFindWithinRange, root with <= -- and, among the registered edges that
+ * START at such a node, those for which explicitEdgeCheck(S, edge, ob) is true.  edge_ids receives
+ * their ids in ascending order (two-call capacity pattern).  An inactive obstacle collides with
+ * nothing (R/DRRT_Q.jl:1777). */
+int rrtx_graph_edges_append(rrtx_ctx *ctx, const int32_t *start_idx, const int32_t *end_idx, int64_t n,
+                            int64_t *first_id);
+int64_t rrtx_graph_edges_count(rrtx_ctx *ctx);
+int rrtx_graph_edges_clear(rrtx_ctx *ctx);
+int rrtx_obstacle_sweep(rrtx_ctx *ctx, int obstacle, double search_range, double robot_radius, int32_t *edge_ids,
+                        int64_t cap, int64_t *needed);
 /* explicitPointCheck (R/DRRT_Q.jl:1520-1556; quick=0: explicitPointCheck3D,
  * :1558-1590).  unsafe[i] in {0,1}; clearance[i] = the returned certificate
  * (0.0 when unsafe). kind as above. */

@@ -78,6 +78,10 @@ SYMBOLS = [
     ("rrtx_nn_radius", C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP, C.c_int64, c_int64_p]),
     ("rrtx_edges_check", C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP]),
     ("rrtx_edges_check_idx", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP, _VP]),
+    ("rrtx_graph_edges_append", C.c_int, [_VP, _VP, _VP, C.c_int64, c_int64_p]),
+    ("rrtx_graph_edges_count", C.c_int64, [_VP]),
+    ("rrtx_graph_edges_clear", C.c_int, [_VP]),
+    ("rrtx_obstacle_sweep", C.c_int, [_VP, C.c_int, C.c_double, C.c_double, _VP, C.c_int64, c_int64_p]),
     ("rrtx_points_check", C.c_int, [_VP, C.c_int, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP]),
     ("rrtx_simple_steer", C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP]),
     ("rrtx_dubins_steer", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP]),

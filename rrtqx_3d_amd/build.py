@@ -18,9 +18,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "librrtx_hip.so")
 
-SOURCES = ["rrtx_capi.hip", "kernels_nn.hip", "kernels_nearest.hip", "kernels_slab.hip", "kernels_collide.hip",
+SOURCES = ["rrtx_capi.hip", "kernels_nn.hip", "kernels_nearest.hip", "kernels_slab.hip", "kernels_sweep.hip", "kernels_collide.hip",
            "kernels_dubins.hip"]
-HEADERS = ["rrtx_internal.hpp", "exact_math.hpp", "nn_device.hpp", os.path.join("..", "..", "include", "rrtx.h")]
+HEADERS = ["rrtx_internal.hpp", "exact_math.hpp", "nn_device.hpp", "collide_device.hpp", os.path.join("..", "..", "include", "rrtx.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

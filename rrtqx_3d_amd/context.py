@@ -313,6 +313,38 @@ class Context:
     def pack_hits_dev(self, hit_out_ptr: int, hit_in_ptr: int, n_valid_ptr: int, cap: int, words_ptr: int):
         self._check(self._lib.rrtx_pack_hits_dev(self._h, hit_out_ptr, hit_in_ptr, n_valid_ptr, cap, words_ptr))
 
+    # ---- obstacle sweeps over the device mirror of the planner's edges ----------------
+    def graph_edges_append(self, start_idx, end_idx) -> int:
+        a = np.ascontiguousarray(start_idx, dtype=np.int32).reshape(-1)
+        b = np.ascontiguousarray(end_idx, dtype=np.int32).reshape(-1)
+        assert a.shape == b.shape
+        first = C.c_int64()
+        self._check(self._lib.rrtx_graph_edges_append(self._h, _capi._ptr(a), _capi._ptr(b), a.shape[0], C.byref(first)))
+        return first.value
+
+    @property
+    def n_graph_edges(self) -> int:
+        return int(self._lib.rrtx_graph_edges_count(self._h))
+
+    def graph_edges_clear(self):
+        self._check(self._lib.rrtx_graph_edges_clear(self._h))
+
+    def obstacle_sweep(self, obstacle: int, search_range: float, robot_radius: float, cap: Optional[int] = None):
+        """addNewObstacle's edge loop: ids (ascending) of the registered edges that start within
+        search_range of sphere `obstacle` and collide with it."""
+        if cap is None:
+            cap = 4096
+        while True:
+            ids = np.empty(max(cap, 1), dtype=np.int32)
+            needed = C.c_int64()
+            rc = self._lib.rrtx_obstacle_sweep(self._h, obstacle, search_range, robot_radius, _capi._ptr(ids), cap,
+                                               C.byref(needed))
+            if rc == _capi.RRTX_E_CAPACITY:
+                cap = int(needed.value)
+                continue
+            self._check(rc)
+            return ids[:int(needed.value)]
+
     def edges_check_idx(self, start_idx, end_idx, robot_radius: float, obstacle: int = -1, obstacle_mask=None,
                         want_first: bool = True):
         """Edges as node-index pairs (obstacle sweeps, R/DRRT_Q.jl:3220-3362)."""

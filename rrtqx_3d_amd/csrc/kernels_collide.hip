@@ -5,8 +5,7 @@
 // gfx950 only.  Lane = edge (or point); the obstacle loop is wave-uniform so
 // obstacle records arrive through scalar loads; a wave leaves the loop as soon
 // as every lane has its answer (ballot early-out).
-#include "exact_math.hpp"
-#include "rrtx_internal.hpp"
+#include "collide_device.hpp"
 
 #include <limits>
 
@@ -15,19 +14,7 @@ namespace rrtx {
 namespace {
 
 // ------------------------------------------------------------ spheres -------
-// distancePointToSegment + explicitEdgeCheck3D for one (edge, sphere) pair.
-// Returns true on collision.  t = dot/edgeLen (NOT edgeLen^2) is the
-// reference's formula (R/DRRT_Q.jl:1208) and is reproduced on purpose.
-__device__ __forceinline__ bool edge_hits_sphere(double p0x, double p0y, double p0z, double bx, double by,
-                                                 double bz, double edge_len, const SphRec &ob) {
-  double a0 = ob.cx - p0x, a1 = ob.cy - p0y, a2 = ob.cz - p0z;
-  double dot = (a0 * bx + a1 * by) + a2 * bz;
-  double t = jl_clamp01(dot / edge_len);
-  double qx = p0x + t * bx, qy = p0y + t * by, qz = p0z + t * bz;
-  double s = sq3(ob.cx, ob.cy, ob.cz, qx, qy, qz);
-  // distS > robotRadius + radius  <=>  s >= thr ; collision unless that holds
-  return !(s >= ob.thr);
-}
+// (edge_hits_sphere: collide_device.hpp, shared with kernels_sweep.hip)
 
 // ---- conservative reach test (never decides a result) ---------------------------
 // A sphere can only collide with an edge if its centre is within

@@ -368,8 +368,11 @@ int rrtx_destroy(rrtx_ctx *ctx) {
                     &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr, &ctx->ws_mask, &ctx->ws_i32a, &ctx->ws_i32b,
                     &ctx->ws_slab_hist, &ctx->ws_slab_start, &ctx->ws_slab_sr, &ctx->ws_slab_params, &ctx->ws_copies_s,
                     &ctx->ws_meta_s, &ctx->ws_cb, &ctx->ws_qhist, &ctx->ws_bkt_idx,
-                    &ctx->ws_bkt_d2, &ctx->ws_ev_a, &ctx->ws_ev_cnt, &ctx->ws_confirm_args, &ctx->ws_sph_lists, &ctx->d_sph_sample};
+                    &ctx->ws_bkt_d2, &ctx->ws_ev_a, &ctx->ws_ev_cnt, &ctx->ws_confirm_args, &ctx->ws_sph_lists, &ctx->d_sph_sample,
+                    &ctx->ws_sweep_mark, &ctx->ws_sweep_flag, &ctx->ws_sweep_cnt, &ctx->ws_sweep_start};
   for (auto b : bufs) b->release();
+  if (ctx->ge_start) (void)hipFree(ctx->ge_start);
+  if (ctx->ge_end) (void)hipFree(ctx->ge_end);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return RRTX_OK;
@@ -717,6 +720,72 @@ int rrtx_edges_check_idx(rrtx_ctx *ctx, const int32_t *start_idx, const int32_t 
   if (first_hit)
     RRTX_HIP(ctx, hipMemcpyAsync(first_hit, ctx->ws_out_i32.p, sizeof(int32_t) * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
+// ---- obstacle sweeps over a device mirror of the planner's edges -----------------------
+int64_t rrtx_graph_edges_count(rrtx_ctx *ctx) { return ctx ? ctx->ge_n : 0; }
+
+int rrtx_graph_edges_clear(rrtx_ctx *ctx) {
+  CHECK_CTX(ctx);
+  ctx->ge_n = 0;
+  return RRTX_OK;
+}
+
+int rrtx_graph_edges_append(rrtx_ctx *ctx, const int32_t *start_idx, const int32_t *end_idx, int64_t n,
+                            int64_t *first_id) {
+  CHECK_CTX(ctx);
+  if (n < 0 || (n > 0 && (!start_idx || !end_idx))) return fail(ctx, RRTX_E_INVALID, "graph_edges_append: bad arguments");
+  if (first_id) *first_id = ctx->ge_n;
+  if (n == 0) return RRTX_OK;
+  for (int64_t i = 0; i < n; ++i)
+    if (start_idx[i] < 0 || start_idx[i] >= ctx->n_nodes || end_idx[i] < 0 || end_idx[i] >= ctx->n_nodes)
+      return fail(ctx, RRTX_E_INVALID, "graph_edges_append: edge %lld references a node outside [0, %lld)",
+                  (long long)i, (long long)ctx->n_nodes);
+  if (ctx->ge_n + n > 0x7fffffffll) return fail(ctx, RRTX_E_CAPACITY, "edge ids are int32");
+  if (ctx->ge_n + n > ctx->ge_cap) {
+    int64_t nc = ctx->ge_cap > 0 ? ctx->ge_cap : 4096;
+    while (nc < ctx->ge_n + n) nc *= 2;
+    RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc;
+    if ((rc = regrow(ctx, ctx->ge_start, nc, ctx->ge_n))) return rc;
+    if ((rc = regrow(ctx, ctx->ge_end, nc, ctx->ge_n))) return rc;
+    ctx->ge_cap = nc;
+  }
+  RRTX_HIP(ctx, hipMemcpyAsync(ctx->ge_start + ctx->ge_n, start_idx, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  RRTX_HIP(ctx, hipMemcpyAsync(ctx->ge_end + ctx->ge_n, end_idx, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->ge_n += n;
+  return RRTX_OK;
+}
+
+int rrtx_obstacle_sweep(rrtx_ctx *ctx, int obstacle, double search_range, double robot_radius, int32_t *edge_ids,
+                        int64_t cap, int64_t *needed) {
+  CHECK_CTX(ctx);
+  const int m = (int)ctx->sph_active.size();
+  if (obstacle < 0 || obstacle >= m) return fail(ctx, RRTX_E_INVALID, "obstacle_sweep: obstacle %d out of range (%d spheres)", obstacle, m);
+  if (cap < 0 || (cap > 0 && !edge_ids)) return fail(ctx, RRTX_E_INVALID, "obstacle_sweep: bad arguments");
+  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "obstacle_sweep on an empty tree");
+  if (ctx->dim != 3) return fail(ctx, RRTX_E_STATE, "obstacle_sweep is the SimpleEdge (dim=3) path");
+  const double *c = &ctx->sph[4 * (size_t)obstacle];
+  SphRec ob;
+  ob.cx = c[0]; ob.cy = c[1]; ob.cz = c[2];
+  ob.thr = thr_first_gt(robot_radius + c[3]);
+  const int64_t dcap = cap > 0 ? cap : 1;
+  RRTX_HIP(ctx, ctx->ws_out_i32.ensure(sizeof(int32_t) * (size_t)dcap));
+  long long *total_dev = nullptr;
+  int rc = launch_obstacle_sweep(ctx, c, thr_first_ge(search_range), thr_first_gt(search_range), ob,
+                                 ctx->sph_active[obstacle] ? 1 : 0, ctx->ws_out_i32.as<int32_t>(), cap, &total_dev);
+  if (rc) return rc;
+  long long total = 0;
+  RRTX_HIP(ctx, hipMemcpyAsync(&total, total_dev, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (needed) *needed = total;
+  if (total > cap) return fail(ctx, RRTX_E_CAPACITY, "obstacle_sweep: %lld colliding edges, capacity %lld", total, (long long)cap);
+  if (total > 0) {
+    RRTX_HIP(ctx, hipMemcpyAsync(edge_ids, ctx->ws_out_i32.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return RRTX_OK;
 }
 

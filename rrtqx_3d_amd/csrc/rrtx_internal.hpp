@@ -164,6 +164,11 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_i32a, ws_i32b;  // staged index arrays
   rrtx::DevBuf ws_sph_lists;      // per sample: spheres its candidate edges can touch (+ counts)
 
+  // device mirror of the planner's directed edges (obstacle sweeps, kernels_sweep.hip)
+  int32_t *ge_start = nullptr, *ge_end = nullptr;
+  int64_t ge_n = 0, ge_cap = 0;
+  rrtx::DevBuf ws_sweep_mark, ws_sweep_flag, ws_sweep_cnt, ws_sweep_start;
+
   // radius -> threshold cache
   double thr_cache_r = -1.0, thr_cache_lt = 0.0, thr_cache_gt = 0.0;
 
@@ -248,6 +253,9 @@ int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int
 int launch_nearest_from_lists(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
                               const int32_t *idx_dev, const double *dist_dev, int32_t *nearest_idx_dev,
                               double *nearest_dist_dev);
+
+int launch_obstacle_sweep(rrtx_ctx *ctx, const double centre[3], double thr_lt, double thr_gt, const SphRec &ob,
+                          int active, int32_t *out_dev, int64_t cap, long long **total_dev);
 
 int launch_pack_hits(rrtx_ctx *ctx, const uint8_t *hit_out, const uint8_t *hit_in, const int64_t *n_valid_dev,
                      int64_t cap, uint64_t *words);

@@ -542,3 +542,23 @@ def obstacleSweepEdgeChecks(S: CSpace, KD: HipTree, edges: Sequence[SimpleEdge],
         mask.append(1 if ok else 0)
     hit, _ = S.ctx.edges_check_idx(s, g, S.robotRadius, obstacle=-1, obstacle_mask=mask, want_first=False)
     return hit.astype(bool)
+
+
+# ------------------------------------- device mirror of the planner's edges ----
+def registerEdges(KD: HipTree, edges: Sequence[SimpleEdge]) -> int:
+    """Mirror graph edges (what RRTNodeNeighborIterator walks: out-neighbour edges and parent
+    edges) on the device; returns the id of the first one, ids are consecutive."""
+    if not edges:
+        return KD.ctx.n_graph_edges
+    return KD.ctx.graph_edges_append([e.startNode.index for e in edges], [e.endNode.index for e in edges])
+
+
+def obstacleSweep(S: CSpace, KD: HipTree, ob) -> np.ndarray:
+    """addNewObstacle's edge loop in one call (R/DRRT_Q.jl:3220-3290): ids of the registered edges
+    that start at a node within robotRadius + delta + ob.radius of `ob` and collide with it
+    (explicitEdgeCheck(S, edge, ob)); the caller sets those edges' dist = Inf and updates its queues."""
+    if S.spaceHasTime or S.spaceHasTheta:
+        error("this type of obstacle not coded for this type of space")
+    S.bind(KD)
+    _sync_obstacles(S)
+    return KD.ctx.obstacle_sweep(_list_position(S, ob), S.robotRadius + S.delta + ob.radius, S.robotRadius)
