@@ -27,6 +27,7 @@ mutable struct HipTree{T}
   ctx::Ptr{Cvoid}
   nodes::Vector{T}             # device index (0-based) + 1 -> node; the reference has no node ids
   obsSig::UInt64               # signature of the obstacle list last uploaded
+  indexOf::IdDict{Any,Int32}   # node -> 0-based device index (for edges given as node pairs)
 
   function HipTree{T}(d::Int; device::Int = 0, capacity::Int = 1 << 16) where {T}
     ref = Ref{Ptr{Cvoid}}(C_NULL)
@@ -36,6 +37,7 @@ mutable struct HipTree{T}
     t.ctx = ref[]
     t.nodes = Vector{T}()
     t.obsSig = UInt64(0)
+    t.indexOf = IdDict{Any,Int32}()
     finalizer(x -> ccall((:rrtx_destroy, LIBRRTX), Cint, (Ptr{Cvoid},), x.ctx), t)
     return t
   end
@@ -70,6 +72,7 @@ function kdInsert(tree::HipTree{T}, node::T) where {T}
   GC.@preserve pos rrtx_check(tree, ccall((:rrtx_nodes_append, LIBRRTX), Cint,
       (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Ref{Int64}), tree.ctx, pos, 1, first))
   push!(tree.nodes, node)
+  tree.indexOf[node] = Int32(first[])
   if tree.treeSize == 0
     tree.root = node
   end
@@ -251,5 +254,50 @@ function extend_candidates(tree::HipTree, S::TS, positions::Array{Float64,2}, hy
     rrtx_check(tree, rc)
     n = Int(needed[])
     return ExtendCandidates(offsets, idx[1:n], cost[1:n], hout[1:n], hin[1:n], nidx, ndist, unsafe)
+  end
+end
+
+# ---------------------------------------------------------------------------
+# addNewObstacle's edge loop (R/DRRT_Q.jl:3220-3290) against a device mirror of the planner's
+# directed edges.  registerEdges is called where the planner creates edges (makeNeighborOf,
+# makeInitialOutNeighborOf, makeParentOf); it returns the id of the first edge, ids are
+# consecutive, the caller keeps `edges[id + 1]`.  obstacleSweep returns the 0-based ids of the
+# registered edges that start within robotRadius + delta + ob.radius of `ob` and for which
+# explicitEdgeCheck(S, edge, ob) is true; the caller sets their dist = Inf and updates its queues.
+function registerEdges(tree::HipTree, edges::Vector{TE}) where {TE}
+  n = length(edges)
+  s = Int32[tree.indexOf[e.startNode] for e in edges]
+  g = Int32[tree.indexOf[e.endNode] for e in edges]
+  first = Ref{Int64}(0)
+  GC.@preserve s g rrtx_check(tree, ccall((:rrtx_graph_edges_append, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Int64, Ref{Int64}), tree.ctx, s, g, n, first))
+  return Int(first[])
+end
+
+function obstacleSweep(tree::HipTree, S::TS, ob::SphereObstacle) where {TS}
+  syncObstacles(tree, S)
+  which = -1                                  # list position of ob (0-based)
+  ptr = S.obstacles.front
+  for i = 1:S.obstacles.length
+    if ptr.data === ob
+      which = i - 1
+      break
+    end
+    ptr = ptr.child
+  end
+  which >= 0 || error("obstacle is not in CSpace.obstacles")
+  cap = 4096
+  while true
+    ids = Vector{Int32}(undef, cap)
+    needed = Ref{Int64}(0)
+    rc = GC.@preserve ids ccall((:rrtx_obstacle_sweep, LIBRRTX), Cint,
+        (Ptr{Cvoid}, Cint, Cdouble, Cdouble, Ptr{Int32}, Int64, Ref{Int64}),
+        tree.ctx, which, S.robotRadius + S.delta + ob.radius, S.robotRadius, ids, cap, needed)
+    if rc == RRTX_E_CAPACITY
+      cap = Int(needed[])
+      continue
+    end
+    rrtx_check(tree, rc)
+    return ids[1:Int(needed[])]
   end
 end
