@@ -467,8 +467,13 @@ __global__ __launch_bounds__(256) void dubins_edges_check_kernel(
     uint8_t *__restrict__ hit, int32_t *__restrict__ traj_len) {
   __shared__ WaveDubins wd[4];
   WaveDubins &w = wd[threadIdx.x >> 6];
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < ne;
+  // Edges arrive grouped by their sample, and the cost of an edge is decided by where its sample
+  // lies (near a polygon every polyline has to be walked, elsewhere none): a wave therefore takes
+  // every n_waves-th edge instead of 64 neighbours, so that all waves get the same mix.
+  const long long n_waves = (ne + 63) / 64;
+  const long long gw = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long i = (long long)(threadIdx.x & 63) * n_waves + gw;
+  const bool valid = gw < n_waves && i < ne;
   const long long ic = valid ? i : ne - 1;        // inactive lanes repeat the last edge (ne > 0)
   Steer st;
   dubins_steer<true>(s + 4 * ic, g + 4 * ic, r_min, st);
