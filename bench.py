@@ -94,6 +94,51 @@ def cpu_baseline_all_cores(cfg, pts, Q, sph, r, per_q, budget_s=4.0):
                       "not the reference's (single-threaded) behaviour"}
 
 
+def concurrent_agents(k, torch, dev, pts, sph, r, B, cap, N, rounds=20):
+    """Side measurement, never `value`: k independent planners (the reference drives 4 agents, each
+    with its own tree and obstacle list, R/rrtqx.jl:29-31) share the GPU, one context and one HIP
+    stream per agent, every agent stepping its own batch.  Shows how much of the step is launch
+    latency that other agents' kernels can fill."""
+    from rrtqx_3d_amd import synth
+    from rrtqx_3d_amd.context import Context
+    agents = []
+    for a in range(k):
+        c = Context(3, device=dev.index or 0, node_capacity=N)
+        st = torch.cuda.Stream(device=dev)
+        c.set_stream(st.cuda_stream)
+        c.spheres_set(sph)
+        c.nodes_append(pts)
+        q = torch.from_numpy(synth.queries(B, 3, seed=synth.SEED + 77 + a)).to(dev)
+        buf = dict(off=torch.empty(B + 1, dtype=torch.int64, device=dev), idx=torch.empty(cap, dtype=torch.int32, device=dev),
+                   cost=torch.empty(cap, dtype=torch.float64, device=dev), ho=torch.empty(cap, dtype=torch.uint8, device=dev),
+                   hi=torch.empty(cap, dtype=torch.uint8, device=dev), need=torch.zeros(1, dtype=torch.int64, device=dev),
+                   ni=torch.empty(B, dtype=torch.int32, device=dev), nd=torch.empty(B, dtype=torch.float64, device=dev),
+                   un=torch.empty(B, dtype=torch.uint8, device=dev))
+        agents.append((c, st, q, buf))
+
+    def step(ag):
+        c, st, q, b = ag
+        c.extend_candidates_dev(q.data_ptr(), B, r, ROBOT_RADIUS, b["off"].data_ptr(), b["idx"].data_ptr(),
+                                b["cost"].data_ptr(), b["ho"].data_ptr(), b["hi"].data_ptr(), cap, b["need"].data_ptr(),
+                                b["ni"].data_ptr(), b["nd"].data_ptr(), b["un"].data_ptr())
+
+    for _ in range(3):
+        for ag in agents:
+            step(ag)
+    torch.cuda.synchronize()
+    edges = sum(2 * int(ag[3]["need"].item()) for ag in agents)
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        for ag in agents:
+            step(ag)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for ag in agents:
+        ag[0].close()
+    return {"agents": k, "edges_per_s": edges * rounds / dt, "ms_per_round": 1e3 * dt / rounds,
+            "note": "k contexts on k streams, each stepping its own batch of the same config; not `value`"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +153,7 @@ def main():
     ap.add_argument("--scan-items", type=int, default=0, help="tuning: target (tile, segment) work items")
     ap.add_argument("--tile-q", type=int, default=0, help="tuning: query copies per workgroup tile")
     ap.add_argument("--nn-cull", type=int, default=1, help="slab culling of the range scan: 0 off, 1 auto, 2 always")
+    ap.add_argument("--agents", type=int, default=4, help="side measurement: k independent planners sharing the GPU (0/1: off)")
     args = ap.parse_args()
 
     import torch
@@ -349,6 +395,8 @@ def main():
                 ctx.extend_candidates(Q, r, ROBOT_RADIUS, cap=cap)
             out["host_buffer_path"] = {"edges_per_s": edges_per_step * 5 / (time.perf_counter() - t1),
                                        "note": "PCIe-inclusive: host numpy in/out through rrtx_extend_candidates"}
+        if world == 1 and args.agents > 1:
+            out["concurrent_agents"] = concurrent_agents(args.agents, torch, dev, pts, sph, r, B, cap, N)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, pts, Q, sph, r)
         print(json.dumps(out))
