@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--scan-items", type=int, default=0, help="tuning: target (tile, segment) work items")
     ap.add_argument("--tile-q", type=int, default=0, help="tuning: query copies per workgroup tile")
     ap.add_argument("--nn-cull", type=int, default=1, help="slab culling of the range scan: 0 off, 1 auto, 2 always")
-    ap.add_argument("--agents", type=int, default=4, help="side measurement: k independent planners sharing the GPU (0/1: off)")
+    ap.add_argument("--agents", type=int, default=0, help="side measurement: k independent planners sharing the GPU (0/1: off)")
     args = ap.parse_args()
 
     import torch
