@@ -58,8 +58,8 @@ typedef struct {
   int64_t last_pairs;        /* (query copy, node) visits */
   int64_t last_neighbors;    /* sum of k */
   int32_t last_tile_q;       /* query copies that shared one streamed pass of the node arrays */
-  int32_t last_scan_units;   /* slab-culled range scan: (64-copy tile, 512-node chunk) units the last call
-                              * visited; 0 when the last call streamed every node for every tile */
+  int32_t last_scan_units;   /* slab-culled range scan: (tile of last_tile_q copies, 512-node chunk) pairs the
+                              * last call streamed; 0 when it streamed every node for every tile */
 } rrtx_stats_t;
 
 /* ---- lifetime ------------------------------------------------------------ */

@@ -18,7 +18,7 @@ constexpr int kChunk = 64 * kScanU;  // nodes per wave per chunk
 struct Scalars {
   unsigned long long total;        // records produced by scan + rootfix
   int n_copies;                    // valid query copies
-  int n_units;                     // (tile, chunk) units of the culled range scan
+  int n_units;                     // unused (the culled search reports its chunk visits per wave)
   unsigned long long q_absmax;     // bit pattern of max |coordinate| over the query copies
 };
 
