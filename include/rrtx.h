@@ -90,9 +90,9 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
 #define RRTX_OPT_SCAN_BLOCKS 2
 #define RRTX_OPT_SCAN_TILE_Q 3
 #define RRTX_OPT_SCAN_ITEMS 4  /* target number of (tile, node segment) work items */
-/*   RRTX_OPT_NN_CULL (default 1): the range search keeps a second copy of the fp32 shadow
- *   ordered by equal-width x slabs and sorts each call's query copies by x, so a tile of
- *   copies only streams the node chunks whose x extent can reach it.  Purely a skip of
+/*   RRTX_OPT_NN_CULL (default 1): the range search keeps a second copy of the node shadow
+ *   ordered by (x, y) grid cell and buckets each call's query copies by cell, so a tile of
+ *   copies only streams the 512-node chunks whose x/y extent can reach it.  Purely a skip of
  *   pairs that provably fail the exact test; results are identical.  0 = off (every tile
  *   streams every node), 1 = on for trees of at least 8192 nodes, 2 = always on. */
 #define RRTX_OPT_NN_CULL 5
@@ -142,6 +142,15 @@ int rrtx_obstacle_update(rrtx_ctx *ctx, int which, double radius, uint8_t active
  * Ties on distance resolve to the lowest index (the reference's tie order is
  * its tree-visit order). */
 int rrtx_nn_nearest(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double *dist);
+/* kdFindKNearest (R/kdTree_general.jl:696-723; helpers :580-593, :605-692), batched.  The
+ * reference seeds its heap with the root and an Inf-keyed dummy, so it hands back max(k, 2)
+ * nodes (fewer when the tree is smaller): rows of idx/dist are max(k, 2) wide, count[i] says
+ * how many entries of row i are filled (unused slots: idx -1, dist +Inf).  Rows come sorted by
+ * ascending (distance, index) -- the reference returns heap order -- and ties at the last place
+ * go to the lowest indices.  Nodes at a non-finite distance are never returned.  1 <= k <= 2048.
+ * Like the reference (:711-713) the call fails on a wrapped space (RRTX_E_STATE).  The reference
+ * itself never calls this search (RRT^X uses the radius search): the kernel is exact, not tuned. */
+int rrtx_nn_knearest(rrtx_ctx *ctx, const double *q, int nq, int k, int32_t *idx, double *dist, int32_t *count);
 /* kdFindWithinRange (R/kdTree_general.jl:889-919), batched: for query i the
  * nodes with KDdist < r[i] (the root, index 0, with <=), wrapped dimensions
  * handled with the reference's ghost rule; each list sorted by node index,

@@ -88,6 +88,23 @@ function kdFindNearest(tree::HipTree{T}, queryPoint::Array{Float64}) where {T}
   return (tree.nodes[idx[] + 1], dist[])
 end
 
+# kdFindKNearest (R/kdTree_general.jl:696-723) -> Array of nodes, node.data = distance.
+# max(k, 2) nodes like the reference (its heap starts with root + dummy); ascending distance.
+function kdFindKNearest(tree::HipTree{T}, k::Int, queryPoint::Array{Float64}) where {T}
+  q = vec(queryPoint)
+  w = max(k, 2)
+  idx = Array{Int32}(undef, w); dist = Array{Float64}(undef, w); cnt = Ref{Int32}(0)
+  GC.@preserve q idx dist rrtx_check(tree, ccall((:rrtx_nn_knearest, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Ptr{Int32}, Ptr{Cdouble}, Ref{Int32}),
+      tree.ctx, q, 1, k, idx, dist, cnt))
+  ret = Array{T}(undef, cnt[], 1)
+  for j = 1:cnt[]
+    ret[j, 1] = tree.nodes[idx[j] + 1]
+    ret[j, 1].data = dist[j]
+  end
+  return ret
+end
+
 # addToRangeList (R/kdTree_general.jl:765-771)
 function addToRangeList(S::Tlist, thisNode::T, key::Float64) where {Tlist, T}
   if thisNode.inHeap

@@ -74,6 +74,9 @@ def lib() -> C.CDLL:
     L.orc_list_read.restype = C.c_int64
     L.orc_list_read.argtypes = [C.c_void_p, C.c_int64, c_int32_p, c_double_p]
     L.orc_kd_empty_range_list.argtypes = [C.c_void_p, C.c_void_p]
+    for f in (L.orc_kd_knearest, L.orc_kd_knearest_naive):
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_int64, c_double_p, C.c_int64, c_int32_p, c_double_p]
     L.orc_range_naive.restype = C.c_int64
     L.orc_range_naive.argtypes = [C.c_void_p, C.c_double, c_double_p, C.c_int64, c_int32_p, c_double_p]
     L.orc_ghost_points.restype = C.c_int
@@ -195,6 +198,19 @@ class KDTree:
         L.orc_list_read(lst, n, idx.ctypes.data_as(c_int32_p), _dp(key))
         L.orc_kd_empty_range_list(self._h, lst)
         return idx, key
+
+    def knearest(self, k: int, q, naive: bool = False):
+        """kdFindKNearest / kdFindKNearestNaive: (idx, key) in heap order; raises where the
+        reference does (wrapped space)."""
+        q = _vec(q)
+        f = lib().orc_kd_knearest_naive if naive else lib().orc_kd_knearest
+        cap = max(int(k), 2) + 1
+        idx = np.empty(cap, dtype=np.int32)
+        key = np.empty(cap, dtype=np.float64)
+        n = f(self._h, int(k), _dp(q), cap, idx.ctypes.data_as(c_int32_p), _dp(key))
+        if n < 0:
+            raise RuntimeError("knn search has not been implimented for wrapped space")
+        return idx[:n].copy(), key[:n].copy()
 
     def range_naive(self, r: float, q):
         q = _vec(q)

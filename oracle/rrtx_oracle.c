@@ -415,6 +415,165 @@ int64_t orc_range_naive(orc_kd *t, double r, const double *q, int64_t cap, int32
 }
 
 /* ------------------------------------------------------------------------ */
+/* A3b  k nearest (no caller in the reference; restated for completeness)     */
+/* ------------------------------------------------------------------------ */
+
+/* The "B" (max-on-top) binary heap of R/heap.jl:358-461 over (node, key) pairs;
+ * node -1 is the dummy of R/kdTree_general.jl:704-706.  1-based like the source. */
+typedef struct {
+  int64_t *node; double *key;
+  int64_t last, parent_of_last, cap;
+  orc_kd *t; int dummy_marked;
+} knn_heap;
+
+static int kh_marked(const knn_heap *h, int64_t n) { return n < 0 ? h->dummy_marked : h->t->in_heap[n]; }
+static void kh_mark(knn_heap *h, int64_t n, int v) { if (n < 0) h->dummy_marked = v; else h->t->in_heap[n] = (uint8_t)v; }
+static void kh_swap(knn_heap *h, int64_t a, int64_t b) {
+  int64_t tn = h->node[a]; h->node[a] = h->node[b]; h->node[b] = tn;
+  double tk = h->key[a]; h->key[a] = h->key[b]; h->key[b] = tk;
+}
+
+static void kh_bubble_up(knn_heap *h, int64_t n) {          /* heap.jl:358-378 */
+  if (n == 1) return;
+  int64_t parent = n / 2;
+  while (n != 1 && h->key[parent] < h->key[n]) {
+    kh_swap(h, parent, n);
+    n = parent; parent = n / 2;
+  }
+}
+
+static void kh_bubble_down(knn_heap *h, int64_t n) {        /* heap.jl:383-419 */
+  int64_t child;
+  if (2 * n == h->last) child = 2 * n;
+  else if (2 * n + 1 > h->last) return;
+  else if (h->key[2 * n] > h->key[2 * n + 1]) child = 2 * n;
+  else child = 2 * n + 1;
+  while (n <= h->parent_of_last && h->key[child] > h->key[n]) {
+    kh_swap(h, child, n);
+    n = child;
+    if (2 * n == h->last) child = 2 * n;
+    else if (2 * n + 1 > h->last) return;
+    else if (h->key[2 * n] > h->key[2 * n + 1]) child = 2 * n;
+    else child = 2 * n + 1;
+  }
+}
+
+static void kh_add(knn_heap *h, int64_t node, double key) { /* heap.jl:422-440 */
+  if (h->last == h->cap) {
+    h->cap *= 2;
+    h->node = (int64_t *)realloc(h->node, sizeof(int64_t) * (h->cap + 1));
+    h->key = (double *)realloc(h->key, sizeof(double) * (h->cap + 1));
+  }
+  if (!kh_marked(h, node)) {
+    h->last += 1;
+    h->parent_of_last = h->last / 2;
+    h->node[h->last] = node; h->key[h->last] = key;
+    kh_bubble_up(h, h->last);
+    kh_mark(h, node, 1);
+  }
+}
+
+static void kh_pop(knn_heap *h) {                           /* heap.jl:447-461 */
+  if (h->last < 1) return;
+  int64_t old = h->node[1];
+  h->node[1] = h->node[h->last]; h->key[1] = h->key[h->last];
+  h->last -= 1;
+  h->parent_of_last = h->last / 2;
+  kh_bubble_down(h, 1);
+  kh_mark(h, old, 0);
+}
+
+/* addToKNNHeap, R/kdTree_general.jl:580-593 */
+static void add_to_knn_heap(knn_heap *h, int64_t node, double key, int64_t k) {
+  if (kh_marked(h, node)) return;
+  if (h->last < k) kh_add(h, node, key);
+  else if (h->key[1] > key) { kh_pop(h); kh_add(h, node, key); }
+}
+
+/* kdFindKNearestInSubtree, R/kdTree_general.jl:605-692 */
+static void kd_knearest_in_subtree(orc_kd *t, int64_t root, int64_t k, const double *q, knn_heap *h) {
+  int64_t parent = root;
+  double worst = h->key[1];
+  for (;;) {                                   /* :612-630 */
+    int s = t->split[parent];
+    if (q[s] < KPOS(t, parent)[s]) {
+      if (t->cl[parent] < 0) break;
+      parent = t->cl[parent];
+    } else {
+      if (t->cr[parent] < 0) break;
+      parent = t->cr[parent];
+    }
+  }
+  double nd = orc_euclid(q, KPOS(t, parent), t->d);   /* :632-636 */
+  if (nd < worst) { add_to_knn_heap(h, parent, nd, k); worst = h->key[1]; }
+  for (;;) {                                   /* :639-691 */
+    int s = t->split[parent];
+    double hyper = q[s] - KPOS(t, parent)[s];
+    if (hyper > worst) {                       /* :646-657 */
+      if (parent == root) return;
+      parent = t->parent[parent];
+      continue;
+    }
+    if (!t->in_heap[parent]) {                 /* :663-669 */
+      nd = orc_euclid(q, KPOS(t, parent), t->d);
+      if (nd < worst) { add_to_knn_heap(h, parent, nd, k); worst = h->key[1]; }
+    }
+    if (q[s] < KPOS(t, parent)[s] && t->cr[parent] >= 0) {          /* :672-676 */
+      kd_knearest_in_subtree(t, t->cr[parent], k, q, h);
+      worst = h->key[1];
+    } else if (KPOS(t, parent)[s] <= q[s] && t->cl[parent] >= 0) {  /* :677-682 */
+      kd_knearest_in_subtree(t, t->cl[parent], k, q, h);
+      worst = h->key[1];
+    }
+    if (parent == root) return;
+    parent = t->parent[parent];
+  }
+}
+
+/* kdFindKNearest, R/kdTree_general.jl:696-723.  Writes the heap array front to
+ * back (the order cleanHeapB hands out) and returns its length, or -1 where the
+ * reference raises (wrapped spaces, :711-713).  The heap is seeded with the
+ * root and an Inf-keyed dummy, so k = 1 ends with TWO nodes. */
+int64_t orc_kd_knearest(orc_kd *t, int64_t k, const double *q, int64_t cap, int32_t *idx, double *key) {
+  if (t->nwraps > 0) return -1;
+  knn_heap h;
+  h.cap = k > 0 ? k : 1;
+  h.node = (int64_t *)malloc(sizeof(int64_t) * (h.cap + 1));
+  h.key = (double *)malloc(sizeof(double) * (h.cap + 1));
+  h.last = 0; h.parent_of_last = -1; h.t = t; h.dummy_marked = 0;
+  kh_add(&h, 0, orc_euclid(q, KPOS(t, 0), t->d));   /* :699-701 */
+  kh_add(&h, -1, INFINITY);                         /* :703-706 */
+  kd_knearest_in_subtree(t, 0, k, q, &h);
+  if (h.node[1] == -1) kh_pop(&h);                  /* :716-720 */
+  int64_t n = h.last;
+  for (int64_t i = 1; i <= n; ++i) {                /* cleanHeap, heap.jl:338-350 */
+    if (i - 1 < cap) { if (idx) idx[i - 1] = (int32_t)h.node[i]; if (key) key[i - 1] = h.key[i]; }
+    kh_mark(&h, h.node[i], 0);
+  }
+  free(h.node); free(h.key);
+  return n;
+}
+
+/* kdFindKNearestNaive, R/kdTree_general.jl:563-574: every node into the heap, pop
+ * down to k.  Returned in heap order like the above. */
+int64_t orc_kd_knearest_naive(orc_kd *t, int64_t k, const double *q, int64_t cap, int32_t *idx, double *key) {
+  knn_heap h;
+  h.cap = 64;
+  h.node = (int64_t *)malloc(sizeof(int64_t) * (h.cap + 1));
+  h.key = (double *)malloc(sizeof(double) * (h.cap + 1));
+  h.last = 0; h.parent_of_last = -1; h.t = t; h.dummy_marked = 0;
+  for (int64_t i = 0; i < t->n; ++i) kh_add(&h, i, orc_euclid(q, KPOS(t, i), t->d));
+  while (h.last > k) kh_pop(&h);
+  int64_t n = h.last;
+  for (int64_t i = 1; i <= n; ++i) {
+    if (i - 1 < cap) { if (idx) idx[i - 1] = (int32_t)h.node[i]; if (key) key[i - 1] = h.key[i]; }
+    kh_mark(&h, h.node[i], 0);
+  }
+  free(h.node); free(h.key);
+  return n;
+}
+
+/* ------------------------------------------------------------------------ */
 /* A9  sphere edge check                                                     */
 /* ------------------------------------------------------------------------ */
 

@@ -62,6 +62,12 @@ void orc_kd_empty_range_list(orc_kd *t, orc_list *l);
 int64_t orc_range_naive(orc_kd *t, double r, const double *q, int64_t cap,
                         int32_t *idx, double *key);
 
+/* kdFindKNearest (R/kdTree_general.jl:696-723): heap order, returns the length
+ * (k nodes, but TWO for k = 1: the heap starts with root + dummy), -1 where the
+ * reference raises (wrapped space).  _naive = kdFindKNearestNaive (:563-574). */
+int64_t orc_kd_knearest(orc_kd *t, int64_t k, const double *q, int64_t cap, int32_t *idx, double *key);
+int64_t orc_kd_knearest_naive(orc_kd *t, int64_t k, const double *q, int64_t cap, int32_t *idx, double *key);
+
 /* ghost iterator exposed for tests (R/ghostPoint.jl:60-111).  Writes up to cap
  * ghosts (each d doubles) and returns how many were produced for bestDist. */
 int orc_ghost_points(const orc_kd *t, const double *q, double best_dist, int cap, double *out);

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("rrtx_polygons_set", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int]),
     ("rrtx_obstacle_update", C.c_int, [_VP, C.c_int, C.c_double, C.c_uint8]),
     ("rrtx_nn_nearest", C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
+    ("rrtx_nn_knearest", C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP]),
     ("rrtx_nn_radius", C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP, C.c_int64, c_int64_p]),
     ("rrtx_edges_check", C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP]),
     ("rrtx_edges_check_idx", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP, _VP]),

@@ -124,6 +124,19 @@ class Context:
         self._check(self._lib.rrtx_nn_nearest(self._h, _capi._ptr(q), nq, _capi._ptr(idx), _capi._ptr(dist)))
         return idx, dist
 
+    def nn_knearest(self, q, k: int):
+        """kdFindKNearest per query: (idx, dist, count); rows are max(k, 2) wide, sorted by
+        (distance, index), count[i] entries of row i are filled."""
+        q = f64(q, (-1, self.dim))
+        nq = q.shape[0]
+        stride = max(int(k), 2)
+        idx = np.empty((nq, stride), dtype=np.int32)
+        dist = np.empty((nq, stride), dtype=np.float64)
+        count = np.empty(nq, dtype=np.int32)
+        self._check(self._lib.rrtx_nn_knearest(self._h, _capi._ptr(q), nq, int(k), _capi._ptr(idx), _capi._ptr(dist),
+                                               _capi._ptr(count)))
+        return idx, dist, count
+
     def nn_radius(self, q, r, cap: Optional[int] = None):
         """Returns CSR (offsets[nq+1], idx, dist). r: scalar or per-query array."""
         q = f64(q, (-1, self.dim))

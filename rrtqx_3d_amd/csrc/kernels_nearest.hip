@@ -390,6 +390,179 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
   return RRTX_OK;
 }
 
+// ------------------------------------------------------------- k nearest -----
+// kdFindKNearest (R/kdTree_general.jl:696-723) for a batch, by exact selection: one workgroup
+// per query finds the kk-th smallest squared distance with an 8-pass radix select over the bit
+// pattern of the unfused fp64 sum (monotone for non-negative doubles; NaN sorts last), gathers
+// the kk selected nodes and sorts them by (distance, index).  Where several nodes tie at the
+// kk-th distance the lowest indices are taken (the reference's choice there is its tree-visit
+// order).  The reference has no caller for this search, so the kernel is exact and
+// deterministic rather than tuned: it streams the node arrays nine times per query.
+namespace {
+constexpr int kKnnMax = 2048;
+constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
+
+template <int D>
+__device__ __forceinline__ unsigned long long knn_key(const double (&g)[4], const double *__restrict__ nx,
+                                                      const double *__restrict__ ny,
+                                                      const double *__restrict__ nz,
+                                                      const double *__restrict__ nw, int n) {
+  double s;
+  if constexpr (D == 4) s = sq4(g[0], g[1], g[2], g[3], nx[n], ny[n], nz[n], nw[n]);
+  else s = sq3(g[0], g[1], g[2], nx[n], ny[n], nz[n]);
+  return (s != s) ? ~0ull : (unsigned long long)__double_as_longlong(s);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void nn_knearest_kernel(
+    const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
+    const double *__restrict__ nw, int n_nodes, const double *__restrict__ q, int kk, int stride,
+    int32_t *__restrict__ idx_out, double *__restrict__ dist_out, int32_t *__restrict__ count_out) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ unsigned s_rank, s_less, s_ties, s_cnt;
+  __shared__ unsigned long long skey[kKnnMax];
+  __shared__ int sidx[kKnnMax];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int qi = blockIdx.x;
+  double g[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < D; ++k) g[k] = q[(size_t)qi * D + k];
+
+  unsigned long long prefix = 0;
+  unsigned rank = (unsigned)kk - 1u, less = 0, ties = 0;
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 56 - 8 * pass;
+    hist[tid] = 0;
+    __syncthreads();
+    for (int base = 0; base < n_nodes; base += 256) {
+      const int n = base + tid;
+      bool m = n < n_nodes;
+      unsigned digit = 0;
+      if (m) {
+        const unsigned long long key = knn_key<D>(g, nx, ny, nz, nw, n);
+        m = (pass == 0) || ((key >> (shift + 8)) == prefix);
+        digit = (unsigned)(key >> shift) & 255u;
+      }
+      // most keys share the leading exponent bytes: one add per wave when they agree
+      const unsigned long long mask = __ballot(m);
+      if (mask == 0) continue;
+      const int lead = __ffsll((long long)mask) - 1;
+      const unsigned d0 = (unsigned)__shfl((int)digit, lead);
+      const unsigned long long same = __ballot(m && digit == d0);
+      if (same == mask) {
+        if (lane == lead) atomicAdd(&hist[d0], (unsigned)__popcll(mask));
+      } else if (m) {
+        atomicAdd(&hist[digit], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      unsigned c[4], tot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { c[j] = hist[4 * tid + j]; tot += c[j]; }
+      unsigned inc = tot;
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)inc, o);
+        if (tid >= o) inc += v;
+      }
+      unsigned run = inc - tot;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (rank >= run && rank < run + c[j]) {
+          s_prefix = (prefix << 8) | (unsigned long long)(4 * tid + j);
+          s_rank = rank - run;
+          s_less = less + run;
+          s_ties = c[j];
+        }
+        run += c[j];
+      }
+    }
+    __syncthreads();
+    prefix = s_prefix; rank = s_rank; less = s_less; ties = s_ties;
+  }
+  // prefix = the kk-th smallest key T; `less` keys lie below it, `ties` equal it
+  const unsigned long long T = prefix;
+  const unsigned need = (unsigned)kk - less;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  const bool all_ties = (ties == need);
+  for (int n = tid; n < n_nodes; n += 256) {
+    const unsigned long long key = knn_key<D>(g, nx, ny, nz, nw, n);
+    if (key < T || (all_ties && key == T)) {
+      const unsigned at = atomicAdd(&s_cnt, 1u);
+      skey[at] = key; sidx[at] = n;
+    }
+  }
+  if (!all_ties && tid < 64) {     // more ties than places: lowest indices first
+    unsigned got = 0;
+    for (int base = 0; base < n_nodes && got < need; base += 64) {
+      const int n = base + tid;
+      const bool tie = n < n_nodes && knn_key<D>(g, nx, ny, nz, nw, n) == T;
+      const unsigned long long mask = __ballot(tie);
+      const unsigned r = got + (unsigned)__popcll(mask & ((1ull << tid) - 1ull));
+      if (tie && r < need) { skey[less + r] = T; sidx[less + r] = n; }
+      got += (unsigned)__popcll(mask);
+    }
+  }
+  int P = 1;
+  while (P < kk) P <<= 1;
+  for (int i = kk + tid; i < P; i += 256) { skey[i] = ~0ull; sidx[i] = 0x7fffffff; }
+  __syncthreads();
+  for (int k2 = 2; k2 <= P; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long ka = skey[i], kb = skey[l];
+          const int ia = sidx[i], ib = sidx[l];
+          const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
+          const bool up = (i & k2) == 0;
+          if (up ? a_gt_b : !a_gt_b) { skey[i] = kb; skey[l] = ka; sidx[i] = ib; sidx[l] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // nodes at a non-finite distance never pass the reference's `newDist < worst` test (:633,:665)
+  for (int j = tid; j < stride; j += 256) {
+    const bool ok = j < kk && skey[j] < kInfBits;
+    idx_out[(size_t)qi * stride + j] = ok ? sidx[j] : -1;
+    dist_out[(size_t)qi * stride + j] = ok ? sqrt_rn(__longlong_as_double((long long)skey[j])) : __builtin_inf();
+    if (ok && (j + 1 == kk || skey[j + 1] >= kInfBits)) count_out[qi] = j + 1;
+  }
+  if (tid == 0 && !(skey[0] < kInfBits)) count_out[qi] = 0;
+}
+}  // namespace
+
+// row width of rrtx_nn_knearest: the reference's heap starts with the root and a dummy, so a
+// search for k = 1 comes back with two nodes (R/kdTree_general.jl:699-706, 580-593)
+int knearest_row(int k, int64_t n_nodes) {
+  int64_t kk = k < 2 ? 2 : k;
+  return (int)(kk < n_nodes ? kk : n_nodes);
+}
+
+int launch_nn_knearest(rrtx_ctx *ctx, const double *q_dev, int nq, int k, int32_t *idx_dev, double *dist_dev,
+                       int32_t *count_dev) {
+  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "k-nearest search on an empty tree");
+  if (ctx->n_wraps > 0) return fail(ctx, RRTX_E_STATE, "knn search has not been implimented for wrapped space");
+  if (k < 1 || k > kKnnMax) return fail(ctx, RRTX_E_INVALID, "nn_knearest: k must be in 1..2048");
+  if (nq <= 0) return RRTX_OK;
+  const int kk = knearest_row(k, ctx->n_nodes);
+  const int stride = k < 2 ? 2 : k;
+  const int n_nodes = (int)ctx->n_nodes;
+  span_begin(ctx, KF_NN_NEAREST);
+  if (ctx->dim == 4)
+    hipLaunchKernelGGL(nn_knearest_kernel<4>, dim3(nq), dim3(256), 0, ctx->stream, ctx->nodes[0], ctx->nodes[1],
+                       ctx->nodes[2], ctx->nodes[3], n_nodes, q_dev, kk, stride, idx_dev, dist_dev, count_dev);
+  else
+    hipLaunchKernelGGL(nn_knearest_kernel<3>, dim3(nq), dim3(256), 0, ctx->stream, ctx->nodes[0], ctx->nodes[1],
+                       ctx->nodes[2], ctx->nodes[2], n_nodes, q_dev, kk, stride, idx_dev, dist_dev, count_dev);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
 int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev, bool exact) {
   if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "nearest search on an empty tree");
   if (nq <= 0) return RRTX_OK;

@@ -605,6 +605,27 @@ int rrtx_nn_nearest(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double
   return RRTX_OK;
 }
 
+int rrtx_nn_knearest(rrtx_ctx *ctx, const double *q, int nq, int k, int32_t *idx, double *dist, int32_t *count) {
+  CHECK_CTX(ctx);
+  if (nq < 0 || (nq > 0 && (!q || !idx || !dist || !count)))
+    return fail(ctx, RRTX_E_INVALID, "nn_knearest: bad arguments");
+  if (nq == 0) return RRTX_OK;
+  const size_t stride = (size_t)(k < 2 ? 2 : k);
+  int rc = stage_in(ctx, ctx->ws_q, q, sizeof(double) * (size_t)nq * ctx->dim);
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_idx.ensure(sizeof(int32_t) * ((size_t)nq * stride + (size_t)nq)));
+  RRTX_HIP(ctx, ctx->ws_out_dist.ensure(sizeof(double) * (size_t)nq * stride));
+  int32_t *idx_dev = ctx->ws_out_idx.as<int32_t>();
+  int32_t *count_dev = idx_dev + (size_t)nq * stride;
+  rc = launch_nn_knearest(ctx, ctx->ws_q.as<double>(), nq, k, idx_dev, ctx->ws_out_dist.as<double>(), count_dev);
+  if (rc) return rc;
+  RRTX_HIP(ctx, hipMemcpyAsync(idx, idx_dev, sizeof(int32_t) * (size_t)nq * stride, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipMemcpyAsync(dist, ctx->ws_out_dist.p, sizeof(double) * (size_t)nq * stride, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipMemcpyAsync(count, count_dev, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
 int rrtx_nn_radius_dev(rrtx_ctx *ctx, const double *q, double r, int nq, int64_t *offsets, int32_t *idx,
                        double *dist, int64_t cap, int64_t *needed_dev) {
   CHECK_CTX(ctx);

@@ -214,6 +214,9 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_or_
                      int nq, int64_t *offsets_dev, int32_t *idx_dev, double *dist_dev, int64_t cap,
                      int64_t *needed_dev, int32_t *owner_dev = nullptr, int32_t *nearest_idx_dev = nullptr,
                      double *nearest_dist_dev = nullptr);
+int knearest_row(int k, int64_t n_nodes);
+int launch_nn_knearest(rrtx_ctx *ctx, const double *q_dev, int nq, int k, int32_t *idx_dev, double *dist_dev,
+                       int32_t *count_dev);
 int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev,
                       bool exact = false);
 int nearest_candidates(rrtx_ctx *ctx, long long *total);

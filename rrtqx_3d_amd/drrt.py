@@ -112,6 +112,7 @@ class RRTNode:
         self.inHeap = False            # "inHeap is a misnomer since this is a list" (R/kdTree_general.jl:769)
         self.position = None if position is None else np.asarray(position, dtype=np.float64).reshape(1, -1)
         self.index = -1                # insertion order == device index (the reference has no ids)
+        self.data = 0.0                # key of the k-NN heap (addToKNNHeap, R/kdTree_general.jl:585)
         self.rrtLMC = Inf
         self.rrtTreeCost = Inf
         self.rrtParentUsed = False
@@ -180,6 +181,19 @@ def kdFindNearest(tree: HipTree, queryPoint) -> Tuple[RRTNode, float]:
     """R/kdTree_general.jl:357-385"""
     idx, dist = tree.ctx.nn_nearest(_q(tree, queryPoint))
     return tree.nodes[int(idx[0])], float(dist[0])
+
+
+def kdFindKNearest(tree: HipTree, k: int, queryPoint) -> List[RRTNode]:
+    """R/kdTree_general.jl:696-723: the nodes of the final heap, each with `.data` = its distance.
+    Like the reference this is max(k, 2) nodes (the heap is seeded with root + dummy) and raises
+    for a wrapped space; the order here is ascending distance (the reference's is heap order)."""
+    idx, dist, count = tree.ctx.nn_knearest(_q(tree, queryPoint), k)
+    out = []
+    for i, d in zip(idx[0, :int(count[0])], dist[0, :int(count[0])]):
+        n = tree.nodes[int(i)]
+        n.data = float(d)
+        out.append(n)
+    return out
 
 
 def _push_range(tree: HipTree, L: JList, idx: np.ndarray, key: np.ndarray):

@@ -78,6 +78,39 @@ def test_radius_full_size_properties(oracle, cfg_name):
                 assert idx[k] == ni and dist[k] == nd
 
 
+def test_knearest_c4_cross_checks(oracle):
+    """k nearest at N = 200 k: the three searches are separate kernels, so they check each other --
+    row[0] is kdFindNearest's answer, and the range search with the k-th distance as radius returns
+    exactly the nodes ranked before it (+ the root rule); oracle spot checks on top."""
+    cfg = synth.CONFIGS["C4"]
+    N, B, k = cfg.n_nodes, 2048, 16
+    pts = synth.nodes(N, 3)
+    Q = synth.queries(B, 3)
+    with Context(3, node_capacity=N) as ctx:
+        ctx.nodes_append(pts)
+        idx, dist, count = ctx.nn_knearest(Q, k)
+        assert (count == k).all() and (np.diff(dist, axis=1) >= 0).all()
+        n_idx, n_dist = ctx.nn_nearest(Q)
+        assert np.array_equal(idx[:, 0], n_idx) and np.array_equal(dist[:, 0], n_dist)
+        d = Q[:, None, :] - pts[idx]
+        ref = np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2])
+        assert np.array_equal(dist, ref)
+        off, ridx, rdist = ctx.nn_radius(Q, dist[:, k - 1])          # per-query radius = k-th distance
+        for i in range(B):
+            inside = set(idx[i, dist[i] < dist[i, k - 1]].tolist())
+            d0 = Q[i] - pts[0]
+            if math.sqrt((d0[0] * d0[0] + d0[1] * d0[1]) + d0[2] * d0[2]) <= dist[i, k - 1]:
+                inside.add(0)                                         # the root is taken with <=
+            assert set(ridx[off[i]:off[i + 1]].tolist()) == inside
+        tree = oracle.KDTree(3)
+        tree.insert_many(pts)
+        for i in np.random.default_rng(3).choice(B, 32, replace=False):
+            oi, ok = tree.knearest(k, Q[i])
+            o = np.argsort(oi)
+            g = np.argsort(idx[i])
+            assert np.array_equal(idx[i][g], oi[o]) and np.array_equal(dist[i][g], ok[o])
+
+
 def test_extend_candidates_c4_full(oracle):
     cfg = synth.CONFIGS["C4"]
     N, M, B = cfg.n_nodes, cfg.n_obstacles, cfg.batch

@@ -155,6 +155,46 @@ def test_kd_equals_naive(oracle, d):
         assert np.array_equal(idx[o], nidx) and np.array_equal(key[o], nkey)
 
 
+@pytest.mark.parametrize("d", [3, 4])
+def test_kd_knearest_equals_naive(oracle, d):
+    """kdFindKNearest vs kdFindKNearestNaive (the reference's own differential design,
+    R/kdTree_general.jl:1064): same node set, same keys, for k >= 2."""
+    rng = np.random.default_rng(300 + d)
+    pts = rng.random((3000, d))
+    t = oracle.KDTree(d)
+    t.insert_many(pts)
+    for k in (2, 3, 17, 64):
+        for q in rng.random((40, d)):
+            idx, key = t.knearest(k, q)
+            nidx, nkey = t.knearest(k, q, naive=True)
+            assert len(idx) == k
+            o, no = np.argsort(idx), np.argsort(nidx)
+            assert np.array_equal(idx[o], nidx[no]) and np.array_equal(key[o], nkey[no])
+            assert key.max() == key[0]                      # heap order: the farthest is on top
+
+
+def test_kd_knearest_seed_quirks(oracle):
+    # the heap starts with root + an Inf dummy (R/kdTree_general.jl:699-706): k = 1 hands back the
+    # TWO nearest nodes; a tree smaller than k hands back all of it; wrapped spaces raise (:711-713)
+    t = oracle.KDTree(2)
+    for p in [[0, 0], [1, 0], [3, 0], [7, 0]]:
+        t.insert(p)
+    idx, key = t.knearest(1, [2.9, 0])
+    assert sorted(idx) == [1, 2] and sorted(key) == [pytest.approx(0.1), pytest.approx(1.9)]
+    idx, _ = t.knearest(1, [-1.0, 0])
+    assert sorted(idx) == [0, 1]
+    idx, key = t.knearest(9, [0, 0])
+    assert sorted(idx) == [0, 1, 2, 3] and sorted(key) == [0.0, 1.0, 3.0, 7.0]
+    one = oracle.KDTree(2)
+    one.insert([5, 5])
+    idx, key = one.knearest(3, [5, 6])
+    assert list(idx) == [0] and list(key) == [1.0]
+    w = oracle.KDTree(2, wraps=[1], wrap_points=[1.0])
+    w.insert([.5, .5])
+    with pytest.raises(RuntimeError):
+        w.knearest(2, [.1, .1])
+
+
 def test_kd_range_list_order_is_reverse_discovery(oracle):
     # JlistPush inserts at the front: the root (added first when within range) is the LAST element
     t = oracle.KDTree(2)
