@@ -129,10 +129,25 @@ int rrtx_spheres_set(rrtx_ctx *ctx, const double *cxyzr, const uint8_t *active, 
 /* polygon Obstacles (legacy 2-D path, R/DRRT_data_structures.jl:135-265), list
  * order.  vert_off is m+1 CSR offsets into vxy (2 doubles per vertex);
  * centre_radius is m x 3 (the Obstacle(3, polygon) ctor values, :229-241, or
- * NULL to have the library apply that ctor); kind[i] is 1 (ball) or 3
- * (polygon). */
+ * NULL to have the library apply that ctor); kind[i] is 1 (ball), 3 (polygon), or 6 / 7 (polygon
+ * moving in time along a path, :140-143; give the paths with rrtx_polygon_paths_set).  Kinds 2, 4
+ * and 5 raise or cannot be constructed in the reference (R/DRRT.jl:1546, data_structures:256) and
+ * are refused. */
 int rrtx_polygons_set(rrtx_ctx *ctx, const int32_t *vert_off, const double *vxy,
                       const double *centre_radius, const uint8_t *kind, const uint8_t *active, int m);
+/* Obstacle.path of the moving kinds 6 and 7 (R/DRRT_data_structures.jl:184-187; read by
+ * readTimeObstaclesFromfile, R/DRRT_Q.jl:1022-1061): path_off is m+1 CSR row offsets into path_xyt,
+ * 3 doubles per row (dx, dy, t) = offset of the obstacle from its ctor position at time t, t
+ * ascending; m is the count last given to rrtx_polygons_set (which clears all paths); static kinds
+ * have empty ranges.  For kind 7 this is the path the robot currently assumes -- call again after
+ * the host recomputed it (changeObstacleDirection, R/DRRT.jl:370-443).  With such obstacles in the
+ * list, rrtx_edges_check* / rrtx_points_check* read TIME from the third coordinate of their points
+ * (startPoint[3], R/DRRT_Q.jl:1703; point[3], :1369): edges are tested at the closest approach of
+ * the two centres against the bounding circle (:1699-1771), points against the polygon moved to its
+ * place at that time (R/DRRT.jl:1289-1305, 1395-1420).  A moving obstacle without a path, and Dubins
+ * edge checks against moving obstacles (which need the time-stamped trajectory of
+ * R/DRRT_DubinsEdge_functions.jl:660-697), fail with RRTX_E_STATE. */
+int rrtx_polygon_paths_set(rrtx_ctx *ctx, const int32_t *path_off, const double *path_xyt, int m);
 /* obstacleAugmentation / expiry (R/obstacleAugmentation.jl:106-114,
  * R/DRRT_Q.jl:3301): change radius and/or active flag of sphere `which`. */
 int rrtx_obstacle_update(rrtx_ctx *ctx, int which, double radius, uint8_t active);

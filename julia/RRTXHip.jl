@@ -169,6 +169,43 @@ function syncObstacles(tree::HipTree, S::TS) where {TS}
   end
 end
 
+# the same for List{Obstacle} (legacy 2-D / Dubins path): kinds 1, 3 and the moving kinds 6 / 7, whose
+# Obstacle.path (rows dx, dy, t) goes up with rrtx_polygon_paths_set.  Call again whenever the host
+# changed a path (changeObstacleDirection, R/DRRT.jl:370-443).  Edge / point checks then go through
+# rrtx_edges_check / rrtx_points_check with kind = 1 and read time from the third coordinate.
+function syncPolygonObstacles(tree::HipTree, S::TS) where {TS}
+  m = S.obstacles.length
+  vertOff = zeros(Int32, m + 1); pathOff = zeros(Int32, m + 1)
+  vxy = Float64[]; pxyt = Float64[]
+  cr = Array{Float64}(undef, 3, m)
+  kind = Vector{UInt8}(undef, m); active = Vector{UInt8}(undef, m)
+  ptr = S.obstacles.front
+  for i = 1:m
+    ob = ptr.data
+    moving = (ob.kind == 6 || ob.kind == 7)
+    kind[i] = ob.kind
+    active[i] = (ob.obstacleUnused || ob.lifeSpan <= 0) ? 0x00 : 0x01
+    cr[1:2, i] = ob.position[1:2]; cr[3, i] = ob.radius
+    poly = moving ? ob.originalPolygon : (ob.kind == 1 ? zeros(0, 2) : ob.polygon)
+    for v = 1:size(poly, 1)
+      push!(vxy, poly[v, 1], poly[v, 2])
+    end
+    vertOff[i + 1] = vertOff[i] + size(poly, 1)
+    if moving
+      for v = 1:size(ob.path, 1)
+        push!(pxyt, ob.path[v, 1], ob.path[v, 2], ob.path[v, 3])
+      end
+    end
+    pathOff[i + 1] = pathOff[i] + (moving ? size(ob.path, 1) : 0)
+    ptr = ptr.child
+  end
+  GC.@preserve vertOff vxy cr kind active rrtx_check(tree, ccall((:rrtx_polygons_set, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{UInt8}, Ptr{UInt8}, Cint),
+      tree.ctx, vertOff, vxy, cr, kind, active, m))
+  GC.@preserve pathOff pxyt rrtx_check(tree, ccall((:rrtx_polygon_paths_set, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Ptr{Int32}, Ptr{Cdouble}, Cint), tree.ctx, pathOff, pxyt, m))
+end
+
 # explicitEdgeCheck(C, edge) (R/DRRT_Q.jl:1802-1826) for SimpleEdge on sphere obstacles.
 # The tree travels in a global per agent because the reference signature has no tree argument.
 const HIP_TREE_OF = IdDict{Any, Any}()          # CSpace -> HipTree (set once per agent)

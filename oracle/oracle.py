@@ -27,7 +27,8 @@ class Sphere(C.Structure):
 class Polygon(C.Structure):
     _fields_ = [("kind", C.c_int32), ("nverts", C.c_int32), ("verts", c_double_p),
                 ("cx", C.c_double), ("cy", C.c_double), ("radius", C.c_double),
-                ("life_span", C.c_double), ("unused", C.c_int32), ("pad", C.c_int32)]
+                ("life_span", C.c_double), ("unused", C.c_int32), ("npath", C.c_int32),
+                ("path", c_double_p)]
 
 
 def build(force: bool = False) -> str:
@@ -297,12 +298,19 @@ def polygon_ctor(verts):
 
 
 class PolygonSet:
-    """A list of kind-3 polygon obstacles (plus optional kind-1 balls) in list order."""
+    """A list of polygon obstacles in list order: kind 3 (static), 1 (ball), 6 / 7 (moving along
+    paths[i], rows of (dx, dy, t))."""
 
-    def __init__(self, polys, kinds=None, active=None):
+    def __init__(self, polys, kinds=None, active=None, paths=None):
         self.verts = [np.ascontiguousarray(np.asarray(p, dtype=np.float64).reshape(-1, 2)) for p in polys]
         self.m = len(self.verts)
         self.arr = (Polygon * max(self.m, 1))()
+        self.paths = [None] * self.m
+        for i in range(self.m):
+            if paths is not None and paths[i] is not None and len(paths[i]):
+                self.paths[i] = np.ascontiguousarray(np.asarray(paths[i], dtype=np.float64).reshape(-1, 3))
+                self.arr[i].npath = self.paths[i].shape[0]
+                self.arr[i].path = _dp(self.paths[i])
         for i, v in enumerate(self.verts):
             cx, cy, r = polygon_ctor(v)
             a = self.arr[i]

@@ -757,7 +757,61 @@ double orc_dist_to_polygon_sqrd(const double *pt, const double *v, int P) {
   return best;
 }
 
-/* explicitEdgeCheck2D, R/DRRT.jl:1523-1578 (kinds 1 and 3; only coords [1:2]) */
+/* findIndexBeforeTime, R/DRRT_Q.jl:1351-1362 (= R/DRRT.jl:1207-1218); 1-based result, -1 for no path */
+static int index_before_time(const double *path, int rows, double t) {
+  if (rows < 1) return -1;
+  int i = 0;
+  while (i + 1 <= rows && path[3 * i + 2] < t) i += 1;
+  return i;
+}
+
+/* findTransformObsToTimeOfPoint, R/DRRT_Q.jl:1367-1391: offset of a moving obstacle at time t */
+static void transform_obs_to_time(const orc_polygon *ob, double t, double *dx, double *dy) {
+  const double *path = ob->path;
+  int before = index_before_time(path, ob->npath, t);
+  if (before < 1) { *dx = path[0]; *dy = path[1]; return; }
+  if (before == ob->npath) { *dx = path[3 * (before - 1)]; *dy = path[3 * (before - 1) + 1]; return; }
+  const double *b = path + 3 * (before - 1), *a = path + 3 * before;
+  double along = (t - b[2]) / (a[2] - b[2]);
+  *dx = b[0] + along * (a[0] - b[0]);
+  *dy = b[1] + along * (a[1] - b[1]);
+}
+
+/* explicitEdgeCheck2D, kinds 6 and 7 (R/DRRT_Q.jl:1699-1771 = R/DRRT.jl:1579-1651): the robot moves
+ * start -> end in (x, y, time); every obstacle path segment that overlaps it in time is tested at the
+ * time of closest approach of the two centres, against the bounding circle only. */
+static int edge_check_moving(const orc_polygon *ob, const double *start, const double *end, double robot_radius) {
+  const double *early, *late;
+  if (start[2] < end[2]) { early = start; late = end; } else { late = start; early = end; }
+  int first = index_before_time(ob->path, ob->npath, early[2]);
+  if (first < 1) first = 1;
+  int last = 1 + index_before_time(ob->path, ob->npath, late[2]);
+  if (last > ob->npath) last = ob->npath;
+  if (last <= first) return 0;
+  for (int is = first; is <= last - 1; ++is) {
+    const double *pa = ob->path + 3 * (is - 1), *pb = ob->path + 3 * is;
+    double x_1 = early[0], y_1 = early[1], T_1 = early[2];
+    double x_2 = pa[0] + ob->cx, y_2 = pa[1] + ob->cy, T_2 = pa[2];
+    double m_x1 = (late[0] - x_1) / (late[2] - T_1);
+    double m_y1 = (late[1] - y_1) / (late[2] - T_1);
+    double m_x2 = ((pb[0] + ob->cx) - x_2) / (pb[2] - T_2);
+    double m_y2 = ((pb[1] + ob->cy) - y_2) / (pb[2] - T_2);
+    double num = (((m_x1 * m_x1) * T_1 + m_x2 * (((m_x2 * T_2) + x_1) - x_2)) -
+                  m_x1 * (((m_x2 * (T_1 + T_2)) + x_1) - x_2)) +
+                 (m_y1 - m_y2) * ((((m_y1 * T_1) - (m_y2 * T_2)) - y_1) + y_2);
+    double den = (m_x1 - m_x2) * (m_x1 - m_x2) + (m_y1 - m_y2) * (m_y1 - m_y2);
+    double T_c = num / den;
+    if (T_c < jl_max(T_1, T_2)) T_c = jl_max(T_1, T_2);
+    else if (T_c > jl_min(late[2], pb[2])) T_c = jl_min(late[2], pb[2]);
+    double r_x = m_x1 * (T_c - T_1) + x_1, r_y = m_y1 * (T_c - T_1) + y_1;
+    double o_x = m_x2 * (T_c - T_2) + x_2, o_y = m_y2 * (T_c - T_2) + y_2;
+    double rr = ob->radius + robot_radius;
+    if ((r_x - o_x) * (r_x - o_x) + (r_y - o_y) * (r_y - o_y) < rr * rr) return 1;
+  }
+  return 0;
+}
+
+/* explicitEdgeCheck2D, R/DRRT.jl:1523-1653 (kinds 1 and 3 read only coords [1:2]; 6/7 also [3] = time) */
 int orc_edge_check_polygon(const orc_polygon *ob, const double *p0, const double *p1, double robot_radius) {
   if (ob->unused || ob->life_span <= 0) return 0;
   if (1 <= ob->kind && ob->kind <= 5) {
@@ -777,6 +831,7 @@ int orc_edge_check_polygon(const orc_polygon *ob, const double *p0, const double
       A[0] = B[0]; A[1] = B[1];
     }
   }
+  if (ob->kind == 6 || ob->kind == 7) return edge_check_moving(ob, p0, p1, robot_radius);
   return 0;
 }
 
@@ -791,6 +846,13 @@ int orc_edge_check_polygons(const orc_polygon *obs, int m, const double *p0, con
   }
   if (first_hit) *first_hit = -1;
   return 0;
+}
+
+/* polygon[:, 1:2] = originalPolygon .+ (dx, dy)  (R/DRRT.jl:1301-1302, 1411-1412) */
+static double *moved_polygon(const orc_polygon *ob, double dx, double dy) {
+  double *v = (double *)malloc(sizeof(double) * 2 * (ob->nverts > 0 ? ob->nverts : 1));
+  for (int i = 0; i < ob->nverts; ++i) { v[2 * i] = ob->verts[2 * i] + dx; v[2 * i + 1] = ob->verts[2 * i + 1] + dy; }
+  return v;
 }
 
 /* explicitPointCheck over polygons: quickCheck pass (R/DRRT.jl:1258-1284) then
@@ -808,6 +870,16 @@ int orc_point_check_polygons(const orc_polygon *obs, int m, const double *p, dou
       if (clearance) *clearance = 0.0;
       return 1;
     }
+    if (ob->kind == 6 || ob->kind == 7) {           /* R/DRRT.jl:1289-1305 */
+      double dx, dy;
+      transform_obs_to_time(ob, p[2], &dx, &dy);
+      double cm[2] = {ob->cx + dx, ob->cy + dy};
+      if (orc_euclid(cm, p, 2) > ob->radius) continue;
+      double *mv = moved_polygon(ob, dx, dy);
+      int in = orc_point_in_polygon(p, mv, ob->nverts);
+      free(mv);
+      if (in) { if (clearance) *clearance = 0.0; return 1; }
+    }
   }
   double ret_cert = INFINITY;
   for (int i = 0; i < m; ++i) {
@@ -815,9 +887,21 @@ int orc_point_check_polygons(const orc_polygon *obs, int m, const double *p, dou
     double this_cert = ret_cert;
     if (!(ob->unused || ob->life_span <= 0)) {
       double c[2] = {ob->cx, ob->cy};
+      double dx = 0.0, dy = 0.0;
+      const int moving = (ob->kind == 6 || ob->kind == 7);
+      if (moving) {                                  /* R/DRRT.jl:1395-1408 */
+        transform_obs_to_time(ob, p[2], &dx, &dy);
+        c[0] = ob->cx + dx; c[1] = ob->cy + dy;
+      }
       double this_dist = orc_euclid(c, p, 2) - robot_radius;
       if (!(this_dist - ob->radius > ret_cert)) {
-        if (ob->kind == 1) {
+        if (moving) {                                /* :1410-1420 */
+          double *mv = moved_polygon(ob, dx, dy);
+          int in = orc_point_in_polygon(p, mv, ob->nverts);
+          if (!in) this_dist = sqrt(orc_dist_to_polygon_sqrd(p, mv, ob->nverts)) - robot_radius;
+          free(mv);
+          if (in || this_dist < 0.0) { if (clearance) *clearance = 0.0; return 1; }
+        } else if (ob->kind == 1) {
           this_dist = this_dist - ob->radius;
           if (this_dist < 0.0) { if (clearance) *clearance = 0.0; return 1; }
         } else if (ob->kind == 3) {
@@ -1074,6 +1158,8 @@ void orc_dubins_steer(const double *s, const double *g, double r_min, double *co
 int orc_dubins_edge_check_polygons(const orc_polygon *obs, int m, const double *s, const double *g,
                                    const double *traj, int traj_len, double robot_radius,
                                    double r_min, int32_t *first_hit) {
+  for (int i = 0; i < m; ++i)
+    if ((obs[i].kind == 6 || obs[i].kind == 7) && !(obs[i].unused || obs[i].life_span <= 0)) return -1;
   for (int i = 0; i < m; ++i) {
     const orc_polygon *ob = &obs[i];
     if (!orc_edge_check_polygon(ob, s, g, robot_radius + 2 * r_min)) continue;

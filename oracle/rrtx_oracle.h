@@ -92,16 +92,18 @@ int orc_edge_check_spheres(const orc_sphere *obs, int m, const double *p0, const
 int orc_point_check_spheres(const orc_sphere *obs, int m, const double *p, double robot_radius,
                             int quick, double *clearance);
 
-/* ---- A10: polygon obstacles (R/DRRT.jl:1009-1106,1144-1202,1258-1470,1523-1578) */
+/* ---- A10: polygon obstacles (R/DRRT.jl:1009-1106,1144-1202,1258-1470,1523-1653).
+ * For the moving kinds 6/7 the points handed to the checks carry time in their third coordinate. */
 typedef struct {
-  int32_t kind;        /* 1 ball, 3 polygon */
+  int32_t kind;        /* 1 ball, 3 polygon, 6 / 7 polygon moving along `path` (R/DRRT_data_structures.jl:136-143) */
   int32_t nverts;
-  const double *verts; /* nverts x 2 row-major */
-  double cx, cy;       /* Obstacle(3, polygon) ctor centre */
+  const double *verts; /* nverts x 2 row-major (kinds 6/7: originalPolygon) */
+  double cx, cy;       /* Obstacle(kind, polygon) ctor centre */
   double radius;
   double life_span;
   int32_t unused;
-  int32_t pad;
+  int32_t npath;       /* kinds 6/7: rows of path */
+  const double *path;  /* npath x 3 row-major (dx, dy, t): offsets from the ctor position vs time */
 } orc_polygon;
 
 /* Obstacle(kind=3, polygon) ctor: bbox centre + max vertex distance
@@ -125,6 +127,8 @@ int orc_point_check_polygons(const orc_polygon *obs, int m, const double *p, dou
 void orc_dubins_steer(const double *s, const double *g, double r_min, double *cost,
                       char *word, double *traj, int traj_cap, int *traj_len);
 /* explicitEdgeCheck(S, DubinsEdge, obstacle) (:750-774) over a list */
+/* (returns -1 when the list holds a moving obstacle: those need the time-parameterised
+ * trajectory of :660-697, which is not restated) */
 int orc_dubins_edge_check_polygons(const orc_polygon *obs, int m, const double *s, const double *g,
                                    const double *traj, int traj_len, double robot_radius,
                                    double r_min, int32_t *first_hit);

@@ -54,11 +54,31 @@ int main(void) {
   bad += orc_edge_check_spheres(sp, 4, z, z, 0.5, &fh) != 1;
   double clr; (void)orc_point_check_spheres(sp, 4, p0, 0.5, 1, &clr);
   double sq[8] = {0, 0, 1, 0, 1, 1, 0, 1};
-  orc_polygon pg; pg.kind = 3; pg.nverts = 4; pg.verts = sq; pg.life_span = INFINITY; pg.unused = 0; pg.pad = 0;
+  orc_polygon pg; pg.kind = 3; pg.nverts = 4; pg.verts = sq; pg.life_span = INFINITY; pg.unused = 0; pg.npath = 0; pg.path = 0;
   orc_polygon_ctor(sq, 4, &pg.cx, &pg.cy, &pg.radius);
   double e0[2] = {-1, .5}, e1[2] = {2, .5};
   bad += orc_edge_check_polygons(&pg, 1, e0, e1, 0.1, &fh) != 1;
   (void)orc_point_check_polygons(&pg, 1, e0, 0.1, &clr);
+  /* moving obstacle (kind 6) + k nearest under the sanitizers */
+  double mpath[6] = {0, 0, 0, 10, 0, 10};
+  orc_polygon mv = pg; mv.kind = 6; mv.npath = 2; mv.path = mpath;
+  double m0[3] = {5, -5, 0}, m1[3] = {5, 5, 10}, m2[3] = {5, -5, 20}, m3[3] = {5, 5, 30};
+  bad += orc_edge_check_polygons(&mv, 1, m0, m1, 0.1, &fh) != 1;
+  bad += orc_edge_check_polygons(&mv, 1, m2, m3, 6.0, &fh) != 0;
+  double mp[3] = {5.5, 0.5, 5};
+  bad += orc_point_check_polygons(&mv, 1, mp, 0.5, &clr) != 1;
+  {
+    orc_kd *kt = orc_kd_create(3);
+    for (int i = 0; i < 500; ++i) { double p[3] = {frand(&seed), frand(&seed), frand(&seed)}; orc_kd_insert(kt, p); }
+    int32_t ki[40]; double kd[40];
+    for (int i = 0; i < 50; ++i) {
+      double q[3] = {frand(&seed), frand(&seed), frand(&seed)};
+      bad += orc_kd_knearest(kt, 1, q, 40, ki, kd) != 2;
+      bad += orc_kd_knearest(kt, 33, q, 40, ki, kd) != 33;
+      bad += orc_kd_knearest_naive(kt, 7, q, 40, ki, kd) != 7;
+    }
+    orc_kd_destroy(kt);
+  }
   double traj[2 * 1024]; int tl; double cost; char word[4];
   for (int k = 0; k < 2000; ++k) {
     double s[4] = {20 * frand(&seed), 20 * frand(&seed), 0, 6.28 * frand(&seed)};

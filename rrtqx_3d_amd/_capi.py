@@ -73,6 +73,7 @@ SYMBOLS = [
     ("rrtx_set_wrap", C.c_int, [_VP, C.c_int, C.c_double]),
     ("rrtx_spheres_set", C.c_int, [_VP, _VP, _VP, C.c_int]),
     ("rrtx_polygons_set", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int]),
+    ("rrtx_polygon_paths_set", C.c_int, [_VP, _VP, _VP, C.c_int]),
     ("rrtx_obstacle_update", C.c_int, [_VP, C.c_int, C.c_double, C.c_uint8]),
     ("rrtx_nn_nearest", C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     ("rrtx_nn_knearest", C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP]),

@@ -100,8 +100,9 @@ class Context:
     def obstacle_update(self, which: int, radius: float, active: bool):
         self._check(self._lib.rrtx_obstacle_update(self._h, which, radius, 1 if active else 0))
 
-    def polygons_set(self, polys, kinds=None, active=None, centre_radius=None):
-        """polys: list of (P_i x 2) vertex arrays in list order."""
+    def polygons_set(self, polys, kinds=None, active=None, centre_radius=None, paths=None):
+        """polys: list of (P_i x 2) vertex arrays in list order; paths: per obstacle an (M_i x 3) array of
+        (dx, dy, t) rows for the moving kinds 6 / 7 (None or empty for the others)."""
         polys = [f64(p, (-1, 2)) for p in polys]
         m = len(polys)
         off = np.zeros(m + 1, dtype=np.int32)
@@ -114,6 +115,18 @@ class Context:
         cr = None if centre_radius is None else f64(centre_radius, (-1, 3))
         self._check(self._lib.rrtx_polygons_set(self._h, _capi._ptr(off), _capi._ptr(vxy), _capi._ptr(cr),
                                                 _capi._ptr(k), _capi._ptr(a), m))
+        if paths is not None:
+            self.polygon_paths_set(paths)
+
+    def polygon_paths_set(self, paths):
+        """Obstacle.path of every polygon obstacle (list order); see rrtx_polygon_paths_set."""
+        rows = [np.zeros((0, 3)) if p is None else f64(p, (-1, 3)) for p in paths]
+        m = len(rows)
+        off = np.zeros(m + 1, dtype=np.int32)
+        for i, p in enumerate(rows):
+            off[i + 1] = off[i] + p.shape[0]
+        xyt = f64(np.concatenate(rows, axis=0) if m else np.zeros((0, 3)), (-1, 3))
+        self._check(self._lib.rrtx_polygon_paths_set(self._h, _capi._ptr(off), _capi._ptr(xyt), m))
 
     # ---- nearest neighbours ---------------------------------------------------------
     def nn_nearest(self, q) -> Tuple[np.ndarray, np.ndarray]:

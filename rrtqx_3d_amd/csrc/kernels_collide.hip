@@ -408,28 +408,93 @@ __device__ bool edge_hits_polygon(double ax, double ay, double bx, double by, do
   return false;
 }
 
+// findIndexBeforeTime, R/DRRT_Q.jl:1351-1362: 1-based row count with path[i, 3] < t
+__device__ __forceinline__ int index_before_time(const double *__restrict__ path, int rows, double t) {
+  if (rows < 1) return -1;
+  int i = 0;
+  while (i + 1 <= rows && path[3 * i + 2] < t) i += 1;
+  return i;
+}
+
+// findTransformObsToTimeOfPoint, R/DRRT_Q.jl:1367-1391
+__device__ __forceinline__ void transform_obs_to_time(const double *__restrict__ path, int rows, double t,
+                                                      double &dx, double &dy) {
+  const int before = index_before_time(path, rows, t);
+  if (before < 1) { dx = path[0]; dy = path[1]; return; }
+  if (before == rows) { dx = path[3 * (before - 1)]; dy = path[3 * (before - 1) + 1]; return; }
+  const double *b = path + 3 * (before - 1), *a = path + 3 * before;
+  const double along = (t - b[2]) / (a[2] - b[2]);
+  dx = b[0] + along * (a[0] - b[0]);
+  dy = b[1] + along * (a[1] - b[1]);
+}
+
+// explicitEdgeCheck2D, kinds 6 and 7 (R/DRRT_Q.jl:1699-1771 = R/DRRT.jl:1579-1651): robot edge in
+// (x, y, time) against the obstacle's bounding circle carried along its path; every path segment that
+// overlaps the edge in time is tested at the time of closest approach of the two centres.
+__device__ bool edge_hits_moving(double sx, double sy, double st, double ex, double ey, double et,
+                                 double robot_radius, double cx, double cy, double rad,
+                                 const double *__restrict__ path, int rows) {
+  double x_1, y_1, T_1, lx, ly, lt;
+  if (st < et) { x_1 = sx; y_1 = sy; T_1 = st; lx = ex; ly = ey; lt = et; }
+  else { lx = sx; ly = sy; lt = st; x_1 = ex; y_1 = ey; T_1 = et; }
+  int first = index_before_time(path, rows, T_1);
+  if (first < 1) first = 1;
+  int last = 1 + index_before_time(path, rows, lt);
+  if (last > rows) last = rows;
+  if (last <= first) return false;
+  const double m_x1 = (lx - x_1) / (lt - T_1);
+  const double m_y1 = (ly - y_1) / (lt - T_1);
+  const double rr = rad + robot_radius;
+  for (int is = first; is <= last - 1; ++is) {
+    const double *pa = path + 3 * (is - 1), *pb = path + 3 * is;
+    const double x_2 = pa[0] + cx, y_2 = pa[1] + cy, T_2 = pa[2];
+    const double m_x2 = ((pb[0] + cx) - x_2) / (pb[2] - T_2);
+    const double m_y2 = ((pb[1] + cy) - y_2) / (pb[2] - T_2);
+    const double num = (((m_x1 * m_x1) * T_1 + m_x2 * (((m_x2 * T_2) + x_1) - x_2)) -
+                        m_x1 * (((m_x2 * (T_1 + T_2)) + x_1) - x_2)) +
+                       (m_y1 - m_y2) * ((((m_y1 * T_1) - (m_y2 * T_2)) - y_1) + y_2);
+    const double den = (m_x1 - m_x2) * (m_x1 - m_x2) + (m_y1 - m_y2) * (m_y1 - m_y2);
+    double T_c = num / den;
+    if (T_c < jl_max(T_1, T_2)) T_c = jl_max(T_1, T_2);
+    else if (T_c > jl_min(lt, pb[2])) T_c = jl_min(lt, pb[2]);
+    const double r_x = m_x1 * (T_c - T_1) + x_1, r_y = m_y1 * (T_c - T_1) + y_1;
+    const double o_x = m_x2 * (T_c - T_2) + x_2, o_y = m_y2 * (T_c - T_2) + y_2;
+    if ((r_x - o_x) * (r_x - o_x) + (r_y - o_y) * (r_y - o_y) < rr * rr) return true;
+  }
+  return false;
+}
+
 __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__restrict__ p0,
                                                              const double *__restrict__ p1, int stride,
                                                              long long ne, const double *__restrict__ meta,
                                                              const int32_t *__restrict__ off,
                                                              const double *__restrict__ vxy,
+                                                             const int32_t *__restrict__ path_off,
+                                                             const double *__restrict__ path, int has_moving,
                                                              const int32_t *__restrict__ orig, int m_begin,
                                                              int m_end, double robot_radius,
                                                              uint8_t *__restrict__ hit,
                                                              int32_t *__restrict__ first_hit) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = i < ne;
-  double ax = 0, ay = 0, bx = 0, by = 0;
+  double ax = 0, ay = 0, at = 0, bx = 0, by = 0, bt = 0;
   if (act) {
     ax = p0[i * stride + 0]; ay = p0[i * stride + 1];
     bx = p1[i * stride + 0]; by = p1[i * stride + 1];
+    if (has_moving) { at = p0[i * stride + 2]; bt = p1[i * stride + 2]; }   // startPoint[3] = time
   }
   bool done = !act;
   int first = -1;
   for (int j = m_begin; j < m_end; ++j) {
-    if (!done && edge_hits_polygon(ax, ay, bx, by, robot_radius, meta, off, vxy, j)) {
-      done = true;
-      first = orig[j];
+    if (!done) {
+      const int kind = (int)meta[4 * j + 3];
+      bool h;
+      if (kind == 6 || kind == 7)
+        h = edge_hits_moving(ax, ay, at, bx, by, bt, robot_radius, meta[4 * j + 0], meta[4 * j + 1],
+                             meta[4 * j + 2], path + 3 * (size_t)path_off[j], path_off[j + 1] - path_off[j]);
+      else
+        h = edge_hits_polygon(ax, ay, bx, by, robot_radius, meta, off, vxy, j);
+      if (h) { done = true; first = orig[j]; }
     }
     if (__ballot(!done) == 0ull) break;
   }
@@ -440,13 +505,19 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
 }
 
 // pointInPolygon (MacMartin crossings), R/DRRT.jl:1009-1056
-__device__ bool point_in_polygon(double px, double py, const double *__restrict__ vxy, int b, int e) {
+// MOV: the vertices are originalPolygon .+ (ox, oy), the transformed copy kinds 6 / 7 test against
+// (R/DRRT.jl:1301-1302)
+template <bool MOV = false>
+__device__ bool point_in_polygon(double px, double py, const double *__restrict__ vxy, int b, int e,
+                                 double ox = 0.0, double oy = 0.0) {
   const int P = e - b;
   if (P < 2) return false;
   int crossings = 0;
   double sx = vxy[2 * (e - 1)], sy = vxy[2 * (e - 1) + 1];
+  if (MOV) { sx = sx + ox; sy = sy + oy; }
   for (int v = b; v < e; ++v) {
     double ex = vxy[2 * v], ey = vxy[2 * v + 1];
+    if (MOV) { ex = ex + ox; ey = ey + oy; }
     if ((sy > py && ey < py) || (sy < py && ey > py)) {
       if (sx > px && ex > px) {
         crossings += 1;
@@ -464,11 +535,15 @@ __device__ bool point_in_polygon(double px, double py, const double *__restrict_
 }
 
 // distToPolygonSqrd, R/DRRT.jl:1087-1106
-__device__ double dist_to_polygon_sqrd(double px, double py, const double *__restrict__ vxy, int b, int e) {
+template <bool MOV = false>
+__device__ double dist_to_polygon_sqrd(double px, double py, const double *__restrict__ vxy, int b, int e,
+                                       double ox = 0.0, double oy = 0.0) {
   double best = __builtin_inf();
   double sx = vxy[2 * (e - 1)], sy = vxy[2 * (e - 1) + 1];
+  if (MOV) { sx = sx + ox; sy = sy + oy; }
   for (int v = b; v < e; ++v) {
     double ex = vxy[2 * v], ey = vxy[2 * v + 1];
+    if (MOV) { ex = ex + ox; ey = ey + oy; }
     double dd = dist_sqrd_point_to_segment(px, py, sx, sy, ex, ey);
     if (dd < best) best = dd;
     sx = ex; sy = ey;
@@ -481,18 +556,29 @@ __device__ double dist_to_polygon_sqrd(double px, double py, const double *__res
 __global__ __launch_bounds__(256) void points_polygons_kernel(const double *__restrict__ p, int stride,
                                                               long long np, const double *__restrict__ meta,
                                                               const int32_t *__restrict__ off,
-                                                              const double *__restrict__ vxy, int m,
-                                                              double robot_radius,
+                                                              const double *__restrict__ vxy,
+                                                              const int32_t *__restrict__ path_off,
+                                                              const double *__restrict__ path, int has_moving,
+                                                              int m, double robot_radius,
                                                               uint8_t *__restrict__ unsafe,
                                                               double *__restrict__ clearance) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= np) return;
   const double px = p[i * stride + 0], py = p[i * stride + 1];
+  const double pt = has_moving ? p[i * stride + 2] : 0.0;      // point[3] = time (kinds 6 / 7)
   for (int j = 0; j < m; ++j) {
-    const double cx = meta[4 * j + 0], cy = meta[4 * j + 1], rad = meta[4 * j + 2];
+    double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
+    const double rad = meta[4 * j + 2];
     const int kind = (int)meta[4 * j + 3];
+    const bool mov = (kind == 6 || kind == 7);
+    double dx = 0.0, dy = 0.0;
+    if (mov) {                                                 // R/DRRT.jl:1289-1305
+      transform_obs_to_time(path + 3 * (size_t)path_off[j], path_off[j + 1] - path_off[j], pt, dx, dy);
+      cx = cx + dx; cy = cy + dy;
+    }
     if (sqrt_rn(sq2(cx, cy, px, py)) > rad) continue;
-    if (kind == 1 || (kind == 3 && point_in_polygon(px, py, vxy, off[j], off[j + 1]))) {
+    if (kind == 1 || (kind == 3 && point_in_polygon(px, py, vxy, off[j], off[j + 1])) ||
+        (mov && point_in_polygon<true>(px, py, vxy, off[j], off[j + 1], dx, dy))) {
       unsafe[i] = 1;
       if (clearance) clearance[i] = 0.0;
       return;
@@ -500,13 +586,27 @@ __global__ __launch_bounds__(256) void points_polygons_kernel(const double *__re
   }
   double ret_cert = __builtin_inf();
   for (int j = 0; j < m; ++j) {
-    const double cx = meta[4 * j + 0], cy = meta[4 * j + 1], rad = meta[4 * j + 2];
+    double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
+    const double rad = meta[4 * j + 2];
     const int kind = (int)meta[4 * j + 3];
+    const bool mov = (kind == 6 || kind == 7);
+    double dx = 0.0, dy = 0.0;
+    if (mov) {                                                 // R/DRRT.jl:1395-1420
+      transform_obs_to_time(path + 3 * (size_t)path_off[j], path_off[j + 1] - path_off[j], pt, dx, dy);
+      cx = cx + dx; cy = cy + dy;
+    }
     double this_cert = ret_cert;
     double this_dist = sqrt_rn(sq2(cx, cy, px, py)) - robot_radius;
     if (!(this_dist - rad > ret_cert)) {
       bool bad = false;
-      if (kind == 1) {
+      if (mov) {
+        if (point_in_polygon<true>(px, py, vxy, off[j], off[j + 1], dx, dy)) {
+          bad = true;
+        } else {
+          this_dist = sqrt_rn(dist_to_polygon_sqrd<true>(px, py, vxy, off[j], off[j + 1], dx, dy)) - robot_radius;
+          bad = this_dist < 0.0;
+        }
+      } else if (kind == 1) {
         this_dist = this_dist - rad;
         bad = this_dist < 0.0;
       } else if (kind == 3) {
@@ -681,9 +781,19 @@ int sync_polygons(rrtx_ctx *ctx) {
   const int m = (int)ctx->poly_active.size();
   std::vector<double> meta;
   std::vector<int32_t> off(1, 0), orig;
-  std::vector<double> vxy;
+  std::vector<double> vxy, path;
+  std::vector<int32_t> path_off(1, 0);
+  bool moving = false;
   for (int i = 0; i < m; ++i) {
     if (!ctx->poly_active[i]) continue;
+    const int pr0 = ctx->poly_path_off[i], pr1 = ctx->poly_path_off[i + 1];
+    if (ctx->poly_kind[i] == 6 || ctx->poly_kind[i] == 7) {
+      // findTransformObsToTimeOfPoint reads path[1, :] unconditionally (R/DRRT_Q.jl:1373-1376)
+      if (pr1 <= pr0) return fail(ctx, RRTX_E_STATE, "moving obstacle %d has no path (rrtx_polygon_paths_set)", i);
+      moving = true;
+    }
+    path.insert(path.end(), ctx->poly_path.begin() + 3 * (size_t)pr0, ctx->poly_path.begin() + 3 * (size_t)pr1);
+    path_off.push_back((int32_t)(path.size() / 3));
     meta.push_back(ctx->poly_cr[3 * (size_t)i + 0]);
     meta.push_back(ctx->poly_cr[3 * (size_t)i + 1]);
     meta.push_back(ctx->poly_cr[3 * (size_t)i + 2]);
@@ -708,7 +818,13 @@ int sync_polygons(rrtx_ctx *ctx) {
     if (!vxy.empty())
       RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_vxy.p, vxy.data(), sizeof(double) * vxy.size(), hipMemcpyHostToDevice));
     RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_orig.p, orig.data(), sizeof(int32_t) * na, hipMemcpyHostToDevice));
+    RRTX_HIP(ctx, ctx->d_poly_path_off.ensure(sizeof(int32_t) * path_off.size()));
+    RRTX_HIP(ctx, ctx->d_poly_path.ensure(sizeof(double) * (path.size() + 3)));
+    RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_path_off.p, path_off.data(), sizeof(int32_t) * path_off.size(), hipMemcpyHostToDevice));
+    if (!path.empty())
+      RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_path.p, path.data(), sizeof(double) * path.size(), hipMemcpyHostToDevice));
   }
+  ctx->poly_has_moving = moving;
   ctx->poly_dirty = false;
   return RRTX_OK;
 }
@@ -810,7 +926,8 @@ int launch_edges_polygons(rrtx_ctx *ctx, const double *p0_dev, const double *p1_
   span_begin(ctx, KF_EDGES);
   hipLaunchKernelGGL(edges_polygons_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
                      p1_dev, ctx->dim, (long long)ne, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
-                     ctx->d_poly_vxy.as<double>(), ctx->d_poly_orig.as<int32_t>(), pb, pe, robot_radius, hit_dev,
+                     ctx->d_poly_vxy.as<double>(), ctx->d_poly_path_off.as<int32_t>(), ctx->d_poly_path.as<double>(),
+                     ctx->poly_has_moving ? 1 : 0, ctx->d_poly_orig.as<int32_t>(), pb, pe, robot_radius, hit_dev,
                      first_hit_dev);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
@@ -839,7 +956,8 @@ int launch_points_polygons(rrtx_ctx *ctx, const double *p_dev, int64_t np, doubl
   span_begin(ctx, KF_POINTS);
   hipLaunchKernelGGL(points_polygons_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, p_dev,
                      ctx->dim, (long long)np, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
-                     ctx->d_poly_vxy.as<double>(), ctx->poly_n_active, robot_radius, unsafe_dev, clearance_dev);
+                     ctx->d_poly_vxy.as<double>(), ctx->d_poly_path_off.as<int32_t>(), ctx->d_poly_path.as<double>(),
+                     ctx->poly_has_moving ? 1 : 0, ctx->poly_n_active, robot_radius, unsafe_dev, clearance_dev);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;

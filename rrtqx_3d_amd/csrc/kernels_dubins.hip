@@ -521,6 +521,10 @@ int launch_candidate_dubins(rrtx_ctx *ctx, const double *q_dev, int nq, const in
   if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
   int rc = sync_polygons(ctx);
   if (rc) return rc;
+  // kinds 6 / 7 test each trajectory piece at its time stamp (R/DRRT_DubinsEdge_functions.jl:660-697 builds
+  // the time-parameterised polyline); this library steers in a space without time
+  if (ctx->poly_has_moving)
+    return fail(ctx, RRTX_E_STATE, "Dubins edges against moving obstacles (kind 6/7) need time-parameterised trajectories");
   span_begin(ctx, KF_DUBINS);
   hipLaunchKernelGGL(candidate_dubins_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, q_dev,
                      offsets_dev, nq, idx_dev, owner_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[3],
@@ -565,6 +569,10 @@ int launch_dubins_edges_check(rrtx_ctx *ctx, const double *s_dev, const double *
   if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
   int rc = sync_polygons(ctx);
   if (rc) return rc;
+  // kinds 6 / 7 test each trajectory piece at its time stamp (R/DRRT_DubinsEdge_functions.jl:660-697 builds
+  // the time-parameterised polyline); this library steers in a space without time
+  if (ctx->poly_has_moving)
+    return fail(ctx, RRTX_E_STATE, "Dubins edges against moving obstacles (kind 6/7) need time-parameterised trajectories");
   span_begin(ctx, KF_DUBINS);
   hipLaunchKernelGGL(dubins_edges_check_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream,
                      s_dev, g_dev, (long long)ne, r_min, robot_radius, ctx->d_poly_meta.as<double>(),

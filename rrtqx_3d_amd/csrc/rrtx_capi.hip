@@ -362,7 +362,7 @@ int rrtx_destroy(rrtx_ctx *ctx) {
   ctx->d_absmax.release();
   ctx->d_xrange.release();
   DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_reach, &ctx->d_sph_reach_f, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
-                    &ctx->d_poly_orig, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
+                    &ctx->d_poly_orig, &ctx->d_poly_path_off, &ctx->d_poly_path, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
                     &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_bsum, &ctx->ws_scalars, &ctx->ws_scalars_nn, &ctx->ws_tmp_idx,
                     &ctx->ws_tmp_d2, &ctx->ws_owner, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
                     &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr, &ctx->ws_mask, &ctx->ws_i32a, &ctx->ws_i32b,
@@ -538,8 +538,9 @@ int rrtx_polygons_set(rrtx_ctx *ctx, const int32_t *vert_off, const double *vxy,
   if (active) for (int i = 0; i < m; ++i) ctx->poly_active[i] = active[i] ? 1 : 0;
   ctx->poly_cr.assign(3 * (size_t)m, 0.0);
   for (int i = 0; i < m; ++i) {
-    if (ctx->poly_kind[i] != 1 && ctx->poly_kind[i] != 3)
-      return fail(ctx, RRTX_E_INVALID, "polygons_set: obstacle kind %d not supported (1 or 3)", (int)ctx->poly_kind[i]);
+    const int kd = ctx->poly_kind[i];
+    if (kd != 1 && kd != 3 && kd != 6 && kd != 7)
+      return fail(ctx, RRTX_E_INVALID, "polygons_set: obstacle kind %d not supported (1, 3, 6 or 7)", kd);
     if (centre_radius) {
       for (int k = 0; k < 3; ++k) ctx->poly_cr[3 * (size_t)i + k] = centre_radius[3 * (size_t)i + k];
       continue;
@@ -563,6 +564,24 @@ int rrtx_polygons_set(rrtx_ctx *ctx, const int32_t *vert_off, const double *vxy,
     ctx->poly_cr[3 * (size_t)i + 1] = py;
     ctx->poly_cr[3 * (size_t)i + 2] = std::sqrt(best);
   }
+  ctx->poly_path_off.assign((size_t)m + 1, 0);
+  ctx->poly_path.clear();
+  ctx->poly_dirty = true;
+  return RRTX_OK;
+}
+
+int rrtx_polygon_paths_set(rrtx_ctx *ctx, const int32_t *path_off, const double *path_xyt, int m) {
+  CHECK_CTX(ctx);
+  if (m != (int)ctx->poly_kind.size())
+    return fail(ctx, RRTX_E_INVALID, "polygon_paths_set: %d paths for %d polygons", m, (int)ctx->poly_kind.size());
+  if (m > 0 && !path_off) return fail(ctx, RRTX_E_INVALID, "polygon_paths_set: bad arguments");
+  if (m == 0) return RRTX_OK;
+  if (path_off[0] != 0) return fail(ctx, RRTX_E_INVALID, "polygon_paths_set: path_off must start at 0");
+  for (int i = 0; i < m; ++i)
+    if (path_off[i + 1] < path_off[i]) return fail(ctx, RRTX_E_INVALID, "polygon_paths_set: path_off not monotone");
+  if (path_off[m] > 0 && !path_xyt) return fail(ctx, RRTX_E_INVALID, "polygon_paths_set: bad arguments");
+  ctx->poly_path_off.assign(path_off, path_off + m + 1);
+  ctx->poly_path.assign(path_xyt, path_xyt + 3 * (size_t)path_off[m]);
   ctx->poly_dirty = true;
   return RRTX_OK;
 }

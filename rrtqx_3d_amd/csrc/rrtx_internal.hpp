@@ -137,6 +137,11 @@ struct rrtx_ctx {
   int poly_n_active = 0;
   rrtx::DevBuf d_poly_off, d_poly_vxy, d_poly_meta; // meta: per active obstacle {cx, cy, radius, kind} doubles
   rrtx::DevBuf d_poly_orig;
+  // kinds 6 / 7 (polygons moving in time): per obstacle rows of (dx, dy, t), CSR over all m obstacles
+  std::vector<int32_t> poly_path_off;
+  std::vector<double> poly_path;
+  rrtx::DevBuf d_poly_path_off, d_poly_path;   // packed over the active obstacles like d_poly_off
+  bool poly_has_moving = false;                // an active obstacle of kind 6 or 7 exists
 
   // workspaces
   rrtx::DevBuf ws_q;        // staged queries / points

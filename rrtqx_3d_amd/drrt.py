@@ -271,10 +271,16 @@ class Obstacle:
             self.position = np.asarray(a, dtype=np.float64).reshape(-1)[:2].copy()
             self.radius = float(b)
             self.polygon = np.zeros((0, 2))
-        elif self.kind == 3:
+        elif self.kind in (3, 6, 7):
             self.polygon = np.asarray(a, dtype=np.float64).reshape(-1, 2).copy()
             self.position = None       # centre / radius come from the library's ctor restatement (:229-241)
             self.radius = None
+            if self.kind != 3:         # polygon moving in time (:140-143, 181-192); set by the file readers
+                self.velocity = 0.0
+                self.path = np.zeros((0, 3))           # rows (dx, dy, t) the robot knows about
+                self.originalPolygon = self.polygon
+                self.unknownPath = np.zeros((0, 3))    # kind 7: what the obstacle will really do
+                self.nextDirectionChangeTime = -Inf
         else:
             error("need to impliment this")   # the reference's message for unsupported kinds (R/DRRT.jl:1546)
 
@@ -337,6 +343,21 @@ def addObsToCSpace(S: CSpace, ob):
     listPush(S.obstacles, ob)
 
 
+def readTimeObstaclesFromfile(S: CSpace, filename: str, obsMult: int = 1):
+    """R/DRRT_Q.jl:1022-1061: polygons that move along a known path (kind 6)."""
+    from . import envio
+    env = envio.read_time_obstacles(filename)
+    for poly, speed, path in zip(env.polygons, env.speed, env.paths):
+        for _ in range(obsMult):
+            ob = Obstacle(6, poly)
+            ob.senseableObstacle = False
+            ob.obstacleUnusedAfterSense = False
+            ob.obstacleUnused = False
+            ob.velocity = float(speed)
+            ob.path = path.copy()
+            addObsToCSpace(S, ob)
+
+
 def _is_active(ob) -> bool:
     return not (ob.obstacleUnused or ob.lifeSpan <= 0)     # R/DRRT_Q.jl:1777
 
@@ -349,13 +370,14 @@ def _sync_obstacles(S: CSpace) -> int:
     if poly and any(isinstance(o, SphereObstacle) for o in obs):
         error("CSpace.obstacles mixes SphereObstacle and Obstacle")
     if poly:
-        sig = ("p", tuple((id(o), o.kind, _is_active(o), o.radius if o.kind == 1 else o.polygon.tobytes()) for o in obs))
+        sig = ("p", tuple((id(o), o.kind, _is_active(o), o.radius if o.kind == 1 else o.polygon.tobytes(),
+                           np.asarray(o.path, dtype=np.float64).tobytes() if o.kind in (6, 7) else b"") for o in obs))
     else:
         sig = ("s", tuple((id(o), o.radius, _is_active(o), tuple(o.position)) for o in obs))
     key = (id(ctx), sig)
     if S._sig != key:
         if poly:
-            polys = [o.polygon if o.kind == 3 else np.zeros((0, 2)) for o in obs]
+            polys = [o.polygon if o.kind != 1 else np.zeros((0, 2)) for o in obs]
             cr = None
             if any(o.kind == 1 for o in obs):
                 from . import _capi  # noqa: F401  (centre/radius must be given for balls)
@@ -368,8 +390,9 @@ def _sync_obstacles(S: CSpace) -> int:
                         px = (v[:, 0].max() + v[:, 0].min()) / 2.0
                         py = (v[:, 1].max() + v[:, 1].min()) / 2.0
                         cr[i] = [px, py, math.sqrt(((v - [px, py]) ** 2).sum(axis=1).max())]
+            paths = [o.path if o.kind in (6, 7) else None for o in obs]
             ctx.polygons_set(polys, kinds=[o.kind for o in obs], active=[_is_active(o) for o in obs],
-                                  centre_radius=cr)
+                             centre_radius=cr, paths=paths if any(p is not None for p in paths) else None)
         else:
             c = np.array([[*o.position[:3], o.radius] for o in obs], dtype=np.float64).reshape(-1, 4)
             ctx.spheres_set(c, [_is_active(o) for o in obs])

@@ -15,6 +15,16 @@ the planner loads obstacles from, so fixtures load without Julia.
       x, y   (x nverts)  > per obstacle
       behaviour        /
 
+  moving polygons  (R/DRRT_Q.jl:1022-1061 = R/DRRT.jl:877-916, readTimeObstaclesFromfile, kind 6;
+             readDynamicTimeObstaclesFromfile :1067-1109 reads the same grammar into kind 7's
+             unknownPath; e.g. environments/rand_StaticTime.txt):
+      count
+      nverts           \\
+      x, y   (x nverts)   |
+      speed               > per obstacle
+      npath               |
+      dx, dy, t (x npath) /   offsets from the polygon's ctor position vs time (ascending t)
+
 Obstacles are pushed to the FRONT of CSpace.obstacles (addObsToCSpace ->
 listPush, R/list.jl:53-58), so list order is the reverse of file order;
 `list_order()` applies that.  Behaviour 1 ("appears") starts with
@@ -59,6 +69,16 @@ class PolygonEnv:
         return [p.copy() for p in self.polygons[::-1]], self.active()[::-1].copy()
 
 
+@dataclass
+class TimeObstacleEnv:
+    polygons: List[np.ndarray]   # each P x 2 (originalPolygon), FILE order
+    speed: np.ndarray            # obsSpeed per obstacle (Obstacle.velocity)
+    paths: List[np.ndarray]      # each M x 3 rows of (dx, dy, t)
+
+    def list_order(self):
+        return [p.copy() for p in self.polygons[::-1]], [p.copy() for p in self.paths[::-1]]
+
+
 def read_sphere_obstacles(path: str) -> SphereEnv:
     with open(path) as f:
         lines = [ln for ln in f.read().splitlines() if ln.strip() != ""]
@@ -97,6 +117,41 @@ def read_polygon_obstacles(path: str) -> PolygonEnv:
         beh.append(b)
         p += nv + 2
     return PolygonEnv(polys, np.array(beh, dtype=np.int32))
+
+
+def read_time_obstacles(path: str) -> TimeObstacleEnv:
+    with open(path) as f:
+        lines = [ln for ln in f.read().splitlines() if ln.strip() != ""]
+    n = int(lines[0])
+    polys, speed, paths = [], [], []
+    p = 1
+    for _ in range(n):
+        nv = int(lines[p])
+        v = np.stack([str2array(lines[p + 1 + k]) for k in range(nv)], axis=0)
+        if v.shape[1] != 2:
+            raise ValueError(f"{path}: expected 'x, y' vertex rows")
+        p += 1 + nv
+        speed.append(float(lines[p]))
+        m = int(lines[p + 1])
+        mp = np.stack([str2array(lines[p + 2 + k]) for k in range(m)], axis=0)
+        if mp.shape[1] != 3:
+            raise ValueError(f"{path}: expected 'dx, dy, t' path rows")
+        p += 2 + m
+        polys.append(v)
+        paths.append(mp)
+    return TimeObstacleEnv(polys, np.array(speed, dtype=np.float64), paths)
+
+
+def write_time_obstacles(path: str, env: TimeObstacleEnv):
+    with open(path, "w") as f:
+        f.write(f"{len(env.polygons)}\n")
+        for v, sp, mp in zip(env.polygons, env.speed, env.paths):
+            f.write(f"{v.shape[0]}\n")
+            for x, y in v:
+                f.write(f"{x:f}, {y:f}\n")
+            f.write(f"{sp:f}\n{mp.shape[0]}\n")
+            for dx, dy, t in mp:
+                f.write(f"{dx:f}, {dy:f}, {t:f}\n")
 
 
 def write_sphere_obstacles(path: str, env: SphereEnv):

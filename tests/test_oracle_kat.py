@@ -261,6 +261,45 @@ def test_point_checks(oracle):
     assert oracle.point_check_spheres(sp, 0, [0, 0, 0], 0.5) == (False, float("inf"))
 
 
+def test_moving_obstacle_edge_kats(oracle):
+    """Kinds 6 / 7 (R/DRRT_Q.jl:1699-1771), derived by hand.  Obstacle: unit square about the origin
+    (ctor centre (0,0), radius sqrt 2) sliding along +x at speed 1: path (0,0,t=0) -> (10,0,t=10).
+    M1  robot (5,-5,t=0) -> (5,5,t=10): slopes (0,1) vs (1,0); T_c = (5 + 5)/2 = 5, both centres at
+        (5,0) => hit.  M1' the same edge given end-first is re-ordered past->future => hit.
+    M2  the same crossing 20 time units later lies after the path's last row: firstObsInd = 2,
+        lastObsInd = min(3, 2) = 2 => "does not overlap in time" => no hit, although the obstacle is
+        assumed to rest at (10,0) and a robot-radius of 6 would reach it (reference behaviour).
+    M3  robot parallel to the obstacle, 3 apart: slopes equal => 0/0 = NaN => every comparison is
+        false => no hit for sum of radii <= 3 ... and also none above it (NaN distance): a quirk."""
+    sq = [[-1, -1], [1, -1], [1, 1], [-1, 1]]
+    path = [[0, 0, 0], [10, 0, 10]]
+    ps = oracle.PolygonSet([sq], kinds=[6], paths=[path])
+    chk = lambda a, b, rr: int(oracle.edges_check_polygons(ps, np.array([a], float), np.array([b], float), rr)[0][0])
+    assert chk([5, -5, 0], [5, 5, 10], 0.1) == 1
+    assert chk([5, 5, 10], [5, -5, 0], 0.1) == 1
+    assert chk([5, -5, 20], [5, 5, 30], 6.0) == 0
+    assert chk([0, 3, 0], [10, 3, 10], 0.5) == 0
+    assert chk([0, 3, 0], [10, 3, 10], 5.0) == 0
+    # a miss in space-time: the robot crosses x = 5 when the obstacle is still at x = 1
+    assert chk([5, -5, 0], [5, 5, 2], 0.1) == 0
+    ps7 = oracle.PolygonSet([sq], kinds=[7], paths=[path])
+    assert int(oracle.edges_check_polygons(ps7, np.array([[5., -5, 0]]), np.array([[5., 5, 10]]), 0.1)[0][0]) == 1
+
+
+def test_moving_obstacle_point_kats(oracle):
+    """findTransformObsToTimeOfPoint (R/DRRT_Q.jl:1367-1391) + the kind 6 branches of quickCheck2D /
+    explicitPointCheck2D (R/DRRT.jl:1289-1305, 1395-1420); same obstacle as above."""
+    sq = [[-1, -1], [1, -1], [1, 1], [-1, 1]]
+    ps = oracle.PolygonSet([sq], kinds=[6], paths=[[[0, 0, 0], [10, 0, 10]]])
+    assert oracle.point_check_polygons(ps, [5, 0, 5], 0.5) == (True, 0.0)          # square is at x = 5
+    unsafe, clr = oracle.point_check_polygons(ps, [5, 0, 0], 0.5)                    # square still at 0
+    assert not unsafe and clr == 3.5
+    assert oracle.point_check_polygons(ps, [10.5, 0, 100], 0.5) == (True, 0.0)       # rests at path[end]
+    assert oracle.point_check_polygons(ps, [0.5, 0, -3], 0.5) == (True, 0.0)         # before: path[1]
+    unsafe, clr = oracle.point_check_polygons(ps, [2.5 + 1 + 0.75, 0, 2.5], 0.5)     # 0.75 off the edge
+    assert not unsafe and clr == 0.25
+
+
 def test_reference_env_files_as_inputs(oracle):
     """the two environment fixtures the reference ships are inputs, not expected outputs; the parsed
     copies under tests/golden must load and have the documented shape"""
