@@ -100,6 +100,10 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
  *   range-search kernel is bracketed by HIP events (an event record between two kernels drains the
  *   pipeline for several microseconds); rrtx_stats then reports the timed launches only. */
 #define RRTX_OPT_PROFILE_EVERY 6
+/*   RRTX_OPT_KNN_LISTS (default 1): rrtx_nn_knearest takes the k nearest of a query from its
+ *   range-search list (radius guessed from a sample of the batch) and runs the exhaustive
+ *   selection kernel only for queries whose list holds fewer than k nodes; 0 = exhaustive for all. */
+#define RRTX_OPT_KNN_LISTS 7
 int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value);
 
 /* Host-only helper (no GPU needed): the exact thresholds on SQUARED distances the kernels
@@ -164,7 +168,7 @@ int rrtx_nn_nearest(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double
  * ascending (distance, index) -- the reference returns heap order -- and ties at the last place
  * go to the lowest indices.  Nodes at a non-finite distance are never returned.  1 <= k <= 2048.
  * Like the reference (:711-713) the call fails on a wrapped space (RRTX_E_STATE).  The reference
- * itself never calls this search (RRT^X uses the radius search): the kernel is exact, not tuned. */
+ * itself never calls this search (RRT^X uses the radius search).  See RRTX_OPT_KNN_LISTS. */
 int rrtx_nn_knearest(rrtx_ctx *ctx, const double *q, int nq, int k, int32_t *idx, double *dist, int32_t *count);
 /* kdFindWithinRange (R/kdTree_general.jl:889-919), batched: for query i the
  * nodes with KDdist < r[i] (the root, index 0, with <=), wrapped dimensions

@@ -2,6 +2,8 @@
 // exact fp64 scan and the screened fast path.  gfx950 only.
 #include "nn_device.hpp"
 
+#include <algorithm>
+#include <cmath>
 #include <limits>
 
 namespace rrtx {
@@ -400,6 +402,7 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
 // deterministic rather than tuned: it streams the node arrays nine times per query.
 namespace {
 constexpr int kKnnMax = 2048;
+constexpr int kKnnU = 4;
 constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
 
 template <int D>
@@ -413,18 +416,60 @@ __device__ __forceinline__ unsigned long long knn_key(const double (&g)[4], cons
   return (s != s) ? ~0ull : (unsigned long long)__double_as_longlong(s);
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void nn_knearest_kernel(
+// sorts the n gathered (key, index) pairs by (distance, index) and writes the first kk as row qi
+__device__ void knn_sort_emit(unsigned long long *skey, int *sidx, int n, int kk, int stride, int qi,
+                              int32_t *__restrict__ idx_out, double *__restrict__ dist_out,
+                              int32_t *__restrict__ count_out) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  int P = 1;
+  while (P < n) P <<= 1;
+  for (int i = n + tid; i < P; i += nt) { skey[i] = ~0ull; sidx[i] = 0x7fffffff; }
+  __syncthreads();
+  for (int k2 = 2; k2 <= P; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += nt) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long ka = skey[i], kb = skey[l];
+          const int ia = sidx[i], ib = sidx[l];
+          const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
+          const bool up = (i & k2) == 0;
+          if (up ? a_gt_b : !a_gt_b) { skey[i] = kb; skey[l] = ka; sidx[i] = ib; sidx[l] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // nodes at a non-finite distance never pass the reference's `newDist < worst` test (:633,:665)
+  for (int j = tid; j < stride; j += nt) {
+    const bool ok = j < kk && skey[j] < kInfBits;
+    idx_out[(size_t)qi * stride + j] = ok ? sidx[j] : -1;
+    dist_out[(size_t)qi * stride + j] = ok ? sqrt_rn(__longlong_as_double((long long)skey[j])) : __builtin_inf();
+    if (ok && (j + 1 == kk || skey[j + 1] >= kInfBits)) count_out[qi] = j + 1;
+  }
+  if (tid == 0 && !(skey[0] < kInfBits)) count_out[qi] = 0;
+}
+
+// Launched with 256 threads per workgroup for whole batches (throughput) and with 1024 for the few
+// queries of a list (one workgroup's speed is set by how many node loads it keeps in flight).
+template <int D, int NT>
+__global__ __launch_bounds__(NT) void nn_knearest_kernel(
     const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
     const double *__restrict__ nw, int n_nodes, const double *__restrict__ q, int kk, int stride,
-    int32_t *__restrict__ idx_out, double *__restrict__ dist_out, int32_t *__restrict__ count_out) {
+    int32_t *__restrict__ idx_out, double *__restrict__ dist_out, int32_t *__restrict__ count_out,
+    const int *__restrict__ qlist, const int *__restrict__ n_list) {
   __shared__ unsigned hist[256];
   __shared__ unsigned long long s_prefix;
   __shared__ unsigned s_rank, s_less, s_ties, s_cnt;
   __shared__ unsigned long long skey[kKnnMax];
   __shared__ int sidx[kKnnMax];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int qi = blockIdx.x;
+  constexpr int nt = NT;
+  int qi = blockIdx.x;
+  if (qlist) {                       // only the queries the list names (workgroups past its end leave)
+    if (qi >= *n_list) return;
+    qi = qlist[qi];
+  }
   double g[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < D; ++k) g[k] = q[(size_t)qi * D + k];
@@ -433,27 +478,32 @@ __global__ __launch_bounds__(256) void nn_knearest_kernel(
   unsigned rank = (unsigned)kk - 1u, less = 0, ties = 0;
   for (int pass = 0; pass < 8; ++pass) {
     const int shift = 56 - 8 * pass;
-    hist[tid] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    for (int base = 0; base < n_nodes; base += 256) {
-      const int n = base + tid;
-      bool m = n < n_nodes;
-      unsigned digit = 0;
-      if (m) {
-        const unsigned long long key = knn_key<D>(g, nx, ny, nz, nw, n);
-        m = (pass == 0) || ((key >> (shift + 8)) == prefix);
-        digit = (unsigned)(key >> shift) & 255u;
+    for (int base = 0; base < n_nodes; base += nt * kKnnU) {
+      unsigned long long key[kKnnU];
+      bool valid[kKnnU];
+#pragma unroll
+      for (int u = 0; u < kKnnU; ++u) {          // kKnnU independent node loads in flight per thread
+        const int n = base + u * nt + tid;
+        valid[u] = n < n_nodes;
+        key[u] = valid[u] ? knn_key<D>(g, nx, ny, nz, nw, n) : 0ull;
       }
-      // most keys share the leading exponent bytes: one add per wave when they agree
-      const unsigned long long mask = __ballot(m);
-      if (mask == 0) continue;
-      const int lead = __ffsll((long long)mask) - 1;
-      const unsigned d0 = (unsigned)__shfl((int)digit, lead);
-      const unsigned long long same = __ballot(m && digit == d0);
-      if (same == mask) {
-        if (lane == lead) atomicAdd(&hist[d0], (unsigned)__popcll(mask));
-      } else if (m) {
-        atomicAdd(&hist[digit], 1u);
+#pragma unroll
+      for (int u = 0; u < kKnnU; ++u) {
+        const bool m = valid[u] && ((pass == 0) || ((key[u] >> (shift + 8)) == prefix));
+        const unsigned digit = (unsigned)(key[u] >> shift) & 255u;
+        // most keys share the leading exponent bytes: one add per wave when they agree
+        const unsigned long long mask = __ballot(m);
+        if (mask == 0) continue;
+        const int lead = __ffsll((long long)mask) - 1;
+        const unsigned d0 = (unsigned)__shfl((int)digit, lead);
+        const unsigned long long same = __ballot(m && digit == d0);
+        if (same == mask) {
+          if (lane == lead) atomicAdd(&hist[d0], (unsigned)__popcll(mask));
+        } else if (m) {
+          atomicAdd(&hist[digit], 1u);
+        }
       }
     }
     __syncthreads();
@@ -487,11 +537,20 @@ __global__ __launch_bounds__(256) void nn_knearest_kernel(
   if (tid == 0) s_cnt = 0;
   __syncthreads();
   const bool all_ties = (ties == need);
-  for (int n = tid; n < n_nodes; n += 256) {
-    const unsigned long long key = knn_key<D>(g, nx, ny, nz, nw, n);
-    if (key < T || (all_ties && key == T)) {
-      const unsigned at = atomicAdd(&s_cnt, 1u);
-      skey[at] = key; sidx[at] = n;
+  for (int base = 0; base < n_nodes; base += nt * kKnnU) {
+    unsigned long long key[kKnnU];
+#pragma unroll
+    for (int u = 0; u < kKnnU; ++u) {
+      const int n = base + u * nt + tid;
+      key[u] = n < n_nodes ? knn_key<D>(g, nx, ny, nz, nw, n) : ~0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < kKnnU; ++u) {
+      const int n = base + u * nt + tid;
+      if (n < n_nodes && (key[u] < T || (all_ties && key[u] == T))) {
+        const unsigned at = atomicAdd(&s_cnt, 1u);
+        skey[at] = key[u]; sidx[at] = n;
+      }
     }
   }
   if (!all_ties && tid < 64) {     // more ties than places: lowest indices first
@@ -505,33 +564,45 @@ __global__ __launch_bounds__(256) void nn_knearest_kernel(
       got += (unsigned)__popcll(mask);
     }
   }
-  int P = 1;
-  while (P < kk) P <<= 1;
-  for (int i = kk + tid; i < P; i += 256) { skey[i] = ~0ull; sidx[i] = 0x7fffffff; }
-  __syncthreads();
-  for (int k2 = 2; k2 <= P; k2 <<= 1) {
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < P; i += 256) {
-        const int l = i ^ j;
-        if (l > i) {
-          const unsigned long long ka = skey[i], kb = skey[l];
-          const int ia = sidx[i], ib = sidx[l];
-          const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
-          const bool up = (i & k2) == 0;
-          if (up ? a_gt_b : !a_gt_b) { skey[i] = kb; skey[l] = ka; sidx[i] = ib; sidx[l] = ia; }
-        }
-      }
-      __syncthreads();
-    }
+  knn_sort_emit(skey, sidx, kk, kk, stride, qi, idx_out, dist_out, count_out);
+}
+// Fast path: the k nearest of a query are the k smallest of its range-search list whenever that list
+// (every node with distance < r0, found by the culled search) holds at least kk nodes.  One workgroup
+// per query recomputes the exact squared distances of its list entries and sorts them; queries whose
+// list is too short (or too long for LDS) are appended to fb_list for the exhaustive kernel above.
+template <int D>
+__global__ __launch_bounds__(256) void nn_knearest_lists_kernel(
+    const double *__restrict__ nx, const double *__restrict__ ny, const double *__restrict__ nz,
+    const double *__restrict__ nw, const double *__restrict__ q, int q_first, const int64_t *__restrict__ offsets,
+    const int32_t *__restrict__ lidx, int kk, int stride, int32_t *__restrict__ idx_out,
+    double *__restrict__ dist_out, int32_t *__restrict__ count_out, int *__restrict__ fb_list,
+    int *__restrict__ n_fb) {
+  __shared__ unsigned long long skey[kKnnMax];
+  __shared__ int sidx[kKnnMax];
+  const int tid = threadIdx.x;
+  const int qi = q_first + blockIdx.x;
+  const long long b = offsets[blockIdx.x], e = offsets[blockIdx.x + 1];
+  const int L = (int)(e - b);
+  if (L < kk || e - b > kKnnMax) {
+    if (tid == 0) fb_list[atomicAdd(n_fb, 1)] = qi;
+    return;
   }
-  // nodes at a non-finite distance never pass the reference's `newDist < worst` test (:633,:665)
-  for (int j = tid; j < stride; j += 256) {
-    const bool ok = j < kk && skey[j] < kInfBits;
-    idx_out[(size_t)qi * stride + j] = ok ? sidx[j] : -1;
-    dist_out[(size_t)qi * stride + j] = ok ? sqrt_rn(__longlong_as_double((long long)skey[j])) : __builtin_inf();
-    if (ok && (j + 1 == kk || skey[j + 1] >= kInfBits)) count_out[qi] = j + 1;
+  double g[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < D; ++k) g[k] = q[(size_t)qi * D + k];
+  for (int j = tid; j < L; j += 256) {
+    const int id = lidx[b + j];
+    skey[j] = knn_key<D>(g, nx, ny, nz, nw, id);
+    sidx[j] = id;
   }
-  if (tid == 0 && !(skey[0] < kInfBits)) count_out[qi] = 0;
+  knn_sort_emit(skey, sidx, L, kk, stride, qi, idx_out, dist_out, count_out);
+}
+
+// the kk-th distances of the sampled queries (row qlist[i], column kk - 1)
+__global__ void knn_gather_kth_kernel(const double *__restrict__ dist_out, int stride, int kk,
+                                      const int *__restrict__ qlist, int n, double *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = dist_out[(size_t)qlist[i] * stride + kk - 1];
 }
 }  // namespace
 
@@ -540,6 +611,20 @@ __global__ __launch_bounds__(256) void nn_knearest_kernel(
 int knearest_row(int k, int64_t n_nodes) {
   int64_t kk = k < 2 ? 2 : k;
   return (int)(kk < n_nodes ? kk : n_nodes);
+}
+
+static void knearest_exhaustive(rrtx_ctx *ctx, const double *q_dev, int n_blocks, int kk, int stride,
+                                int32_t *idx_dev, double *dist_dev, int32_t *count_dev, const int *qlist,
+                                const int *n_list) {
+  const int n_nodes = (int)ctx->n_nodes;
+  const double *nw = ctx->nodes[ctx->dim == 4 ? 3 : 2];
+#define RRTX_KNN_LAUNCH(D, NT)                                                                                  \
+  hipLaunchKernelGGL((nn_knearest_kernel<D, NT>), dim3(n_blocks), dim3(NT), 0, ctx->stream, ctx->nodes[0],      \
+                     ctx->nodes[1], ctx->nodes[2], nw, n_nodes, q_dev, kk, stride, idx_dev, dist_dev, count_dev, \
+                     qlist, n_list)
+  if (ctx->dim == 4) { if (qlist) RRTX_KNN_LAUNCH(4, 1024); else RRTX_KNN_LAUNCH(4, 256); }
+  else { if (qlist) RRTX_KNN_LAUNCH(3, 1024); else RRTX_KNN_LAUNCH(3, 256); }
+#undef RRTX_KNN_LAUNCH
 }
 
 int launch_nn_knearest(rrtx_ctx *ctx, const double *q_dev, int nq, int k, int32_t *idx_dev, double *dist_dev,
@@ -551,14 +636,87 @@ int launch_nn_knearest(rrtx_ctx *ctx, const double *q_dev, int nq, int k, int32_
   const int kk = knearest_row(k, ctx->n_nodes);
   const int stride = k < 2 ? 2 : k;
   const int n_nodes = (int)ctx->n_nodes;
-  span_begin(ctx, KF_NN_NEAREST);
-  if (ctx->dim == 4)
-    hipLaunchKernelGGL(nn_knearest_kernel<4>, dim3(nq), dim3(256), 0, ctx->stream, ctx->nodes[0], ctx->nodes[1],
-                       ctx->nodes[2], ctx->nodes[3], n_nodes, q_dev, kk, stride, idx_dev, dist_dev, count_dev);
-  else
-    hipLaunchKernelGGL(nn_knearest_kernel<3>, dim3(nq), dim3(256), 0, ctx->stream, ctx->nodes[0], ctx->nodes[1],
-                       ctx->nodes[2], ctx->nodes[2], n_nodes, q_dev, kk, stride, idx_dev, dist_dev, count_dev);
-  span_end(ctx);
+  hipStream_t st = ctx->stream;
+
+  // The range search does the heavy lifting when it pays: big tree (so it culls), a batch worth the
+  // extra launches, and lists that fit the LDS sort.  Otherwise every query runs the exhaustive kernel.
+  constexpr int kSample = 32;
+  const bool culls = ctx->opt_nn_filter && (ctx->opt_nn_cull == 2 || (ctx->opt_nn_cull == 1 && n_nodes >= 8192));
+  const bool fast = culls && ctx->opt_knn_lists && nq >= 8 * kSample && kk <= 128 && kk * 16 <= n_nodes;
+  if (!fast) {
+    span_begin(ctx, KF_NN_NEAREST);
+    knearest_exhaustive(ctx, q_dev, nq, kk, stride, idx_dev, dist_dev, count_dev, nullptr, nullptr);
+    span_end(ctx);
+    RRTX_HIP(ctx, hipGetLastError());
+    return RRTX_OK;
+  }
+
+  // 1. radius guess: exhaustive search on a strided sample; r0 = twice the median kk-th distance, so a
+  //    query in uniform surroundings gets a list of about 8 kk nodes and one at a face of the cloud 4 kk
+  RRTX_HIP(ctx, ctx->ws_knn_misc.ensure(sizeof(int) * ((size_t)nq + kSample + 4) + sizeof(double) * kSample));
+  double *kth_dev = ctx->ws_knn_misc.as<double>();
+  int *sample_dev = reinterpret_cast<int *>(kth_dev + kSample);
+  int *n_fb = sample_dev + kSample;          // [0] fallback count, [1] sample count
+  int *fb_list = n_fb + 4;
+  int sample[kSample];
+  for (int i = 0; i < kSample; ++i) sample[i] = (int)((long long)i * nq / kSample);
+  const int head[2] = {0, kSample};
+  RRTX_HIP(ctx, hipMemcpyAsync(sample_dev, sample, sizeof(sample), hipMemcpyHostToDevice, st));
+  RRTX_HIP(ctx, hipMemcpyAsync(n_fb, head, sizeof(head), hipMemcpyHostToDevice, st));
+  knearest_exhaustive(ctx, q_dev, kSample, kk, stride, idx_dev, dist_dev, count_dev, sample_dev, n_fb + 1);
+  hipLaunchKernelGGL(knn_gather_kth_kernel, dim3(1), dim3(64), 0, st, dist_dev, stride, kk, sample_dev, kSample, kth_dev);
+  double kth[kSample];
+  RRTX_HIP(ctx, hipMemcpyAsync(kth, kth_dev, sizeof(kth), hipMemcpyDeviceToHost, st));
+  RRTX_HIP(ctx, hipStreamSynchronize(st));   // also keeps `sample` / `head` alive long enough
+  int n_fin = 0;
+  for (int i = 0; i < kSample; ++i)
+    if (std::isfinite(kth[i])) kth[n_fin++] = kth[i];
+  if (n_fin < kSample / 2) {                 // mostly non-finite queries or nodes: nothing to guess from
+    knearest_exhaustive(ctx, q_dev, nq, kk, stride, idx_dev, dist_dev, count_dev, nullptr, nullptr);
+    RRTX_HIP(ctx, hipGetLastError());
+    return RRTX_OK;
+  }
+  std::sort(kth, kth + n_fin);
+  const double r0 = 2.0 * kth[n_fin / 2];
+
+  // 2. per batch of queries: range search with r0 -> select from the lists -> exhaustive for the rest
+  const long long cap_max = 16ll << 20;
+  long long per_q = (long long)kk * 12;
+  int batch = (int)std::min<long long>(nq, std::max<long long>(256, cap_max / per_q));
+  for (int first = 0; first < nq; first += batch) {
+    const int nb = std::min(batch, nq - first);
+    const int64_t cap = (int64_t)nb * per_q + 4096;
+    RRTX_HIP(ctx, ctx->ws_knn_off.ensure(sizeof(int64_t) * ((size_t)nb + 2)));
+    RRTX_HIP(ctx, ctx->ws_knn_idx.ensure(sizeof(int32_t) * (size_t)cap));
+    RRTX_HIP(ctx, ctx->ws_knn_dist.ensure(sizeof(double) * (size_t)cap));
+    int64_t *off = ctx->ws_knn_off.as<int64_t>();
+    int64_t *needed_dev = off + nb + 1;
+    const double *qb = q_dev + (size_t)first * ctx->dim;
+    int rc = launch_nn_radius(ctx, qb, nullptr, r0, nb, off, ctx->ws_knn_idx.as<int32_t>(),
+                              ctx->ws_knn_dist.as<double>(), cap, needed_dev);
+    if (rc) return rc;
+    int64_t needed = 0;
+    RRTX_HIP(ctx, hipMemcpyAsync(&needed, needed_dev, sizeof(needed), hipMemcpyDeviceToHost, st));
+    RRTX_HIP(ctx, hipStreamSynchronize(st));
+    span_begin(ctx, KF_NN_NEAREST);
+    if (needed > cap) {
+      // far denser around these queries than around the sample: the lists were cut off, do not use them
+      knearest_exhaustive(ctx, qb, nb, kk, stride, idx_dev + (size_t)first * stride, dist_dev + (size_t)first * stride,
+                          count_dev + first, nullptr, nullptr);
+    } else {
+      RRTX_HIP(ctx, hipMemsetAsync(n_fb, 0, sizeof(int), st));
+      if (ctx->dim == 4)
+        hipLaunchKernelGGL(nn_knearest_lists_kernel<4>, dim3(nb), dim3(256), 0, st, ctx->nodes[0], ctx->nodes[1],
+                           ctx->nodes[2], ctx->nodes[3], q_dev, first, off, ctx->ws_knn_idx.as<int32_t>(), kk, stride,
+                           idx_dev, dist_dev, count_dev, fb_list, n_fb);
+      else
+        hipLaunchKernelGGL(nn_knearest_lists_kernel<3>, dim3(nb), dim3(256), 0, st, ctx->nodes[0], ctx->nodes[1],
+                           ctx->nodes[2], ctx->nodes[2], q_dev, first, off, ctx->ws_knn_idx.as<int32_t>(), kk, stride,
+                           idx_dev, dist_dev, count_dev, fb_list, n_fb);
+      knearest_exhaustive(ctx, q_dev, nb, kk, stride, idx_dev, dist_dev, count_dev, fb_list, n_fb);
+    }
+    span_end(ctx);
+  }
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
 }

@@ -362,7 +362,8 @@ int rrtx_destroy(rrtx_ctx *ctx) {
   ctx->d_absmax.release();
   ctx->d_xrange.release();
   DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_reach, &ctx->d_sph_reach_f, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
-                    &ctx->d_poly_orig, &ctx->d_poly_path_off, &ctx->d_poly_path, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
+                    &ctx->d_poly_orig, &ctx->d_poly_path_off, &ctx->d_poly_path, &ctx->ws_knn_off, &ctx->ws_knn_idx,
+                    &ctx->ws_knn_dist, &ctx->ws_knn_misc, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
                     &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_bsum, &ctx->ws_scalars, &ctx->ws_scalars_nn, &ctx->ws_tmp_idx,
                     &ctx->ws_tmp_d2, &ctx->ws_owner, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
                     &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr, &ctx->ws_mask, &ctx->ws_i32a, &ctx->ws_i32b,
@@ -413,6 +414,7 @@ int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value) {
     case RRTX_OPT_SCAN_TILE_Q: ctx->opt_tile_q = value > 0 ? (int)value : 0; return RRTX_OK;
     case RRTX_OPT_NN_CULL: ctx->opt_nn_cull = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RRTX_OK;
     case RRTX_OPT_PROFILE_EVERY: ctx->opt_profile_every = value > 1 ? (int)value : 1; return RRTX_OK;
+    case RRTX_OPT_KNN_LISTS: ctx->opt_knn_lists = value != 0; return RRTX_OK;
     default: return fail(ctx, RRTX_E_INVALID, "set_option: unknown option %d", option);
   }
 }

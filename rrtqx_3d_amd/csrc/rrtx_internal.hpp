@@ -137,6 +137,8 @@ struct rrtx_ctx {
   int poly_n_active = 0;
   rrtx::DevBuf d_poly_off, d_poly_vxy, d_poly_meta; // meta: per active obstacle {cx, cy, radius, kind} doubles
   rrtx::DevBuf d_poly_orig;
+  rrtx::DevBuf ws_knn_off, ws_knn_idx, ws_knn_dist, ws_knn_misc;   // k-nearest via range-search lists
+  int opt_knn_lists = 1;
   // kinds 6 / 7 (polygons moving in time): per obstacle rows of (dx, dy, t), CSR over all m obstacles
   std::vector<int32_t> poly_path_off;
   std::vector<double> poly_path;

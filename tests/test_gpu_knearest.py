@@ -41,6 +41,37 @@ def test_knearest_matches_reference_search(oracle, d):
             _check_rows(t, pts, queries, k, idx, dist, count)
 
 
+@pytest.mark.parametrize("n_cluster_queries", [3, 400])
+def test_knearest_list_path_equals_exhaustive(oracle, n_cluster_queries):
+    """Large batches on a big tree take the k nearest from range-search lists (radius guessed from a
+    sample) and fall back to the exhaustive kernel per query; both must agree bit for bit.  The scene
+    forces every branch: uniform background, a dense cluster (lists too long for the LDS sort, or --
+    with many such queries -- more hits than the list buffer holds), queries far outside the cloud
+    (lists too short) and a NaN query."""
+    rng = np.random.default_rng(2024)
+    pts = np.r_[rng.uniform(-50, 50, (40000, 3)), rng.normal(0, 0.5, (20000, 3)) + [10.0, 10.0, 10.0]]
+    Q = np.r_[rng.uniform(-50, 50, (1500, 3)), rng.normal(0, 0.5, (n_cluster_queries, 3)) + [10.0, 10.0, 10.0],
+              rng.uniform(200, 300, (60, 3)), [[np.nan, 0.0, 0.0]]]
+    Q = Q[rng.permutation(len(Q))]
+    t = oracle.KDTree(3)
+    t.insert_many(pts)
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        for k in (1, 16, 128, 129):
+            ctx.set_option(_capi.RRTX_OPT_KNN_LISTS, 1)
+            a = ctx.nn_knearest(Q, k)
+            ctx.set_option(_capi.RRTX_OPT_KNN_LISTS, 0)
+            b = ctx.nn_knearest(Q, k)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y, equal_nan=True)
+            ok = ~np.isnan(Q[:, 0])
+            assert (a[2][ok] == max(k, 2)).all() and (a[2][~ok] == 0).all()
+            for i in rng.choice(np.flatnonzero(ok), 24, replace=False):
+                oi, okey = t.knearest(k, Q[i])
+                o, g = np.argsort(oi), np.argsort(a[0][i])
+                assert np.array_equal(a[0][i][g], oi[o]) and np.array_equal(a[1][i][g], okey[o])
+
+
 def test_knearest_small_trees_and_appends(oracle):
     rng = np.random.default_rng(77)
     pts = rng.uniform(-5, 5, (9, 3))
