@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -116,6 +117,12 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m rrtqx_3d_amd.build` "
             "(the HIP extension is the only implementation; there is no CPU fallback)")
+    # A process that also uses PyTorch holds two ROCm runtimes (the wheel bundles its own; this library
+    # links the system one) and the bundled one has to be initialised first, or torch later reports
+    # "No HIP GPUs are available".  If torch is already imported, bring its runtime up now.
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.init()
     L = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(L, name)  # AttributeError if the symbol is not exported

@@ -464,6 +464,15 @@ __device__ bool edge_hits_moving(double sx, double sy, double st, double ex, dou
   return false;
 }
 
+// per-wave scratch of edges_polygons_kernel: the wave's 64 edges, the survivor masks of the current
+// group of 32 obstacles with their prefix sum, and each edge's first hit (list position)
+struct PolyWave {
+  double e[6][64];     // ax, ay, at, bx, by, bt per lane
+  int pre[65];
+  unsigned cand[64];
+  int first[64];
+};
+
 __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__restrict__ p0,
                                                              const double *__restrict__ p1, int stride,
                                                              long long ne, const double *__restrict__ meta,
@@ -483,18 +492,81 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
     bx = p1[i * stride + 0]; by = p1[i * stride + 1];
     if (has_moving) { at = p0[i * stride + 2]; bt = p1[i * stride + 2]; }   // startPoint[3] = time
   }
+  // The list is walked 32 obstacles at a time.  First every lane (= edge) drops, with a box test, the
+  // obstacles whose bounding circle it cannot reach (explicitEdgeCheck2D's first test, :1536-1539,
+  // fails for them for certain) and keeps the rest as a bit mask.  The
+  // surviving (edge, obstacle) pairs of the wave -- typically fewer than one per edge -- are then numbered
+  // through by a prefix sum and dealt out one per lane for the full test, whichever edge they belong to,
+  // so the wave does not wait on the one or two edges that lie near several obstacles.  An edge's first
+  // hit is the smallest list position among its hits; an edge that has hit takes no part in later
+  // groups.  The set of tests that can decide a result and the arithmetic of each are unchanged.
+  __shared__ PolyWave s_w[4];
+  PolyWave &w = s_w[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  w.e[0][lane] = ax; w.e[1][lane] = ay; w.e[2][lane] = at;
+  w.e[3][lane] = bx; w.e[4][lane] = by; w.e[5][lane] = bt;
+  w.first[lane] = 0x7fffffff;
+  // (NaN-propagating min / max: an edge with a NaN coordinate must keep every obstacle)
+  const double exmin = jl_min(ax, bx), exmax = jl_max(ax, bx), eymin = jl_min(ay, by), eymax = jl_max(ay, by);
+  const double eslack = 1e-9 * jl_max(jl_max(fabs(ax), fabs(bx)), jl_max(fabs(ay), fabs(by)));
   bool done = !act;
   int first = -1;
-  for (int j = m_begin; j < m_end; ++j) {
+  for (int j0 = m_begin; j0 < m_end; j0 += 32) {
+    const int jn = min(32, m_end - j0);
+    unsigned cand = 0;
     if (!done) {
-      const int kind = (int)meta[4 * j + 3];
-      bool h;
-      if (kind == 6 || kind == 7)
-        h = edge_hits_moving(ax, ay, at, bx, by, bt, robot_radius, meta[4 * j + 0], meta[4 * j + 1],
-                             meta[4 * j + 2], path + 3 * (size_t)path_off[j], path_off[j + 1] - path_off[j]);
-      else
-        h = edge_hits_polygon(ax, ay, bx, by, robot_radius, meta, off, vxy, j);
-      if (h) { done = true; first = orig[j]; }
+      for (int b = 0; b < jn; ++b) {
+        const int j = j0 + b;
+        const int kind = (int)meta[4 * j + 3];
+        bool c = true;                                     // kinds 6 / 7 have no bounding test (:1532)
+        if (kind != 6 && kind != 7) {
+          // the edge's box against the circle's box, widened by far more than any rounding of the
+          // exact test (1e-9 relative against ~1e-15): a pair dropped here fails it for certain;
+          // NaN / overflow make every comparison false and the pair stays
+          const double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
+          const double R = fabs(robot_radius + meta[4 * j + 2]) * (1.0 + 1e-9) +
+                           1e-9 * (1.0 + fabs(cx) + fabs(cy)) + eslack;
+          c = !(exmax < cx - R || exmin > cx + R || eymax < cy - R || eymin > cy + R);
+        }
+        cand |= (c ? 1u : 0u) << b;
+      }
+    }
+    int incl = __popc(cand);
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    const int total = __shfl(incl, 63);
+    if (total > 0) {
+      w.cand[lane] = cand;
+      w.pre[lane + 1] = incl;
+      if (lane == 0) w.pre[0] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int p = lane; p < total; p += 64) {
+        int owner = 0;                                     // largest L with pre[L] <= p
+        for (int step = 32; step > 0; step >>= 1)
+          if (w.pre[owner + step] <= p) owner += step;
+        unsigned bits = w.cand[owner];
+        for (int r = p - w.pre[owner]; r > 0; --r) bits &= bits - 1;
+        const int j = j0 + __ffs((int)bits) - 1;
+        const double eax = w.e[0][owner], eay = w.e[1][owner], ebx = w.e[3][owner], eby = w.e[4][owner];
+        const int kind = (int)meta[4 * j + 3];
+        bool h;
+        if (kind == 6 || kind == 7)
+          h = edge_hits_moving(eax, eay, w.e[2][owner], ebx, eby, w.e[5][owner], robot_radius, meta[4 * j + 0],
+                               meta[4 * j + 1], meta[4 * j + 2], path + 3 * (size_t)path_off[j],
+                               path_off[j + 1] - path_off[j]);
+        else
+          h = edge_hits_polygon(eax, eay, ebx, eby, robot_radius, meta, off, vxy, j);
+        if (h) atomicMin(&w.first[owner], j);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int f = w.first[lane];
+      if (!done && f != 0x7fffffff) { done = true; first = orig[f]; }
     }
     if (__ballot(!done) == 0ull) break;
   }

@@ -12,6 +12,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_finish(session):
+    """PyTorch wheels bundle their own ROCm runtime while librrtx_hip.so links the system one; of two
+    runtimes in one process the bundled one has to come up first (the other order leaves torch with "No
+    HIP GPUs are available").  GPU tests that use torch may run after tests that only use the library, so
+    bring torch's runtime up before the first GPU test, whatever the selection or order."""
+    if not any(item.get_closest_marker("gpu") for item in session.items):
+        return
+    try:
+        import torch
+    except ImportError:
+        return
+    if torch.cuda.is_available():
+        torch.cuda.init()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """CPU oracle (test infrastructure): builds oracle/_build/librrtx_oracle.so with gcc if stale."""

@@ -425,6 +425,47 @@ def test_polygons_edges_and_points(oracle):
         assert np.array_equal(clr, rc)
 
 
+def test_polygons_edges_degenerate_and_boundary_inputs(oracle):
+    """The polygon edge kernel drops far obstacles with a box test before the reference's tests run;
+    that shortcut must never change an answer: NaN / inf / huge coordinates, zero-length edges, edges
+    that graze a bounding circle within rounding, balls (kind 1), many obstacles (several groups of
+    32), negative robot radius -- all against the oracle, first-hit indices included."""
+    rng = np.random.default_rng(77)
+    polys, kinds = [], []
+    for i in range(150):
+        c = rng.uniform(-40, 40, 2)
+        ang = np.sort(rng.uniform(0, 2 * np.pi, rng.integers(3, 7)))
+        polys.append(c + np.c_[np.cos(ang), np.sin(ang)] * rng.uniform(0.5, 6))
+        kinds.append(1 if i % 5 == 0 else 3)
+    ps = oracle.PolygonSet(polys, kinds=kinds)
+    cr = ps.centre_radius()
+    n = 6000
+    p0 = np.zeros((n, 3)); p1 = np.zeros((n, 3))
+    p0[:, :2] = rng.uniform(-45, 45, (n, 2))
+    p1[:, :2] = p0[:, :2] + rng.normal(0, 5.0, (n, 2))
+    # grazing edges: tangent to a bounding circle at distance (robot + radius) * (1 +- a few ulp)
+    for i in range(1500):
+        j = i % len(polys)
+        for_r = 0.5 + cr[j, 2]
+        d = for_r * (1.0 + (i % 7 - 3) * 2.0 ** -52)
+        t = rng.uniform(0, 2 * np.pi)
+        nrm = np.array([np.cos(t), np.sin(t)]); tan = np.array([-nrm[1], nrm[0]])
+        mid = cr[j, :2] + nrm * d
+        p0[i, :2] = mid - tan * 2.0; p1[i, :2] = mid + tan * 2.0
+    p1[1500:1540] = p0[1500:1540]                                   # zero-length edges
+    p0[1540:1550, 0] = np.nan; p1[1550:1560, 1] = np.nan            # NaN endpoints
+    p0[1560:1570, 0] = np.inf; p1[1570:1580, 1] = -np.inf
+    p0[1580:1590, :2] = 1e300; p1[1590:1600, 0] = -1e300
+    with Context(3) as ctx:
+        ctx.nodes_append([[0, 0, 0]])
+        ctx.polygons_set(polys, kinds=kinds)
+        for rr in (0.5, 0.0, 3.0, -2.0):
+            hit, first = ctx.edges_check(p0, p1, rr, kind=1)
+            rh, rf = oracle.edges_check_polygons(ps, p0, p1, rr)
+            assert np.array_equal(hit, rh) and np.array_equal(first, rf)
+        assert 0 < hit.sum() < len(hit)
+
+
 def test_polygon_kat_k7(oracle):
     with Context(3) as ctx:
         ctx.nodes_append([[0, 0, 0]])

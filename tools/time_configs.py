@@ -45,6 +45,15 @@ def main():
             if name == "C4":
                 _, wall, k = timed(ctx, lambda: ctx.nn_nearest(Q))
                 print(json.dumps({"case": "C4 nn_nearest (full scan)", "wall_ms": round(wall, 3), "kernel_ms": k}))
+                # the same candidate edges (both directions) against 256 random polygons, projected to (x, y)
+                # as explicitEdgeCheck2D does (R/DRRT.jl:1536): the straight-edge polygon kernel at C4 scale
+                owner = np.repeat(np.arange(cfg.batch), np.diff(out["offsets"]))
+                p0 = np.concatenate([Q[owner], pts[out["idx"]]])
+                p1 = np.concatenate([pts[out["idx"]], Q[owner]])
+                ctx.polygons_set(synth.polygons(cfg.n_obstacles))
+                (hit, _), wall, k = timed(ctx, lambda: ctx.edges_check(p0, p1, 0.5, kind=1))
+                print(json.dumps({"case": "C4 edges_check vs 256 polygons (host buffers)", "edges": int(len(p0)),
+                                  "hit_fraction": round(float(hit.mean()), 4), "wall_ms": round(wall, 3), "kernel_ms": k}))
     cfg = synth.CONFIGS["C3"]
     pts, Q = synth.nodes(cfg.n_nodes, 4), synth.queries(cfg.batch, 4)
     polys = synth.polygons(cfg.n_obstacles)
