@@ -335,7 +335,9 @@ __device__ bool seg_hits_polygon(double ax, double ay, double bx, double by, dou
 // reference walks the obstacle list and, for an obstacle whose inflated chord test (stage 1) does
 // not clear it, every polyline piece (stage 2); the answer is the OR over all (obstacle, piece)
 // tests, so the work may be dealt differently:
-//   stage 1, lane = edge: marks of up to 64 obstacles in a bit mask;
+//   stage 1, a: lane = edge drops the obstacles the chord cannot reach (box test); b: the surviving
+//     (edge, obstacle) pairs of the wave are dealt one per lane for the inflated chord test and mark
+//     up to 64 obstacles in the edge's bit mask;
 //   stage 2, lane = (edge, polyline piece): the pieces of all 64 edges of the wave are numbered
 //     through (prefix sum of the row counts) and handed out 64 at a time, so lanes stay busy
 //     whatever the lengths of the individual polylines are; an edge that has collided drops
@@ -344,6 +346,8 @@ __device__ bool seg_hits_polygon(double ax, double ay, double bx, double by, dou
 struct WaveDubins {
   Piece pc[64][3];
   unsigned long long mask[64];
+  unsigned long long cand[64];
+  double chord[4][64];
   int pstart[65];
   int done[64];
 };
@@ -361,22 +365,60 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
   const int lane = threadIdx.x & 63;
   w.pc[lane][0] = st.pc[0]; w.pc[lane][1] = st.pc[1]; w.pc[lane][2] = st.pc[2];
   w.done[lane] = 0;
+  w.chord[0][lane] = sx; w.chord[1][lane] = sy; w.chord[2][lane] = gx; w.chord[3][lane] = gy;
   const int rows = st.pc[0].len + st.pc[1].len + st.pc[2].len;
   for (int j0 = 0; j0 < m; j0 += 64) {
     const int j1 = (j0 + 64 < m) ? j0 + 64 : m;
-    // ---- stage 1 (lane = edge) ----
-    unsigned long long mask = 0ull;
-    if (valid && !w.done[lane])
-      for (int j = j0; j < j1; ++j)
-        if (seg_hits_polygon(sx, sy, gx, gy, robot_radius + 2 * r_min, meta, off, vxy, j)) mask |= 1ull << (j - j0);
-    w.mask[lane] = mask;
-    const int segs = (mask != 0ull && rows > 1) ? rows - 1 : 0;
-    int incl = segs;
+    // ---- stage 1a (lane = edge): obstacles whose bounding circle, inflated like the chord test, the
+    // chord's box cannot reach fail that test for certain (box widened by 1e-9 against ~1e-15 of
+    // rounding; NaN / overflow keep the obstacle)
+    unsigned long long cand = 0ull;
+    if (valid && !w.done[lane]) {
+      // (NaN-propagating min / max: a chord with a NaN coordinate keeps every obstacle)
+      const double cxmin = jl_min(sx, gx), cxmax = jl_max(sx, gx), cymin = jl_min(sy, gy), cymax = jl_max(sy, gy);
+      const double cslack = 1e-9 * jl_max(jl_max(fabs(sx), fabs(gx)), jl_max(fabs(sy), fabs(gy)));
+      for (int j = j0; j < j1; ++j) {
+        const double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
+        const double R = fabs((robot_radius + 2 * r_min) + meta[4 * j + 2]) * (1.0 + 1e-9) +
+                         1e-9 * (1.0 + fabs(cx) + fabs(cy)) + cslack;
+        const bool c = !(cxmax < cx - R || cxmin > cx + R || cymax < cy - R || cymin > cy + R);
+        cand |= (c ? 1ull : 0ull) << (j - j0);
+      }
+    }
+    w.cand[lane] = cand;
+    w.mask[lane] = 0ull;
+    int incl = __popcll(cand);
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int v = __shfl_up(incl, o);
       if (lane >= o) incl += v;
     }
+    w.pstart[lane + 1] = incl;
+    if (lane == 0) w.pstart[0] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int pairs = __shfl(incl, 63);
+    // ---- stage 1b (lane = one surviving (edge, obstacle) pair): the inflated chord test (:757-760) ----
+    for (int p = lane; p < pairs; p += 64) {
+      int e = 0;
+      for (int step = 32; step > 0; step >>= 1)
+        if (w.pstart[e + step] <= p) e += step;
+      unsigned long long bits = w.cand[e];
+      for (int r = p - w.pstart[e]; r > 0; --r) bits &= bits - 1ull;
+      const int b = __ffsll((long long)bits) - 1;
+      if (seg_hits_polygon(w.chord[0][e], w.chord[1][e], w.chord[2][e], w.chord[3][e], robot_radius + 2 * r_min, meta,
+                           off, vxy, j0 + b))
+        atomicOr(&w.mask[e], 1ull << b);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long mask = w.mask[lane];
+    const int segs = (mask != 0ull && rows > 1) ? rows - 1 : 0;
+    incl = segs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    __builtin_amdgcn_wave_barrier();
     w.pstart[lane + 1] = incl;
     if (lane == 0) w.pstart[0] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -414,7 +456,7 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
 // Candidate Dubins edges of extend(): CSR entry e = (sample qi, node idx[e]); both directed edges
 // sample->near and near->sample are steered and checked (R/DRRT_Q.jl:1951-1963, 2600-2602 with
 // Edge = DubinsEdge).
-__global__ __launch_bounds__(256) void candidate_dubins_kernel(
+__global__ __launch_bounds__(256, 3) void candidate_dubins_kernel(
     const double *__restrict__ q, const int64_t *__restrict__ offsets, int nq, const int32_t *__restrict__ idx,
     const int32_t *__restrict__ owner, const double *__restrict__ nx, const double *__restrict__ ny,
     const double *__restrict__ nz, const double *__restrict__ nw, int n_nodes, long long cap, double r_min,

@@ -452,6 +452,23 @@ def test_polygons_edges_degenerate_and_boundary_inputs(oracle):
         nrm = np.array([np.cos(t), np.sin(t)]); tan = np.array([-nrm[1], nrm[0]])
         mid = cr[j, :2] + nrm * d
         p0[i, :2] = mid - tan * 2.0; p1[i, :2] = mid + tan * 2.0
+    # edges parallel to a polygon side at distance robot * (1 +- a few ulp) (segment-level threshold), and
+    # edges exactly collinear with a side of an axis-aligned box but disjoint from it: the reference's
+    # side tests then say "crossing" and segmentDistSqrd returns 0.0 (R/DRRT.jl:1149-1193)
+    boxes = [np.array([[x, y], [x + 4, y], [x + 4, y + 2], [x, y + 2]], dtype=np.float64)
+             for x, y in ((-30.0, -30.0), (10.0, 20.0), (25.0, -12.0))]
+    polys += boxes; kinds += [3, 3, 3]
+    ps = oracle.PolygonSet(polys, kinds=kinds)
+    k = 1600
+    for bx in boxes:
+        x0, y0 = bx[0]
+        for i in range(7):
+            off = 0.5 * (1.0 + (i - 3) * 2.0 ** -52)
+            p0[k, :2] = [x0 + 0.5, y0 - off]; p1[k, :2] = [x0 + 3.5, y0 - off]; k += 1    # below the bottom side
+            p0[k, :2] = [x0 + 4 + off, y0 + 0.25]; p1[k, :2] = [x0 + 4 + off, y0 + 1.75]; k += 1   # right of the right side
+        p0[k, :2] = [x0 + 4.75, y0]; p1[k, :2] = [x0 + 5.5, y0]; k += 1               # collinear with the bottom side
+        p0[k, :2] = [x0 - 1.5, y0 + 2]; p1[k, :2] = [x0 - 0.75, y0 + 2]; k += 1       # collinear with the top side
+        p0[k, :2] = [x0, y0 - 1.5]; p1[k, :2] = [x0, y0 - 0.75]; k += 1               # collinear with the left side
     p1[1500:1540] = p0[1500:1540]                                   # zero-length edges
     p0[1540:1550, 0] = np.nan; p1[1550:1560, 1] = np.nan            # NaN endpoints
     p0[1560:1570, 0] = np.inf; p1[1570:1580, 1] = -np.inf
