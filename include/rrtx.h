@@ -104,6 +104,12 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
  *   range-search list (radius guessed from a sample of the batch) and runs the exhaustive
  *   selection kernel only for queries whose list holds fewer than k nodes; 0 = exhaustive for all. */
 #define RRTX_OPT_KNN_LISTS 7
+/*   RRTX_OPT_EXTEND_OBSTACLES (default 0): which obstacle list rrtx_extend_candidates* checks the
+ *   candidate edges and the samples against -- 0 = the sphere list (explicitEdgeCheck3D, the 3-D
+ *   planner of R/rrtqx.jl), 1 = the polygon list (explicitEdgeCheck2D on the (x, y) projection and the
+ *   polygon explicitPointCheck, R/DRRT.jl:1434-1470, 1523-1678; time in the third coordinate for the
+ *   moving kinds).  This one DOES select behaviour: it says which CSpace.obstacles the caller has. */
+#define RRTX_OPT_EXTEND_OBSTACLES 8
 int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value);
 
 /* Host-only helper (no GPU needed): the exact thresholds on SQUARED distances the kernels

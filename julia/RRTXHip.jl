@@ -174,6 +174,8 @@ end
 # changed a path (changeObstacleDirection, R/DRRT.jl:370-443).  Edge / point checks then go through
 # rrtx_edges_check / rrtx_points_check with kind = 1 and read time from the third coordinate.
 function syncPolygonObstacles(tree::HipTree, S::TS) where {TS}
+  # extend_candidates then checks against this list (RRTX_OPT_EXTEND_OBSTACLES = 8, value 1 = polygons)
+  rrtx_check(tree, ccall((:rrtx_set_option, LIBRRTX), Cint, (Ptr{Cvoid}, Cint, Int64), tree.ctx, 8, 1))
   m = S.obstacles.length
   vertOff = zeros(Int32, m + 1); pathOff = zeros(Int32, m + 1)
   vxy = Float64[]; pxyt = Float64[]

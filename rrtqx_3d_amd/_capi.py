@@ -27,6 +27,7 @@ RRTX_OPT_SCAN_ITEMS = 4
 RRTX_OPT_NN_CULL = 5
 RRTX_OPT_PROFILE_EVERY = 6
 RRTX_OPT_KNN_LISTS = 7
+RRTX_OPT_EXTEND_OBSTACLES = 8
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

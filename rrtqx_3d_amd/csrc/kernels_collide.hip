@@ -473,9 +473,24 @@ struct PolyWave {
   int first[64];
 };
 
+// Second edge source of edges_polygons_kernel: the candidate edges of extend() straight from the CSR
+// neighbour lists -- thread 2e is sample -> neighbour of entry e, thread 2e + 1 the reverse edge
+// (R/DRRT_Q.jl:1951-1963, 2600-2602).  q == nullptr selects the p0 / p1 arrays.
+struct PolyCsr {
+  const double *q;
+  const int64_t *offsets;
+  const int32_t *idx;
+  const int32_t *owner;
+  const double4 *nodes_aos;
+  uint8_t *hit_in;
+  long long cap;
+  int nq, n_nodes;
+};
+
 __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__restrict__ p0,
                                                              const double *__restrict__ p1, int stride,
-                                                             long long ne, const double *__restrict__ meta,
+                                                             long long ne, PolyCsr csr,
+                                                             const double *__restrict__ meta,
                                                              const int32_t *__restrict__ off,
                                                              const double *__restrict__ vxy,
                                                              const int32_t *__restrict__ path_off,
@@ -485,12 +500,30 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
                                                              uint8_t *__restrict__ hit,
                                                              int32_t *__restrict__ first_hit) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool act = i < ne;
+  bool act;
   double ax = 0, ay = 0, at = 0, bx = 0, by = 0, bt = 0;
-  if (act) {
-    ax = p0[i * stride + 0]; ay = p0[i * stride + 1];
-    bx = p1[i * stride + 0]; by = p1[i * stride + 1];
-    if (has_moving) { at = p0[i * stride + 2]; bt = p1[i * stride + 2]; }   // startPoint[3] = time
+  if (csr.q) {
+    const long long total = csr.offsets[csr.nq];
+    if (total > csr.cap) return;          // capacity overflow: the CSR arrays are only partly written
+    act = i < 2 * total;
+    if (act) {
+      const int qi = csr.owner[i >> 1], n = csr.idx[i >> 1];
+      act = (unsigned)qi < (unsigned)csr.nq && (unsigned)n < (unsigned)csr.n_nodes;   // defensive
+      if (act) {
+        const double *s = csr.q + (size_t)qi * stride;
+        const double4 g = csr.nodes_aos[n];
+        if (i & 1) { ax = g.x; ay = g.y; at = g.z; bx = s[0]; by = s[1]; bt = s[2]; }
+        else { ax = s[0]; ay = s[1]; at = s[2]; bx = g.x; by = g.y; bt = g.z; }
+      }
+    }
+    if (__ballot(act) == 0ull) return;    // the grid covers the caller's capacity
+  } else {
+    act = i < ne;
+    if (act) {
+      ax = p0[i * stride + 0]; ay = p0[i * stride + 1];
+      bx = p1[i * stride + 0]; by = p1[i * stride + 1];
+      if (has_moving) { at = p0[i * stride + 2]; bt = p1[i * stride + 2]; }   // startPoint[3] = time
+    }
   }
   // The list is walked 32 obstacles at a time.  First every lane (= edge) drops, with a box test, the
   // obstacles whose bounding circle it cannot reach (explicitEdgeCheck2D's first test, :1536-1539,
@@ -571,8 +604,12 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
     if (__ballot(!done) == 0ull) break;
   }
   if (act) {
-    hit[i] = first >= 0 ? 1 : 0;
-    if (first_hit) first_hit[i] = first;
+    if (csr.q) {
+      ((i & 1) ? csr.hit_in : hit)[i >> 1] = first >= 0 ? 1 : 0;
+    } else {
+      hit[i] = first >= 0 ? 1 : 0;
+      if (first_hit) first_hit[i] = first;
+    }
   }
 }
 
@@ -981,6 +1018,44 @@ int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int
   return RRTX_OK;
 }
 
+// candidate edges of extend() against the polygon list (SimpleEdge in a space whose obstacles are
+// Obstacle polygons): both directed edges of every CSR entry, plus explicitPointCheck of the samples
+int launch_candidate_edges_polygons(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
+                                    const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap,
+                                    double robot_radius, uint8_t *hit_out_dev, uint8_t *hit_in_dev,
+                                    uint8_t *sample_unsafe_dev) {
+  if (nq <= 0) return RRTX_OK;
+  int rc = sync_polygons(ctx);
+  if (rc) return rc;
+  if (sample_unsafe_dev) {
+    if (ctx->poly_n_active > 0) {
+      rc = launch_points_polygons(ctx, q_dev, nq, robot_radius, sample_unsafe_dev, nullptr);
+      if (rc) return rc;
+    } else {
+      RRTX_HIP(ctx, hipMemsetAsync(sample_unsafe_dev, 0, (size_t)nq, ctx->stream));
+    }
+  }
+  if (cap <= 0) return RRTX_OK;
+  if (ctx->poly_n_active == 0) {
+    RRTX_HIP(ctx, hipMemsetAsync(hit_out_dev, 0, (size_t)cap, ctx->stream));
+    RRTX_HIP(ctx, hipMemsetAsync(hit_in_dev, 0, (size_t)cap, ctx->stream));
+    return RRTX_OK;
+  }
+  PolyCsr csr;
+  csr.q = q_dev; csr.offsets = offsets_dev; csr.idx = idx_dev; csr.owner = owner_dev;
+  csr.nodes_aos = reinterpret_cast<const double4 *>(ctx->nodes_aos);
+  csr.hit_in = hit_in_dev; csr.cap = (long long)cap; csr.nq = nq; csr.n_nodes = (int)ctx->n_nodes;
+  span_begin(ctx, KF_EDGES);
+  hipLaunchKernelGGL(edges_polygons_kernel, dim3((unsigned)((2 * cap + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const double *)nullptr, (const double *)nullptr, ctx->dim, 0ll, csr, ctx->d_poly_meta.as<double>(),
+                     ctx->d_poly_off.as<int32_t>(), ctx->d_poly_vxy.as<double>(), ctx->d_poly_path_off.as<int32_t>(),
+                     ctx->d_poly_path.as<double>(), ctx->poly_has_moving ? 1 : 0, ctx->d_poly_orig.as<int32_t>(), 0,
+                     ctx->poly_n_active, robot_radius, hit_out_dev, (int32_t *)nullptr);
+  span_end(ctx);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
 int launch_edges_polygons(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
                           double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,
                           uint8_t *hit_dev, int32_t *first_hit_dev) {
@@ -997,7 +1072,7 @@ int launch_edges_polygons(rrtx_ctx *ctx, const double *p0_dev, const double *p1_
   if (pe <= pb) return zero_outputs(ctx, ne, hit_dev, first_hit_dev);
   span_begin(ctx, KF_EDGES);
   hipLaunchKernelGGL(edges_polygons_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
-                     p1_dev, ctx->dim, (long long)ne, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
+                     p1_dev, ctx->dim, (long long)ne, PolyCsr{}, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
                      ctx->d_poly_vxy.as<double>(), ctx->d_poly_path_off.as<int32_t>(), ctx->d_poly_path.as<double>(),
                      ctx->poly_has_moving ? 1 : 0, ctx->d_poly_orig.as<int32_t>(), pb, pe, robot_radius, hit_dev,
                      first_hit_dev);

@@ -331,7 +331,7 @@ __device__ __forceinline__ typename QRecFT<D>::type never_pass_qrecf() {
 template <int D>
 __global__ void nn_filter_prep_kernel(const typename QRecT<D>::type *__restrict__ copies,
                                       const Scalars *__restrict__ sc,
-                                      const unsigned long long *__restrict__ node_absmax, int n_copies_max,
+                                      const unsigned long long *__restrict__ node_absmax, int /*n_copies_max*/,
                                       double ox, double oy, double oz, double ow,
                                       typename QRecFT<D>::type *__restrict__ copies_f) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -415,6 +415,7 @@ int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value) {
     case RRTX_OPT_NN_CULL: ctx->opt_nn_cull = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return RRTX_OK;
     case RRTX_OPT_PROFILE_EVERY: ctx->opt_profile_every = value > 1 ? (int)value : 1; return RRTX_OK;
     case RRTX_OPT_KNN_LISTS: ctx->opt_knn_lists = value != 0; return RRTX_OK;
+    case RRTX_OPT_EXTEND_OBSTACLES: ctx->opt_extend_polygons = value == 1; return RRTX_OK;
     default: return fail(ctx, RRTX_E_INVALID, "set_option: unknown option %d", option);
   }
 }
@@ -988,6 +989,9 @@ int rrtx_extend_candidates_dev(rrtx_ctx *ctx, const double *q, int nq, double r,
                             ctx->ws_owner.as<int32_t>(), want_nearest ? nearest_idx : nullptr,
                             want_nearest ? nearest_dist : nullptr);
   if (rc) return rc;
+  if (ctx->opt_extend_polygons)
+    return launch_candidate_edges_polygons(ctx, q, nq, offsets, idx, ctx->ws_owner.as<int32_t>(), cap, robot_radius,
+                                           hit_out, hit_in, sample_unsafe);
   // one pass over the spheres per sample: explicitPointCheck + the sample's sphere list, then the edges
   rc = launch_candidate_edges(ctx, q, nq, offsets, idx, ctx->ws_owner.as<int32_t>(), cap, robot_radius, hit_out,
                               hit_in, (r >= 0.0) ? r : -1.0, sample_unsafe);

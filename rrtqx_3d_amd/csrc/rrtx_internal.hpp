@@ -139,6 +139,7 @@ struct rrtx_ctx {
   rrtx::DevBuf d_poly_orig;
   rrtx::DevBuf ws_knn_off, ws_knn_idx, ws_knn_dist, ws_knn_misc;   // k-nearest via range-search lists
   int opt_knn_lists = 1;
+  int opt_extend_polygons = 0;   // rrtx_extend_candidates checks against the polygon list instead of the spheres
   // kinds 6 / 7 (polygons moving in time): per obstacle rows of (dx, dy, t), CSR over all m obstacles
   std::vector<int32_t> poly_path_off;
   std::vector<double> poly_path;
@@ -260,6 +261,10 @@ int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int
                            const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap, double robot_radius,
                            uint8_t *hit_out_dev, uint8_t *hit_in_dev, double r = -1.0,
                            uint8_t *sample_unsafe_dev = nullptr);
+int launch_candidate_edges_polygons(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
+                                    const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap,
+                                    double robot_radius, uint8_t *hit_out_dev, uint8_t *hit_in_dev,
+                                    uint8_t *sample_unsafe_dev);
 int launch_nearest_from_lists(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
                               const int32_t *idx_dev, const double *dist_dev, int32_t *nearest_idx_dev,
                               double *nearest_dist_dev);

@@ -522,7 +522,9 @@ def extend_candidates(tree: HipTree, S: CSpace, newPositions, hyberBallRad_: flo
     if tree.d != 3:
         error("extend_candidates is the SimpleEdge (3-D) path")
     S.bind(tree)
-    _sync_obstacles(S)
+    kind = _sync_obstacles(S)          # 0: List{SphereObstacle}, 1: List{Obstacle} (polygons, (x, y) projection)
+    from . import _capi
+    tree.ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, kind)
     q = np.asarray(newPositions, dtype=np.float64).reshape(-1, 3)
     out = tree.ctx.extend_candidates(q, float(hyberBallRad_), S.robotRadius)
     if S.inWarmupTime:

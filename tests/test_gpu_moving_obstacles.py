@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from rrtqx_3d_amd import _capi, drrt, envio
+from rrtqx_3d_amd import _capi, drrt, envio, synth
 from rrtqx_3d_amd.context import Context
 
 pytestmark = pytest.mark.gpu
@@ -153,3 +153,13 @@ def test_mirror_reads_time_obstacle_files(oracle, tmp_path):
     assert np.array_equal(np.asarray(got, dtype=np.uint8), oracle.edges_check_polygons(ps, p0, p1, 0.5)[0])
     u, c = drrt.explicitPointCheck(S, p0[0])
     assert (u, c) == oracle.point_check_polygons(ps, p0[0], 0.5)
+    # the batched preamble picks the polygon list by itself when CSpace.obstacles holds Obstacles
+    nodes = rng.uniform([-50, -50, 0], [50, 50, 40], (400, 3))
+    for p in nodes:
+        drrt.kdInsert(tree, drrt.RRTNode(p))
+    samples = rng.uniform([-50, -50, 0], [50, 50, 40], (64, 3))
+    out = drrt.extend_candidates(tree, S, samples, 25.0)
+    q0, q1 = synth.candidate_edges(samples, nodes, out["offsets"], out["idx"])
+    rh = oracle.edges_check_polygons(ps, q0, q1, 0.5)[0]
+    k = len(out["idx"])
+    assert k > 200 and np.array_equal(out["hit_out"], rh[:k]) and np.array_equal(out["hit_in"], rh[k:])

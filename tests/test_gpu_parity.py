@@ -9,7 +9,7 @@ import math
 import numpy as np
 import pytest
 
-from rrtqx_3d_amd import synth
+from rrtqx_3d_amd import _capi, synth
 from rrtqx_3d_amd.context import Context
 
 pytestmark = pytest.mark.gpu
@@ -481,6 +481,51 @@ def test_polygons_edges_degenerate_and_boundary_inputs(oracle):
             rh, rf = oracle.edges_check_polygons(ps, p0, p1, rr)
             assert np.array_equal(hit, rh) and np.array_equal(first, rf)
         assert 0 < hit.sum() < len(hit)
+
+
+@pytest.mark.parametrize("with_moving", [False, True])
+def test_extend_candidates_against_polygon_list(oracle, with_moving):
+    """RRTX_OPT_EXTEND_OBSTACLES = 1: the fused preamble checks both directed candidate edges and the
+    samples against the polygon list (the candidate edges come straight from the CSR lists on the
+    device); compared with the one-at-a-time oracle calls.  With moving polygons the third coordinate
+    of samples and nodes is time."""
+    rng = np.random.default_rng(31)
+    n, b = 20000, 700
+    pts = rng.uniform(-50, 50, (n, 3))
+    Q = rng.uniform(-50, 50, (b, 3))
+    polys = synth.polygons(48)
+    kinds, paths, active = [3] * 48, None, [1] * 48
+    active[5] = 0
+    if with_moving:
+        pts[:, 2] = rng.uniform(0, 40, n); Q[:, 2] = rng.uniform(0, 40, b)
+        kinds = [6 if i % 4 == 1 else 3 for i in range(48)]
+        paths = [None if k == 3 else np.c_[rng.uniform(-20, 20, (5, 2)), np.sort(rng.uniform(0, 40, 5))] for k in kinds]
+    ps = oracle.PolygonSet(polys, kinds=kinds, active=active, paths=paths)
+    tree = oracle.KDTree(3)
+    tree.insert_many(pts)
+    r = 6.0
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        ctx.polygons_set(polys, kinds=kinds, active=active, paths=paths)
+        ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 1)
+        out = ctx.extend_candidates(Q, r, ROBOT_RADIUS)
+        off, idx = out["offsets"], out["idx"]
+        _check_csr(off, idx, out["cost"], _oracle_lists(tree, Q, r))
+        p0, p1 = synth.candidate_edges(Q, pts, off, idx)
+        rh, _ = oracle.edges_check_polygons(ps, p0, p1, ROBOT_RADIUS)
+        k = len(idx)
+        assert k > 5000 and np.array_equal(out["hit_out"], rh[:k]) and np.array_equal(out["hit_in"], rh[k:])
+        assert 0 < rh.sum() < len(rh)
+        exp_unsafe = np.array([oracle.point_check_polygons(ps, qq, ROBOT_RADIUS)[0] for qq in Q])
+        assert np.array_equal(out["sample_unsafe"].astype(bool), exp_unsafe)
+        for i in range(b):
+            if off[i + 1] > off[i]:
+                ni, nd = tree.nearest(Q[i])
+                assert out["nearest_idx"][i] == ni and out["nearest_dist"][i] == nd
+        # same context, back to the sphere list (empty): nothing collides
+        ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 0)
+        out0 = ctx.extend_candidates(Q, r, ROBOT_RADIUS)
+        assert not out0["hit_out"].any() and not out0["sample_unsafe"].any()
 
 
 def test_polygon_kat_k7(oracle):

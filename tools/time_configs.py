@@ -11,7 +11,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from rrtqx_3d_amd import synth  # noqa: E402
+from rrtqx_3d_amd import _capi, synth  # noqa: E402
 from rrtqx_3d_amd.context import Context  # noqa: E402
 
 
@@ -54,6 +54,12 @@ def main():
                 (hit, _), wall, k = timed(ctx, lambda: ctx.edges_check(p0, p1, 0.5, kind=1))
                 print(json.dumps({"case": "C4 edges_check vs 256 polygons (host buffers)", "edges": int(len(p0)),
                                   "hit_fraction": round(float(hit.mean()), 4), "wall_ms": round(wall, 3), "kernel_ms": k}))
+                # and the fused preamble against the polygon list (edges formed on the device from the lists)
+                ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 1)
+                out, wall, k = timed(ctx, lambda: ctx.extend_candidates(Q, r, 0.5, cap=96 * cfg.batch))
+                ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 0)
+                print(json.dumps({"case": "C4 extend_candidates vs 256 polygons (host buffers)", "neighbors": int(len(out["idx"])),
+                                  "wall_ms": round(wall, 3), "kernel_ms": k}))
     cfg = synth.CONFIGS["C3"]
     pts, Q = synth.nodes(cfg.n_nodes, 4), synth.queries(cfg.batch, 4)
     polys = synth.polygons(cfg.n_obstacles)
