@@ -660,8 +660,57 @@ __device__ double dist_to_polygon_sqrd(double px, double py, const double *__res
   return best;
 }
 
-// explicitPointCheck over polygons: quickCheck pass (R/DRRT.jl:1258-1284) then
-// explicitPointCheck2D (:1340-1427); Wdist over the first two coordinates.
+// One polygon against one point with the wave's lanes dealt over the polygon's edges (all lanes hold the
+// same point): pointInPolygon's crossing count (:1009-1056) and distToPolygonSqrd's minimum (:1087-1106).
+// Each edge's contribution is computed as the sequential loops do; a crossing count is an integer sum and
+// the minimum (NaN never taken, as `dd < best` never takes it) does not depend on the order.
+template <bool MOV>
+__device__ void wave_point_vs_polygon(double px, double py, const double *__restrict__ vxy, int b, int e, double ox,
+                                      double oy, bool &inside, double &dsq) {
+  const int lane = threadIdx.x & 63;
+  int crossings = 0;
+  double best = __builtin_inf();
+  for (int v0 = b; v0 < e; v0 += 64) {
+    const int v = v0 + lane;
+    bool c = false;
+    if (v < e) {
+      const int sv = (v == b) ? e - 1 : v - 1;
+      double sx = vxy[2 * sv], sy = vxy[2 * sv + 1], ex = vxy[2 * v], ey = vxy[2 * v + 1];
+      if (MOV) { sx = sx + ox; sy = sy + oy; ex = ex + ox; ey = ey + oy; }
+      if ((sy > py && ey < py) || (sy < py && ey > py)) {
+        if (sx > px && ex > px) {
+          c = true;
+        } else if (sx < px && ex < px) {
+        } else {
+          const double T = 2 * jl_max(sx, ex);
+          const double x = (-((sx * ey - sy * ex) * (px - T)) + ((sx - ex) * (px * py - py * T))) /
+                           ((sy - ey) * (px - T));
+          c = x > px;
+        }
+      }
+      const double dd = dist_sqrd_point_to_segment(px, py, sx, sy, ex, ey);
+      if (dd < best) best = dd;
+    }
+    crossings += __popcll(__ballot(c));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double other = __shfl_xor(best, o);
+    if (other < best) best = other;
+  }
+  inside = (e - b >= 2) && (crossings & 1) != 0;
+  dsq = best;
+}
+
+// explicitPointCheck over polygons (R/DRRT.jl:1434-1470): quickCheck pass (:1258-1331) then the
+// explicitPointCheck2D loop (:1343-1427); Wdist over the first two coordinates.  One wave per point.
+//   quick pass: lane = obstacle, 64 at a time; "inside any obstacle" is an OR, so order is free.
+//   explicit pass: the reference skips obstacle j when (centre distance - robotRadius) - radius exceeds
+//   the running certificate, which only changes when an obstacle is evaluated; so between two
+//   evaluations the next obstacle to evaluate is the first one in list order that the current
+//   certificate does not skip -- found with a ballot over the 64 obstacles of the chunk -- and the
+//   evaluation itself (polygon containment + distance) is dealt over the polygon's edges.  Same
+//   obstacles evaluated in the same order with the same arithmetic as the sequential loop.
 __global__ __launch_bounds__(256) void points_polygons_kernel(const double *__restrict__ p, int stride,
                                                               long long np, const double *__restrict__ meta,
                                                               const int32_t *__restrict__ off,
@@ -671,72 +720,85 @@ __global__ __launch_bounds__(256) void points_polygons_kernel(const double *__re
                                                               int m, double robot_radius,
                                                               uint8_t *__restrict__ unsafe,
                                                               double *__restrict__ clearance) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= np) return;
   const double px = p[i * stride + 0], py = p[i * stride + 1];
   const double pt = has_moving ? p[i * stride + 2] : 0.0;      // point[3] = time (kinds 6 / 7)
-  for (int j = 0; j < m; ++j) {
-    double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
-    const double rad = meta[4 * j + 2];
-    const int kind = (int)meta[4 * j + 3];
-    const bool mov = (kind == 6 || kind == 7);
-    double dx = 0.0, dy = 0.0;
-    if (mov) {                                                 // R/DRRT.jl:1289-1305
-      transform_obs_to_time(path + 3 * (size_t)path_off[j], path_off[j + 1] - path_off[j], pt, dx, dy);
-      cx = cx + dx; cy = cy + dy;
+  // ---- quickCheck ----
+  for (int j0 = 0; j0 < m; j0 += 64) {
+    const int j = j0 + lane;
+    bool in = false;
+    if (j < m) {
+      double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
+      const double rad = meta[4 * j + 2];
+      const int kind = (int)meta[4 * j + 3];
+      const bool mov = (kind == 6 || kind == 7);
+      double dx = 0.0, dy = 0.0;
+      if (mov) {                                               // R/DRRT.jl:1289-1305
+        transform_obs_to_time(path + 3 * (size_t)path_off[j], path_off[j + 1] - path_off[j], pt, dx, dy);
+        cx = cx + dx; cy = cy + dy;
+      }
+      if (!(sqrt_rn(sq2(cx, cy, px, py)) > rad))
+        in = kind == 1 || (kind == 3 && point_in_polygon(px, py, vxy, off[j], off[j + 1])) ||
+             (mov && point_in_polygon<true>(px, py, vxy, off[j], off[j + 1], dx, dy));
     }
-    if (sqrt_rn(sq2(cx, cy, px, py)) > rad) continue;
-    if (kind == 1 || (kind == 3 && point_in_polygon(px, py, vxy, off[j], off[j + 1])) ||
-        (mov && point_in_polygon<true>(px, py, vxy, off[j], off[j + 1], dx, dy))) {
-      unsafe[i] = 1;
-      if (clearance) clearance[i] = 0.0;
+    if (__ballot(in) != 0ull) {
+      if (lane == 0) { unsafe[i] = 1; if (clearance) clearance[i] = 0.0; }
       return;
     }
   }
+  // ---- explicitPointCheck2D over the list ----
   double ret_cert = __builtin_inf();
-  for (int j = 0; j < m; ++j) {
-    double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
-    const double rad = meta[4 * j + 2];
-    const int kind = (int)meta[4 * j + 3];
-    const bool mov = (kind == 6 || kind == 7);
-    double dx = 0.0, dy = 0.0;
-    if (mov) {                                                 // R/DRRT.jl:1395-1420
-      transform_obs_to_time(path + 3 * (size_t)path_off[j], path_off[j + 1] - path_off[j], pt, dx, dy);
-      cx = cx + dx; cy = cy + dy;
+  for (int j0 = 0; j0 < m; j0 += 64) {
+    const int j = j0 + lane;
+    const bool valid = j < m;
+    double rad = 0.0, dx = 0.0, dy = 0.0, tdc = 0.0;
+    int kind = 0;
+    if (valid) {
+      double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
+      rad = meta[4 * j + 2];
+      kind = (int)meta[4 * j + 3];
+      if (kind == 6 || kind == 7) {                            // R/DRRT.jl:1395-1408
+        transform_obs_to_time(path + 3 * (size_t)path_off[j], path_off[j + 1] - path_off[j], pt, dx, dy);
+        cx = cx + dx; cy = cy + dy;
+      }
+      tdc = sqrt_rn(sq2(cx, cy, px, py)) - robot_radius;       // distance from the robot boundary to the centre
     }
-    double this_cert = ret_cert;
-    double this_dist = sqrt_rn(sq2(cx, cy, px, py)) - robot_radius;
-    if (!(this_dist - rad > ret_cert)) {
-      bool bad = false;
-      if (mov) {
-        if (point_in_polygon<true>(px, py, vxy, off[j], off[j + 1], dx, dy)) {
-          bad = true;
-        } else {
-          this_dist = sqrt_rn(dist_to_polygon_sqrd<true>(px, py, vxy, off[j], off[j + 1], dx, dy)) - robot_radius;
-          bad = this_dist < 0.0;
-        }
-      } else if (kind == 1) {
-        this_dist = this_dist - rad;
+    unsigned long long todo = __ballot(valid);
+    for (;;) {
+      const unsigned long long c = __ballot(valid && !(tdc - rad > ret_cert)) & todo;
+      if (c == 0ull) break;
+      const int l = __ffsll((long long)c) - 1;                 // next obstacle of the list that is not skipped
+      todo &= ~((2ull << l) - 1ull);
+      const int jl = j0 + l;
+      const int kind_l = __shfl(kind, l);
+      double this_dist = __shfl(tdc, l);
+      bool bad;
+      if (kind_l == 1) {
+        this_dist = this_dist - __shfl(rad, l);
         bad = this_dist < 0.0;
-      } else if (kind == 3) {
-        if (point_in_polygon(px, py, vxy, off[j], off[j + 1])) {
+      } else {
+        bool inside;
+        double dsq;
+        if (kind_l == 3) wave_point_vs_polygon<false>(px, py, vxy, off[jl], off[jl + 1], 0.0, 0.0, inside, dsq);
+        else wave_point_vs_polygon<true>(px, py, vxy, off[jl], off[jl + 1], __shfl(dx, l), __shfl(dy, l), inside, dsq);
+        if (inside) {
           bad = true;
         } else {
-          this_dist = sqrt_rn(dist_to_polygon_sqrd(px, py, vxy, off[j], off[j + 1])) - robot_radius;
+          this_dist = sqrt_rn(dsq) - robot_radius;
           bad = this_dist < 0.0;
         }
       }
       if (bad) {
-        unsafe[i] = 1;
-        if (clearance) clearance[i] = 0.0;
+        if (lane == 0) { unsafe[i] = 1; if (clearance) clearance[i] = 0.0; }
         return;
       }
-      this_cert = jl_min(ret_cert, this_dist);
+      const double this_cert = jl_min(ret_cert, this_dist);
+      if (this_cert < ret_cert) ret_cert = this_cert;
     }
-    if (this_cert < ret_cert) ret_cert = this_cert;
   }
-  unsafe[i] = 0;
-  if (clearance) clearance[i] = ret_cert;
+  if (lane == 0) { unsafe[i] = 0; if (clearance) clearance[i] = ret_cert; }
 }
 
 // calculateTrajectory(S, ::SimpleEdge), R/DRRT_SimpleEdge_functions.jl:177-181
@@ -1101,7 +1163,7 @@ int launch_points_polygons(rrtx_ctx *ctx, const double *p_dev, int64_t np, doubl
   int rc = sync_polygons(ctx);
   if (rc) return rc;
   span_begin(ctx, KF_POINTS);
-  hipLaunchKernelGGL(points_polygons_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, p_dev,
+  hipLaunchKernelGGL(points_polygons_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, ctx->stream, p_dev,
                      ctx->dim, (long long)np, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
                      ctx->d_poly_vxy.as<double>(), ctx->d_poly_path_off.as<int32_t>(), ctx->d_poly_path.as<double>(),
                      ctx->poly_has_moving ? 1 : 0, ctx->poly_n_active, robot_radius, unsafe_dev, clearance_dev);
