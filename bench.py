@@ -395,6 +395,26 @@ def main():
                 ctx.extend_candidates(Q, r, ROBOT_RADIUS, cap=cap)
             out["host_buffer_path"] = {"edges_per_s": edges_per_step * 5 / (time.perf_counter() - t1),
                                        "note": "PCIe-inclusive: host numpy in/out through rrtx_extend_candidates"}
+        if world == 1:
+            # BASELINE.json's config text says "polygon obstacles": the reference's 3-D planner checks
+            # spheres (explicitEdgeCheck3D) and `value` above is that; this is the same step against 256
+            # random polygons in the (x, y) projection (explicitEdgeCheck2D), device-resident, reported only.
+            ctx.set_stream(stream.cuda_stream)
+            ctx.polygons_set(synth.polygons(M))
+            ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 1)
+            for _ in range(3):
+                compute()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                compute()
+            torch.cuda.synchronize()
+            dtp = (time.perf_counter() - t1) / 20
+            out["polygon_obstacles"] = {"edges_per_s": edges_per_step / dtp, "ms_per_step": dtp * 1e3, "n_polygons": M,
+                                        "colliding_fraction": float((d_hout[:k_total].sum() + d_hin[:k_total].sum()).item()) / edges_per_step,
+                                        "note": "same samples and tree, candidate edges and samples checked against the polygon list"}
+            ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 0)
+            ctx.set_stream(None)
         if world == 1 and args.agents > 1:
             out["concurrent_agents"] = concurrent_agents(args.agents, torch, dev, pts, sph, r, B, cap, N)
         if world == 1 and not args.no_cpu_baseline:
