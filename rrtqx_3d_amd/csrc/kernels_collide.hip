@@ -312,14 +312,22 @@ __global__ __launch_bounds__(64 * kSampleWaves) void sample_spheres_kernel(
   const int per = (m + kSampleWaves - 1) / kSampleWaves;
   const int j0 = wave * per, j1 = min(j0 + per, m);
   bool bad = false;
-  for (int j = j0; j < j1; ++j) {
-    const SampleSph sp = tab[j];
-    const double s = sq3(sp.cx, sp.cy, sp.cz, px, py, pz);
-    bad = bad | !(s >= sp.thr_in) | (s < sp.thr_pt);
-    const double B = base_b + sp.reach;
-    if (act && !(s > B * B * (1.0 + 1e-12))) {
-      const int at = atomicAdd(&s_n[lane], 1);
-      if (at < kSphListCap) s_list[lane][at] = j;
+  constexpr int kU = 8;                  // sphere records fetched together (wave-uniform loads in flight)
+  for (int jb = j0; jb < j1; jb += kU) {
+    SampleSph sp[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) sp[u] = tab[min(jb + u, j1 - 1)];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int j = jb + u;
+      if (j >= j1) break;
+      const double s = sq3(sp[u].cx, sp[u].cy, sp[u].cz, px, py, pz);
+      bad = bad | !(s >= sp[u].thr_in) | (s < sp[u].thr_pt);
+      const double B = base_b + sp[u].reach;
+      if (act && !(s > B * B * (1.0 + 1e-12))) {
+        const int at = atomicAdd(&s_n[lane], 1);
+        if (at < kSphListCap) s_list[lane][at] = j;
+      }
     }
   }
   if (bad) atomicOr(&s_bad[lane], 1);
