@@ -88,6 +88,10 @@ function kdFindNearest(tree::HipTree{T}, queryPoint::Array{Float64}) where {T}
   return (tree.nodes[idx[] + 1], dist[])
 end
 
+# kdFindNearestWithGuesstree (R/kdTree_general.jl:503-534): the guess only seeds the reference's descent
+kdFindNearestWithGuesstree(tree::HipTree{T}, queryPoint::Array{Float64}, guess::T) where {T} =
+  kdFindNearest(tree, queryPoint)
+
 # kdFindKNearest (R/kdTree_general.jl:696-723) -> Array of nodes, node.data = distance.
 # max(k, 2) nodes like the reference (its heap starts with root + dummy); ascending distance.
 function kdFindKNearest(tree::HipTree{T}, k::Int, queryPoint::Array{Float64}) where {T}

@@ -183,6 +183,13 @@ def kdFindNearest(tree: HipTree, queryPoint) -> Tuple[RRTNode, float]:
     return tree.nodes[int(idx[0])], float(dist[0])
 
 
+def kdFindNearestWithGuesstree(tree: HipTree, queryPoint, guess: RRTNode) -> Tuple[RRTNode, float]:
+    """R/kdTree_general.jl:503-534: the search seeded at `guess` instead of the root.  The seed only
+    shortens the reference's descent; the answer is kdFindNearest's (on an exact distance tie the
+    reference keeps the guess, this returns the lowest index).  No caller in the reference."""
+    return kdFindNearest(tree, queryPoint)
+
+
 def kdFindKNearest(tree: HipTree, k: int, queryPoint) -> List[RRTNode]:
     """R/kdTree_general.jl:696-723: the nodes of the final heap, each with `.data` = its distance.
     Like the reference this is max(k, 2) nodes (the heap is seeded with root + dummy) and raises

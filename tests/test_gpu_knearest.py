@@ -141,3 +141,5 @@ def test_kdFindKNearest_mirror(oracle):
     assert sorted(n.index for n in nodes) == sorted(oi)
     assert sorted(n.data for n in nodes) == sorted(ok)
     assert len(drrt.kdFindKNearest(tree, 1, q)) == 2                   # the seed quirk
+    n, d = drrt.kdFindNearestWithGuesstree(tree, q, tree.nodes[17])
+    assert (n.index, d) == t.nearest(q)
