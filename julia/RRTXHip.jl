@@ -151,6 +151,36 @@ end
 # popFromRangeList / emptyRangeList (R/kdTree_general.jl:774-787) work on the JList unchanged.
 
 # ---------------------------------------------------------------------------
+# file dumps: the reference's writers recurse over kdChildL / kdChildR (R/DRRT_Q.jl:250-364), which a
+# HipTree does not have; these walk tree.nodes in insertion order (same rows, different row order).
+function saveRRTTree(tree::HipTree{T}, fileName) where {T}
+  fptr = open(fileName, "w")
+  for node in tree.nodes
+    if node.rrtParentUsed
+      writedlm(fptr, [node.position node.rrtTreeCost], ',')
+      writedlm(fptr, [node.rrtParentEdge.endNode.position node.rrtParentEdge.endNode.rrtTreeCost], ',')
+    end
+  end
+  close(fptr)
+end
+
+function saveRRTNodes(tree::HipTree{T}, fileName) where {T}
+  fptr = open(fileName, "w")
+  for node in tree.nodes
+    writedlm(fptr, [node.position node.rrtTreeCost node.rrtLMC], ',')
+  end
+  close(fptr)
+end
+
+function saveRRTNodesCollision(tree::HipTree{T}, fileName) where {T}
+  fptr = open(fileName, "w")
+  for node in tree.nodes
+    writedlm(fptr, [node.position min(node.rrtTreeCost, node.rrtLMC)], ',')
+  end
+  close(fptr)
+end
+
+# ---------------------------------------------------------------------------
 # obstacle list upload: CSpace.obstacles in list order (front first, R/list.jl:53-58)
 function syncObstacles(tree::HipTree, S::TS) where {TS}
   m = S.obstacles.length

@@ -541,6 +541,38 @@ def extend_candidates(tree: HipTree, S: CSpace, newPositions, hyberBallRad_: flo
     return out
 
 
+# ------------------------------------------------------------ file dumps ----
+# The reference's dump writers walk the kd-tree's child pointers (R/DRRT_Q.jl:250-364); with the device
+# tree there are none, so these walk HipTree.nodes in insertion order instead.  Same rows, same number
+# format (Julia's writedlm), different row order -- the MATLAB viewers read them as unordered sets
+# (R/make_videoUAMExample.m:88-285).
+def saveRRTTree(tree: HipTree, fileName: str):
+    """R/DRRT_Q.jl:250-275: each node with a parent, followed by that parent (edge form)."""
+    from . import envio
+    with open(fileName, "w") as f:
+        for n in tree.nodes:
+            if n.rrtParentUsed:
+                envio.writedlm_row(f, [*n.position.reshape(-1), n.rrtTreeCost])
+                par = n.rrtParentEdge.endNode
+                envio.writedlm_row(f, [*par.position.reshape(-1), par.rrtTreeCost])
+
+
+def saveRRTNodes(tree: HipTree, fileName: str):
+    """R/DRRT_Q.jl:310-333: position, rrtTreeCost, rrtLMC of every node."""
+    from . import envio
+    with open(fileName, "w") as f:
+        for n in tree.nodes:
+            envio.writedlm_row(f, [*n.position.reshape(-1), n.rrtTreeCost, n.rrtLMC])
+
+
+def saveRRTNodesCollision(tree: HipTree, fileName: str):
+    """R/DRRT_Q.jl:336-362: position and min(rrtTreeCost, rrtLMC)."""
+    from . import envio
+    with open(fileName, "w") as f:
+        for n in tree.nodes:
+            envio.writedlm_row(f, [*n.position.reshape(-1), min(n.rrtTreeCost, n.rrtLMC)])
+
+
 # ------------------------------------------------------- obstacle sweeps ----
 def findPointsInConflictWithObstacle(S: CSpace, KD: HipTree, ob, root=None) -> JList:
     """R/DRRT_Q.jl:3195-3215: nodes within robotRadius + delta + ob.radius of the obstacle."""

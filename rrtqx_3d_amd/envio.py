@@ -43,6 +43,42 @@ def str2array(s: str) -> np.ndarray:
     return np.array([float(t) for t in s.strip().split(",") if t.strip() != ""], dtype=np.float64)
 
 
+def jl_float_str(x: float) -> str:
+    """A Float64 the way Julia 1.0's writedlm / show prints it (base/grisu/grisu.jl `_show`): shortest
+    round-trip digits; plain notation while the decimal point position pt satisfies -4 < pt <= 6, else
+    d.ddde<exp>; always at least one digit after the point; Inf / -Inf / NaN."""
+    x = float(x)
+    if x != x:
+        return "NaN"
+    if x in (float("inf"), float("-inf")):
+        return "Inf" if x > 0 else "-Inf"
+    sign = "-" if (x < 0 or (x == 0 and str(x).startswith("-"))) else ""
+    r = repr(abs(x))
+    if "e" in r:
+        mant, exp = r.split("e")
+        exp = int(exp)
+    else:
+        mant, exp = r, 0
+    ip, _, fp = mant.partition(".")
+    digits = (ip + fp).lstrip("0")
+    pt = len(ip.lstrip("0")) + exp if ip.strip("0") else exp - (len(fp) - len(fp.lstrip("0")))
+    digits = digits.rstrip("0")
+    if not digits:
+        return sign + "0.0"
+    if pt <= -4 or pt > 6:
+        return sign + digits[0] + "." + (digits[1:] or "0") + "e" + str(pt - 1)
+    if pt <= 0:
+        return sign + "0." + "0" * (-pt) + digits
+    if pt >= len(digits):
+        return sign + digits + "0" * (pt - len(digits)) + ".0"
+    return sign + digits[:pt] + "." + digits[pt:]
+
+
+def writedlm_row(f, values):
+    """One row of writedlm(fptr, row, ',')."""
+    f.write(",".join(jl_float_str(v) for v in values) + "\n")
+
+
 @dataclass
 class SphereEnv:
     cxyzr: np.ndarray        # m x 4, FILE order

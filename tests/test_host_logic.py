@@ -70,6 +70,35 @@ def test_env_readers_roundtrip(tmp_path):
     assert list(envio.str2array("1.5, -2, 3e2\n")) == [1.5, -2.0, 300.0]
 
 
+def test_julia_float_printing_and_tree_dumps(tmp_path):
+    """The dump files the MATLAB viewers read (R/DRRT_Q.jl:250-364) are written with Julia's writedlm;
+    the kd-free writers of the mirror print numbers the same way (base/grisu/grisu.jl `_show`:
+    shortest digits, plain notation for -4 < pt <= 6)."""
+    cases = {1.0: "1.0", 0.1: "0.1", 1e-5: "1.0e-5", 1e-4: "0.0001", 123456.789: "123456.789", 999999.0: "999999.0",
+             1e6: "1.0e6", 1234567.0: "1.234567e6", 1.5e10: "1.5e10", -2.5: "-2.5", 0.0: "0.0", 100000.0: "100000.0",
+             0.00012: "0.00012", 1e21: "1.0e21", 5e-324: "5.0e-324", math.inf: "Inf", -math.inf: "-Inf"}
+    for x, want in cases.items():
+        assert envio.jl_float_str(x) == want
+        if math.isfinite(x):
+            assert float(envio.jl_float_str(x)) == x
+    assert envio.jl_float_str(math.nan) == "NaN"
+    rng = np.random.default_rng(0)
+    for x in np.concatenate([rng.uniform(-100, 100, 2000), 10.0 ** rng.uniform(-12, 25, 2000)]):
+        assert float(envio.jl_float_str(x)) == x                       # round trip, whatever the notation
+    from types import SimpleNamespace as NS
+    from rrtqx_3d_amd import drrt
+    root = NS(position=np.array([[15.0, 15.0, 15.0]]), rrtTreeCost=0.0, rrtLMC=0.0, rrtParentUsed=False, rrtParentEdge=None)
+    kid = NS(position=np.array([[1.5, -2.0, 1e-5]]), rrtTreeCost=21.25, rrtLMC=math.inf, rrtParentUsed=True,
+             rrtParentEdge=NS(endNode=root))
+    tree = NS(nodes=[root, kid])
+    drrt.saveRRTNodes(tree, str(tmp_path / "nodes.txt"))
+    drrt.saveRRTTree(tree, str(tmp_path / "edges.txt"))
+    drrt.saveRRTNodesCollision(tree, str(tmp_path / "cnodes.txt"))
+    assert open(tmp_path / "nodes.txt").read() == "15.0,15.0,15.0,0.0,0.0\n1.5,-2.0,1.0e-5,21.25,Inf\n"
+    assert open(tmp_path / "edges.txt").read() == "1.5,-2.0,1.0e-5,21.25\n15.0,15.0,15.0,0.0\n"
+    assert open(tmp_path / "cnodes.txt").read() == "15.0,15.0,15.0,0.0\n1.5,-2.0,1.0e-5,21.25\n"
+
+
 def test_synth_workloads_match_the_survey():
     assert abs(synth.ball_radius(200_000, 3) - 3.1497) < 1e-4 and abs(synth.ball_radius(10_000, 3) - 7.7837) < 1e-4
     assert synth.ball_radius(50_000, 4, gamma=100.0, delta=10.0) == 10.0
