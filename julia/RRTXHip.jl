@@ -164,6 +164,19 @@ function saveRRTTree(tree::HipTree{T}, fileName) where {T}
   close(fptr)
 end
 
+function saveRRTGraph(tree::HipTree{T}, fileName) where {T}          # R/DRRT_Q.jl:279-306
+  fptr = open(fileName, "w")
+  for node in tree.nodes
+    listItem = node.rrtNeighborsOut.front
+    for i = 1:node.rrtNeighborsOut.length
+      writedlm(fptr, node.position, ',')
+      writedlm(fptr, listItem.data.position, ',')
+      listItem = listItem.child
+    end
+  end
+  close(fptr)
+end
+
 function saveRRTNodes(tree::HipTree{T}, fileName) where {T}
   fptr = open(fileName, "w")
   for node in tree.nodes
