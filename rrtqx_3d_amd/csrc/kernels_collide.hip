@@ -476,6 +476,7 @@ __device__ bool edge_hits_moving(double sx, double sy, double st, double ex, dou
 // group of 32 obstacles with their prefix sum, and each edge's first hit (list position)
 struct PolyWave {
   double e[6][64];     // ax, ay, at, bx, by, bt per lane
+  float4 box[32];      // current group: bounding boxes (xlo, xhi, ylo, yhi) rounded outward to fp32
   int pre[65];
   unsigned cand[64];
   int first[64];
@@ -547,28 +548,43 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
   w.e[0][lane] = ax; w.e[1][lane] = ay; w.e[2][lane] = at;
   w.e[3][lane] = bx; w.e[4][lane] = by; w.e[5][lane] = bt;
   w.first[lane] = 0x7fffffff;
-  // (NaN-propagating min / max: an edge with a NaN coordinate must keep every obstacle)
-  const double exmin = jl_min(ax, bx), exmax = jl_max(ax, bx), eymin = jl_min(ay, by), eymax = jl_max(ay, by);
-  const double eslack = 1e-9 * jl_max(jl_max(fabs(ax), fabs(bx)), jl_max(fabs(ay), fabs(by)));
+  // The edge's own box, widened by far more than any rounding of the exact test (1e-9 relative against
+  // ~1e-15) and rounded outward to fp32.  NaN-propagating min / max: an edge with a NaN coordinate keeps
+  // every obstacle (all comparisons below are false); inf / overflow give an unbounded box.
+  float exlo, exhi, eylo, eyhi;
+  {
+    const double eslack = 1e-9 * jl_max(jl_max(fabs(ax), fabs(bx)), jl_max(fabs(ay), fabs(by)));
+    exlo = __double2float_rd(jl_min(ax, bx) - eslack); exhi = __double2float_ru(jl_max(ax, bx) + eslack);
+    eylo = __double2float_rd(jl_min(ay, by) - eslack); eyhi = __double2float_ru(jl_max(ay, by) + eslack);
+  }
   bool done = !act;
   int first = -1;
   for (int j0 = m_begin; j0 < m_end; j0 += 32) {
     const int jn = min(32, m_end - j0);
+    // boxes of the group's bounding circles (lane b = obstacle j0 + b), widened the same way and
+    // rounded outward to fp32: a pair whose boxes are disjoint fails the reference's first test for
+    // certain.  Kinds 6 / 7 have no bounding test (:1532): unbounded box.
+    if (lane < jn) {
+      const int j = j0 + lane;
+      const int kind = (int)meta[4 * j + 3];
+      const float inf = __builtin_inff();
+      float4 o = {-inf, inf, -inf, inf};
+      if (kind != 6 && kind != 7) {
+        const double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
+        const double R = fabs(robot_radius + meta[4 * j + 2]) * (1.0 + 1e-9) + 1e-9 * (1.0 + fabs(cx) + fabs(cy));
+        o.x = __double2float_rd(cx - R); o.y = __double2float_ru(cx + R);
+        o.z = __double2float_rd(cy - R); o.w = __double2float_ru(cy + R);
+      }
+      w.box[lane] = o;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     unsigned cand = 0;
     if (!done) {
       for (int b = 0; b < jn; ++b) {
-        const int j = j0 + b;
-        const int kind = (int)meta[4 * j + 3];
-        bool c = true;                                     // kinds 6 / 7 have no bounding test (:1532)
-        if (kind != 6 && kind != 7) {
-          // the edge's box against the circle's box, widened by far more than any rounding of the
-          // exact test (1e-9 relative against ~1e-15): a pair dropped here fails it for certain;
-          // NaN / overflow make every comparison false and the pair stays
-          const double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
-          const double R = fabs(robot_radius + meta[4 * j + 2]) * (1.0 + 1e-9) +
-                           1e-9 * (1.0 + fabs(cx) + fabs(cy)) + eslack;
-          c = !(exmax < cx - R || exmin > cx + R || eymax < cy - R || eymin > cy + R);
-        }
+        const float4 o = w.box[b];
+        const bool c = !(exhi < o.x || exlo > o.y || eyhi < o.z || eylo > o.w);
         cand |= (c ? 1u : 0u) << b;
       }
     }
