@@ -438,7 +438,13 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_tile_kernel(
   const int2 *__restrict__ blk = ev + (size_t)blockIdx.x * (kScanThreads / 64) * (size_t)slice_cap;
   int visited = 0;                          // chunks this wave screened (statistics)
 
-  for (int tile = blockIdx.x / n_parts; tile < n_tiles; tile += gridDim.x / n_parts) {
+  // Workgroups are dealt to the 8 XCDs round-robin (b and b + 8 share an XCD and its L2).  Tiles are in
+  // cell order, so neighbouring tiles stream the same chunks: give each XCD one contiguous eighth of the
+  // tile range instead of every eighth tile, and its L2 keeps serving the chunks of that eighth.
+  const int n_slots = (int)gridDim.x / n_parts;            // tiles in flight per sweep of the grid
+  const int slot = (int)blockIdx.x / n_parts;
+  const int my = (n_slots % 8 == 0) ? (slot % 8) * (n_slots / 8) + slot / 8 : slot;   // a permutation of the slots
+  for (int tile = my; tile < n_tiles; tile += n_slots) {
     const int q0 = tile * kTileB;
     const int q1 = min(q0 + kTileB, n_copies);
     int wn = 0;                             // wave-uniform: entries in the slice
