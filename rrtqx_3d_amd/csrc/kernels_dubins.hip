@@ -338,10 +338,10 @@ __device__ bool seg_hits_polygon(double ax, double ay, double bx, double by, dou
 //   stage 1, a: lane = edge drops the obstacles the chord cannot reach (box test); b: the surviving
 //     (edge, obstacle) pairs of the wave are dealt one per lane for the inflated chord test and mark
 //     up to 64 obstacles in the edge's bit mask;
-//   stage 2, lane = (edge, polyline piece): the pieces of all 64 edges of the wave are numbered
-//     through (prefix sum of the row counts) and handed out 64 at a time, so lanes stay busy
-//     whatever the lengths of the individual polylines are; an edge that has collided drops
-//     its remaining pieces.
+//   stage 2, lane = (edge, polyline piece): the next eight pieces of every still-undecided edge of
+//     the wave are numbered through (prefix sum) and handed out 64 at a time, so lanes stay busy
+//     whatever the lengths of the individual polylines are, and an edge that has collided drops
+//     out of the numbering.
 // Same set of tests, same arithmetic in each.  Every lane of the wave calls this together.
 struct WaveDubins {
   Piece pc[64][3];
@@ -412,39 +412,46 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
     __builtin_amdgcn_wave_barrier();
     const unsigned long long mask = w.mask[lane];
     const int segs = (mask != 0ull && rows > 1) ? rows - 1 : 0;
-    incl = segs;
+    // ---- stage 2 (lane = one polyline piece of one edge), kPieceWin pieces of every live edge at a
+    // time: an edge that has collided leaves the numbering at the next window, so its remaining pieces
+    // stop taking up lanes (most candidate edges do collide somewhere along the polyline) ----
+    constexpr int kPieceWin = 8;
+    for (int base = 0;; base += kPieceWin) {
+      const bool live = segs > base && !w.done[lane];
+      if (__ballot(live) == 0ull) break;
+      incl = live ? min(kPieceWin, segs - base) : 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o);
-      if (lane >= o) incl += v;
-    }
-    __builtin_amdgcn_wave_barrier();
-    w.pstart[lane + 1] = incl;
-    if (lane == 0) w.pstart[0] = 0;
-    __builtin_amdgcn_wave_barrier();
-    const int total = __shfl(incl, 63);
-    // ---- stage 2 (lane = one polyline piece of one edge) ----
-    for (int i0 = 0; i0 < total; i0 += 64) {
-      const int i = i0 + lane;
-      if (i < total) {
-        int lo = 0, hi = 64;                       // edge e with pstart[e] <= i < pstart[e + 1]
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (w.pstart[mid] <= i) lo = mid; else hi = mid;
-        }
-        const int e = lo;
-        if (!w.done[e]) {
-          const int row = i - w.pstart[e] + 1;
-          double px, py, x, y;
-          polyline_point(w.pc[e], row - 1, r_min, px, py);
-          polyline_point(w.pc[e], row, r_min, x, y);
-          unsigned long long mm = w.mask[e];
-          while (mm != 0ull) {
-            const int j = j0 + __ffsll((long long)mm) - 1;
-            mm &= mm - 1ull;
-            if (seg_hits_polygon(px, py, x, y, robot_radius, meta, off, vxy, j)) { w.done[e] = 1; break; }
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      w.pstart[lane + 1] = incl;
+      if (lane == 0) w.pstart[0] = 0;
+      __builtin_amdgcn_wave_barrier();
+      const int total = __shfl(incl, 63);
+      for (int i0 = 0; i0 < total; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < total) {
+          int lo = 0, hi = 64;                     // edge e with pstart[e] <= i < pstart[e + 1]
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (w.pstart[mid] <= i) lo = mid; else hi = mid;
+          }
+          const int e = lo;
+          if (!w.done[e]) {
+            const int row = base + (i - w.pstart[e]) + 1;
+            double px, py, x, y;
+            polyline_point(w.pc[e], row - 1, r_min, px, py);
+            polyline_point(w.pc[e], row, r_min, x, y);
+            unsigned long long mm = w.mask[e];
+            while (mm != 0ull) {
+              const int j = j0 + __ffsll((long long)mm) - 1;
+              mm &= mm - 1ull;
+              if (seg_hits_polygon(px, py, x, y, robot_radius, meta, off, vxy, j)) { w.done[e] = 1; break; }
+            }
           }
         }
+        __builtin_amdgcn_wave_barrier();
       }
       __builtin_amdgcn_wave_barrier();
     }
