@@ -346,9 +346,11 @@ __device__ bool seg_hits_polygon(double ax, double ay, double bx, double by, dou
 struct WaveDubins {
   Piece pc[64][3];
   unsigned long long mask[64];
-  unsigned long long cand[64];
-  double chord[4][64];
+  unsigned long long cand[64];    // stage 1: obstacles the chord's box reaches; stage 2: those a piece reaches
+  double chord[4][64];            // stage 1: the edges' chords; stage 2: end points of the round's 64 pieces
+  int piece_edge[64];
   int pstart[65];
+  int pairs[65];
   int done[64];
 };
 
@@ -365,13 +367,13 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
   const int lane = threadIdx.x & 63;
   w.pc[lane][0] = st.pc[0]; w.pc[lane][1] = st.pc[1]; w.pc[lane][2] = st.pc[2];
   w.done[lane] = 0;
-  w.chord[0][lane] = sx; w.chord[1][lane] = sy; w.chord[2][lane] = gx; w.chord[3][lane] = gy;
   const int rows = st.pc[0].len + st.pc[1].len + st.pc[2].len;
   for (int j0 = 0; j0 < m; j0 += 64) {
     const int j1 = (j0 + 64 < m) ? j0 + 64 : m;
     // ---- stage 1a (lane = edge): obstacles whose bounding circle, inflated like the chord test, the
     // chord's box cannot reach fail that test for certain (box widened by 1e-9 against ~1e-15 of
     // rounding; NaN / overflow keep the obstacle)
+    w.chord[0][lane] = sx; w.chord[1][lane] = sy; w.chord[2][lane] = gx; w.chord[3][lane] = gy;   // (stage 2 reuses it)
     unsigned long long cand = 0ull;
     if (valid && !w.done[lane]) {
       // (NaN-propagating min / max: a chord with a NaN coordinate keeps every obstacle)
@@ -430,26 +432,59 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
       __builtin_amdgcn_wave_barrier();
       const int total = __shfl(incl, 63);
       for (int i0 = 0; i0 < total; i0 += 64) {
+        // a) lane = piece: its end points, and which of the edge's marked obstacles it can touch at all
+        //    (the polygon test's own first step, :1536-1539: outside the bounding circle => no hit)
         const int i = i0 + lane;
+        unsigned long long near = 0ull;
+        int e = 0;
+        double px = 0.0, py = 0.0, x = 0.0, y = 0.0;
         if (i < total) {
           int lo = 0, hi = 64;                     // edge e with pstart[e] <= i < pstart[e + 1]
           while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (w.pstart[mid] <= i) lo = mid; else hi = mid;
           }
-          const int e = lo;
+          e = lo;
           if (!w.done[e]) {
             const int row = base + (i - w.pstart[e]) + 1;
-            double px, py, x, y;
             polyline_point(w.pc[e], row - 1, r_min, px, py);
             polyline_point(w.pc[e], row, r_min, x, y);
             unsigned long long mm = w.mask[e];
             while (mm != 0ull) {
-              const int j = j0 + __ffsll((long long)mm) - 1;
+              const int b = __ffsll((long long)mm) - 1;
               mm &= mm - 1ull;
-              if (seg_hits_polygon(px, py, x, y, robot_radius, meta, off, vxy, j)) { w.done[e] = 1; break; }
+              const int j = j0 + b;
+              const double rr = robot_radius + meta[4 * j + 2];
+              if (!(dspts(meta[4 * j + 0], meta[4 * j + 1], px, py, x, y) > rr * rr)) near |= 1ull << b;
             }
           }
+        }
+        w.chord[0][lane] = px; w.chord[1][lane] = py; w.chord[2][lane] = x; w.chord[3][lane] = y;
+        w.cand[lane] = near;
+        w.piece_edge[lane] = e;
+        int pin = __popcll(near);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(pin, o);
+          if (lane >= o) pin += v;
+        }
+        w.pairs[lane + 1] = pin;
+        if (lane == 0) w.pairs[0] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const int n_pairs = __shfl(pin, 63);
+        // b) lane = one (piece, obstacle) pair that got past the bounding circle: the full test
+        for (int p = lane; p < n_pairs; p += 64) {
+          int it = 0;
+          for (int step = 32; step > 0; step >>= 1)
+            if (w.pairs[it + step] <= p) it += step;
+          const int ee = w.piece_edge[it];
+          if (w.done[ee]) continue;
+          unsigned long long bits = w.cand[it];
+          for (int r = p - w.pairs[it]; r > 0; --r) bits &= bits - 1ull;
+          const int j = j0 + __ffsll((long long)bits) - 1;
+          if (seg_hits_polygon(w.chord[0][it], w.chord[1][it], w.chord[2][it], w.chord[3][it], robot_radius, meta, off,
+                               vxy, j))
+            w.done[ee] = 1;
         }
         __builtin_amdgcn_wave_barrier();
       }
