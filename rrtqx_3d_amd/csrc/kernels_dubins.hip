@@ -308,14 +308,27 @@ __device__ double seg_dist_sqrd(double pax, double pay, double pbx, double pby, 
   r = jl_min(r, dspts(qbx, qby, pax, pay, pbx, pby));
   return r;
 }
+// explicitEdgeCheck2D (R/DRRT.jl:1523-1578) in two steps: the bounding-circle test (:1536-1539) ...
+__device__ __forceinline__ bool seg_outside_circle(double ax, double ay, double bx, double by, double robot_radius,
+                                                   const double *__restrict__ meta, int j) {
+  const double dsq = dspts(meta[4 * j + 0], meta[4 * j + 1], ax, ay, bx, by);
+  const double rr = robot_radius + meta[4 * j + 2];
+  return dsq > rr * rr;
+}
+// ... and what follows it (:1542-1577)
+__device__ bool seg_hits_polygon_past_circle(double ax, double ay, double bx, double by, double robot_radius,
+                                             const double *__restrict__ meta, const int32_t *__restrict__ off,
+                                             const double *__restrict__ vxy, int j);
 __device__ bool seg_hits_polygon(double ax, double ay, double bx, double by, double robot_radius,
                                  const double *__restrict__ meta, const int32_t *__restrict__ off,
                                  const double *__restrict__ vxy, int j) {
-  const double cx = meta[4 * j + 0], cy = meta[4 * j + 1], rad = meta[4 * j + 2];
+  if (seg_outside_circle(ax, ay, bx, by, robot_radius, meta, j)) return false;
+  return seg_hits_polygon_past_circle(ax, ay, bx, by, robot_radius, meta, off, vxy, j);
+}
+__device__ bool seg_hits_polygon_past_circle(double ax, double ay, double bx, double by, double robot_radius,
+                                             const double *__restrict__ meta, const int32_t *__restrict__ off,
+                                             const double *__restrict__ vxy, int j) {
   const int kind = (int)meta[4 * j + 3];
-  double dsq = dspts(cx, cy, ax, ay, bx, by);
-  double rr = robot_radius + rad;
-  if (dsq > rr * rr) return false;
   if (kind == 1) return true;
   if (kind == 3) {
     const int b = off[j], e = off[j + 1];
@@ -453,9 +466,7 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
             while (mm != 0ull) {
               const int b = __ffsll((long long)mm) - 1;
               mm &= mm - 1ull;
-              const int j = j0 + b;
-              const double rr = robot_radius + meta[4 * j + 2];
-              if (!(dspts(meta[4 * j + 0], meta[4 * j + 1], px, py, x, y) > rr * rr)) near |= 1ull << b;
+              if (!seg_outside_circle(px, py, x, y, robot_radius, meta, j0 + b)) near |= 1ull << b;
             }
           }
         }
@@ -482,8 +493,8 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
           unsigned long long bits = w.cand[it];
           for (int r = p - w.pairs[it]; r > 0; --r) bits &= bits - 1ull;
           const int j = j0 + __ffsll((long long)bits) - 1;
-          if (seg_hits_polygon(w.chord[0][it], w.chord[1][it], w.chord[2][it], w.chord[3][it], robot_radius, meta, off,
-                               vxy, j))
+          if (seg_hits_polygon_past_circle(w.chord[0][it], w.chord[1][it], w.chord[2][it], w.chord[3][it], robot_radius,
+                                           meta, off, vxy, j))
             w.done[ee] = 1;
         }
         __builtin_amdgcn_wave_barrier();
