@@ -210,6 +210,8 @@ function syncObstacles(tree::HipTree, S::TS) where {TS}
     ptr = ptr.child
   end
   if sig != tree.obsSig
+    # extend_candidates checks against the sphere list (RRTX_OPT_EXTEND_OBSTACLES = 8, value 0)
+    rrtx_check(tree, ccall((:rrtx_set_option, LIBRRTX), Cint, (Ptr{Cvoid}, Cint, Int64), tree.ctx, 8, 0))
     GC.@preserve cxyzr active rrtx_check(tree, ccall((:rrtx_spheres_set, LIBRRTX), Cint,
         (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{UInt8}, Cint), tree.ctx, cxyzr, active, m))
     tree.obsSig = sig
