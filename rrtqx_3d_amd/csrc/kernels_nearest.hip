@@ -394,15 +394,16 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
 
 // ------------------------------------------------------------- k nearest -----
 // kdFindKNearest (R/kdTree_general.jl:696-723) for a batch, by exact selection: one workgroup
-// per query finds the kk-th smallest squared distance with an 8-pass radix select over the bit
+// per query finds the kk-th smallest squared distance with a 6-pass radix select over the bit
 // pattern of the unfused fp64 sum (monotone for non-negative doubles; NaN sorts last), gathers
 // the kk selected nodes and sorts them by (distance, index).  Where several nodes tie at the
 // kk-th distance the lowest indices are taken (the reference's choice there is its tree-visit
 // order).  The reference has no caller for this search, so the kernel is exact and
-// deterministic rather than tuned: it streams the node arrays nine times per query.
+// deterministic rather than tuned: it streams the node arrays seven times per query.
 namespace {
 constexpr int kKnnMax = 2048;
 constexpr int kKnnU = 4;
+constexpr int kKnnBins = 2048;
 constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
 
 template <int D>
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(NT) void nn_knearest_kernel(
     const double *__restrict__ nw, int n_nodes, const double *__restrict__ q, int kk, int stride,
     int32_t *__restrict__ idx_out, double *__restrict__ dist_out, int32_t *__restrict__ count_out,
     const int *__restrict__ qlist, const int *__restrict__ n_list) {
-  __shared__ unsigned hist[256];
+  __shared__ unsigned hist[kKnnBins];
   __shared__ unsigned long long s_prefix;
   __shared__ unsigned s_rank, s_less, s_ties, s_cnt;
   __shared__ unsigned long long skey[kKnnMax];
@@ -476,9 +477,12 @@ __global__ __launch_bounds__(NT) void nn_knearest_kernel(
 
   unsigned long long prefix = 0;
   unsigned rank = (unsigned)kk - 1u, less = 0, ties = 0;
-  for (int pass = 0; pass < 8; ++pass) {
-    const int shift = 56 - 8 * pass;
-    if (tid < 256) hist[tid] = 0;
+  // digits from the top: five of 11 bits, then one of 9 (64 bits in six passes)
+  for (int pass = 0; pass < 6; ++pass) {
+    const int width = pass < 5 ? 11 : 9;
+    const int shift = pass < 5 ? 53 - 11 * pass : 0;
+    const unsigned n_bins = 1u << width;
+    for (unsigned b = tid; b < n_bins; b += nt) hist[b] = 0;
     __syncthreads();
     for (int base = 0; base < n_nodes; base += nt * kKnnU) {
       unsigned long long key[kKnnU];
@@ -491,9 +495,10 @@ __global__ __launch_bounds__(NT) void nn_knearest_kernel(
       }
 #pragma unroll
       for (int u = 0; u < kKnnU; ++u) {
-        const bool m = valid[u] && ((pass == 0) || ((key[u] >> (shift + 8)) == prefix));
-        const unsigned digit = (unsigned)(key[u] >> shift) & 255u;
-        // most keys share the leading exponent bytes: one add per wave when they agree
+        bool m = valid[u];
+        if (pass > 0) m = m && ((key[u] >> (shift + width)) == prefix);
+        const unsigned digit = (unsigned)(key[u] >> shift) & (n_bins - 1u);
+        // most keys share the leading exponent bits: one add per wave when they agree
         const unsigned long long mask = __ballot(m);
         if (mask == 0) continue;
         const int lead = __ffsll((long long)mask) - 1;
@@ -507,25 +512,25 @@ __global__ __launch_bounds__(NT) void nn_knearest_kernel(
       }
     }
     __syncthreads();
-    if (tid < 64) {
-      unsigned c[4], tot = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { c[j] = hist[4 * tid + j]; tot += c[j]; }
+    if (tid < 64) {                               // wave 0: the bin that holds rank `rank`
+      const unsigned per = n_bins / 64u;
+      unsigned tot = 0;
+      for (unsigned j = 0; j < per; ++j) tot += hist[per * tid + j];
       unsigned inc = tot;
       for (int o = 1; o < 64; o <<= 1) {
         const unsigned v = (unsigned)__shfl_up((int)inc, o);
         if (tid >= o) inc += v;
       }
       unsigned run = inc - tot;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (rank >= run && rank < run + c[j]) {
-          s_prefix = (prefix << 8) | (unsigned long long)(4 * tid + j);
+      for (unsigned j = 0; j < per; ++j) {
+        const unsigned c = hist[per * tid + j];
+        if (rank >= run && rank < run + c) {
+          s_prefix = (prefix << width) | (unsigned long long)(per * tid + j);
           s_rank = rank - run;
           s_less = less + run;
-          s_ties = c[j];
+          s_ties = c;
         }
-        run += c[j];
+        run += c;
       }
     }
     __syncthreads();
