@@ -287,6 +287,16 @@ int rrtx_extend_candidates_dev(rrtx_ctx *ctx, const double *q, int nq, double r,
                                uint8_t *hit_out, uint8_t *hit_in, int64_t cap, int64_t *needed_dev,
                                int32_t *nearest_idx, double *nearest_dist, uint8_t *sample_unsafe);
 
+/* device-pointer form of rrtx_extend_candidates_dubins; *needed_dev receives the number of entries (entries
+ * beyond cap are not written).  With wrapped dimensions nearest_* come from the nearest scan (and, like
+ * rrtx_nn_nearest_dev, without the host-side fallback for an overflowing candidate buffer); without them
+ * samples whose ball is empty get nearest_idx -1. */
+int rrtx_extend_candidates_dubins_dev(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius,
+                                      double r_min, int64_t *offsets, int32_t *idx, double *key, double *cost_out,
+                                      double *cost_in, uint8_t *word_out, uint8_t *word_in, uint8_t *hit_out,
+                                      uint8_t *hit_in, int64_t cap, int64_t *needed_dev, int32_t *nearest_idx,
+                                      double *nearest_dist, uint8_t *sample_unsafe);
+
 /* Per-edge collision bitmask for the multi-GPU exchange (RCCL all-reduce over
  * xGMI): bit e (e < cap) = hit_out[e], bit cap+e = hit_in[e]; entries at or
  * beyond *n_valid_dev read as 0.  words has (2*cap+63)/64 uint64 entries. */

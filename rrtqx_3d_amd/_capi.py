@@ -96,6 +96,8 @@ SYMBOLS = [
                                          C.c_int64, c_int64_p, _VP, _VP, _VP]),
     ("rrtx_extend_candidates_dubins", C.c_int, [_VP, _VP, C.c_int, C.c_double, C.c_double, C.c_double, _VP, _VP, _VP, _VP,
                                                 _VP, _VP, _VP, _VP, _VP, C.c_int64, c_int64_p, _VP, _VP, _VP]),
+    ("rrtx_extend_candidates_dubins_dev", C.c_int, [_VP, _VP, C.c_int, C.c_double, C.c_double, C.c_double, _VP, _VP, _VP,
+                                                    _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     ("rrtx_nn_nearest_dev", C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     ("rrtx_nn_radius_dev", C.c_int, [_VP, _VP, C.c_double, C.c_int, _VP, _VP, _VP, C.c_int64, _VP]),
     ("rrtx_edges_check_dev", C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int,

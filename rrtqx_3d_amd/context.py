@@ -336,6 +336,16 @@ class Context:
                                                          cost_ptr, hit_out_ptr, hit_in_ptr, cap, needed_ptr,
                                                          nearest_idx_ptr, nearest_dist_ptr, unsafe_ptr))
 
+    def extend_candidates_dubins_dev(self, q_ptr: int, nq: int, r: float, robot_radius: float, r_min: float,
+                                     offsets_ptr: int, idx_ptr: int, key_ptr: int, cost_out_ptr: int, cost_in_ptr: int,
+                                     word_out_ptr: Optional[int], word_in_ptr: Optional[int], hit_out_ptr: int,
+                                     hit_in_ptr: int, cap: int, needed_ptr: int, nearest_idx_ptr: Optional[int] = None,
+                                     nearest_dist_ptr: Optional[int] = None, unsafe_ptr: Optional[int] = None):
+        self._check(self._lib.rrtx_extend_candidates_dubins_dev(
+            self._h, q_ptr, nq, r, robot_radius, r_min, offsets_ptr, idx_ptr, key_ptr, cost_out_ptr, cost_in_ptr,
+            word_out_ptr, word_in_ptr, hit_out_ptr, hit_in_ptr, cap, needed_ptr, nearest_idx_ptr, nearest_dist_ptr,
+            unsafe_ptr))
+
     def pack_hits_dev(self, hit_out_ptr: int, hit_in_ptr: int, n_valid_ptr: int, cap: int, words_ptr: int):
         self._check(self._lib.rrtx_pack_hits_dev(self._h, hit_out_ptr, hit_in_ptr, n_valid_ptr, cap, words_ptr))
 

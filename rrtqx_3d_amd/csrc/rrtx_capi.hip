@@ -1063,6 +1063,39 @@ int rrtx_extend_candidates(rrtx_ctx *ctx, const double *q, int nq, double r, dou
   return RRTX_OK;
 }
 
+int rrtx_extend_candidates_dubins_dev(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius,
+                                      double r_min, int64_t *offsets, int32_t *idx, double *key, double *cost_out,
+                                      double *cost_in, uint8_t *word_out, uint8_t *word_in, uint8_t *hit_out,
+                                      uint8_t *hit_in, int64_t cap, int64_t *needed_dev, int32_t *nearest_idx,
+                                      double *nearest_dist, uint8_t *sample_unsafe) {
+  CHECK_CTX(ctx);
+  if (nq < 0 || cap < 0 || (nq > 0 && (!q || !offsets)) ||
+      (cap > 0 && (!idx || !key || !cost_out || !cost_in || !hit_out || !hit_in)))
+    return fail(ctx, RRTX_E_INVALID, "extend_candidates_dubins: bad arguments");
+  if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "extend_candidates_dubins needs a dim=4 [x y t theta] context");
+  if (nq == 0) return RRTX_OK;
+  RRTX_HIP(ctx, ctx->ws_owner.ensure(sizeof(int32_t) * (size_t)(cap > 0 ? cap : 1)));
+  const bool want_nearest = nearest_idx && nearest_dist;
+  // with wrapped dimensions a list key is the distance to the copy that found the node FIRST
+  // (addToRangeList), not the minimum over the copies, so kdFindNearest cannot be read off the list
+  const bool nearest_from_list = want_nearest && ctx->n_wraps == 0;
+  int rc = launch_nn_radius(ctx, q, nullptr, r, nq, offsets, idx, key, cap, needed_dev, ctx->ws_owner.as<int32_t>(),
+                            nearest_from_list ? nearest_idx : nullptr, nearest_from_list ? nearest_dist : nullptr);
+  if (rc) return rc;
+  rc = launch_candidate_dubins(ctx, q, nq, offsets, idx, ctx->ws_owner.as<int32_t>(), cap, r_min, robot_radius, cost_out,
+                               cost_in, word_out, word_in, hit_out, hit_in);
+  if (rc) return rc;
+  if (sample_unsafe) {
+    rc = launch_points_polygons(ctx, q, nq, robot_radius, sample_unsafe, nullptr);
+    if (rc) return rc;
+  }
+  if (want_nearest && !nearest_from_list) {
+    rc = nearest_with_fallback(ctx, q, nq, nearest_idx, nearest_dist);
+    if (rc) return rc;
+  }
+  return RRTX_OK;
+}
+
 int rrtx_extend_candidates_dubins(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius,
                                   double r_min, int64_t *offsets, int32_t *idx, double *key, double *cost_out,
                                   double *cost_in, uint8_t *word_out, uint8_t *word_in, uint8_t *hit_out,
@@ -1090,26 +1123,12 @@ int rrtx_extend_candidates_dubins(rrtx_ctx *ctx, const double *q, int nq, double
   double *key_dev = ctx->ws_out_dist.as<double>(), *co_dev = key_dev + dcap, *ci_dev = co_dev + dcap;
   uint8_t *wo_dev = ctx->ws_out_u8a.as<uint8_t>(), *wi_dev = wo_dev + 3 * dcap, *ho_dev = wi_dev + 3 * dcap,
           *hi_dev = ho_dev + dcap, *unsafe_dev = hi_dev + dcap;
-  // with wrapped dimensions a list key is the distance to the copy that found the node FIRST
-  // (addToRangeList), not the minimum over the copies, so kdFindNearest cannot be read off the list
-  const bool nearest_from_list = want_nearest && ctx->n_wraps == 0;
-  rc = launch_nn_radius(ctx, ctx->ws_q.as<double>(), nullptr, r, nq, off_dev, ctx->ws_out_idx.as<int32_t>(), key_dev,
-                        cap, needed_dev, ctx->ws_owner.as<int32_t>(),
-                        nearest_from_list ? ctx->ws_out_i32.as<int32_t>() : nullptr,
-                        nearest_from_list ? ctx->ws_out_f64.as<double>() : nullptr);
+  rc = rrtx_extend_candidates_dubins_dev(ctx, ctx->ws_q.as<double>(), nq, r, robot_radius, r_min, off_dev,
+                                         ctx->ws_out_idx.as<int32_t>(), key_dev, co_dev, ci_dev, wo_dev, wi_dev, ho_dev,
+                                         hi_dev, cap, needed_dev, want_nearest ? ctx->ws_out_i32.as<int32_t>() : nullptr,
+                                         want_nearest ? ctx->ws_out_f64.as<double>() : nullptr,
+                                         sample_unsafe ? unsafe_dev : nullptr);
   if (rc) return rc;
-  rc = launch_candidate_dubins(ctx, ctx->ws_q.as<double>(), nq, off_dev, ctx->ws_out_idx.as<int32_t>(),
-                               ctx->ws_owner.as<int32_t>(), cap, r_min, robot_radius, co_dev, ci_dev, wo_dev, wi_dev,
-                               ho_dev, hi_dev);
-  if (rc) return rc;
-  if (sample_unsafe) {
-    rc = launch_points_polygons(ctx, ctx->ws_q.as<double>(), nq, robot_radius, unsafe_dev, nullptr);
-    if (rc) return rc;
-  }
-  if (want_nearest && !nearest_from_list) {
-    rc = nearest_with_fallback(ctx, ctx->ws_q.as<double>(), nq, ctx->ws_out_i32.as<int32_t>(), ctx->ws_out_f64.as<double>());
-    if (rc) return rc;
-  }
   int64_t total = 0;
   RRTX_HIP(ctx, hipMemcpyAsync(offsets, off_dev, sizeof(int64_t) * ((size_t)nq + 1), hipMemcpyDeviceToHost, ctx->stream));
   RRTX_HIP(ctx, hipMemcpyAsync(&total, needed_dev, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -91,3 +91,44 @@ def test_dev_entry_points_match_host_forms():
             st.synchronize()
             assert np.array_equal(d_un.cpu().numpy(), hu) and np.array_equal(d_clr.cpu().numpy(), hc)
         dctx.set_stream(None)
+
+
+def test_dubins_preamble_dev_matches_host_form():
+    torch = pytest.importorskip("torch")
+    import math
+    dev = torch.device("cuda", 0)
+    n, nq, r, r_min = 12_000, 300, 9.0, 1.0
+    pts, Q, polys = synth.nodes(n, 4), synth.queries(nq, 4), synth.polygons(24)
+    with Context(4) as ctx:
+        ctx.set_wrap(3, 2 * math.pi)
+        ctx.nodes_append(pts)
+        ctx.polygons_set(polys)
+        ref = ctx.extend_candidates_dubins(Q, r, RR, r_min)
+        k = len(ref["idx"])
+        cap = k + 11
+        st = torch.cuda.Stream(device=dev)
+        ctx.set_stream(st.cuda_stream)
+        with torch.cuda.stream(st):
+            d_q = torch.from_numpy(Q).to(dev)
+            f64 = lambda m: torch.empty(m, dtype=torch.float64, device=dev)
+            u8 = lambda m: torch.empty(m, dtype=torch.uint8, device=dev)
+            d_off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+            d_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+            d_key, d_co, d_ci = f64(cap), f64(cap), f64(cap)
+            d_wo, d_wi, d_ho, d_hi, d_un = u8(3 * cap), u8(3 * cap), u8(cap), u8(cap), u8(nq)
+            d_need = torch.zeros(1, dtype=torch.int64, device=dev)
+            d_ni = torch.empty(nq, dtype=torch.int32, device=dev)
+            d_nd = f64(nq)
+            st.synchronize()
+            ctx.extend_candidates_dubins_dev(d_q.data_ptr(), nq, r, RR, r_min, d_off.data_ptr(), d_idx.data_ptr(),
+                                             d_key.data_ptr(), d_co.data_ptr(), d_ci.data_ptr(), d_wo.data_ptr(),
+                                             d_wi.data_ptr(), d_ho.data_ptr(), d_hi.data_ptr(), cap, d_need.data_ptr(),
+                                             d_ni.data_ptr(), d_nd.data_ptr(), d_un.data_ptr())
+            st.synchronize()
+        ctx.set_stream(None)
+        assert int(d_need.item()) == k and k > 1000
+        assert np.array_equal(d_off.cpu().numpy(), ref["offsets"])
+        for name, t in (("idx", d_idx), ("key", d_key), ("cost_out", d_co), ("cost_in", d_ci), ("hit_out", d_ho), ("hit_in", d_hi)):
+            assert np.array_equal(t.cpu().numpy()[:k], ref[name]), name
+        assert np.array_equal(d_un.cpu().numpy(), ref["sample_unsafe"])
+        assert np.array_equal(d_ni.cpu().numpy(), ref["nearest_idx"]) and np.array_equal(d_nd.cpu().numpy(), ref["nearest_dist"])
