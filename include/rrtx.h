@@ -275,6 +275,10 @@ int rrtx_extend_candidates_dubins(rrtx_ctx *ctx, const double *q, int nq, double
 
 /* ---- device-resident variants (inputs/outputs are DEVICE pointers) ------------ */
 int rrtx_nn_nearest_dev(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double *dist);
+/* rows max(k, 2) wide as in rrtx_nn_knearest.  The list path (RRTX_OPT_KNN_LISTS) reads two small values
+ * back from the device on the way (its radius guess and the size of the lists), so this call waits on the
+ * stream internally; the result kernels themselves are only enqueued. */
+int rrtx_nn_knearest_dev(rrtx_ctx *ctx, const double *q, int nq, int k, int32_t *idx, double *dist, int32_t *count);
 int rrtx_nn_radius_dev(rrtx_ctx *ctx, const double *q, double r, int nq, int64_t *offsets,
                        int32_t *idx, double *dist, int64_t cap, int64_t *needed_dev);
 int rrtx_edges_check_dev(rrtx_ctx *ctx, int kind, const double *p0, const double *p1, int64_t ne,

@@ -99,6 +99,7 @@ SYMBOLS = [
     ("rrtx_extend_candidates_dubins_dev", C.c_int, [_VP, _VP, C.c_int, C.c_double, C.c_double, C.c_double, _VP, _VP, _VP,
                                                     _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     ("rrtx_nn_nearest_dev", C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
+    ("rrtx_nn_knearest_dev", C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP]),
     ("rrtx_nn_radius_dev", C.c_int, [_VP, _VP, C.c_double, C.c_int, _VP, _VP, _VP, C.c_int64, _VP]),
     ("rrtx_edges_check_dev", C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int,
                                        _VP, _VP]),

@@ -313,6 +313,9 @@ class Context:
     def nn_nearest_dev(self, q_ptr: int, nq: int, idx_ptr: int, dist_ptr: int):
         self._check(self._lib.rrtx_nn_nearest_dev(self._h, q_ptr, nq, idx_ptr, dist_ptr))
 
+    def nn_knearest_dev(self, q_ptr: int, nq: int, k: int, idx_ptr: int, dist_ptr: int, count_ptr: int):
+        self._check(self._lib.rrtx_nn_knearest_dev(self._h, q_ptr, nq, k, idx_ptr, dist_ptr, count_ptr))
+
     def nn_radius_dev(self, q_ptr: int, r: float, nq: int, offsets_ptr: int, idx_ptr: int, dist_ptr: int, cap: int,
                       needed_ptr: int):
         self._check(self._lib.rrtx_nn_radius_dev(self._h, q_ptr, r, nq, offsets_ptr, idx_ptr, dist_ptr, cap,

@@ -627,6 +627,13 @@ int rrtx_nn_nearest(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double
   return RRTX_OK;
 }
 
+int rrtx_nn_knearest_dev(rrtx_ctx *ctx, const double *q, int nq, int k, int32_t *idx, double *dist, int32_t *count) {
+  CHECK_CTX(ctx);
+  if (nq < 0 || (nq > 0 && (!q || !idx || !dist || !count)))
+    return fail(ctx, RRTX_E_INVALID, "nn_knearest: bad arguments");
+  return launch_nn_knearest(ctx, q, nq, k, idx, dist, count);
+}
+
 int rrtx_nn_knearest(rrtx_ctx *ctx, const double *q, int nq, int k, int32_t *idx, double *dist, int32_t *count) {
   CHECK_CTX(ctx);
   if (nq < 0 || (nq > 0 && (!q || !idx || !dist || !count)))

@@ -132,3 +132,26 @@ def test_dubins_preamble_dev_matches_host_form():
             assert np.array_equal(t.cpu().numpy()[:k], ref[name]), name
         assert np.array_equal(d_un.cpu().numpy(), ref["sample_unsafe"])
         assert np.array_equal(d_ni.cpu().numpy(), ref["nearest_idx"]) and np.array_equal(d_nd.cpu().numpy(), ref["nearest_dist"])
+
+
+def test_knearest_dev_matches_host_form():
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n, nq, k = 40_000, 900, 9
+    pts, Q = synth.nodes(n, 3), synth.queries(nq, 3)
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        ref = ctx.nn_knearest(Q, k)
+        st = torch.cuda.Stream(device=dev)
+        ctx.set_stream(st.cuda_stream)
+        with torch.cuda.stream(st):
+            d_q = torch.from_numpy(Q).to(dev)
+            d_idx = torch.empty((nq, k), dtype=torch.int32, device=dev)
+            d_dist = torch.empty((nq, k), dtype=torch.float64, device=dev)
+            d_cnt = torch.empty(nq, dtype=torch.int32, device=dev)
+            st.synchronize()
+            ctx.nn_knearest_dev(d_q.data_ptr(), nq, k, d_idx.data_ptr(), d_dist.data_ptr(), d_cnt.data_ptr())
+            st.synchronize()
+        ctx.set_stream(None)
+        assert np.array_equal(d_idx.cpu().numpy(), ref[0]) and np.array_equal(d_dist.cpu().numpy(), ref[1])
+        assert np.array_equal(d_cnt.cpu().numpy(), ref[2])
