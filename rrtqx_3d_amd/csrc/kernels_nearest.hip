@@ -647,7 +647,7 @@ int launch_nn_knearest(rrtx_ctx *ctx, const double *q_dev, int nq, int k, int32_
   // extra launches, and lists that fit the LDS sort.  Otherwise every query runs the exhaustive kernel.
   constexpr int kSample = 32;
   const bool culls = ctx->opt_nn_filter && (ctx->opt_nn_cull == 2 || (ctx->opt_nn_cull == 1 && n_nodes >= 8192));
-  const bool fast = culls && ctx->opt_knn_lists && nq >= 8 * kSample && kk <= 128 && kk * 16 <= n_nodes;
+  const bool fast = culls && ctx->opt_knn_lists && nq >= 8 * kSample && kk <= 512 && kk * 16 <= n_nodes;
   if (!fast) {
     span_begin(ctx, KF_NN_NEAREST);
     knearest_exhaustive(ctx, q_dev, nq, kk, stride, idx_dev, dist_dev, count_dev, nullptr, nullptr);
@@ -682,11 +682,12 @@ int launch_nn_knearest(rrtx_ctx *ctx, const double *q_dev, int nq, int k, int32_
     return RRTX_OK;
   }
   std::sort(kth, kth + n_fin);
-  const double r0 = 2.0 * kth[n_fin / 2];
+  // (larger k: 1.6 x -> about 4 kk nodes, so that the lists still fit the 2048-entry LDS sort)
+  const double r0 = (kk <= 128 ? 2.0 : 1.6) * kth[n_fin / 2];
 
   // 2. per batch of queries: range search with r0 -> select from the lists -> exhaustive for the rest
   const long long cap_max = 16ll << 20;
-  long long per_q = (long long)kk * 12;
+  long long per_q = (long long)kk * (kk <= 128 ? 12 : 7);
   int batch = (int)std::min<long long>(nq, std::max<long long>(256, cap_max / per_q));
   for (int first = 0; first < nq; first += batch) {
     const int nb = std::min(batch, nq - first);

@@ -57,7 +57,7 @@ def test_knearest_list_path_equals_exhaustive(oracle, n_cluster_queries):
     t.insert_many(pts)
     with Context(3) as ctx:
         ctx.nodes_append(pts)
-        for k in (1, 16, 128, 129):
+        for k in (1, 16, 128, 129, 400, 513):
             ctx.set_option(_capi.RRTX_OPT_KNN_LISTS, 1)
             a = ctx.nn_knearest(Q, k)
             ctx.set_option(_capi.RRTX_OPT_KNN_LISTS, 0)

@@ -32,7 +32,7 @@ for sc in range(n_scen):
     nq = int(rng.integers(256, 2500))
     Q = pts[rng.integers(0, n, nq)] + rng.normal(0, span / 20, (nq, d))
     Q[:3] = span * 50                                            # far outside
-    k = int(rng.choice([1, 2, 7, 16, 64, 128]))
+    k = int(rng.choice([1, 2, 7, 16, 64, 128, 200, 512]))
     with Context(d) as ctx:
         ctx.nodes_append(pts)
         ctx.set_option(_capi.RRTX_OPT_KNN_LISTS, 1)
