@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--scan-items", type=int, default=0, help="tuning: target (tile, segment) work items")
     ap.add_argument("--tile-q", type=int, default=0, help="tuning: query copies per workgroup tile")
     ap.add_argument("--nn-cull", type=int, default=1, help="slab culling of the range scan: 0 off, 1 auto, 2 always")
+    ap.add_argument("--tune", type=int, default=0, help="RRTX_OPT_TUNE bit mask (kernel variants under measurement)")
     ap.add_argument("--agents", type=int, default=0, help="side measurement: k independent planners sharing the GPU (0/1: off)")
     args = ap.parse_args()
 
@@ -201,6 +202,8 @@ def main():
     if args.tile_q:
         ctx.set_option(_capi.RRTX_OPT_SCAN_TILE_Q, args.tile_q)
     ctx.set_option(_capi.RRTX_OPT_NN_CULL, args.nn_cull)
+    if args.tune:
+        ctx.set_option(_capi.RRTX_OPT_TUNE, args.tune)
 
     # ---- inputs resident in HBM before the timed region -----------------------
     d_pts = torch.from_numpy(pts).to(dev)

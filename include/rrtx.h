@@ -110,6 +110,14 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
  *   polygon explicitPointCheck, R/DRRT.jl:1434-1470, 1523-1678; time in the third coordinate for the
  *   moving kinds).  This one DOES select behaviour: it says which CSpace.obstacles the caller has. */
 #define RRTX_OPT_EXTEND_OBSTACLES 8
+/*   RRTX_OPT_NEAREST_REC_CAP (testing, default 0 = sized from the batch): candidate records the screened
+ *   nearest scan may keep; queries that lose one are answered again exactly on the device. */
+#define RRTX_OPT_NEAREST_REC_CAP 9
+/*   RRTX_OPT_BUCKET_MULT (default 2, grows by itself after a call whose lists overflowed): capacity of the
+ *   per-query hit buckets of the range search in units of cap / nq; 2, 4, 8 or 16. */
+#define RRTX_OPT_BUCKET_MULT 10
+/*   RRTX_OPT_TUNE (default 0): bit mask of kernel variants under measurement; results are identical. */
+#define RRTX_OPT_TUNE 11
 int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value);
 
 /* Host-only helper (no GPU needed): the exact thresholds on SQUARED distances the kernels

@@ -28,6 +28,9 @@ RRTX_OPT_NN_CULL = 5
 RRTX_OPT_PROFILE_EVERY = 6
 RRTX_OPT_KNN_LISTS = 7
 RRTX_OPT_EXTEND_OBSTACLES = 8
+RRTX_OPT_NEAREST_REC_CAP = 9
+RRTX_OPT_BUCKET_MULT = 10
+RRTX_OPT_TUNE = 11
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

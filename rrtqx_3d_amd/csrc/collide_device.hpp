@@ -21,5 +21,13 @@ __device__ __forceinline__ bool edge_hits_sphere(double p0x, double p0y, double 
   return !(s >= ob.thr);
 }
 
+// Per-sample sphere lists of the fused extend path (sample_spheres_kernel / nn_finish_kernel):
+// everything the sample pass needs about one active sphere, one 64-byte record:
+//   thr_in  : quickCheck, inside the sphere            <=> !(s >= thr_in)   (R/DRRT_Q.jl:1410)
+//   thr_pt  : (sqrt(s) - robotRadius) - radius < 0     <=>  s < thr_pt      (thr_point_clear)
+//   reach   : inflated robotRadius + radius (or +inf)
+struct alignas(64) SampleSph { double cx, cy, cz, thr_in, thr_pt, reach, pad0, pad1; };
+constexpr int kSphListCap = 8;   // spheres listed per sample; a longer list sends the sample's edges to the full loop
+
 }  // namespace
 }  // namespace rrtx

@@ -281,12 +281,7 @@ __global__ __launch_bounds__(256) void points_spheres_kernel(const double *__res
 // r + robotRadius + radius (+ slack) from the sample cannot collide with any of those edges.
 // A list longer than kSphListCap is marked as overflowed (count = cap + 1) and the edges of
 // that sample take the full obstacle loop.  Never decides a result by itself.
-constexpr int kSphListCap = 8;
-// everything the sample pass needs about one sphere, one 64-byte record:
-//   thr_in  : quickCheck, inside the sphere            <=> !(s >= thr_in)   (R/DRRT_Q.jl:1410)
-//   thr_pt  : (sqrt(s) - robotRadius) - radius < 0     <=>  s < thr_pt      (thr_point_clear)
-//   reach   : inflated robotRadius + radius (or +inf)
-struct alignas(64) SampleSph { double cx, cy, cz, thr_in, thr_pt, reach, pad0, pad1; };
+// (SampleSph, kSphListCap: collide_device.hpp)
 
 // lane = sample; the kSampleWaves waves of a workgroup share the same 64 samples and split the
 // sphere table between them, so every sphere record is a wave-uniform (scalar) load; the partial

@@ -1,0 +1,584 @@
+// kernels_finish.hip -- the last launch of the range search: one kernel turns the per-query hit
+// buckets into the caller's CSR lists and, for the fused extend() preamble against the sphere list,
+// also runs the sample pass and the candidate-edge checks on the lists while they are in registers.
+//
+// Replaces, per workgroup of 16 queries (half a wave each):
+//   offsets : exclusive scan of the list lengths -- workgroup b adds up the 16 b counts before it
+//             (16-byte loads; cheaper than a launch of its own for batches up to 65536 queries)
+//   scatter : a query whose list outgrew its bucket gathers its records from the shared overflow
+//             list itself (rare; after a call that overflowed, the next one widens the buckets and
+//             may pre-scatter with nn_offsets + nn_scatter, kernels_nn.hip)
+//   order   : sort by node index, dist = sqrt(d2) (the key the reference stores,
+//             R/kdTree_general.jl:829-831), owner, nearest of the list; lists longer than 64 entries
+//             are sorted by the whole workgroup (bitonic network in LDS up to 2048 entries)
+//   nearest : a sample whose ball is empty gets kdFindNearest's answer from an expanding search
+//             over the slab index (block_nearest, nn_device.hpp) -- no -1 leaves the device
+//   extend  : explicitPointCheck of the sample + the spheres its candidate edges can touch, then
+//             both directed edges of every list entry against those spheres
+//             (R/DRRT_Q.jl:1520-1556, 1775-1826, 1951-1963, 2600-2602)
+// gfx950 only.
+#include "collide_device.hpp"
+#include "nn_device.hpp"
+
+namespace rrtx {
+
+namespace {
+
+constexpr int kFinThreads = 512;
+constexpr int kFinQ = kFinThreads / 32;   // queries per workgroup
+constexpr int kBigSort = 2048;
+
+struct FinishArgs {
+  const int *count;
+  int nq, bcap;
+  const BktRec *bkt;           // [nq][bcap]
+  BktRec *tmp;                 // entry j >= bcap of query q lives at tmp[offsets[q] + j]
+  const HitRec *ovf;           // shared overflow list
+  long long ovf_cap;
+  const Scalars *sc;           // ->total: records in the overflow list
+  int prescattered;            // 1: nn_offsets + nn_scatter already ran (offsets valid, tmp filled)
+  int want_nearest_fix;        // 1: resolve empty balls with block_nearest
+  int64_t *offsets;
+  int64_t *needed;
+  int32_t *idx;
+  double *dist;
+  long long out_cap;
+  int32_t *owner;
+  int32_t *nearest_idx;
+  double *nearest_dist;
+  int *qhist;                  // bucket histogram of the culled search, re-zeroed for the next call
+  int n_qhist;
+  unsigned *mailbox;           // host-mapped: [0] = overflow records of this call
+  const double *q;             // query points (nearest of empty balls, sample pass)
+  double r_start;
+  NearestIndex ni;
+  int tune;
+};
+
+struct ExtendArgs {
+  const double4 *naos;         // node coordinates, one 32-byte record per node
+  const SphRec *sph;
+  const SampleSph *stab;
+  const float *reach_f;        // fp32 reach table (sync_spheres)
+  double ox, oy, oz;
+  int m;                       // active spheres
+  int n_nodes;
+  double r_bound;              // radius of the ball the lists were built with, < 0: no lists (full loop)
+  uint8_t *hit_out, *hit_in, *sample_unsafe;
+};
+
+struct FinLds {
+  long long red[kFinThreads / 64];
+  long long off[kFinQ + 1];
+  int kfull[kFinQ];            // list length as counted
+  int todo[kFinQ];             // the list needs the whole workgroup
+  int empty[kFinQ];
+  int nl[kFinQ];
+  int sl[kFinQ][kSphListCap];
+  int gcnt;
+  int s_idx[kBigSort];
+  double s_d2[kBigSort];
+  double r_best[kFinThreads / 64];
+  int r_besti[kFinThreads / 64];
+  NearestScratch ns;
+};
+
+// entry j of the (unordered) list of query q; the part behind the bucket is read with agent-scope
+// loads (it may have been written by this workgroup a moment ago)
+__device__ __forceinline__ BktRec load_rec(const FinishArgs &a, int q, long long b, long long j) {
+  if (j < a.bcap) return a.bkt[(size_t)q * (size_t)a.bcap + (size_t)j];
+  const unsigned long long *p = reinterpret_cast<const unsigned long long *>(a.tmp + b + j);
+  BktRec r;
+  const unsigned long long w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  r.idx = (int)(unsigned)(w0 & 0xffffffffull);
+  r.pad = 0;
+  r.d2 = __longlong_as_double((long long)w1);
+  return r;
+}
+
+// Both directed edges sample <-> node against the sphere list (the body of candidate_edges_kernel,
+// kernels_collide.hip, for one list entry).  Every lane of the wave calls this together.
+__device__ __forceinline__ void candidate_edge(const ExtendArgs &x, bool act, double sx, double sy, double sz, int node,
+                                               int nl_in, const int *list, bool &out_hit, bool &in_hit) {
+  double tx = 0, ty = 0, tz = 0;
+  act = act && (unsigned)node < (unsigned)x.n_nodes;     // defensive: never index out of range
+  if (act) {
+    const double4 nd = x.naos[node];
+    tx = nd.x; ty = nd.y; tz = nd.z;
+  }
+  // out: sample -> near ; in: near -> sample.  edgeLen is the same value either way
+  const double bx = tx - sx, by = ty - sy, bz = tz - sz;
+  const double cx = sx - tx, cy = sy - ty, cz = sz - tz;
+  const double len = sqrt_rn(sq3(sx, sy, sz, tx, ty, tz));
+  out_hit = false; in_hit = false;
+  if (__ballot(act) == 0ull) return;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const double cmax = fmax(fmax(fmax(fabs(sx), fabs(sy)), fmax(fabs(sz), fabs(tx))), fmax(fabs(ty), fabs(tz)));
+  const bool usable = (len > 0.0) && (len < 1e30) && (cmax < 1e30) && (sx == sx) && (sy == sy) && (sz == sz) &&
+                      (tx == tx) && (ty == ty) && (tz == tz);
+  // ---- fast path: only the spheres on the sample's list ----
+  bool need_full = act;
+  if (x.r_bound >= 0.0) {
+    int nl = 0;
+    if (act) {
+      nl = nl_in;
+      // the list only covers edges inside the ball it was built for
+      need_full = !usable || nl > kSphListCap || !(len <= x.r_bound);
+      if (need_full) nl = 0;
+    }
+    for (int c = 0; __ballot(c < nl) != 0ull; ++c) {
+      if (c < nl && !(out_hit && in_hit)) {
+        const SphRec ob = x.sph[list[c]];
+        if (!out_hit) out_hit = edge_hits_sphere(sx, sy, sz, bx, by, bz, len, ob);
+        if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len, ob);
+      }
+    }
+    if (__ballot(need_full) == 0ull) return;
+  }
+  // ---- full obstacle loop for the lanes that need it (packed fp32 midpoint screen, exact test
+  //      of what it cannot rule out; see candidate_edges_kernel) ----
+  float mxf, myf, mzf, hlsf;
+  {
+    const double mx = 0.5 * (sx + tx) - x.ox, my = 0.5 * (sy + ty) - x.oy, mz = 0.5 * (sz + tz) - x.oz;
+    mxf = (float)mx; myf = (float)my; mzf = (float)mz;
+    const double eps = 5.9604644775390625e-08;
+    const double h = (0.5 * len * (1.0 + 1e-12) + 3.0 * eps * (fabs(mx) + fabs(my) + fabs(mz)) + 1e-30) * (1.0 + 8.0 * eps);
+    hlsf = usable ? __double2float_ru(h) : __builtin_inff();
+    if (!usable) { mxf = 0.f; myf = 0.f; mzf = 0.f; }
+  }
+  const f32x2 m2x = {mxf, mxf}, m2y = {myf, myf}, m2z = {mzf, mzf}, h2 = {hlsf, hlsf};
+  constexpr int G = 8;
+  const int m = x.m;
+  for (int j0 = 0; j0 < m; j0 += G) {
+    const float *gp = x.reach_f + (size_t)(j0 / 8) * 32;
+    unsigned touch = 0u;
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      const f32x2 ccx = {gp[8 * pr + 0], gp[8 * pr + 1]}, ccy = {gp[8 * pr + 2], gp[8 * pr + 3]};
+      const f32x2 ccz = {gp[8 * pr + 4], gp[8 * pr + 5]}, rr = {gp[8 * pr + 6], gp[8 * pr + 7]};
+      const f32x2 dx = ccx - m2x, dy = ccy - m2y, dz = ccz - m2z;
+      f32x2 dm2 = dx * dx;
+      dm2 = __builtin_elementwise_fma(dy, dy, dm2);
+      dm2 = __builtin_elementwise_fma(dz, dz, dm2);
+      const f32x2 bound = rr + h2;
+      const f32x2 b2 = bound * bound;
+      touch |= (!(dm2.x > b2.x) ? 1u : 0u) << (2 * pr);
+      touch |= (!(dm2.y > b2.y) ? 1u : 0u) << (2 * pr + 1);
+    }
+    if (j0 + G > m) touch &= (1u << (m - j0)) - 1u;
+    if (!need_full) touch = 0u;
+    if (__ballot(touch != 0u) == 0ull) continue;
+    for (int g = 0; g < G; ++g) {
+      if (__ballot((touch >> g) & 1u) == 0ull) continue;
+      if (((touch >> g) & 1u) && !(out_hit && in_hit)) {
+        const SphRec ob = x.sph[j0 + g];
+        if (!out_hit) out_hit = edge_hits_sphere(sx, sy, sz, bx, by, bz, len, ob);
+        if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len, ob);
+      }
+    }
+    if (__ballot(need_full && !(out_hit && in_hit)) == 0ull) break;
+  }
+}
+
+// D: coordinates per query point; EXT: fused extend() work against the sphere list (D == 3)
+template <int D, bool EXT, int OCC>
+__global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs a, ExtendArgs x) {
+  __shared__ FinLds sm;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int hl = t & 31, hw = t >> 5;
+  const int q0 = (int)blockIdx.x * kFinQ;
+  const int q = q0 + hw;
+  const bool qv = q < a.nq;
+
+  // ---- housekeeping for the next call ----
+  for (int k = (int)blockIdx.x * kFinThreads + t; k < a.n_qhist; k += (int)gridDim.x * kFinThreads) a.qhist[k] = 0;
+  if (blockIdx.x == 0 && t == 0 && a.mailbox && !(a.tune & 8)) {
+    const unsigned long long tot = a.sc->total;
+    a.mailbox[0] = tot > 0xffffffffull ? 0xffffffffu : (unsigned)tot;
+  }
+
+  // Everything below up to the barrier depends only on the query, not on where its list goes: the
+  // loads (count, bucket records, node records, sphere table) are issued before the workgroup meets
+  // for the offsets, so the prefix over the preceding counts travels beside them.
+  // (No workgroup barrier on the way: a barrier waits for every outstanding load.  Each half wave
+  // resets its own LDS words; LDS operations of one wave execute in order.)
+  if (hl == 0) { sm.todo[hw] = 0; sm.empty[hw] = 0; sm.nl[hw] = 0; }
+  int kfull = 0;
+  if (qv) kfull = a.count[q];
+  const int kInt = 0x7fffffff;
+  BktRec e0, e1;
+  e0.idx = kInt; e0.pad = 0; e0.d2 = __builtin_inf();
+  e1 = e0;
+  // the first 32 slots of the bucket are requested before the count has arrived (bcap >= 8; slots past
+  // the count hold stale records and are masked below)
+  if (qv && hl < a.bcap) e0 = a.bkt[(size_t)q * (size_t)a.bcap + (size_t)hl];
+  double px = 0, py = 0, pz = 0;
+  if constexpr (EXT) {
+    if (qv) { px = a.q[(size_t)q * D + 0]; py = a.q[(size_t)q * D + 1]; pz = a.q[(size_t)q * D + 2]; }
+  }
+  long long psum = 0;
+  if (!a.prescattered && !(a.tune & 2)) {
+    // 16 b counts precede workgroup b
+    const int4 *c4 = reinterpret_cast<const int4 *>(a.count);
+    const int n4 = (int)blockIdx.x * (kFinQ / 4);
+#pragma unroll 4
+    for (int j = t; j < n4; j += kFinThreads) {
+      const int4 v = c4[j];
+      psum += (long long)v.x + v.y + v.z + v.w;
+    }
+  }
+  // a list the half wave cannot finish alone: longer than 64 entries, or overflowed its bucket
+  const bool small = kfull <= 64 && kfull <= a.bcap;
+  const int kk = (qv && small) ? kfull : 0;
+  if (!(hl < kk)) { e0.idx = kInt; e0.d2 = __builtin_inf(); }
+  if (hl + 32 < kk) e1 = a.bkt[(size_t)q * (size_t)a.bcap + (size_t)(hl + 32)];
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- sample pass (EXT): explicitPointCheck + the spheres the candidate edges can touch ----
+  if constexpr (EXT) {
+    bool bad = false;
+    if (x.m > 0) {
+      const double rb = x.r_bound >= 0.0 ? x.r_bound : 0.0;
+      const double pmax = fmax(fmax(fabs(px), fabs(py)), fabs(pz));
+      // slack for the rounding of the foot point and of this distance; NaN / inf sample: everything is a candidate
+      const double base_b = rb + 1e-12 * (pmax + 1.0);
+      const double mx = px - x.ox, my = py - x.oy, mz = pz - x.oz;
+      const bool usable = (pmax < 1e30) && (px == px) && (py == py) && (pz == pz) && (base_b < 1e30);
+      const double eps = 5.9604644775390625e-08;
+      const double h = (base_b * (1.0 + 1e-12) + 3.0 * eps * (fabs(mx) + fabs(my) + fabs(mz)) + 1e-30) * (1.0 + 8.0 * eps);
+      const float hf = usable ? __double2float_ru(h) : __builtin_inff();
+      const float mxf = usable ? (float)mx : 0.f, myf = usable ? (float)my : 0.f, mzf = usable ? (float)mz : 0.f;
+      const int n_pairs = (x.m + 1) / 2;
+      const float4 *tp = reinterpret_cast<const float4 *>(x.reach_f);
+      for (int pr0 = 0; pr0 < n_pairs; pr0 += 32) {
+        const int pr = pr0 + hl;
+        unsigned near = 0u;
+        if (qv && pr < n_pairs) {
+          const float4 u = tp[2 * pr], v = tp[2 * pr + 1];   // {cxA,cxB,cyA,cyB} {czA,czB,RA,RB}
+          const float dxa = u.x - mxf, dya = u.z - myf, dza = v.x - mzf;
+          const float dxb = u.y - mxf, dyb = u.w - myf, dzb = v.y - mzf;
+          float da = dxa * dxa; da = __builtin_fmaf(dya, dya, da); da = __builtin_fmaf(dza, dza, da);
+          float db = dxb * dxb; db = __builtin_fmaf(dyb, dyb, db); db = __builtin_fmaf(dzb, dzb, db);
+          const float ba = v.z + hf, bb = v.w + hf;
+          near = (!(da > ba * ba) ? 1u : 0u) | (!(db > bb * bb) ? 2u : 0u);
+        }
+        // the few spheres within reach: exact evaluation
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int j = 2 * pr + h2;
+          if (((near >> h2) & 1u) && j < x.m) {
+            const SampleSph sp = x.stab[j];
+            const double s = sq3(sp.cx, sp.cy, sp.cz, px, py, pz);
+            bad = bad | !(s >= sp.thr_in) | (s < sp.thr_pt);
+            const double B = base_b + sp.reach;
+            if (x.r_bound >= 0.0 && !(s > B * B * (1.0 + 1e-12))) {
+              const int at = atomicAdd(&sm.nl[hw], 1);
+              if (at < kSphListCap) sm.sl[hw][at] = j;
+            }
+          }
+        }
+      }
+    }
+    const unsigned long long bm = __ballot(bad);
+    const bool any_bad = ((bm >> (32 * (hw & 1))) & 0xffffffffull) != 0ull;
+    if (qv && hl == 0 && x.sample_unsafe) x.sample_unsafe[q] = any_bad ? 1 : 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // LDS list of this half wave: written above, read below
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- short lists: rank by node index inside the half wave ----
+  const int m0 = e0.idx, m1 = e1.idx;
+  const double d0 = e0.d2, d1 = e1.d2;
+  int r0 = 0, r1 = 0;
+  {
+    const int kmax = max(kk, __shfl_xor(kk, 32));      // the two halves of a wave run the same loops
+    for (int j = 0; j < min(kmax, 32); ++j) {
+      const int o = __shfl(m0, j, 32);
+      r0 += (o < m0) ? 1 : 0;
+      r1 += (o < m1) ? 1 : 0;
+    }
+    for (int j = 32; j < kmax; ++j) {
+      const int o = __shfl(m1, j - 32, 32);
+      r0 += (o < m0) ? 1 : 0;
+      r1 += (o < m1) ? 1 : 0;
+    }
+  }
+  double nbest = d0;
+  int nbest_i = m0;
+  if (a.nearest_idx) {
+    if ((d1 < nbest) || (d1 == nbest && m1 < nbest_i)) { nbest = d1; nbest_i = m1; }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(nbest, off);
+      const int oi = __shfl_xor(nbest_i, off);
+      if ((ob < nbest) || (ob == nbest && oi < nbest_i)) { nbest = ob; nbest_i = oi; }
+    }
+  }
+  bool ho0 = false, hi0 = false, ho1 = false, hi1 = false;
+  if constexpr (EXT) {
+    // both directed edges of the entries this lane holds
+    const int nl = sm.nl[hw];
+    if (__ballot(kk > 0) != 0ull) {
+      candidate_edge(x, hl < kk, px, py, pz, m0, nl, sm.sl[hw], ho0, hi0);
+      if (__ballot(hl + 32 < kk) != 0ull) candidate_edge(x, hl + 32 < kk, px, py, pz, m1, nl, sm.sl[hw], ho1, hi1);
+    }
+  }
+
+  // ---- offsets of this workgroup's queries ----
+  if (!a.prescattered) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) psum += __shfl_xor(psum, off);
+    if (lane == 0) sm.red[wave] = psum;
+  }
+  if (qv && hl == 0) {
+    sm.kfull[hw] = kfull;
+    if (!small) sm.todo[hw] = 1;
+  }
+  if (!qv && hl == 0) sm.kfull[hw] = 0;
+  __syncthreads();
+  if (t == 0) {
+    long long p = 0;
+    if (a.prescattered) {
+      p = a.offsets[q0];
+    } else {
+      for (int w = 0; w < kFinThreads / 64; ++w) p += sm.red[w];
+    }
+    for (int k = 0; k < kFinQ; ++k) { sm.off[k] = p; p += sm.kfull[k]; }
+    sm.off[kFinQ] = p;
+  }
+  __syncthreads();
+  if (!a.prescattered && t <= kFinQ) {
+    const int qq = q0 + t;
+    if (qq < a.nq) a.offsets[qq] = sm.off[t];
+    if (qq == a.nq) {
+      a.offsets[qq] = sm.off[t];
+      if (a.needed) *a.needed = sm.off[t];
+    }
+  }
+
+  // ---- results of the short lists at their sorted places (never past the caller's capacity) ----
+  {
+    const long long b = qv ? sm.off[hw] : 0;
+    const bool w0 = hl < kk && b + r0 < a.out_cap && !(a.tune & 16), w1 = hl + 32 < kk && b + r1 < a.out_cap && !(a.tune & 16);
+    if (w0) {
+      a.idx[b + r0] = m0;
+      a.dist[b + r0] = sqrt_rn(d0);
+      if (a.owner) a.owner[b + r0] = q;
+      if constexpr (EXT) { x.hit_out[b + r0] = ho0 ? 1 : 0; x.hit_in[b + r0] = hi0 ? 1 : 0; }
+    }
+    if (w1) {
+      a.idx[b + r1] = m1;
+      a.dist[b + r1] = sqrt_rn(d1);
+      if (a.owner) a.owner[b + r1] = q;
+      if constexpr (EXT) { x.hit_out[b + r1] = ho1 ? 1 : 0; x.hit_in[b + r1] = hi1 ? 1 : 0; }
+    }
+    if (a.nearest_idx && qv && small && hl == 0) {
+      if (kk > 0) { a.nearest_idx[q] = nbest_i; a.nearest_dist[q] = sqrt_rn(nbest); }
+      else if (a.want_nearest_fix) sm.empty[hw] = 1;
+      else { a.nearest_idx[q] = -1; a.nearest_dist[q] = __builtin_inf(); }
+    }
+  }
+  __syncthreads();
+
+  // ---- long or overflowed lists: the whole workgroup, one list at a time ----
+  for (int g = 0; g < kFinQ && !(a.tune & 4); ++g) {
+    if (!sm.todo[g]) continue;           // workgroup-uniform
+    const int qq = q0 + g;
+    const long long gb = sm.off[g];
+    const int gfull = sm.kfull[g];
+    long long ge = gb + gfull;
+    if (ge > a.out_cap) ge = a.out_cap;
+    const int gk = ge > gb ? (int)(ge - gb) : 0;
+    if (!a.prescattered && gfull > a.bcap) {
+      // gather this query's records from the shared overflow list behind its bucket part
+      if (t == 0) sm.gcnt = 0;
+      __syncthreads();
+      long long total = (long long)a.sc->total;
+      if (total > a.ovf_cap) total = a.ovf_cap;
+      for (long long i = t; i < total; i += kFinThreads) {
+        const HitRec r = a.ovf[i];
+        if (r.owner == qq) {
+          const long long dst = gb + a.bcap + atomicAdd(&sm.gcnt, 1);
+          if (dst < a.out_cap) {
+            unsigned long long *p = reinterpret_cast<unsigned long long *>(a.tmp + dst);
+            __hip_atomic_store(p, (unsigned long long)(unsigned)r.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p + 1, (unsigned long long)__double_as_longlong(r.d2), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    double best = __builtin_inf();
+    int best_i = 0x7fffffff;
+    double gx = 0, gy = 0, gz = 0;
+    int gnl = 0;
+    if constexpr (EXT) {
+      gx = a.q[(size_t)qq * D + 0]; gy = a.q[(size_t)qq * D + 1]; gz = a.q[(size_t)qq * D + 2];
+      gnl = sm.nl[g];
+    }
+    if (gk <= kBigSort) {
+      int n2 = 64;
+      while (n2 < gk) n2 <<= 1;
+      for (int i = t; i < n2; i += kFinThreads) {
+        BktRec r;
+        r.idx = 0x7fffffff; r.pad = 0; r.d2 = __builtin_inf();
+        if (i < gk) r = load_rec(a, qq, gb, i);
+        sm.s_idx[i] = r.idx;
+        sm.s_d2[i] = r.d2;
+      }
+      __syncthreads();
+      for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+          for (int i = t; i < n2; i += kFinThreads) {
+            const int j = i ^ stride;
+            if (j > i) {
+              const bool up = (i & size) == 0;
+              const int aa = sm.s_idx[i], cc = sm.s_idx[j];
+              if ((aa > cc) == up) {
+                sm.s_idx[i] = cc; sm.s_idx[j] = aa;
+                const double da = sm.s_d2[i];
+                sm.s_d2[i] = sm.s_d2[j]; sm.s_d2[j] = da;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      for (int i0 = 0; i0 < gk; i0 += kFinThreads) {
+        const int i = i0 + t;
+        const bool act = i < gk;
+        int my = 0;
+        double d2 = 0.0;
+        if (act) {
+          my = sm.s_idx[i];
+          d2 = sm.s_d2[i];
+          a.idx[gb + i] = my;
+          a.dist[gb + i] = sqrt_rn(d2);
+          if (a.owner) a.owner[gb + i] = qq;
+          if ((d2 < best) || (d2 == best && my < best_i)) { best = d2; best_i = my; }
+        }
+        if constexpr (EXT) {
+          bool ho, hi;
+          candidate_edge(x, act, gx, gy, gz, my, gnl, sm.sl[g], ho, hi);
+          if (act) { x.hit_out[gb + i] = ho ? 1 : 0; x.hit_in[gb + i] = hi ? 1 : 0; }
+        }
+      }
+    } else {
+      // longer than the LDS sort: rank counting over the unordered list
+      for (int i0 = 0; i0 < gk; i0 += kFinThreads) {
+        const int i = i0 + t;
+        const bool act = i < gk;
+        int my = 0, rank = 0;
+        double d2 = 0.0;
+        if (act) {
+          const BktRec r = load_rec(a, qq, gb, i);
+          my = r.idx; d2 = r.d2;
+          for (int j = 0; j < gk; ++j) rank += (load_rec(a, qq, gb, j).idx < my) ? 1 : 0;
+          a.idx[gb + rank] = my;
+          a.dist[gb + rank] = sqrt_rn(d2);
+          if (a.owner) a.owner[gb + rank] = qq;
+          if ((d2 < best) || (d2 == best && my < best_i)) { best = d2; best_i = my; }
+        }
+        if constexpr (EXT) {
+          bool ho, hi;
+          candidate_edge(x, act, gx, gy, gz, my, gnl, sm.sl[g], ho, hi);
+          if (act) { x.hit_out[gb + rank] = ho ? 1 : 0; x.hit_in[gb + rank] = hi ? 1 : 0; }
+        }
+      }
+    }
+    if (a.nearest_idx) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const int oi = __shfl_xor(best_i, off);
+        if ((ob < best) || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+      }
+      if (lane == 0) { sm.r_best[wave] = best; sm.r_besti[wave] = best_i; }
+      __syncthreads();
+      if (t == 0) {
+        for (int w = 1; w < kFinThreads / 64; ++w)
+          if ((sm.r_best[w] < best) || (sm.r_best[w] == best && sm.r_besti[w] < best_i)) {
+            best = sm.r_best[w]; best_i = sm.r_besti[w];
+          }
+        if (gk > 0) { a.nearest_idx[qq] = best_i; a.nearest_dist[qq] = sqrt_rn(best); }
+        else if (a.want_nearest_fix) sm.empty[g] = 1;       // list cut off by the caller's capacity
+        else { a.nearest_idx[qq] = -1; a.nearest_dist[qq] = __builtin_inf(); }
+      }
+    }
+    __syncthreads();   // LDS is reused by the next list
+  }
+
+  // ---- empty balls: kdFindNearest by expanding search (R/kdTree_general.jl:357-385) ----
+  if (a.nearest_idx && a.want_nearest_fix) {
+    for (int g = 0; g < kFinQ; ++g) {
+      if (!sm.empty[g]) continue;          // workgroup-uniform
+      const int qq = q0 + g;
+      const double ex = a.q[(size_t)qq * D + 0], ey = a.q[(size_t)qq * D + 1], ez = a.q[(size_t)qq * D + 2];
+      double ew = 0.0;
+      if constexpr (D == 4) ew = a.q[(size_t)qq * D + 3];
+      double bs;
+      int bi;
+      block_nearest<D, kFinThreads>(a.ni, ex, ey, ez, ew, a.r_start, sm.ns, bs, bi);
+      if (t == 0) { a.nearest_idx[qq] = bi; a.nearest_dist[qq] = sqrt_rn(bs); }
+    }
+  }
+}
+
+}  // namespace
+
+int launch_nn_finish(rrtx_ctx *ctx, const FinishLaunch &f) {
+  const int D = ctx->dim;
+  FinishArgs a;
+  a.count = f.count; a.nq = f.nq; a.bcap = f.bcap;
+  a.bkt = reinterpret_cast<const BktRec *>(f.bkt);
+  a.tmp = reinterpret_cast<BktRec *>(f.tmp);
+  a.ovf = reinterpret_cast<const HitRec *>(f.ovf);
+  a.ovf_cap = f.ovf_cap;
+  a.sc = reinterpret_cast<const Scalars *>(f.scalars);
+  a.prescattered = f.prescattered ? 1 : 0;
+  a.offsets = f.offsets; a.needed = f.needed;
+  a.idx = f.idx; a.dist = f.dist; a.out_cap = f.out_cap;
+  a.owner = f.owner; a.nearest_idx = f.nearest_idx; a.nearest_dist = f.nearest_dist;
+  a.qhist = f.qhist; a.n_qhist = f.n_qhist;
+  a.mailbox = f.mailbox;
+  a.q = f.q;
+  a.r_start = f.r_start;
+  // empty balls are resolved on the device only where the nearest comes off the lists at all
+  // (no wrapped dimensions: with ghosts a list key is not the distance to the query itself)
+  a.want_nearest_fix = (f.nearest_idx && ctx->n_wraps == 0) ? 1 : 0;
+  a.tune = ctx->opt_tune;
+  a.ni.sx = ctx->sl_d[0]; a.ni.sy = ctx->sl_d[1]; a.ni.sz = ctx->sl_d[2]; a.ni.sw = ctx->sl_d[D == 4 ? 3 : 2];
+  a.ni.sid = ctx->sl_id;
+  a.ni.chunk_ext = reinterpret_cast<const ChunkExt *>(ctx->chunk_ext);
+  a.ni.n_nodes = (int)ctx->n_nodes;
+  a.ni.n_chunks = (int)((ctx->n_nodes + kSlabChunk - 1) / kSlabChunk);
+  ExtendArgs x;
+  std::memset(&x, 0, sizeof(x));
+  x.r_bound = -1.0;
+  const bool ext = f.ext != nullptr;
+  if (ext) {
+    if (D != 3) return fail(ctx, RRTX_E_STATE, "fused extend finish is the SimpleEdge (dim=3) path");
+    x.naos = reinterpret_cast<const double4 *>(ctx->nodes_aos);
+    x.sph = ctx->d_sph.as<SphRec>();
+    x.stab = ctx->d_sph_sample.as<SampleSph>();
+    x.reach_f = ctx->d_sph_reach_f.as<float>();
+    x.ox = ctx->origin[0]; x.oy = ctx->origin[1]; x.oz = ctx->origin[2];
+    x.m = ctx->sph_n_active;
+    x.n_nodes = (int)ctx->n_nodes;
+    x.r_bound = (f.ext->r >= 0.0 && x.m > 0) ? f.ext->r * (1.0 + 1e-12) : -1.0;
+    x.hit_out = f.ext->hit_out; x.hit_in = f.ext->hit_in; x.sample_unsafe = f.ext->sample_unsafe;
+  }
+  const dim3 grid((unsigned)((f.nq + kFinQ - 1) / kFinQ)), block(kFinThreads);
+  if (ext) {
+    if (ctx->opt_tune & 1) hipLaunchKernelGGL((nn_finish_kernel<3, true, 6>), grid, block, 0, ctx->stream, a, x);
+    else hipLaunchKernelGGL((nn_finish_kernel<3, true, 4>), grid, block, 0, ctx->stream, a, x);
+  } else if (D == 4) hipLaunchKernelGGL((nn_finish_kernel<4, false, 4>), grid, block, 0, ctx->stream, a, x);
+  else hipLaunchKernelGGL((nn_finish_kernel<3, false, 4>), grid, block, 0, ctx->stream, a, x);
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+}  // namespace rrtx

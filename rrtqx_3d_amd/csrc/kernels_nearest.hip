@@ -110,7 +110,8 @@ __device__ __forceinline__ void drain_nearest(const int2 *cand, int &wn, const d
                                               const typename QRecT<D>::type *__restrict__ copies,
                                               const int2 *__restrict__ meta, HitRec *__restrict__ recs,
                                               long long cap, Scalars *__restrict__ sc,
-                                              unsigned long long *__restrict__ best_bits) {
+                                              unsigned long long *__restrict__ best_bits,
+                                              int *__restrict__ redo) {
   const int lane = threadIdx.x & 63;
   __builtin_amdgcn_wave_barrier();
   for (int i0 = 0; i0 < wn; i0 += 64) {
@@ -138,6 +139,8 @@ __device__ __forceinline__ void drain_nearest(const int2 *cand, int &wn, const d
         HitRec r;
         r.owner = owner; r.idx = id; r.d2 = s;
         recs[pos] = r;
+      } else {
+        redo[owner] = 1;      // record dropped: this query is answered by nn_nearest_fixup_kernel
       }
     }
   }
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) void nn_nearest_f32_kernel(
     const typename QRecT<D>::type *__restrict__ copies, const typename QRecFT<D>::type *__restrict__ copies_f,
     const int2 *__restrict__ meta, const unsigned long long *__restrict__ node_absmax, int n_seg, int seg_len,
     HitRec *__restrict__ recs, long long cap, Scalars *__restrict__ sc,
-    unsigned long long *__restrict__ best_bits) {
+    unsigned long long *__restrict__ best_bits, int *__restrict__ redo) {
   __shared__ int2 cand_all[4][kCandCap];
   const int seg = blockIdx.x % n_seg;        // XCD-affine node segment
   const int cb = blockIdx.x / n_seg;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void nn_nearest_f32_kernel(
         const unsigned long long m = __ballot(valid && !(t[u] > bound));
         if (m == 0ull) continue;
         const int n = __popcll(m);
-        if (wn + n > kCandCap) drain_nearest<D>(cand, wn, nx, ny, nz, nw, copies, meta, recs, cap, sc, best_bits);
+        if (wn + n > kCandCap) drain_nearest<D>(cand, wn, nx, ny, nz, nw, copies, meta, recs, cap, sc, best_bits, redo);
         if ((m >> lane) & 1ull) cand[wn + __popcll(m & lt_mask)] = make_int2(copy, j + u);
         wn += n;
       }
@@ -240,11 +243,11 @@ __global__ __launch_bounds__(256) void nn_nearest_f32_kernel(
     const unsigned long long m = __ballot(valid);
     if (m == 0ull) break;
     const int n = __popcll(m);
-    if (wn + n > kCandCap) drain_nearest<D>(cand, wn, nx, ny, nz, nw, copies, meta, recs, cap, sc, best_bits);
+    if (wn + n > kCandCap) drain_nearest<D>(cand, wn, nx, ny, nz, nw, copies, meta, recs, cap, sc, best_bits, redo);
     if (valid) cand[wn + __popcll(m & lt_mask)] = make_int2(copy, j);
     wn += n;
   }
-  drain_nearest<D>(cand, wn, nx, ny, nz, nw, copies, meta, recs, cap, sc, best_bits);
+  drain_nearest<D>(cand, wn, nx, ny, nz, nw, copies, meta, recs, cap, sc, best_bits, redo);
 }
 
 // lowest node index among the confirmed candidates that attain the minimum d2
@@ -269,6 +272,49 @@ __global__ void nn_nearest_out_kernel(const unsigned long long *__restrict__ bes
   const unsigned long long b = best_bits[i];
   idx[i] = (b == ~0ull) ? 0x7fffffff : best_idx[i];     // no candidate (NaN query): same as the exact scan
   dist[i] = (b == ~0ull) ? __builtin_inf() : sqrt_rn(__longlong_as_double((long long)b));
+}
+
+// The screened scan keeps about ln(n) candidates per query and segment; an adversarial visiting order
+// (nodes sorted by decreasing distance) can produce more than the record buffer holds.  Queries that
+// lost a record are answered again here, exactly and on the device (no host round trip, so the
+// device-pointer entry points cannot come back wrong): one workgroup per such query, expanding
+// search over the slab index for the query and each of its ghosts (the same 2^w copies the exact
+// scan walks), lexicographic minimum of (d2, index).
+constexpr int kFixThreads = 512;
+template <int D>
+__global__ __launch_bounds__(kFixThreads) void nn_nearest_fixup_kernel(
+    const Scalars *__restrict__ sc, long long cap, const int *__restrict__ redo, const double *__restrict__ q, int nq,
+    int n_wraps, int wd0, int wd1, int wd2, double wp0, double wp1, double wp2, NearestIndex ni,
+    int32_t *__restrict__ idx, double *__restrict__ dist) {
+  __shared__ NearestScratch ns;
+  if ((long long)sc->total <= cap) return;           // nothing was dropped (the normal case)
+  const int wd[3] = {wd0, wd1, wd2};
+  const double wp[3] = {wp0, wp1, wp2};
+  for (int i = blockIdx.x; i < nq; i += gridDim.x) {
+    if (!redo[i]) continue;
+    double p[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < D; ++k) p[k] = q[(size_t)i * D + k];
+    double best = __builtin_inf();
+    int best_i = 0x7fffffff;
+    const int n_slots = 1 << n_wraps;
+    for (int k = 0; k < n_slots; ++k) {
+      double g[4] = {p[0], p[1], p[2], p[3]};
+      for (int w = 0; w < n_wraps; ++w) {
+        if (!((k >> (n_wraps - 1 - w)) & 1)) continue;
+        const int dimi = wd[w];
+        g[dimi] = (p[dimi] < wp[w] / 2.0) ? (p[dimi] + wp[w]) : (p[dimi] - wp[w]);
+      }
+      double bs;
+      int bi;
+      block_nearest<D, kFixThreads>(ni, g[0], g[1], g[2], g[3], 1.0, ns, bs, bi);
+      if ((bs < best) || (bs == best && bi < best_i)) { best = bs; best_i = bi; }
+    }
+    if (threadIdx.x == 0) {
+      idx[i] = best_i;
+      dist[i] = sqrt_rn(best);
+    }
+  }
 }
 
 }  // namespace
@@ -305,9 +351,8 @@ static int launch_nn_nearest_exact(rrtx_ctx *ctx, const double *q_dev, int nq, i
   return RRTX_OK;
 }
 
-// Screened nearest (see nn_nearest_f32_kernel).  *overflow_cap receives the record capacity used;
-// the caller compares it with Scalars.total (rrtx_capi.hip) and falls back to the exact scan when
-// an adversarial visiting order produced more candidates than fit.
+// Screened nearest (see nn_nearest_f32_kernel); queries whose candidates did not fit the record buffer
+// are answered by nn_nearest_fixup_kernel on the device.
 static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev,
                                       double *dist_dev) {
   const int D = ctx->dim;
@@ -317,19 +362,20 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
   const size_t n_copies_max = (size_t)nq * n_slots;
   const size_t qrec_bytes = (D == 4) ? sizeof(QRec4) : sizeof(QRec3);
   const size_t qf_bytes = (D == 4) ? sizeof(QRecF4) : sizeof(QRecF3);
-  const long long rec_cap = (long long)n_copies_max * 1024 + 4096;
+  const long long rec_cap = ctx->opt_nearest_rec_cap > 0 ? ctx->opt_nearest_rec_cap : (long long)n_copies_max * 1024 + 4096;
   RRTX_HIP(ctx, ctx->ws_slots.ensure(n_copies_max * sizeof(SlotRec)));
   RRTX_HIP(ctx, ctx->ws_copies.ensure(n_copies_max * qrec_bytes));
   RRTX_HIP(ctx, ctx->ws_copies_f.ensure((n_copies_max + kQPI) * qf_bytes));
   RRTX_HIP(ctx, ctx->ws_copy_meta.ensure(n_copies_max * sizeof(int2)));
   RRTX_HIP(ctx, ctx->ws_scalars_nn.ensure(sizeof(Scalars)));
   RRTX_HIP(ctx, ctx->ws_recs.ensure((size_t)rec_cap * sizeof(HitRec)));
-  RRTX_HIP(ctx, ctx->ws_partial.ensure((size_t)nq * (sizeof(unsigned long long) + sizeof(int))));
+  RRTX_HIP(ctx, ctx->ws_partial.ensure((size_t)nq * (sizeof(unsigned long long) + 2 * sizeof(int))));
   unsigned long long *best_bits = ctx->ws_partial.as<unsigned long long>();
   int *best_idx = reinterpret_cast<int *>(best_bits + nq);
+  int *redo = best_idx + nq;              // queries that lost a candidate record
   Scalars *sc = ctx->ws_scalars_nn.as<Scalars>();
   hipLaunchKernelGGL(nn_init_kernel, dim3((nq + 255) / 256 < 64 ? (nq + 255) / 256 : 64), dim3(256), 0, st, sc,
-                     (ctx->n_wraps == 0) ? nq : 0, (int *)nullptr, 0, best_bits, nq, ~0ull, best_idx, nq, 0x7fffffff,
+                     (ctx->n_wraps == 0) ? nq : 0, redo, nq, best_bits, nq, ~0ull, best_idx, nq, 0x7fffffff,
                      (ConfirmArgs *)nullptr, ConfirmArgs{});
   const double inf = std::numeric_limits<double>::infinity();
   const double nan = std::numeric_limits<double>::quiet_NaN();
@@ -364,7 +410,7 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
                          ctx->nodes[3], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[3],
                          ctx->nodes_pp, n_nodes, ctx->ws_copies.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(),
                          ctx->ws_copy_meta.as<int2>(), ctx->d_absmax.as<unsigned long long>(), n_seg, seg_len,
-                         ctx->ws_recs.as<HitRec>(), rec_cap, sc, best_bits);
+                         ctx->ws_recs.as<HitRec>(), rec_cap, sc, best_bits, redo);
     } else {
       hipLaunchKernelGGL(nn_pack_kernel<3>, grid, block, 0, st, q_dev, nq, (const double *)nullptr,
                          (const double *)nullptr, inf, nan, ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1],
@@ -380,14 +426,29 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
                          ctx->nodes[2], ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[2],
                          ctx->nodes_pp, n_nodes, ctx->ws_copies.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(),
                          ctx->ws_copy_meta.as<int2>(), ctx->d_absmax.as<unsigned long long>(), n_seg, seg_len,
-                         ctx->ws_recs.as<HitRec>(), rec_cap, sc, best_bits);
+                         ctx->ws_recs.as<HitRec>(), rec_cap, sc, best_bits, redo);
     }
     hipLaunchKernelGGL(nn_nearest_tie_kernel, dim3(1024), dim3(256), 0, st, ctx->ws_recs.as<HitRec>(), rec_cap, sc,
                        best_bits, best_idx);
     hipLaunchKernelGGL(nn_nearest_out_kernel, grid, block, 0, st, best_bits, best_idx, nq, idx_dev, dist_dev);
+    // queries that lost a candidate record (sc->total > rec_cap): answered again, exactly
+    NearestIndex ni;
+    ni.sx = ctx->sl_d[0]; ni.sy = ctx->sl_d[1]; ni.sz = ctx->sl_d[2]; ni.sw = ctx->sl_d[D == 4 ? 3 : 2];
+    ni.sid = ctx->sl_id;
+    ni.chunk_ext = reinterpret_cast<const ChunkExt *>(ctx->chunk_ext);
+    ni.n_nodes = n_nodes;
+    ni.n_chunks = (n_nodes + kSlabChunk - 1) / kSlabChunk;
+    const dim3 fgrid((unsigned)(nq < 2048 ? nq : 2048));
+    if (D == 4)
+      hipLaunchKernelGGL(nn_nearest_fixup_kernel<4>, fgrid, dim3(kFixThreads), 0, st, sc, rec_cap, redo, q_dev, nq,
+                         ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1], ctx->wrap_dim[2], ctx->wrap_period[0],
+                         ctx->wrap_period[1], ctx->wrap_period[2], ni, idx_dev, dist_dev);
+    else
+      hipLaunchKernelGGL(nn_nearest_fixup_kernel<3>, fgrid, dim3(kFixThreads), 0, st, sc, rec_cap, redo, q_dev, nq,
+                         ctx->n_wraps, ctx->wrap_dim[0], ctx->wrap_dim[1], ctx->wrap_dim[2], ctx->wrap_period[0],
+                         ctx->wrap_period[1], ctx->wrap_period[2], ni, idx_dev, dist_dev);
   }
   span_end(ctx);
-  ctx->last_nearest_cap = rec_cap;
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
 }
@@ -730,19 +791,8 @@ int launch_nn_knearest(rrtx_ctx *ctx, const double *q_dev, int nq, int k, int32_
 int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev, bool exact) {
   if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "nearest search on an empty tree");
   if (nq <= 0) return RRTX_OK;
-  ctx->last_nearest_cap = 0;
   if (exact || !ctx->opt_nn_filter) return launch_nn_nearest_exact(ctx, q_dev, nq, idx_dev, dist_dev);
   return launch_nn_nearest_screened(ctx, q_dev, nq, idx_dev, dist_dev);
-}
-
-// number of candidate records the last screened nearest call produced (device scalar)
-int nearest_candidates(rrtx_ctx *ctx, long long *total) {
-  unsigned long long t = 0;
-  RRTX_HIP(ctx, hipMemcpyAsync(&t, &ctx->ws_scalars_nn.as<Scalars>()->total, sizeof(t), hipMemcpyDeviceToHost,
-                               ctx->stream));
-  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  *total = (long long)t;
-  return RRTX_OK;
 }
 
 int launch_nearest_from_lists(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,

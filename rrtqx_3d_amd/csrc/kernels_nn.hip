@@ -153,14 +153,20 @@ constexpr int kEvSlack = 2048;
 // LM (lane-major chunk layout, slab-ordered shadow): the eight nodes sit at p0 + u, eight
 // consecutive doubles per coordinate array; otherwise at p0 + 64 u.
 template <int D, bool LM, class Emit>
-__device__ __forceinline__ void confirm_entry(bool has, int2 en, int n_nodes, const ConfirmArgs &a, const Emit &emit) {
+__device__ __forceinline__ void confirm_entry(bool has, int2 en, int n_nodes, const ConfirmArgs &a, const Emit &emit,
+                                              const typename QRecT<D>::type *tile_copies = nullptr, int tile_q0 = 0) {
   const typename QRecT<D>::type *__restrict__ copies = static_cast<const typename QRecT<D>::type *>(a.copies);
   typename QRecT<D>::type ce;
   ce.x = 0.0; ce.y = 0.0; ce.z = 0.0; ce.thr = 0.0;
   if constexpr (D == 4) ce.w = 0.0;
   int2 m = make_int2(0, 0);
   const int p0 = has ? en.y : 0;
-  if (has) { ce = copies[en.x]; m = a.meta[en.x]; }
+  if (has) {
+    // the tile kernel keeps its 16 copies in LDS: one dependent global load less per entry
+    ce = tile_copies ? tile_copies[en.x - tile_q0] : copies[en.x];
+    // (owner, slot): the slot matters only with ghosts; emitters that want the owner for every hit say so
+    if (Emit::kNeedsOwner || a.n_slots > 1) m = a.meta[en.x];
+  }
   double ex[kScanFU], ey[kScanFU], ez[kScanFU], ew[kScanFU];
   if constexpr (LM) {
     // node arrays are allocated in whole chunks: the 64-byte rows are always readable
@@ -382,52 +388,78 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
 // ---------------------------------------------------------- tile kernel ------
 // Culled range search, one workgroup per (tile of kTileB bucket-ordered copies, part):
 //   1. the tile's reach in x and in y: every copy's coordinate -+ its search radius, rounded outwards;
-//   2. the node chunks whose exact x and y extents both overlap the reach (a chunk outside it
-//      holds no node within range of any copy of the tile: |x_q - x_n| > R, or the same in y,
-//      implies that square alone is >= thr after rounding, and the other squares only add,
-//      exact_math.hpp sq3); part p of a tile takes chunks c = p mod n_parts;
+//   2. the node chunks that can hold a neighbour.  The sorted part of the slab index is ordered by
+//      (x, y) grid cell, rows of cells running alternately left and right, so the cells within reach
+//      are ONE contiguous run of positions per row of cells: wave 0 reads two entries of the cell-start
+//      table per row and lists the chunks those runs touch (no pass over all chunk extents, no
+//      compaction; a row that continues in the chunk the previous one ended in does not list it
+//      twice).  Chunks of the appended tail are few and are tested by extent.  A listed chunk is
+//      still skipped when its own exact x / y extent misses the reach (a chunk outside it holds no
+//      node within range of any copy of the tile: |x_q - x_n| > R, or the same in y, implies that
+//      square alone is >= thr after rounding, and the other squares only add, exact_math.hpp sq3);
+//      part p of a tile takes chunks c = p mod n_parts;
 //   3. the screen of those chunks, one chunk per wave at a time (scan_chunk_f32), entries into the
 //      waves' slices;
 //   4. exact confirmation of the workgroup's entries, hits collected per copy in LDS;
-//   5. one counter update per copy, then the copy's hits go to its query's bucket in one piece.
+//   5. one counter update per copy, then the copy's hits go to its query's bucket in one piece
+//      (16-byte records, consecutive slots).
 constexpr int kTileB = 16;            // copies per tile
 constexpr int kTbLcap = 96;           // hits per copy collected in LDS (more: straight to the bucket)
 constexpr int kTbList = 1024;         // chunk ids per pass of step 2
 constexpr int kTbSlack = 512;
 
+template <int D>
 struct TileLds {
   int list[kTbList];
   int n_list;
   int wcnt[kScanThreads / 64];
   double lo, hi, ylo, yhi;
   int lcnt[kTileB];
-  int hidx[kTileB][kTbLcap];
-  double hd2[kTileB][kTbLcap];
+  typename QRecT<D>::type cp[kTileB];
+  BktRec hrec[kTileB][kTbLcap];
 };
 
+// the (x, y) cell structure of the sorted part of the slab index
+struct TileGrid {
+  const SlabParams *sp;
+  const int *cell_start;       // [Kx * Ky + 1]
+  int n_sorted_chunks;         // chunks [0, n_sorted_chunks) hold sorted positions only
+};
+
+template <int D>
 struct TileEmit {
-  TileLds &sm;
+  static constexpr bool kNeedsOwner = false;
+  TileLds<D> &sm;
   const HitSink &hs;
+  const int2 *meta;
   int q0;
-  __device__ __forceinline__ void operator()(bool h, int q, int owner, int id, double d2) const {
+  __device__ __forceinline__ void operator()(bool h, int q, int /*owner*/, int id, double d2) const {
     int slot = 0;
     const int cl = q - q0;
     if (h) slot = atomicAdd(&sm.lcnt[cl], 1);
     const bool in_lds = h && slot < kTbLcap;
-    if (in_lds) { sm.hidx[cl][slot] = id; sm.hd2[cl][slot] = d2; }
+    if (in_lds) {
+      BktRec br;
+      br.idx = id; br.pad = 0; br.d2 = d2;
+      sm.hrec[cl][slot] = br;
+    }
     const bool spill = h && !in_lds;
-    if (__ballot(spill) != 0ull) emit_hits_grouped(hs, spill, owner, id, d2);   // at most kTileB queries per wave
+    if (__ballot(spill) != 0ull) {
+      int owner = 0;
+      if (spill) owner = meta[q].x;
+      emit_hits_grouped(hs, spill, owner, id, d2);   // at most kTileB queries per wave
+    }
   }
 };
 
 template <int D>
-__global__ __launch_bounds__(kScanThreads, 5) void nn_tile_kernel(
+__global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
     const float *__restrict__ fx, const float *__restrict__ fy, const float *__restrict__ fz,
     const float *__restrict__ fw, const float *__restrict__ fpp, int n_nodes, int n_chunks,
     const ChunkExt *__restrict__ chunk_ext, const typename QRecT<D>::type *__restrict__ copies_s, const typename QRecFT<D>::type *__restrict__ copies_f,
     const Scalars *__restrict__ sc, int n_parts, int2 *__restrict__ ev, int slice_cap,
-    const ConfirmArgs *__restrict__ ca, int *__restrict__ visits) {
-  __shared__ TileLds sm;
+    const ConfirmArgs a, const ConfirmArgs *__restrict__ ca, const TileGrid tg, int *__restrict__ visits) {
+  __shared__ TileLds<D> sm;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int part = blockIdx.x % n_parts;
@@ -455,13 +487,14 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_tile_kernel(
       double lo = __builtin_inf(), hi = -__builtin_inf(), ylo = __builtin_inf(), yhi = -__builtin_inf();
       if (q0 + lane < q1) {
         const typename QRecT<D>::type c = copies_s[q0 + lane];
+        sm.cp[lane] = c;
         // thr NaN / <= 0, x or y NaN or +-inf: the copy can never have a neighbour
         const bool can_hit = (c.thr > 0.0) && (c.x - c.x == 0.0) && (c.y - c.y == 0.0);
         if (can_hit) {
           const double R = sqrt_rn(c.thr) * (1.0 + 1e-15);         // thr = +inf -> R = +inf
-          const double a = c.x - R, b = c.x + R, ya = c.y - R, yb = c.y + R;
-          lo = a - (fabs(a) * 4.5e-16 + 1e-300);
-          hi = b + (fabs(b) * 4.5e-16 + 1e-300);
+          const double xa = c.x - R, xb = c.x + R, ya = c.y - R, yb = c.y + R;
+          lo = xa - (fabs(xa) * 4.5e-16 + 1e-300);
+          hi = xb + (fabs(xb) * 4.5e-16 + 1e-300);
           ylo = ya - (fabs(ya) * 4.5e-16 + 1e-300);
           yhi = yb + (fabs(yb) * 4.5e-16 + 1e-300);
         }
@@ -473,34 +506,79 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_tile_kernel(
         ylo = fmin(ylo, __shfl_xor(ylo, off));
         yhi = fmax(yhi, __shfl_xor(yhi, off));
       }
-      if (lane == 0) { sm.lo = lo; sm.hi = hi; sm.ylo = ylo; sm.yhi = yhi; }
+      if (lane == 0) { sm.lo = lo; sm.hi = hi; sm.ylo = ylo; sm.yhi = yhi; sm.n_list = 0; }
     }
     __syncthreads();
     const double lo = sm.lo, hi = sm.hi, ylo = sm.ylo, yhi = sm.yhi;
     if (lo <= hi) {
       for (int cb = 0; cb < n_chunks; cb += kTbList) {
-        // ---- 2. chunk list of this pass ----
-        if (t == 0) sm.n_list = 0;
-        __syncthreads();
+        // ---- 2. chunk list of this pass: chunk ids in [cb, ce) ----
         const int ce = min(cb + kTbList, n_chunks);
-        // (the order inside the list is whatever the atomics give, so the parts of a tile
-        // split the chunks by chunk number, not by list position)
-        for (int c = cb + t; c < ce; c += kScanThreads)
-          if (c % n_parts == part) {
-            const ChunkExt ce = chunk_ext[c];
-            if (dec_ord(ce.xhi) >= lo && dec_ord(ce.xlo) <= hi && dec_ord(ce.yhi) >= ylo && dec_ord(ce.ylo) <= yhi)
+        if (wave == 0) {
+          const int w_end = min(ce, tg.n_sorted_chunks);
+          if (cb < w_end) {
+            const SlabParams sp = *tg.sp;
+            const int cx0 = slab_of(lo, sp.x0, sp.inv_wx, sp.Kx), cx1 = slab_of(hi, sp.x0, sp.inv_wx, sp.Kx);
+            const int cy0 = slab_of(ylo, sp.y0, sp.inv_wy, sp.Ky), cy1 = slab_of(yhi, sp.y0, sp.inv_wy, sp.Ky);
+            int listed_to = cb - 1;                        // wave-uniform: highest chunk id listed so far
+            for (int r0 = cy0; r0 <= cy1; r0 += 64) {
+              const int cy = r0 + lane;
+              int ca_ = 0, cb_ = -1;                       // this row's chunk range (empty)
+              if (cy <= cy1) {
+                const int base = cy * sp.Kx;
+                const int c_first = base + ((cy & 1) ? (sp.Kx - 1 - cx1) : cx0);
+                const int c_last = base + ((cy & 1) ? (sp.Kx - 1 - cx0) : cx1);
+                const int p0 = tg.cell_start[c_first], p1 = tg.cell_start[c_last + 1];
+                if (p1 > p0) { ca_ = max(p0 / kChunkF, cb); cb_ = min((p1 - 1) / kChunkF, w_end - 1); }
+              }
+              // rows come in increasing position order: a row starts no earlier than where the rows
+              // before it (in this wave instruction and in earlier ones) have already listed
+              int run = cb_;
+#pragma unroll
+              for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(run, off);
+                if (lane >= off) run = max(run, o);
+              }
+              int before = __shfl_up(run, 1);
+              if (lane == 0) before = listed_to;
+              before = max(before, listed_to);
+              ca_ = max(ca_, before + 1);
+              const int cnt = cb_ - ca_ + 1;
+              if (cnt > 0) {
+                const int at = atomicAdd(&sm.n_list, cnt);
+                for (int j = 0; j < cnt; ++j) sm.list[at + j] = ca_ + j;
+              }
+              listed_to = max(listed_to, __shfl(run, 63));
+            }
+          }
+        } else {
+          // appended since the last rebuild (and the chunk the sorted part ends in): by extent
+          for (int c = max(cb, tg.n_sorted_chunks) + (t - 64); c < ce; c += kScanThreads - 64) {
+            const ChunkExt cx = chunk_ext[c];
+            if (dec_ord(cx.xhi) >= lo && dec_ord(cx.xlo) <= hi && dec_ord(cx.yhi) >= ylo && dec_ord(cx.ylo) <= yhi)
               sm.list[atomicAdd(&sm.n_list, 1)] = c;
           }
+        }
         __syncthreads();
         const int nl = sm.n_list;
         // ---- 3. screen ----
         for (int i = wave; i < nl; i += kScanThreads / 64) {
           const int chunk = __builtin_amdgcn_readfirstlane(sm.list[i]);
+          if (n_parts > 1 && chunk % n_parts != part) continue;
+          {
+            const ChunkExt cx = chunk_ext[chunk];          // wave-uniform
+            if (!(dec_ord(cx.xhi) >= lo && dec_ord(cx.xlo) <= hi && dec_ord(cx.yhi) >= ylo && dec_ord(cx.ylo) <= yhi))
+              continue;
+          }
           if (wn + 64 * kTileB > slice_cap) drain_slice<D, true>(mine, wn, n_nodes, ca);
           scan_chunk_f32<D, true>(fx, fy, fz, fw, fpp, chunk * kChunkF, n_nodes, copies_f, q0, q1, mine, wn);
           visited += 1;
         }
-        __syncthreads();      // the list is rebuilt by the next pass
+        if (ce < n_chunks) {  // (trees beyond kTbList chunks) the list is rebuilt by the next pass
+          __syncthreads();
+          if (t == 0) sm.n_list = 0;
+          __syncthreads();
+        }
       }
     }
     // ---- 4. confirm the workgroup's entries ----
@@ -509,8 +587,7 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_tile_kernel(
     // not keep written lines): a workgroup-scope fence orders them before the barrier
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
-    const ConfirmArgs a = *ca;
-    const TileEmit emit{sm, a.hs, q0};
+    const TileEmit<D> emit{sm, a.hs, a.meta, q0};
     const int c0 = sm.wcnt[0], c1 = c0 + sm.wcnt[1], c2 = c1 + sm.wcnt[2], total = c2 + sm.wcnt[3];
     for (int e0 = 0; e0 < total; e0 += kScanThreads) {
       const int e = e0 + t;
@@ -521,7 +598,7 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_tile_kernel(
         const int local = e - (w == 0 ? 0 : (w == 1 ? c0 : (w == 2 ? c1 : c2)));
         en = blk[(size_t)w * (size_t)slice_cap + local];
       }
-      if (__ballot(has) != 0ull) confirm_entry<D, true>(has, en, n_nodes, a, emit);
+      if (__ballot(has) != 0ull) confirm_entry<D, true>(has, en, n_nodes, a, emit, sm.cp, q0);
     }
     __syncthreads();
     // ---- 5. hand the collected hits to the buckets ----
@@ -535,7 +612,10 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_tile_kernel(
       for (int j0 = 0; j0 < n; j0 += 64) {
         const int j = j0 + lane;
         const bool h = j < n;
-        place_hit(a.hs, h, owner, base + j, h ? sm.hidx[cl][j] : 0, h ? sm.hd2[cl][j] : 0.0);
+        BktRec br;
+        br.idx = 0; br.pad = 0; br.d2 = 0.0;
+        if (h) br = sm.hrec[cl][j];
+        place_hit(a.hs, h, owner, base + j, br.idx, br.d2);
       }
     }
     __syncthreads();          // LDS is reused by the next tile
@@ -610,11 +690,13 @@ __global__ __launch_bounds__(256) void nn_offsets_kernel(const int *__restrict__
 
 // ------------------------------------------------------------- scatter ------
 // Entry j of query q's list lives in its bucket for j < bcap and at tmp[offsets[q] + j]
-// otherwise; this kernel moves the overflow list (normally empty) to those places.
+// otherwise; this kernel moves the overflow list to those places.  Only launched (with
+// nn_offsets_kernel in front) after a call whose lists outgrew their buckets by much; normally
+// the finish kernel computes the offsets itself and lets an overflowed query collect its own
+// records (kernels_finish.hip).
 __global__ void nn_scatter_kernel(const HitRec *__restrict__ recs, long long cap,
                                   const Scalars *__restrict__ sc, const int64_t *__restrict__ offsets,
-                                  int *__restrict__ cursor, int bcap, int32_t *__restrict__ tmp_idx,
-                                  double *__restrict__ tmp_d2, long long out_cap) {
+                                  int *__restrict__ cursor, int bcap, BktRec *__restrict__ tmp, long long out_cap) {
   long long total = (long long)sc->total;
   if (total > cap) total = cap;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -622,185 +704,10 @@ __global__ void nn_scatter_kernel(const HitRec *__restrict__ recs, long long cap
     HitRec r = recs[i];
     long long dst = offsets[r.owner] + bcap + atomicAdd(&cursor[r.owner], 1);
     if (dst < out_cap) {
-      tmp_idx[dst] = r.idx;
-      tmp_d2[dst] = r.d2;
+      BktRec br;
+      br.idx = r.idx; br.pad = 0; br.d2 = r.d2;
+      tmp[dst] = br;
     }
-  }
-}
-
-// entry j of the (unordered) list of query q, see nn_scatter_kernel
-struct ListSrc {
-  const int32_t *bidx;
-  const double *bd2;
-  int bcap;
-  int pad;
-  const int32_t *tmp_idx;
-  const double *tmp_d2;
-  __device__ __forceinline__ int idx(int q, long long b, long long j) const {
-    return (j < bcap) ? bidx[(size_t)q * (size_t)bcap + (size_t)j] : tmp_idx[b + j];
-  }
-  __device__ __forceinline__ double d2(int q, long long b, long long j) const {
-    return (j < bcap) ? bd2[(size_t)q * (size_t)bcap + (size_t)j] : tmp_d2[b + j];
-  }
-};
-
-// --------------------------------------------------------------- order ------
-// Half a wave per query (lists of up to 64 entries, two per lane): rank each hit by node index,
-// write idx ascending and dist = sqrt(d2) (the key the reference stores,
-// R/kdTree_general.jl:829-831).  Optionally also: owner[e] = query of CSR entry e, and the
-// nearest node of the list (lexicographic minimum of (d2, idx); -1 when the list is empty).
-__global__ __launch_bounds__(256) void nn_order_kernel(const int64_t *__restrict__ offsets, int nq, ListSrc src,
-                                                       int32_t *__restrict__ idx,
-                                                       double *__restrict__ dist, long long out_cap,
-                                                       int32_t *__restrict__ owner,
-                                                       int32_t *__restrict__ nearest_idx,
-                                                       double *__restrict__ nearest_dist,
-                                                       int *__restrict__ big_list, int *__restrict__ big_count) {
-  const int hl = threadIdx.x & 31;
-  const int q = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5);
-  const bool qv = q < nq;
-  long long b = 0, k = 0;
-  if (qv) {
-    b = offsets[q];
-    long long e = offsets[q + 1];
-    if (e > out_cap) e = out_cap;
-    k = e - b;
-  }
-  const bool small = k <= 64;
-  // long list (obstacle sweeps, Dubins balls): queued for nn_order_big_kernel
-  if (qv && !small && hl == 0) big_list[atomicAdd(big_count, 1)] = q;
-  const int kk = (qv && small) ? (int)k : 0;
-  const int kInt = 0x7fffffff;
-  const int m0 = (hl < kk) ? src.idx(q, b, hl) : kInt;
-  const int m1 = (hl + 32 < kk) ? src.idx(q, b, hl + 32) : kInt;
-  const double d0 = (hl < kk) ? src.d2(q, b, hl) : __builtin_inf();
-  const double d1 = (hl + 32 < kk) ? src.d2(q, b, hl + 32) : __builtin_inf();
-  const int kmax = max(kk, __shfl_xor(kk, 32));      // the two halves of a wave run the same loops
-  int r0 = 0, r1 = 0;
-  for (int j = 0; j < min(kmax, 32); ++j) {
-    const int o = __shfl(m0, j, 32);
-    r0 += (o < m0) ? 1 : 0;
-    r1 += (o < m1) ? 1 : 0;
-  }
-  for (int j = 32; j < kmax; ++j) {
-    const int o = __shfl(m1, j - 32, 32);
-    r0 += (o < m0) ? 1 : 0;
-    r1 += (o < m1) ? 1 : 0;
-  }
-  if (hl < kk) {
-    idx[b + r0] = m0;
-    dist[b + r0] = sqrt_rn(d0);
-    if (owner) owner[b + r0] = q;
-  }
-  if (hl + 32 < kk) {
-    idx[b + r1] = m1;
-    dist[b + r1] = sqrt_rn(d1);
-    if (owner) owner[b + r1] = q;
-  }
-  if (nearest_idx) {
-    double best = d0;
-    int best_i = m0;
-    if ((d1 < best) || (d1 == best && m1 < best_i)) { best = d1; best_i = m1; }
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-      const double ob = __shfl_xor(best, off);
-      const int oi = __shfl_xor(best_i, off);
-      if ((ob < best) || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
-    }
-    if (qv && small && hl == 0) {
-      nearest_idx[q] = (kk > 0) ? best_i : -1;
-      nearest_dist[q] = (kk > 0) ? sqrt_rn(best) : __builtin_inf();
-    }
-  }
-}
-
-// Lists longer than one wave: one workgroup per list, striding over the queue written by
-// nn_order_kernel.  Up to kBigSort entries are sorted by node index with a bitonic network in
-// LDS; longer lists fall back to rank counting with all 256 threads.
-constexpr int kBigSort = 2048;
-__global__ __launch_bounds__(256) void nn_order_big_kernel(const int64_t *__restrict__ offsets, ListSrc src,
-                                                           int32_t *__restrict__ idx, double *__restrict__ dist,
-                                                           long long out_cap, int32_t *__restrict__ owner,
-                                                           int32_t *__restrict__ nearest_idx,
-                                                           double *__restrict__ nearest_dist,
-                                                           const int *__restrict__ big_list,
-                                                           const int *__restrict__ big_count) {
-  __shared__ int s_idx[kBigSort];
-  __shared__ double s_d2[kBigSort];
-  __shared__ double r_best[4];
-  __shared__ int r_besti[4];
-  const int t = threadIdx.x;
-  const int n_big = *big_count;
-  for (int item = blockIdx.x; item < n_big; item += gridDim.x) {
-    const int q = big_list[item];
-    const long long b = offsets[q];
-    long long e = offsets[q + 1];
-    if (e > out_cap) e = out_cap;
-    const int k = (int)(e - b);
-    double best = __builtin_inf();
-    int best_i = 0x7fffffff;
-    if (k <= kBigSort) {
-      int n2 = 64;
-      while (n2 < k) n2 <<= 1;
-      for (int i = t; i < n2; i += 256) {
-        s_idx[i] = (i < k) ? src.idx(q, b, i) : 0x7fffffff;
-        s_d2[i] = (i < k) ? src.d2(q, b, i) : __builtin_inf();
-      }
-      __syncthreads();
-      for (int size = 2; size <= n2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-          for (int i = t; i < n2; i += 256) {
-            const int j = i ^ stride;
-            if (j > i) {
-              const bool up = (i & size) == 0;
-              const int a = s_idx[i], c = s_idx[j];
-              if ((a > c) == up) {
-                s_idx[i] = c; s_idx[j] = a;
-                const double da = s_d2[i];
-                s_d2[i] = s_d2[j]; s_d2[j] = da;
-              }
-            }
-          }
-          __syncthreads();
-        }
-      }
-      for (int i = t; i < k; i += 256) {
-        const int my = s_idx[i];
-        const double d2 = s_d2[i];
-        idx[b + i] = my;
-        dist[b + i] = sqrt_rn(d2);
-        if (owner) owner[b + i] = q;
-        if ((d2 < best) || (d2 == best && my < best_i)) { best = d2; best_i = my; }
-      }
-    } else {
-      for (int i = t; i < k; i += 256) {
-        const int my = src.idx(q, b, i);
-        const double d2 = src.d2(q, b, i);
-        int rank = 0;
-        for (int j = 0; j < k; ++j) rank += (src.idx(q, b, j) < my) ? 1 : 0;
-        idx[b + rank] = my;
-        dist[b + rank] = sqrt_rn(d2);
-        if (owner) owner[b + rank] = q;
-        if ((d2 < best) || (d2 == best && my < best_i)) { best = d2; best_i = my; }
-      }
-    }
-    if (nearest_idx) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        double ob = __shfl_xor(best, off);
-        int oi = __shfl_xor(best_i, off);
-        if ((ob < best) || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
-      }
-      if ((t & 63) == 0) { r_best[t >> 6] = best; r_besti[t >> 6] = best_i; }
-      __syncthreads();
-      if (t == 0) {
-        for (int w = 1; w < 4; ++w)
-          if ((r_best[w] < best) || (r_best[w] == best && r_besti[w] < best_i)) { best = r_best[w]; best_i = r_besti[w]; }
-        nearest_idx[q] = best_i;
-        nearest_dist[q] = sqrt_rn(best);
-      }
-    }
-    __syncthreads();   // LDS is reused by the next list
   }
 }
 
@@ -810,7 +717,7 @@ __global__ __launch_bounds__(256) void nn_order_big_kernel(const int64_t *__rest
 int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr_lt, double r_scalar, int nq,
                      int64_t *offsets_dev, int32_t *idx_dev, double *dist_dev, int64_t cap,
                      int64_t *needed_dev, int32_t *owner_dev, int32_t *nearest_idx_dev,
-                     double *nearest_dist_dev) {
+                     double *nearest_dist_dev, const ExtendFuse *ext) {
   // r_dev_thr_lt: optional device array of 2*nq thresholds (thr_lt[nq] then thr_gt[nq])
   if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "radius search on an empty tree");
   if (nq <= 0) return RRTX_OK;
@@ -841,8 +748,17 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   }
   const long long rec_cap = (long long)(cap > 0 ? cap : 1);
   RRTX_HIP(ctx, ctx->ws_recs.ensure((size_t)rec_cap * sizeof(HitRec)));
-  RRTX_HIP(ctx, ctx->ws_tmp_idx.ensure((size_t)rec_cap * sizeof(int32_t)));
-  RRTX_HIP(ctx, ctx->ws_tmp_d2.ensure((size_t)rec_cap * sizeof(double)));
+  RRTX_HIP(ctx, ctx->ws_tmp.ensure((size_t)rec_cap * sizeof(BktRec)));
+  // What the previous calls reported (host-mapped words written by the finish kernel; possibly one call
+  // stale, which is fine: this only tunes, every setting gives the same lists).  Lists that outgrew
+  // their buckets: wider buckets from now on; many such records: offsets + scatter as launches of their
+  // own in front of the finish kernel instead of every overflowed query collecting its own records.
+  if (!ctx->mailbox) {
+    RRTX_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->mailbox), 64, hipHostMallocMapped));
+    std::memset(ctx->mailbox, 0, 64);
+  }
+  const unsigned prev_overflow = *reinterpret_cast<volatile unsigned *>(ctx->mailbox);
+  if (prev_overflow > 0 && ctx->bkt_mult < 16) ctx->bkt_mult *= 2;
 
   // (the switch is committed once the pack kernel, which resets the other record, is enqueued:
   // an error return before that leaves the pristine record for the next call)
@@ -850,9 +766,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   Scalars *sc = ctx->ws_scalars.as<Scalars>() + flip;
   Scalars *sc_next = ctx->ws_scalars.as<Scalars>() + (flip ^ 1);
   int *count = ctx->ws_counts.as<int>();
-  int *big_count = count + nq;          // zeroed by the pack kernel
-  int *cursor = count + nq + 1;
-  int *big_list = cursor + nq;
+  int *cursor = count + nq + 1;         // (count[nq] is scratch of the pack kernel)
 
   // ---- slab culling: on for large trees unless the worst-case unit list would be huge ----
   const int n_nodes = (int)ctx->n_nodes;
@@ -882,18 +796,18 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
     qhist = ctx->ws_qhist.as<int>();
     cbk = ctx->ws_cb.as<int2>();
   }
-  // ---- hit sink: per-query buckets (2x the average the caller made room for) + overflow list ----
-  long long bcap_ll = (rec_cap + nq - 1) / nq * 2;
+  // ---- hit sink: per-query buckets (bkt_mult x the average the caller made room for, at most 2 GiB
+  //      in all) + overflow list ----
+  long long bcap_ll = (rec_cap + nq - 1) / nq * ctx->bkt_mult;
+  while (bcap_ll > 16 && bcap_ll * nq > (1ll << 27)) bcap_ll /= 2;
   bcap_ll = (bcap_ll + 7) / 8 * 8;
   if (bcap_ll < 8) bcap_ll = 8;
   if (bcap_ll > (1ll << 24)) bcap_ll = 1ll << 24;
   const int bcap = (int)bcap_ll;
-  RRTX_HIP(ctx, ctx->ws_bkt_idx.ensure((size_t)nq * (size_t)bcap * sizeof(int32_t)));
-  RRTX_HIP(ctx, ctx->ws_bkt_d2.ensure((size_t)nq * (size_t)bcap * sizeof(double)));
+  RRTX_HIP(ctx, ctx->ws_bkt.ensure((size_t)nq * (size_t)bcap * sizeof(BktRec)));
   HitSink hs;
   hs.count = count;
-  hs.bidx = ctx->ws_bkt_idx.as<int32_t>();
-  hs.bd2 = ctx->ws_bkt_d2.as<double>();
+  hs.bkt = ctx->ws_bkt.as<BktRec>();
   hs.bcap = bcap;
   hs.pad = 0;
   hs.recs = ctx->ws_recs.as<HitRec>();
@@ -1000,16 +914,20 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
       RRTX_HIP(ctx, ctx->ws_ev_a.ensure((size_t)n_slices * (size_t)slice_cap * sizeof(int2)));
       RRTX_HIP(ctx, ctx->ws_ev_cnt.ensure((size_t)n_slices * sizeof(int)));
       ctx->last_visit_slices = n_slices;
+      TileGrid tg;
+      tg.sp = ctx->ws_slab_params.as<SlabParams>();
+      tg.cell_start = ctx->ws_slab_start.as<int>();
+      tg.n_sorted_chunks = (ctx->ws_slab_params.p && ctx->ws_slab_start.p) ? (int)(ctx->sl_n_sorted / kSlabChunk) : 0;
       if (D == 4)
         hipLaunchKernelGGL(nn_tile_kernel<4>, dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
                            ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, reinterpret_cast<const ChunkExt *>(ctx->chunk_ext),
                            ctx->ws_copies_s.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(), sc, n_parts,
-                           ctx->ws_ev_a.as<int2>(), slice_cap, ca_dev, ctx->ws_ev_cnt.as<int>());
+                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, ctx->ws_ev_cnt.as<int>());
       else
         hipLaunchKernelGGL(nn_tile_kernel<3>, dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
                            ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, reinterpret_cast<const ChunkExt *>(ctx->chunk_ext),
                            ctx->ws_copies_s.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(), sc, n_parts,
-                           ctx->ws_ev_a.as<int2>(), slice_cap, ca_dev, ctx->ws_ev_cnt.as<int>());
+                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, ctx->ws_ev_cnt.as<int>());
     } else if (use_filter) {
       // persistent grid: opt_scan_blocks workgroups (multiple of 8) striding over the work
       unsigned pg = (unsigned)ctx->opt_scan_blocks / 8u * 8u;
@@ -1050,13 +968,12 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   span_end(ctx);
   ctx->last_pairs = (int64_t)n_copies_max * n_nodes;
 
-  RRTX_HIP(ctx, ctx->ws_bsum.ensure(sizeof(long long) * (size_t)((nq + 255) / 256)));
-  long long *bsum = ctx->ws_bsum.as<long long>();
-  ListSrc src;
-  src.bidx = hs.bidx; src.bd2 = hs.bd2; src.bcap = bcap; src.pad = 0;
-  src.tmp_idx = ctx->ws_tmp_idx.as<int32_t>(); src.tmp_d2 = ctx->ws_tmp_d2.as<double>();
+  // ---- finish: offsets, order, (extend work), one launch (kernels_finish.hip) ----
+  const bool prescatter = nq > 65536 || prev_overflow > 8192u;
   span_begin(ctx, KF_NN_FINISH);
-  {
+  if (prescatter) {
+    RRTX_HIP(ctx, ctx->ws_bsum.ensure(sizeof(long long) * (size_t)((nq + 255) / 256)));
+    long long *bsum = ctx->ws_bsum.as<long long>();
     const int nblk = (nq + 255) / 256;
     const long long *bsum_arg = nullptr;
     if (nq > 65536) {                     // large batch: per-256 sums first
@@ -1064,16 +981,24 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
       bsum_arg = bsum;
     }
     hipLaunchKernelGGL(nn_offsets_kernel, dim3(nblk), dim3(256), 0, st, count, nq, bsum_arg, offsets_dev, cursor,
-                       needed_dev, qhist, use_cull ? n_buckets + 1 : 0);
-    // the overflow list is normally empty: a small grid finds that out quickly
-    hipLaunchKernelGGL(nn_scatter_kernel, dim3(64), dim3(256), 0, st, ctx->ws_recs.as<HitRec>(), rec_cap, sc,
-                       offsets_dev, cursor, bcap, ctx->ws_tmp_idx.as<int32_t>(), ctx->ws_tmp_d2.as<double>(),
-                       (long long)cap);
-    hipLaunchKernelGGL(nn_order_kernel, dim3((nq + 7) / 8), dim3(256), 0, st, offsets_dev, nq, src, idx_dev, dist_dev,
-                       (long long)cap, owner_dev, nearest_idx_dev, nearest_dist_dev, big_list, big_count);
-    // lists longer than one wave (queued by nn_order_kernel); exits at once when there are none
-    hipLaunchKernelGGL(nn_order_big_kernel, dim3(nq < 1024 ? nq : 1024), dim3(256), 0, st, offsets_dev, src, idx_dev,
-                       dist_dev, (long long)cap, owner_dev, nearest_idx_dev, nearest_dist_dev, big_list, big_count);
+                       needed_dev, (int *)nullptr, 0);
+    hipLaunchKernelGGL(nn_scatter_kernel, dim3(1024), dim3(256), 0, st, ctx->ws_recs.as<HitRec>(), rec_cap, sc,
+                       offsets_dev, cursor, bcap, ctx->ws_tmp.as<BktRec>(), (long long)cap);
+  }
+  {
+    FinishLaunch f;
+    f.count = count; f.nq = nq; f.bcap = bcap;
+    f.bkt = hs.bkt; f.tmp = ctx->ws_tmp.p; f.ovf = ctx->ws_recs.p; f.ovf_cap = rec_cap; f.scalars = sc;
+    f.prescattered = prescatter;
+    f.offsets = offsets_dev; f.needed = needed_dev; f.idx = idx_dev; f.dist = dist_dev; f.out_cap = (long long)cap;
+    f.owner = owner_dev; f.nearest_idx = nearest_idx_dev; f.nearest_dist = nearest_dist_dev;
+    f.qhist = qhist; f.n_qhist = use_cull ? n_buckets + 1 : 0;
+    f.mailbox = ctx->mailbox;
+    f.q = q_dev;
+    f.r_start = (!r_dev_thr_lt && r_scalar > 0.0) ? 2.0 * r_scalar : 1.0;
+    f.ext = ext;
+    int rc = launch_nn_finish(ctx, f);
+    if (rc) return rc;
   }
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());

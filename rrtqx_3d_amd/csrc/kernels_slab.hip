@@ -13,7 +13,7 @@ namespace {
 // order in which the atomics happened to land, which no result depends on.
 static_assert(kSlabChunk == kChunkF, "the culled scan visits one slab-index chunk per work unit");
 
-struct SlabParams { double x0, inv_wx, y0, inv_wy; int Kx, Ky; };
+// (SlabParams: nn_device.hpp)
 
 __global__ void slab_params_kernel(const unsigned long long *__restrict__ xrange, int Kx, int Ky,
                                    SlabParams *__restrict__ sp, int *__restrict__ hist) {

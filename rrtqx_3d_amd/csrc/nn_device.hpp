@@ -27,10 +27,13 @@ struct Scalars {
 // shared counter sustains only ~88 returning atomics/us on MI355X).  A hit beyond the bucket
 // capacity goes to the shared overflow list, one atomic per wave.  count[q] ends as the exact
 // list length either way.
+// one confirmed neighbour in a query's bucket: node index + squared distance in ONE 16-byte store
+// (separate 4- and 8-byte arrays cost a partial cache line write each)
+struct alignas(16) BktRec { int32_t idx; int32_t pad; double d2; };
+
 struct HitSink {
   int *count;
-  int32_t *bidx;        // [nq][bcap]
-  double *bd2;          // [nq][bcap]
+  BktRec *bkt;          // [nq][bcap]
   int bcap;
   int pad;
   HitRec *recs;         // overflow list
@@ -139,8 +142,9 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
       const bool add = s >= tlt && s < tgt;
       pf.count[i] = add ? 1 : 0;
       if (add) {                               // bcap >= 8: entry 0 of the bucket always exists
-        ca.hs.bidx[(size_t)i * (size_t)ca.hs.bcap] = 0;
-        ca.hs.bd2[(size_t)i * (size_t)ca.hs.bcap] = s;
+        BktRec br;
+        br.idx = 0; br.pad = 0; br.d2 = s;
+        ca.hs.bkt[(size_t)i * (size_t)ca.hs.bcap] = br;
       }
     }
     for (int k = 0; k < n_slots; ++k) {
@@ -222,8 +226,9 @@ __device__ __forceinline__ void place_hit(const HitSink &hs, bool hit, int owner
   const bool inb = hit && slot < hs.bcap;
   if (inb) {
     const size_t at = (size_t)owner * (size_t)hs.bcap + (size_t)slot;
-    hs.bidx[at] = id;
-    hs.bd2[at] = d2;
+    BktRec br;
+    br.idx = id; br.pad = 0; br.d2 = d2;
+    hs.bkt[at] = br;
   }
   const bool ov = hit && !inb;
   const unsigned long long m = __ballot(ov);
@@ -271,6 +276,7 @@ __device__ __forceinline__ void emit_hits_grouped(const HitSink &hs, bool hit, i
 
 // emitters for confirm_entry: what to do with a confirmed neighbour
 struct GlobalEmit {
+  static constexpr bool kNeedsOwner = true;
   const HitSink &hs;
   __device__ __forceinline__ void operator()(bool h, int /*q*/, int owner, int id, double d2) const {
     emit_hit(hs, h, owner, id, d2);
@@ -369,6 +375,106 @@ __device__ __forceinline__ void screen8(const typename QRecFT<D>::type &c, const
     a = __builtin_elementwise_fma(cx2, xx, a);
     t[2 * v] = a.x; t[2 * v + 1] = a.y;
   }
+}
+
+// ---------------------------------------------------------- slab index geometry ------
+// written by slab_params_kernel at every rebuild: the (x, y) grid the sorted part of the slab index
+// is ordered by (cell_of); cell_start[c] = first position of cell c, cell_start[Kx * Ky] = sl_n_sorted
+struct SlabParams { double x0, inv_wx, y0, inv_wy; int Kx, Ky; };
+
+// ------------------------------------------------ exact nearest for one point ------
+// kdFindNearest for ONE point by a whole workgroup (NT threads, all call it together): expanding
+// search over the slab index.  Every chunk whose exact x / y extent overlaps [p - R, p + R] is
+// examined node by node with the unfused fp64 distance; a node outside every examined chunk has
+// |dx| >= R or |dy| >= R, hence s >= R^2 (1 - 2^-51), so the best examined node is the global
+// lexicographic minimum of (s, index) as soon as its s < R^2 (1 - 1e-12).  Otherwise R doubles; with
+// R = +inf every non-empty chunk is examined.  Non-finite points skip the culling.  Result for a
+// point that orders against nothing (NaN coordinate): (inf, INT_MAX), as the exhaustive scan gives.
+// The slab arrays are kept up to date by every append (position = index for the tail), so this
+// works whether or not the range search culls.
+struct NearestIndex {
+  const double *sx, *sy, *sz, *sw;   // fp64 node coordinates by slab POSITION
+  const int32_t *sid;                // node index of a position
+  const ChunkExt *chunk_ext;
+  int n_chunks, n_nodes;
+};
+struct NearestScratch { double s[16]; int i[16]; int skipped; };
+
+template <int D, int NT>
+__device__ __forceinline__ void block_nearest(const NearestIndex &ni, const double px, const double py, const double pz,
+                                           const double pw, double r_start, NearestScratch &sm, double &best_s_out,
+                                           int &best_i_out) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  constexpr int NW = NT / 64;
+  const bool finite_p = (px - px == 0.0) && (py - py == 0.0) && (pz - pz == 0.0) && (D == 3 || (pw - pw == 0.0));
+  double R = (r_start > 0.0 && r_start < 1e300) ? r_start : 1.0;
+  if (!finite_p) R = __builtin_inf();
+  double best = __builtin_inf();
+  int best_i = 0x7fffffff;
+  for (int it = 0;; ++it) {
+    if (it >= 48) R = __builtin_inf();
+    double lo = -__builtin_inf(), hi = __builtin_inf(), ylo = lo, yhi = hi;
+    const bool cull = finite_p && R < 1e300;
+    if (cull) {
+      const double a = px - R, b = px + R, ya = py - R, yb = py + R;
+      lo = a - (fabs(a) * 4.5e-16 + 1e-300);
+      hi = b + (fabs(b) * 4.5e-16 + 1e-300);
+      ylo = ya - (fabs(ya) * 4.5e-16 + 1e-300);
+      yhi = yb + (fabs(yb) * 4.5e-16 + 1e-300);
+    }
+    if (t == 0) sm.skipped = 0;
+    __syncthreads();
+    best = __builtin_inf();
+    best_i = 0x7fffffff;
+    bool skipped = false;
+    for (int c = wave; c < ni.n_chunks; c += NW) {
+      if (cull) {
+        const ChunkExt ce = ni.chunk_ext[c];          // wave-uniform
+        if (!(dec_ord(ce.xhi) >= lo && dec_ord(ce.xlo) <= hi && dec_ord(ce.yhi) >= ylo && dec_ord(ce.ylo) <= yhi)) {
+          skipped = true;
+          continue;
+        }
+      }
+#pragma unroll 2
+      for (int u = 0; u < kChunkF / 64; ++u) {
+        const int pos = c * kChunkF + u * 64 + lane;
+        if (pos < ni.n_nodes) {
+          double s;
+          if constexpr (D == 4) s = sq4(px, py, pz, pw, ni.sx[pos], ni.sy[pos], ni.sz[pos], ni.sw[pos]);
+          else s = sq3(px, py, pz, ni.sx[pos], ni.sy[pos], ni.sz[pos]);
+          const int id = ni.sid[pos];
+          const bool better = (s < best) || (s == best && id < best_i);
+          best = better ? s : best;
+          best_i = better ? id : best_i;
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off);
+      const int oi = __shfl_xor(best_i, off);
+      if ((ob < best) || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+    }
+    if (lane == 0) {
+      sm.s[wave] = best; sm.i[wave] = best_i;
+      if (skipped) sm.skipped = 1;
+    }
+    __syncthreads();
+    best = sm.s[0]; best_i = sm.i[0];
+    for (int w = 1; w < NW; ++w) {
+      const double ob = sm.s[w];
+      const int oi = sm.i[w];
+      if ((ob < best) || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+    }
+    const bool any_skipped = sm.skipped != 0;
+    __syncthreads();                       // sm is reused by the next round / the caller
+    if (!cull || !any_skipped) break;      // everything that can order was examined
+    if (best < R * R * (1.0 - 1e-12)) break;
+    R = R * 2.0;
+  }
+  best_s_out = best;
+  best_i_out = best_i;
 }
 
 // small host helpers shared by the launchers

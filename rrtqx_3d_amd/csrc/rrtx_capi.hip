@@ -364,16 +364,17 @@ int rrtx_destroy(rrtx_ctx *ctx) {
   DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_reach, &ctx->d_sph_reach_f, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_meta,
                     &ctx->d_poly_orig, &ctx->d_poly_path_off, &ctx->d_poly_path, &ctx->ws_knn_off, &ctx->ws_knn_idx,
                     &ctx->ws_knn_dist, &ctx->ws_knn_misc, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
-                    &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_bsum, &ctx->ws_scalars, &ctx->ws_scalars_nn, &ctx->ws_tmp_idx,
-                    &ctx->ws_tmp_d2, &ctx->ws_owner, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
+                    &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_bsum, &ctx->ws_scalars, &ctx->ws_scalars_nn, &ctx->ws_tmp,
+                    &ctx->ws_owner, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
                     &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr, &ctx->ws_mask, &ctx->ws_i32a, &ctx->ws_i32b,
                     &ctx->ws_slab_hist, &ctx->ws_slab_start, &ctx->ws_slab_sr, &ctx->ws_slab_params, &ctx->ws_copies_s,
-                    &ctx->ws_meta_s, &ctx->ws_cb, &ctx->ws_qhist, &ctx->ws_bkt_idx,
-                    &ctx->ws_bkt_d2, &ctx->ws_ev_a, &ctx->ws_ev_cnt, &ctx->ws_confirm_args, &ctx->ws_sph_lists, &ctx->d_sph_sample,
+                    &ctx->ws_meta_s, &ctx->ws_cb, &ctx->ws_qhist, &ctx->ws_bkt,
+                    &ctx->ws_ev_a, &ctx->ws_ev_cnt, &ctx->ws_confirm_args, &ctx->ws_sph_lists, &ctx->d_sph_sample,
                     &ctx->ws_sweep_mark, &ctx->ws_sweep_flag, &ctx->ws_sweep_cnt, &ctx->ws_sweep_start};
   for (auto b : bufs) b->release();
   if (ctx->ge_start) (void)hipFree(ctx->ge_start);
   if (ctx->ge_end) (void)hipFree(ctx->ge_end);
+  if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return RRTX_OK;
@@ -416,6 +417,14 @@ int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value) {
     case RRTX_OPT_PROFILE_EVERY: ctx->opt_profile_every = value > 1 ? (int)value : 1; return RRTX_OK;
     case RRTX_OPT_KNN_LISTS: ctx->opt_knn_lists = value != 0; return RRTX_OK;
     case RRTX_OPT_EXTEND_OBSTACLES: ctx->opt_extend_polygons = value == 1; return RRTX_OK;
+    case RRTX_OPT_TUNE: ctx->opt_tune = (int)value; return RRTX_OK;
+    case RRTX_OPT_NEAREST_REC_CAP: ctx->opt_nearest_rec_cap = value > 0 ? (long long)value : 0; return RRTX_OK;
+    case RRTX_OPT_BUCKET_MULT: {
+      int m = 2;
+      while (m < value && m < 16) m *= 2;
+      ctx->bkt_mult = m;
+      return RRTX_OK;
+    }
     default: return fail(ctx, RRTX_E_INVALID, "set_option: unknown option %d", option);
   }
 }
@@ -596,21 +605,6 @@ int rrtx_nn_nearest_dev(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, do
   return launch_nn_nearest(ctx, q, nq, idx, dist);
 }
 
-// nearest on device buffers with the host-side overflow check of the screened scan
-static int nearest_with_fallback(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev) {
-  int rc = launch_nn_nearest(ctx, q_dev, nq, idx_dev, dist_dev);
-  if (rc) return rc;
-  if (ctx->last_nearest_cap > 0) {
-    // the screened scan keeps ~ln(n) candidates per query and segment; an adversarial visiting order
-    // (nodes sorted by decreasing distance) can exceed the record buffer -> exact scan instead
-    long long total = 0;
-    rc = nearest_candidates(ctx, &total);
-    if (rc) return rc;
-    if (total > ctx->last_nearest_cap) return launch_nn_nearest(ctx, q_dev, nq, idx_dev, dist_dev, true);
-  }
-  return RRTX_OK;
-}
-
 int rrtx_nn_nearest(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double *dist) {
   CHECK_CTX(ctx);
   if (nq < 0 || (nq > 0 && (!q || !idx || !dist))) return fail(ctx, RRTX_E_INVALID, "nn_nearest: bad arguments");
@@ -619,7 +613,7 @@ int rrtx_nn_nearest(rrtx_ctx *ctx, const double *q, int nq, int32_t *idx, double
   if (rc) return rc;
   RRTX_HIP(ctx, ctx->ws_out_idx.ensure(sizeof(int32_t) * (size_t)nq));
   RRTX_HIP(ctx, ctx->ws_out_dist.ensure(sizeof(double) * (size_t)nq));
-  rc = nearest_with_fallback(ctx, ctx->ws_q.as<double>(), nq, ctx->ws_out_idx.as<int32_t>(), ctx->ws_out_dist.as<double>());
+  rc = launch_nn_nearest(ctx, ctx->ws_q.as<double>(), nq, ctx->ws_out_idx.as<int32_t>(), ctx->ws_out_dist.as<double>());
   if (rc) return rc;
   RRTX_HIP(ctx, hipMemcpyAsync(idx, ctx->ws_out_idx.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
   RRTX_HIP(ctx, hipMemcpyAsync(dist, ctx->ws_out_dist.p, sizeof(double) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
@@ -987,23 +981,28 @@ int rrtx_extend_candidates_dev(rrtx_ctx *ctx, const double *q, int nq, double r,
     return fail(ctx, RRTX_E_STATE, "extend_candidates reads kdFindNearest off the range lists, which is only valid "
                                    "without wrapped dimensions (use rrtx_extend_candidates_dubins / the separate calls)");
   if (nq == 0) return RRTX_OK;
-  RRTX_HIP(ctx, ctx->ws_owner.ensure(sizeof(int32_t) * (size_t)(cap > 0 ? cap : 1)));
   const bool want_nearest = nearest_idx && nearest_dist;
-  // nearest falls out of the radius lists (kdFindNearest's answer lies inside the ball whenever
-  // the ball is non-empty); samples with an empty ball get nearest_idx = -1 here and are
-  // resolved with the full nearest scan by the host-pointer entry point below.
-  int rc = launch_nn_radius(ctx, q, nullptr, r, nq, offsets, idx, cost, cap, needed_dev,
-                            ctx->ws_owner.as<int32_t>(), want_nearest ? nearest_idx : nullptr,
-                            want_nearest ? nearest_dist : nullptr);
-  if (rc) return rc;
-  if (ctx->opt_extend_polygons)
+  // nearest falls out of the radius lists (kdFindNearest's answer lies inside the ball whenever the
+  // ball is non-empty); a sample with an empty ball is answered by an expanding search on the device
+  // (kernels_finish.hip), so no -1 reaches the caller.
+  if (ctx->opt_extend_polygons) {
+    RRTX_HIP(ctx, ctx->ws_owner.ensure(sizeof(int32_t) * (size_t)(cap > 0 ? cap : 1)));
+    int rc = launch_nn_radius(ctx, q, nullptr, r, nq, offsets, idx, cost, cap, needed_dev,
+                              ctx->ws_owner.as<int32_t>(), want_nearest ? nearest_idx : nullptr,
+                              want_nearest ? nearest_dist : nullptr);
+    if (rc) return rc;
     return launch_candidate_edges_polygons(ctx, q, nq, offsets, idx, ctx->ws_owner.as<int32_t>(), cap, robot_radius,
                                            hit_out, hit_in, sample_unsafe);
-  // one pass over the spheres per sample: explicitPointCheck + the sample's sphere list, then the edges
-  rc = launch_candidate_edges(ctx, q, nq, offsets, idx, ctx->ws_owner.as<int32_t>(), cap, robot_radius, hit_out,
-                              hit_in, (r >= 0.0) ? r : -1.0, sample_unsafe);
+  }
+  // sphere list: the sample pass and both directed edges of every entry ride in the finish kernel of
+  // the search, which holds the lists in registers (no owner array, no sphere lists through memory)
+  int rc = sync_spheres(ctx, robot_radius);
   if (rc) return rc;
-  return RRTX_OK;
+  ExtendFuse ef;
+  ef.r = (r >= 0.0) ? r : -1.0;
+  ef.hit_out = hit_out; ef.hit_in = hit_in; ef.sample_unsafe = sample_unsafe;
+  return launch_nn_radius(ctx, q, nullptr, r, nq, offsets, idx, cost, cap, needed_dev, nullptr,
+                          want_nearest ? nearest_idx : nullptr, want_nearest ? nearest_dist : nullptr, &ef);
 }
 
 int rrtx_extend_candidates(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius, int64_t *offsets,
@@ -1097,7 +1096,7 @@ int rrtx_extend_candidates_dubins_dev(rrtx_ctx *ctx, const double *q, int nq, do
     if (rc) return rc;
   }
   if (want_nearest && !nearest_from_list) {
-    rc = nearest_with_fallback(ctx, q, nq, nearest_idx, nearest_dist);
+    rc = launch_nn_nearest(ctx, q, nq, nearest_idx, nearest_dist);
     if (rc) return rc;
   }
   return RRTX_OK;

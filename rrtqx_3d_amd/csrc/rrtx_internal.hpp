@@ -107,6 +107,8 @@ struct rrtx_ctx {
   int opt_scan_items = 2048;        // target number of (tile, segment) work items
   int opt_tile_q = 0;               // query copies per workgroup tile (0 = kernel default)
   int opt_nn_cull = 1;              // 0 off, 1 auto (trees of >= 8192 nodes), 2 always
+  long long opt_nearest_rec_cap = 0; // testing: candidate record capacity of the screened nearest scan (0 = default)
+  int opt_tune = 0;                 // experiment switches (RRTX_OPT_TUNE), never change a result
   int opt_profile_every = 1;        // profiling level 1 times every n-th launch of the search kernel
   long long span_tick = 0;
 
@@ -155,7 +157,9 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_copy_meta;// int32 owner, slot per copy
   rrtx::DevBuf ws_copies_s, ws_meta_s;  // copies / meta in x-bucket order (culled scan)
   rrtx::DevBuf ws_cb, ws_qhist;         // (bucket, rank) per copy; bucket histogram
-  rrtx::DevBuf ws_bkt_idx, ws_bkt_d2;   // per-query hit buckets
+  rrtx::DevBuf ws_bkt;      // per-query hit buckets (16-byte records)
+  int bkt_mult = 2;         // bucket capacity in units of the average list length the caller made room for
+  unsigned *mailbox = nullptr;   // host-mapped words the finish kernel reports to: [0] overflow records of a call
   rrtx::DevBuf ws_ev_a, ws_ev_cnt, ws_confirm_args;   // per-wave entry slices, their counts, confirm arguments
   rrtx::DevBuf ws_recs;     // HitRec
   rrtx::DevBuf ws_counts;   // int32 count[nq], cursor[nq]
@@ -163,7 +167,7 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_scalars;  // device scalars of the range search: two records used alternately
   rrtx::DevBuf ws_scalars_nn;  // ... of the nearest search
   int scalars_flip = 0;
-  rrtx::DevBuf ws_tmp_idx, ws_tmp_d2;
+  rrtx::DevBuf ws_tmp;      // list entries that did not fit their bucket, in CSR position
   rrtx::DevBuf ws_owner;    // int32 owner query of every CSR entry (extend_candidates)
   rrtx::DevBuf ws_out_off, ws_out_idx, ws_out_dist, ws_out_u8a, ws_out_u8b, ws_out_i32, ws_out_f64;
   rrtx::DevBuf ws_partial;  // nearest partials
@@ -191,7 +195,6 @@ struct rrtx_ctx {
   int last_tile_q = 0;
   bool last_culled = false;         // the last range search used the slab-culled scan
   int last_visit_slices = 0;        // entries of ws_ev_cnt holding its per-wave chunk counts
-  long long last_nearest_cap = 0;   // record capacity of the last screened nearest call (0: exact scan ran)
 };
 
 namespace rrtx {
@@ -218,16 +221,30 @@ double thr_first_gt(double r);
 double thr_point_clear(double robot_radius, double radius);
 
 // ---- launchers (device pointers, enqueue on ctx->stream) ----------------------
+// Fused extend() work of the finish kernel (sphere list): both directed edges of every list entry and
+// explicitPointCheck of the samples; r = radius the lists were built with
+struct ExtendFuse { double r; uint8_t *hit_out, *hit_in, *sample_unsafe; };
+// the last launch of the range search (kernels_finish.hip); device types passed as void *
+struct FinishLaunch {
+  const int *count; int nq; int bcap;
+  const void *bkt; void *tmp; const void *ovf; long long ovf_cap; const void *scalars;
+  bool prescattered;
+  int64_t *offsets; int64_t *needed; int32_t *idx; double *dist; long long out_cap;
+  int32_t *owner; int32_t *nearest_idx; double *nearest_dist;
+  int *qhist; int n_qhist; unsigned *mailbox;
+  const double *q; double r_start;
+  const ExtendFuse *ext;
+};
+int launch_nn_finish(rrtx_ctx *ctx, const FinishLaunch &f);
 int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_or_null, double r_scalar,
                      int nq, int64_t *offsets_dev, int32_t *idx_dev, double *dist_dev, int64_t cap,
                      int64_t *needed_dev, int32_t *owner_dev = nullptr, int32_t *nearest_idx_dev = nullptr,
-                     double *nearest_dist_dev = nullptr);
+                     double *nearest_dist_dev = nullptr, const ExtendFuse *ext = nullptr);
 int knearest_row(int k, int64_t n_nodes);
 int launch_nn_knearest(rrtx_ctx *ctx, const double *q_dev, int nq, int k, int32_t *idx_dev, double *dist_dev,
                        int32_t *count_dev);
 int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev,
                       bool exact = false);
-int nearest_candidates(rrtx_ctx *ctx, long long *total);
 int scan_units(rrtx_ctx *ctx, int *units);   // (tile, chunk) units of the last culled range scan
 int slab_refresh(rrtx_ctx *ctx);             // bring the slab index up to date (kernels_slab.hip)
 constexpr int kSlabChunk = 512;              // node positions per chunk of the slab index

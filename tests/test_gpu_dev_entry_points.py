@@ -71,9 +71,9 @@ def test_dev_entry_points_match_host_forms():
             assert np.array_equal(d_idx.cpu().numpy()[:k], out["idx"]) and np.array_equal(d_cost.cpu().numpy()[:k], out["cost"])
             assert np.array_equal(d_ho.cpu().numpy()[:k], out["hit_out"]) and np.array_equal(d_hi.cpu().numpy()[:k], out["hit_in"])
             assert np.array_equal(d_un.cpu().numpy(), out["sample_unsafe"])
-            near = d_ni.cpu().numpy()
-            has = np.diff(out["offsets"]) > 0
-            assert np.array_equal(near[has], out["nearest_idx"][has])      # empty balls: -1 here, resolved by the host form
+            # empty balls are answered on the device too (expanding search): no -1 leaves the library
+            assert np.array_equal(d_ni.cpu().numpy(), out["nearest_idx"])
+            assert np.array_equal(d_nd.cpu().numpy(), out["nearest_dist"])
             # stand-alone edge and point checks
             p0, p1 = synth.candidate_edges(Q, pts, out["offsets"], out["idx"])
             ne = len(p0)
@@ -155,3 +155,155 @@ def test_knearest_dev_matches_host_form():
         ctx.set_stream(None)
         assert np.array_equal(d_idx.cpu().numpy(), ref[0]) and np.array_equal(d_dist.cpu().numpy(), ref[1])
         assert np.array_equal(d_cnt.cpu().numpy(), ref[2])
+
+
+def _naive_nearest(pts, q):
+    d = pts - q
+    s = d[:, 0] * d[:, 0]
+    for k in range(1, pts.shape[1]):
+        s = s + d[:, k] * d[:, k]
+    i = int(np.argmin(s))            # first minimum = lowest index among ties
+    return i, float(np.sqrt(s[i]))
+
+
+def test_nearest_dev_adversarial_order_small_record_buffer():
+    """rrtx_nn_nearest_dev has no host round trip, so an overflowing candidate buffer must be repaired on
+    the device: nodes sorted by DEcreasing distance make every node a new running minimum
+    (R/kdTree_general.jl:357-385 still has one answer); with the record capacity forced tiny every query
+    loses records and is answered by the exact fix-up kernel."""
+    torch = pytest.importorskip("torch")
+    from rrtqx_3d_amd import _capi
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    n = 30_000
+    radii = np.linspace(90.0, 1.0, n)
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    pts = u * radii[:, None]
+    pts[n - 5] = pts[n - 1]                                   # exact tie at the minimum: the lower index wins
+    Q = np.concatenate([np.zeros((3, 3)), rng.uniform(-5, 5, (61, 3))])
+    nq = len(Q)
+    for cap in (0, 64):
+        with Context(3) as ctx:
+            ctx.nodes_append(pts)
+            ctx.set_option(_capi.RRTX_OPT_NEAREST_REC_CAP, cap)
+            d_q = torch.from_numpy(Q).to(dev)
+            d_ni = torch.full((nq,), -9, dtype=torch.int32, device=dev)
+            d_nd = torch.empty(nq, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            ctx.nn_nearest_dev(d_q.data_ptr(), nq, d_ni.data_ptr(), d_nd.data_ptr())
+            ctx.sync()
+            gi, gd = d_ni.cpu().numpy(), d_nd.cpu().numpy()
+            for k in range(nq):
+                ri, rd = _naive_nearest(pts, Q[k])
+                assert gi[k] == ri and gd[k] == rd, (cap, k)
+            assert gi[0] == n - 5
+
+
+def test_nearest_dev_fixup_with_wrapped_dimension():
+    """the same repair with ghosts: [x y t theta], theta wrapped -- equals the exact fp64 scan"""
+    torch = pytest.importorskip("torch")
+    import math
+    from rrtqx_3d_amd import _capi
+    dev = torch.device("cuda", 0)
+    n, nq = 9_000, 200
+    pts, Q = synth.nodes(n, 4), synth.queries(nq, 4)
+    with Context(4) as ctx:
+        ctx.set_wrap(3, 2 * math.pi)
+        ctx.nodes_append(pts)
+        ctx.set_option(_capi.RRTX_OPT_NN_FILTER, 0)
+        ei, ed = ctx.nn_nearest(Q)                            # exact scan
+        ctx.set_option(_capi.RRTX_OPT_NN_FILTER, 1)
+        ctx.set_option(_capi.RRTX_OPT_NEAREST_REC_CAP, 32)
+        d_q = torch.from_numpy(Q).to(dev)
+        d_ni = torch.empty(nq, dtype=torch.int32, device=dev)
+        d_nd = torch.empty(nq, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        ctx.nn_nearest_dev(d_q.data_ptr(), nq, d_ni.data_ptr(), d_nd.data_ptr())
+        ctx.sync()
+        assert np.array_equal(d_ni.cpu().numpy(), ei) and np.array_equal(d_nd.cpu().numpy(), ed)
+
+
+def test_extend_dev_resolves_empty_balls_on_device(oracle):
+    """samples whose ball holds no node (outside the cloud, or a tiny radius) get kdFindNearest's
+    answer from the device-side expanding search; culled and unculled trees, growing tail included"""
+    torch = pytest.importorskip("torch")
+    from rrtqx_3d_amd import _capi
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    for n, cull in ((3_000, 1), (40_000, 1), (40_000, 2)):
+        pts = rng.uniform(-50, 50, (n, 3))
+        extra = rng.uniform(-50, 50, (700, 3))                # appended later: sits in the index tail
+        Q = np.concatenate([rng.uniform(-50, 50, (300, 3)), rng.uniform(-400, 400, (300, 3)),
+                            np.array([[1e6, -1e6, 3.0], [50.0, 50.0, 50.0], [np.nan, 0.0, 0.0]])])
+        nq = len(Q)
+        r = 0.9                                               # most balls are empty
+        allp = np.concatenate([pts, extra])
+        with Context(3) as ctx:
+            ctx.set_option(_capi.RRTX_OPT_NN_CULL, cull)
+            ctx.nodes_append(pts)
+            ctx.spheres_set(synth.spheres(16))
+            d_q = torch.from_numpy(Q).to(dev)
+            cap = 64 * nq
+            d_off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+            d_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+            d_cost = torch.empty(cap, dtype=torch.float64, device=dev)
+            d_ho = torch.empty(cap, dtype=torch.uint8, device=dev)
+            d_hi = torch.empty(cap, dtype=torch.uint8, device=dev)
+            d_un = torch.empty(nq, dtype=torch.uint8, device=dev)
+            d_need = torch.zeros(1, dtype=torch.int64, device=dev)
+            d_ni = torch.empty(nq, dtype=torch.int32, device=dev)
+            d_nd = torch.empty(nq, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            for step, cloud in enumerate((pts, allp)):
+                if step == 1:
+                    ctx.nodes_append(extra)
+                ctx.extend_candidates_dev(d_q.data_ptr(), nq, r, RR, d_off.data_ptr(), d_idx.data_ptr(), d_cost.data_ptr(),
+                                          d_ho.data_ptr(), d_hi.data_ptr(), cap, d_need.data_ptr(), d_ni.data_ptr(),
+                                          d_nd.data_ptr(), d_un.data_ptr())
+                ctx.sync()
+                gi, gd = d_ni.cpu().numpy(), d_nd.cpu().numpy()
+                off = d_off.cpu().numpy()
+                assert (np.diff(off) == 0).sum() > 300
+                for k in range(nq - 1):
+                    ri, rd = _naive_nearest(cloud, Q[k])
+                    assert gi[k] == ri and gd[k] == rd, (n, cull, step, k)
+                assert gi[nq - 1] == 0x7fffffff and np.isinf(gd[nq - 1])      # NaN sample orders against nothing
+
+
+def test_radius_lists_that_outgrow_their_buckets(oracle):
+    """a dense cluster makes a few lists many times longer than the average the capacity allows for:
+    their records take the shared overflow list and come back (a) collected by the finish kernel itself,
+    then, once the library has seen the overflow, (b) with wider buckets / (c) pre-scattered -- every call
+    must give the same lists as the exact brute-force path"""
+    from rrtqx_3d_amd import _capi
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.uniform(-50, 50, (20_000, 3)), rng.normal(0, 0.8, (6_000, 3)) + [10, 10, 10]])
+    Q = np.concatenate([rng.uniform(-50, 50, (400, 3)), rng.normal(0, 1.0, (40, 3)) + [10, 10, 10]])
+    r = 3.0
+    with Context(3) as ref:
+        ref.set_option(_capi.RRTX_OPT_NN_FILTER, 0)
+        ref.nodes_append(pts)
+        roff, ridx, rdist = ref.nn_radius(Q, r)
+    assert np.diff(roff).max() > 2500 and np.median(np.diff(roff)) < 10
+    tree = oracle.KDTree(3)
+    tree.insert_many(pts)
+    for k in (5, 411, 425):
+        oi, od = tree.within_range(r, Q[k])
+        o = np.argsort(oi)
+        assert np.array_equal(np.asarray(oi)[o], ridx[roff[k]:roff[k + 1]])
+        assert np.array_equal(np.asarray(od)[o], rdist[roff[k]:roff[k + 1]])
+    for cull in (2, 0):
+        with Context(3) as ctx:
+            ctx.set_option(_capi.RRTX_OPT_NN_CULL, cull)
+            ctx.nodes_append(pts)
+            for call in range(4):                               # tight capacity: buckets of 2 x the average
+                off, idx, dist = ctx.nn_radius(Q, r, cap=len(ridx))
+                assert np.array_equal(off, roff) and np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (cull, call)
+            ctx.spheres_set(synth.spheres(24))
+            out = ctx.extend_candidates(Q, r, RR, cap=len(ridx))
+            assert np.array_equal(out["idx"], ridx) and np.array_equal(out["cost"], rdist)
+            p0, p1 = synth.candidate_edges(Q, pts, roff, ridx)
+            hh, _ = ctx.edges_check(p0, p1, RR)
+            n = len(ridx)
+            assert np.array_equal(out["hit_out"], hh[:n]) and np.array_equal(out["hit_in"], hh[n:])
