@@ -29,5 +29,133 @@ __device__ __forceinline__ bool edge_hits_sphere(double p0x, double p0y, double 
 struct alignas(64) SampleSph { double cx, cy, cz, thr_in, thr_pt, reach, pad0, pad1; };
 constexpr int kSphListCap = 8;   // spheres listed per sample; a longer list sends the sample's edges to the full loop
 
+// what the fused extend() path reads about the sphere list (tables of sync_spheres)
+struct ExtendDev {
+  const SphRec *sph;           // exact records, packed (active only), list order
+  const SampleSph *stab;
+  const float *reach_f;        // fp32 reach table, pair-interleaved, origin-relative
+  const double4 *naos;         // node coordinates by node index, one 32-byte record each
+  double ox, oy, oz;
+  int m;                       // active spheres
+  int pad;
+  double r_bound;              // radius of the ball the lists are built for; < 0: no lists (full loop)
+  uint8_t *sample_unsafe;
+};
+
+// fp32 screen state of a point or segment midpoint for the reach table: centre relative to the
+// origin and the inflated half length  h~ = RU[(half + 3 eps |m|_1)(1 + 8 eps)]  (+inf disables it)
+struct ReachProbe { float mx, my, mz, h; };
+__device__ __forceinline__ ReachProbe reach_probe(const ExtendDev &x, double cx, double cy, double cz, double half,
+                                                  bool usable) {
+  const double mx = cx - x.ox, my = cy - x.oy, mz = cz - x.oz;
+  const double eps = 5.9604644775390625e-08;
+  const double h = (half * (1.0 + 1e-12) + 3.0 * eps * (fabs(mx) + fabs(my) + fabs(mz)) + 1e-30) * (1.0 + 8.0 * eps);
+  ReachProbe p;
+  p.h = usable ? __double2float_ru(h) : __builtin_inff();
+  p.mx = usable ? (float)mx : 0.f; p.my = usable ? (float)my : 0.f; p.mz = usable ? (float)mz : 0.f;
+  return p;
+}
+
+// Both directed edges sample <-> node against the sphere list: explicitEdgeCheck(S, edge) for
+// newNode -> near and near -> newNode (R/DRRT_Q.jl:1951-1963, 2600-2602, 1802-1826).  `list` holds the
+// nl spheres within reach of any edge inside the sample's ball (nl > kSphListCap: not all fit); edges
+// the list does not cover (zero length: t = 0/0 = NaN collides with every active sphere, longer than the
+// ball, non-finite) walk the whole table behind the packed fp32 midpoint screen.  The screens only
+// ever skip pairs that cannot collide; every decision is edge_hits_sphere.  All lanes of the wave call
+// this together.  len = sqrt(sq3(sample, node)).
+__device__ __forceinline__ void edge_flags(const ExtendDev &x, bool act, double sx, double sy, double sz, double tx,
+                                           double ty, double tz, double len, int nl_in, const int *list, bool &out_hit,
+                                           bool &in_hit) {
+  // out: sample -> near ; in: near -> sample.  edgeLen is the same value either way
+  const double bx = tx - sx, by = ty - sy, bz = tz - sz;
+  const double cx = sx - tx, cy = sy - ty, cz = sz - tz;
+  out_hit = false; in_hit = false;
+  if (__ballot(act) == 0ull) return;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const double cmax = fmax(fmax(fmax(fabs(sx), fabs(sy)), fmax(fabs(sz), fabs(tx))), fmax(fabs(ty), fabs(tz)));
+  const bool usable = (len > 0.0) && (len < 1e30) && (cmax < 1e30) && (sx == sx) && (sy == sy) && (sz == sz) &&
+                      (tx == tx) && (ty == ty) && (tz == tz);
+  bool need_full = act;
+  if (x.r_bound >= 0.0) {
+    int nl = 0;
+    if (act) {
+      nl = nl_in;
+      need_full = !usable || nl > kSphListCap || !(len <= x.r_bound);
+      if (need_full) nl = 0;
+    }
+    for (int c = 0; __ballot(c < nl) != 0ull; ++c) {
+      if (c < nl && !(out_hit && in_hit)) {
+        const SphRec ob = x.sph[list[c]];
+        if (!out_hit) out_hit = edge_hits_sphere(sx, sy, sz, bx, by, bz, len, ob);
+        if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len, ob);
+      }
+    }
+    if (__ballot(need_full) == 0ull) return;
+  }
+  const ReachProbe rp = reach_probe(x, 0.5 * (sx + tx), 0.5 * (sy + ty), 0.5 * (sz + tz), 0.5 * len, usable);
+  const f32x2 m2x = {rp.mx, rp.mx}, m2y = {rp.my, rp.my}, m2z = {rp.mz, rp.mz}, h2 = {rp.h, rp.h};
+  constexpr int G = 8;
+  const int m = x.m;
+  for (int j0 = 0; j0 < m; j0 += G) {
+    const float *gp = x.reach_f + (size_t)(j0 / 8) * 32;      // wave-uniform
+    unsigned touch = 0u;
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      const f32x2 ccx = {gp[8 * pr + 0], gp[8 * pr + 1]}, ccy = {gp[8 * pr + 2], gp[8 * pr + 3]};
+      const f32x2 ccz = {gp[8 * pr + 4], gp[8 * pr + 5]}, rr = {gp[8 * pr + 6], gp[8 * pr + 7]};
+      const f32x2 dx = ccx - m2x, dy = ccy - m2y, dz = ccz - m2z;
+      f32x2 dm2 = dx * dx;
+      dm2 = __builtin_elementwise_fma(dy, dy, dm2);
+      dm2 = __builtin_elementwise_fma(dz, dz, dm2);
+      const f32x2 bound = rr + h2;
+      const f32x2 b2 = bound * bound;
+      touch |= (!(dm2.x > b2.x) ? 1u : 0u) << (2 * pr);
+      touch |= (!(dm2.y > b2.y) ? 1u : 0u) << (2 * pr + 1);
+    }
+    if (j0 + G > m) touch &= (1u << (m - j0)) - 1u;
+    if (!need_full) touch = 0u;
+    if (__ballot(touch != 0u) == 0ull) continue;
+    for (int g = 0; g < G; ++g) {
+      if (__ballot((touch >> g) & 1u) == 0ull) continue;
+      if (((touch >> g) & 1u) && !(out_hit && in_hit)) {
+        const SphRec ob = x.sph[j0 + g];
+        if (!out_hit) out_hit = edge_hits_sphere(sx, sy, sz, bx, by, bz, len, ob);
+        if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len, ob);
+      }
+    }
+    if (__ballot(need_full && !(out_hit && in_hit)) == 0ull) break;
+  }
+}
+
+// Sample pass for one (sample, pair of spheres): explicitPointCheck's per-sphere terms
+// (R/DRRT_Q.jl:1402-1415, 1463-1487 as thresholds on the squared distance) and membership in the
+// sample's sphere list.  Spheres the fp32 screen rules out are farther than reach + ball radius from
+// the sample: neither inside, nor closer than the robot radius, nor touchable by an edge in the ball.
+// Returns true if one of the two spheres makes the sample unsafe; listed spheres go to `on_list`.
+// (u, v) = the pair's two table rows {cxA,cxB,cyA,cyB} {czA,czB,RA,RB}, loaded by the caller.
+template <class OnList>
+__device__ __forceinline__ bool sample_pair(const ExtendDev &x, int pr, const float4 u, const float4 v, double px,
+                                            double py, double pz, const ReachProbe &rp, double base_b,
+                                            const OnList &on_list) {
+  const float dxa = u.x - rp.mx, dya = u.z - rp.my, dza = v.x - rp.mz;
+  const float dxb = u.y - rp.mx, dyb = u.w - rp.my, dzb = v.y - rp.mz;
+  float da = dxa * dxa; da = __builtin_fmaf(dya, dya, da); da = __builtin_fmaf(dza, dza, da);
+  float db = dxb * dxb; db = __builtin_fmaf(dyb, dyb, db); db = __builtin_fmaf(dzb, dzb, db);
+  const float ba = v.z + rp.h, bb = v.w + rp.h;
+  const unsigned near = (!(da > ba * ba) ? 1u : 0u) | (!(db > bb * bb) ? 2u : 0u);
+  bool bad = false;
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int j = 2 * pr + h2;
+    if (((near >> h2) & 1u) && j < x.m) {
+      const SampleSph sp = x.stab[j];
+      const double s = sq3(sp.cx, sp.cy, sp.cz, px, py, pz);
+      bad = bad | !(s >= sp.thr_in) | (s < sp.thr_pt);
+      const double B = base_b + sp.reach;
+      if (x.r_bound >= 0.0 && !(s > B * B * (1.0 + 1e-12))) on_list(j);
+    }
+  }
+  return bad;
+}
+
 }  // namespace
 }  // namespace rrtx

@@ -1,6 +1,5 @@
 // kernels_finish.hip -- the last launch of the range search: one kernel turns the per-query hit
-// buckets into the caller's CSR lists and, for the fused extend() preamble against the sphere list,
-// also runs the sample pass and the candidate-edge checks on the lists while they are in registers.
+// buckets into the caller's CSR lists.
 //
 // Replaces, per workgroup of 16 queries (half a wave each):
 //   offsets : exclusive scan of the list lengths -- workgroup b adds up the 16 b counts before it
@@ -13,11 +12,9 @@
 //             are sorted by the whole workgroup (bitonic network in LDS up to 2048 entries)
 //   nearest : a sample whose ball is empty gets kdFindNearest's answer from an expanding search
 //             over the slab index (block_nearest, nn_device.hpp) -- no -1 leaves the device
-//   extend  : explicitPointCheck of the sample + the spheres its candidate edges can touch, then
-//             both directed edges of every list entry against those spheres
-//             (R/DRRT_Q.jl:1520-1556, 1775-1826, 1951-1963, 2600-2602)
+//   extend  : the two collision flags every record of the fused extend() path carries (decided where
+//             the neighbour was found, kernels_nn.hip TileEmit) go to hit_out / hit_in
 // gfx950 only.
-#include "collide_device.hpp"
 #include "nn_device.hpp"
 
 namespace rrtx {
@@ -49,22 +46,10 @@ struct FinishArgs {
   int *qhist;                  // bucket histogram of the culled search, re-zeroed for the next call
   int n_qhist;
   unsigned *mailbox;           // host-mapped: [0] = overflow records of this call
-  const double *q;             // query points (nearest of empty balls, sample pass)
+  const double *q;             // query points (nearest of empty balls)
+  uint8_t *hit_out, *hit_in;   // fused extend(): flags of the records (null otherwise)
   double r_start;
   NearestIndex ni;
-  int tune;
-};
-
-struct ExtendArgs {
-  const double4 *naos;         // node coordinates, one 32-byte record per node
-  const SphRec *sph;
-  const SampleSph *stab;
-  const float *reach_f;        // fp32 reach table (sync_spheres)
-  double ox, oy, oz;
-  int m;                       // active spheres
-  int n_nodes;
-  double r_bound;              // radius of the ball the lists were built with, < 0: no lists (full loop)
-  uint8_t *hit_out, *hit_in, *sample_unsafe;
 };
 
 struct FinLds {
@@ -73,11 +58,10 @@ struct FinLds {
   int kfull[kFinQ];            // list length as counted
   int todo[kFinQ];             // the list needs the whole workgroup
   int empty[kFinQ];
-  int nl[kFinQ];
-  int sl[kFinQ][kSphListCap];
   int gcnt;
   int s_idx[kBigSort];
   double s_d2[kBigSort];
+  unsigned char s_fl[kBigSort];   // the records' edge flags travel with the sort
   double r_best[kFinThreads / 64];
   int r_besti[kFinThreads / 64];
   NearestScratch ns;
@@ -92,98 +76,15 @@ __device__ __forceinline__ BktRec load_rec(const FinishArgs &a, int q, long long
   const unsigned long long w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned long long w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   r.idx = (int)(unsigned)(w0 & 0xffffffffull);
-  r.pad = 0;
+  r.pad = (int)(unsigned)(w0 >> 32);
   r.d2 = __longlong_as_double((long long)w1);
   return r;
 }
 
-// Both directed edges sample <-> node against the sphere list (the body of candidate_edges_kernel,
-// kernels_collide.hip, for one list entry).  Every lane of the wave calls this together.
-__device__ __forceinline__ void candidate_edge(const ExtendArgs &x, bool act, double sx, double sy, double sz, int node,
-                                               int nl_in, const int *list, bool &out_hit, bool &in_hit) {
-  double tx = 0, ty = 0, tz = 0;
-  act = act && (unsigned)node < (unsigned)x.n_nodes;     // defensive: never index out of range
-  if (act) {
-    const double4 nd = x.naos[node];
-    tx = nd.x; ty = nd.y; tz = nd.z;
-  }
-  // out: sample -> near ; in: near -> sample.  edgeLen is the same value either way
-  const double bx = tx - sx, by = ty - sy, bz = tz - sz;
-  const double cx = sx - tx, cy = sy - ty, cz = sz - tz;
-  const double len = sqrt_rn(sq3(sx, sy, sz, tx, ty, tz));
-  out_hit = false; in_hit = false;
-  if (__ballot(act) == 0ull) return;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const double cmax = fmax(fmax(fmax(fabs(sx), fabs(sy)), fmax(fabs(sz), fabs(tx))), fmax(fabs(ty), fabs(tz)));
-  const bool usable = (len > 0.0) && (len < 1e30) && (cmax < 1e30) && (sx == sx) && (sy == sy) && (sz == sz) &&
-                      (tx == tx) && (ty == ty) && (tz == tz);
-  // ---- fast path: only the spheres on the sample's list ----
-  bool need_full = act;
-  if (x.r_bound >= 0.0) {
-    int nl = 0;
-    if (act) {
-      nl = nl_in;
-      // the list only covers edges inside the ball it was built for
-      need_full = !usable || nl > kSphListCap || !(len <= x.r_bound);
-      if (need_full) nl = 0;
-    }
-    for (int c = 0; __ballot(c < nl) != 0ull; ++c) {
-      if (c < nl && !(out_hit && in_hit)) {
-        const SphRec ob = x.sph[list[c]];
-        if (!out_hit) out_hit = edge_hits_sphere(sx, sy, sz, bx, by, bz, len, ob);
-        if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len, ob);
-      }
-    }
-    if (__ballot(need_full) == 0ull) return;
-  }
-  // ---- full obstacle loop for the lanes that need it (packed fp32 midpoint screen, exact test
-  //      of what it cannot rule out; see candidate_edges_kernel) ----
-  float mxf, myf, mzf, hlsf;
-  {
-    const double mx = 0.5 * (sx + tx) - x.ox, my = 0.5 * (sy + ty) - x.oy, mz = 0.5 * (sz + tz) - x.oz;
-    mxf = (float)mx; myf = (float)my; mzf = (float)mz;
-    const double eps = 5.9604644775390625e-08;
-    const double h = (0.5 * len * (1.0 + 1e-12) + 3.0 * eps * (fabs(mx) + fabs(my) + fabs(mz)) + 1e-30) * (1.0 + 8.0 * eps);
-    hlsf = usable ? __double2float_ru(h) : __builtin_inff();
-    if (!usable) { mxf = 0.f; myf = 0.f; mzf = 0.f; }
-  }
-  const f32x2 m2x = {mxf, mxf}, m2y = {myf, myf}, m2z = {mzf, mzf}, h2 = {hlsf, hlsf};
-  constexpr int G = 8;
-  const int m = x.m;
-  for (int j0 = 0; j0 < m; j0 += G) {
-    const float *gp = x.reach_f + (size_t)(j0 / 8) * 32;
-    unsigned touch = 0u;
-#pragma unroll
-    for (int pr = 0; pr < 4; ++pr) {
-      const f32x2 ccx = {gp[8 * pr + 0], gp[8 * pr + 1]}, ccy = {gp[8 * pr + 2], gp[8 * pr + 3]};
-      const f32x2 ccz = {gp[8 * pr + 4], gp[8 * pr + 5]}, rr = {gp[8 * pr + 6], gp[8 * pr + 7]};
-      const f32x2 dx = ccx - m2x, dy = ccy - m2y, dz = ccz - m2z;
-      f32x2 dm2 = dx * dx;
-      dm2 = __builtin_elementwise_fma(dy, dy, dm2);
-      dm2 = __builtin_elementwise_fma(dz, dz, dm2);
-      const f32x2 bound = rr + h2;
-      const f32x2 b2 = bound * bound;
-      touch |= (!(dm2.x > b2.x) ? 1u : 0u) << (2 * pr);
-      touch |= (!(dm2.y > b2.y) ? 1u : 0u) << (2 * pr + 1);
-    }
-    if (j0 + G > m) touch &= (1u << (m - j0)) - 1u;
-    if (!need_full) touch = 0u;
-    if (__ballot(touch != 0u) == 0ull) continue;
-    for (int g = 0; g < G; ++g) {
-      if (__ballot((touch >> g) & 1u) == 0ull) continue;
-      if (((touch >> g) & 1u) && !(out_hit && in_hit)) {
-        const SphRec ob = x.sph[j0 + g];
-        if (!out_hit) out_hit = edge_hits_sphere(sx, sy, sz, bx, by, bz, len, ob);
-        if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len, ob);
-      }
-    }
-    if (__ballot(need_full && !(out_hit && in_hit)) == 0ull) break;
-  }
-}
-
-// D: coordinates per query point; EXT: fused extend() work against the sphere list (D == 3)
-template <int D, bool EXT, int OCC>
-__global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs a, ExtendArgs x) {
+// D: coordinates per query point.  Eight waves per SIMD = four workgroups per CU: the 1024 workgroups of
+// a 16384-query batch are then resident at once and the kernel is one pass of their dependency chain.
+template <int D>
+__global__ __launch_bounds__(kFinThreads, 8) void nn_finish_kernel(FinishArgs a) {
   __shared__ FinLds sm;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -194,7 +95,7 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
 
   // ---- housekeeping for the next call ----
   for (int k = (int)blockIdx.x * kFinThreads + t; k < a.n_qhist; k += (int)gridDim.x * kFinThreads) a.qhist[k] = 0;
-  if (blockIdx.x == 0 && t == 0 && a.mailbox && !(a.tune & 8)) {
+  if (blockIdx.x == 0 && t == 0 && a.mailbox) {
     const unsigned long long tot = a.sc->total;
     a.mailbox[0] = tot > 0xffffffffull ? 0xffffffffu : (unsigned)tot;
   }
@@ -204,7 +105,7 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
   // for the offsets, so the prefix over the preceding counts travels beside them.
   // (No workgroup barrier on the way: a barrier waits for every outstanding load.  Each half wave
   // resets its own LDS words; LDS operations of one wave execute in order.)
-  if (hl == 0) { sm.todo[hw] = 0; sm.empty[hw] = 0; sm.nl[hw] = 0; }
+  if (hl == 0) { sm.todo[hw] = 0; sm.empty[hw] = 0; }
   int kfull = 0;
   if (qv) kfull = a.count[q];
   const int kInt = 0x7fffffff;
@@ -214,12 +115,8 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
   // the first 32 slots of the bucket are requested before the count has arrived (bcap >= 8; slots past
   // the count hold stale records and are masked below)
   if (qv && hl < a.bcap) e0 = a.bkt[(size_t)q * (size_t)a.bcap + (size_t)hl];
-  double px = 0, py = 0, pz = 0;
-  if constexpr (EXT) {
-    if (qv) { px = a.q[(size_t)q * D + 0]; py = a.q[(size_t)q * D + 1]; pz = a.q[(size_t)q * D + 2]; }
-  }
   long long psum = 0;
-  if (!a.prescattered && !(a.tune & 2)) {
+  if (!a.prescattered) {
     // 16 b counts precede workgroup b
     const int4 *c4 = reinterpret_cast<const int4 *>(a.count);
     const int n4 = (int)blockIdx.x * (kFinQ / 4);
@@ -235,57 +132,6 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
   if (!(hl < kk)) { e0.idx = kInt; e0.d2 = __builtin_inf(); }
   if (hl + 32 < kk) e1 = a.bkt[(size_t)q * (size_t)a.bcap + (size_t)(hl + 32)];
   __builtin_amdgcn_wave_barrier();
-
-  // ---- sample pass (EXT): explicitPointCheck + the spheres the candidate edges can touch ----
-  if constexpr (EXT) {
-    bool bad = false;
-    if (x.m > 0) {
-      const double rb = x.r_bound >= 0.0 ? x.r_bound : 0.0;
-      const double pmax = fmax(fmax(fabs(px), fabs(py)), fabs(pz));
-      // slack for the rounding of the foot point and of this distance; NaN / inf sample: everything is a candidate
-      const double base_b = rb + 1e-12 * (pmax + 1.0);
-      const double mx = px - x.ox, my = py - x.oy, mz = pz - x.oz;
-      const bool usable = (pmax < 1e30) && (px == px) && (py == py) && (pz == pz) && (base_b < 1e30);
-      const double eps = 5.9604644775390625e-08;
-      const double h = (base_b * (1.0 + 1e-12) + 3.0 * eps * (fabs(mx) + fabs(my) + fabs(mz)) + 1e-30) * (1.0 + 8.0 * eps);
-      const float hf = usable ? __double2float_ru(h) : __builtin_inff();
-      const float mxf = usable ? (float)mx : 0.f, myf = usable ? (float)my : 0.f, mzf = usable ? (float)mz : 0.f;
-      const int n_pairs = (x.m + 1) / 2;
-      const float4 *tp = reinterpret_cast<const float4 *>(x.reach_f);
-      for (int pr0 = 0; pr0 < n_pairs; pr0 += 32) {
-        const int pr = pr0 + hl;
-        unsigned near = 0u;
-        if (qv && pr < n_pairs) {
-          const float4 u = tp[2 * pr], v = tp[2 * pr + 1];   // {cxA,cxB,cyA,cyB} {czA,czB,RA,RB}
-          const float dxa = u.x - mxf, dya = u.z - myf, dza = v.x - mzf;
-          const float dxb = u.y - mxf, dyb = u.w - myf, dzb = v.y - mzf;
-          float da = dxa * dxa; da = __builtin_fmaf(dya, dya, da); da = __builtin_fmaf(dza, dza, da);
-          float db = dxb * dxb; db = __builtin_fmaf(dyb, dyb, db); db = __builtin_fmaf(dzb, dzb, db);
-          const float ba = v.z + hf, bb = v.w + hf;
-          near = (!(da > ba * ba) ? 1u : 0u) | (!(db > bb * bb) ? 2u : 0u);
-        }
-        // the few spheres within reach: exact evaluation
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const int j = 2 * pr + h2;
-          if (((near >> h2) & 1u) && j < x.m) {
-            const SampleSph sp = x.stab[j];
-            const double s = sq3(sp.cx, sp.cy, sp.cz, px, py, pz);
-            bad = bad | !(s >= sp.thr_in) | (s < sp.thr_pt);
-            const double B = base_b + sp.reach;
-            if (x.r_bound >= 0.0 && !(s > B * B * (1.0 + 1e-12))) {
-              const int at = atomicAdd(&sm.nl[hw], 1);
-              if (at < kSphListCap) sm.sl[hw][at] = j;
-            }
-          }
-        }
-      }
-    }
-    const unsigned long long bm = __ballot(bad);
-    const bool any_bad = ((bm >> (32 * (hw & 1))) & 0xffffffffull) != 0ull;
-    if (qv && hl == 0 && x.sample_unsafe) x.sample_unsafe[q] = any_bad ? 1 : 0;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // LDS list of this half wave: written above, read below
-    __builtin_amdgcn_wave_barrier();
-  }
 
   // ---- short lists: rank by node index inside the half wave ----
   const int m0 = e0.idx, m1 = e1.idx;
@@ -313,15 +159,6 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
       const double ob = __shfl_xor(nbest, off);
       const int oi = __shfl_xor(nbest_i, off);
       if ((ob < nbest) || (ob == nbest && oi < nbest_i)) { nbest = ob; nbest_i = oi; }
-    }
-  }
-  bool ho0 = false, hi0 = false, ho1 = false, hi1 = false;
-  if constexpr (EXT) {
-    // both directed edges of the entries this lane holds
-    const int nl = sm.nl[hw];
-    if (__ballot(kk > 0) != 0ull) {
-      candidate_edge(x, hl < kk, px, py, pz, m0, nl, sm.sl[hw], ho0, hi0);
-      if (__ballot(hl + 32 < kk) != 0ull) candidate_edge(x, hl + 32 < kk, px, py, pz, m1, nl, sm.sl[hw], ho1, hi1);
     }
   }
 
@@ -360,18 +197,18 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
   // ---- results of the short lists at their sorted places (never past the caller's capacity) ----
   {
     const long long b = qv ? sm.off[hw] : 0;
-    const bool w0 = hl < kk && b + r0 < a.out_cap && !(a.tune & 16), w1 = hl + 32 < kk && b + r1 < a.out_cap && !(a.tune & 16);
+    const bool w0 = hl < kk && b + r0 < a.out_cap, w1 = hl + 32 < kk && b + r1 < a.out_cap;
     if (w0) {
       a.idx[b + r0] = m0;
       a.dist[b + r0] = sqrt_rn(d0);
       if (a.owner) a.owner[b + r0] = q;
-      if constexpr (EXT) { x.hit_out[b + r0] = ho0 ? 1 : 0; x.hit_in[b + r0] = hi0 ? 1 : 0; }
+      if (a.hit_out) { a.hit_out[b + r0] = e0.pad & 1; a.hit_in[b + r0] = (e0.pad >> 1) & 1; }
     }
     if (w1) {
       a.idx[b + r1] = m1;
       a.dist[b + r1] = sqrt_rn(d1);
       if (a.owner) a.owner[b + r1] = q;
-      if constexpr (EXT) { x.hit_out[b + r1] = ho1 ? 1 : 0; x.hit_in[b + r1] = hi1 ? 1 : 0; }
+      if (a.hit_out) { a.hit_out[b + r1] = e1.pad & 1; a.hit_in[b + r1] = (e1.pad >> 1) & 1; }
     }
     if (a.nearest_idx && qv && small && hl == 0) {
       if (kk > 0) { a.nearest_idx[q] = nbest_i; a.nearest_dist[q] = sqrt_rn(nbest); }
@@ -382,7 +219,7 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
   __syncthreads();
 
   // ---- long or overflowed lists: the whole workgroup, one list at a time ----
-  for (int g = 0; g < kFinQ && !(a.tune & 4); ++g) {
+  for (int g = 0; g < kFinQ; ++g) {
     if (!sm.todo[g]) continue;           // workgroup-uniform
     const int qq = q0 + g;
     const long long gb = sm.off[g];
@@ -398,11 +235,12 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
       if (total > a.ovf_cap) total = a.ovf_cap;
       for (long long i = t; i < total; i += kFinThreads) {
         const HitRec r = a.ovf[i];
-        if (r.owner == qq) {
+        if ((r.owner & 0x3fffffff) == qq) {
           const long long dst = gb + a.bcap + atomicAdd(&sm.gcnt, 1);
           if (dst < a.out_cap) {
             unsigned long long *p = reinterpret_cast<unsigned long long *>(a.tmp + dst);
-            __hip_atomic_store(p, (unsigned long long)(unsigned)r.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p, (unsigned long long)(unsigned)r.idx | ((unsigned long long)((unsigned)r.owner >> 30) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(p + 1, (unsigned long long)__double_as_longlong(r.d2), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -413,12 +251,6 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
     }
     double best = __builtin_inf();
     int best_i = 0x7fffffff;
-    double gx = 0, gy = 0, gz = 0;
-    int gnl = 0;
-    if constexpr (EXT) {
-      gx = a.q[(size_t)qq * D + 0]; gy = a.q[(size_t)qq * D + 1]; gz = a.q[(size_t)qq * D + 2];
-      gnl = sm.nl[g];
-    }
     if (gk <= kBigSort) {
       int n2 = 64;
       while (n2 < gk) n2 <<= 1;
@@ -428,6 +260,7 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
         if (i < gk) r = load_rec(a, qq, gb, i);
         sm.s_idx[i] = r.idx;
         sm.s_d2[i] = r.d2;
+        sm.s_fl[i] = (unsigned char)r.pad;
       }
       __syncthreads();
       for (int size = 2; size <= n2; size <<= 1) {
@@ -441,6 +274,8 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
                 sm.s_idx[i] = cc; sm.s_idx[j] = aa;
                 const double da = sm.s_d2[i];
                 sm.s_d2[i] = sm.s_d2[j]; sm.s_d2[j] = da;
+                const unsigned char fa = sm.s_fl[i];
+                sm.s_fl[i] = sm.s_fl[j]; sm.s_fl[j] = fa;
               }
             }
           }
@@ -459,11 +294,7 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
           a.dist[gb + i] = sqrt_rn(d2);
           if (a.owner) a.owner[gb + i] = qq;
           if ((d2 < best) || (d2 == best && my < best_i)) { best = d2; best_i = my; }
-        }
-        if constexpr (EXT) {
-          bool ho, hi;
-          candidate_edge(x, act, gx, gy, gz, my, gnl, sm.sl[g], ho, hi);
-          if (act) { x.hit_out[gb + i] = ho ? 1 : 0; x.hit_in[gb + i] = hi ? 1 : 0; }
+          if (a.hit_out) { const int fl = sm.s_fl[i]; a.hit_out[gb + i] = fl & 1; a.hit_in[gb + i] = (fl >> 1) & 1; }
         }
       }
     } else {
@@ -481,11 +312,7 @@ __global__ __launch_bounds__(kFinThreads, OCC) void nn_finish_kernel(FinishArgs 
           a.dist[gb + rank] = sqrt_rn(d2);
           if (a.owner) a.owner[gb + rank] = qq;
           if ((d2 < best) || (d2 == best && my < best_i)) { best = d2; best_i = my; }
-        }
-        if constexpr (EXT) {
-          bool ho, hi;
-          candidate_edge(x, act, gx, gy, gz, my, gnl, sm.sl[g], ho, hi);
-          if (act) { x.hit_out[gb + rank] = ho ? 1 : 0; x.hit_in[gb + rank] = hi ? 1 : 0; }
+          if (a.hit_out) { a.hit_out[gb + rank] = r.pad & 1; a.hit_in[gb + rank] = (r.pad >> 1) & 1; }
         }
       }
     }
@@ -549,34 +376,15 @@ int launch_nn_finish(rrtx_ctx *ctx, const FinishLaunch &f) {
   // empty balls are resolved on the device only where the nearest comes off the lists at all
   // (no wrapped dimensions: with ghosts a list key is not the distance to the query itself)
   a.want_nearest_fix = (f.nearest_idx && ctx->n_wraps == 0) ? 1 : 0;
-  a.tune = ctx->opt_tune;
   a.ni.sx = ctx->sl_d[0]; a.ni.sy = ctx->sl_d[1]; a.ni.sz = ctx->sl_d[2]; a.ni.sw = ctx->sl_d[D == 4 ? 3 : 2];
   a.ni.sid = ctx->sl_id;
   a.ni.chunk_ext = reinterpret_cast<const ChunkExt *>(ctx->chunk_ext);
   a.ni.n_nodes = (int)ctx->n_nodes;
   a.ni.n_chunks = (int)((ctx->n_nodes + kSlabChunk - 1) / kSlabChunk);
-  ExtendArgs x;
-  std::memset(&x, 0, sizeof(x));
-  x.r_bound = -1.0;
-  const bool ext = f.ext != nullptr;
-  if (ext) {
-    if (D != 3) return fail(ctx, RRTX_E_STATE, "fused extend finish is the SimpleEdge (dim=3) path");
-    x.naos = reinterpret_cast<const double4 *>(ctx->nodes_aos);
-    x.sph = ctx->d_sph.as<SphRec>();
-    x.stab = ctx->d_sph_sample.as<SampleSph>();
-    x.reach_f = ctx->d_sph_reach_f.as<float>();
-    x.ox = ctx->origin[0]; x.oy = ctx->origin[1]; x.oz = ctx->origin[2];
-    x.m = ctx->sph_n_active;
-    x.n_nodes = (int)ctx->n_nodes;
-    x.r_bound = (f.ext->r >= 0.0 && x.m > 0) ? f.ext->r * (1.0 + 1e-12) : -1.0;
-    x.hit_out = f.ext->hit_out; x.hit_in = f.ext->hit_in; x.sample_unsafe = f.ext->sample_unsafe;
-  }
+  a.hit_out = f.hit_out; a.hit_in = f.hit_in;
   const dim3 grid((unsigned)((f.nq + kFinQ - 1) / kFinQ)), block(kFinThreads);
-  if (ext) {
-    if (ctx->opt_tune & 1) hipLaunchKernelGGL((nn_finish_kernel<3, true, 6>), grid, block, 0, ctx->stream, a, x);
-    else hipLaunchKernelGGL((nn_finish_kernel<3, true, 4>), grid, block, 0, ctx->stream, a, x);
-  } else if (D == 4) hipLaunchKernelGGL((nn_finish_kernel<4, false, 4>), grid, block, 0, ctx->stream, a, x);
-  else hipLaunchKernelGGL((nn_finish_kernel<3, false, 4>), grid, block, 0, ctx->stream, a, x);
+  if (D == 4) hipLaunchKernelGGL(nn_finish_kernel<4>, grid, block, 0, ctx->stream, a);
+  else hipLaunchKernelGGL(nn_finish_kernel<3>, grid, block, 0, ctx->stream, a);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
 }

@@ -18,6 +18,7 @@
 //   scatter : overflow list -> behind the buckets (normally nothing to do)
 //   order   : per query: sort by node index, dist = sqrt(d2), owner, nearest
 //   order_big: the same for lists longer than 64
+#include "collide_device.hpp"
 #include "nn_device.hpp"
 
 #include <limits>
@@ -417,6 +418,14 @@ struct TileLds {
   int lcnt[kTileB];
   typename QRecT<D>::type cp[kTileB];
   BktRec hrec[kTileB][kTbLcap];
+  // fused extend() path: per copy (= sample) the spheres its candidate edges can touch, and whether
+  // the sample itself is in collision
+  int snl[kTileB];
+  int sbad[kTileB];
+  int sok[kTileB];             // the sample's coordinates are finite and moderate (screens apply)
+  float4 srp[kTileB];          // the sample's probe of the fp32 reach table (centre, inflated ball radius)
+  double sbase[kTileB];        // ball radius + slack of the exact list test
+  int ssl[kTileB][kSphListCap];
 };
 
 // the (x, y) cell structure of the sorted part of the slab index
@@ -426,16 +435,38 @@ struct TileGrid {
   int n_sorted_chunks;         // chunks [0, n_sorted_chunks) hold sorted positions only
 };
 
+// EXT: every confirmed neighbour is a candidate edge of extend().  Both directed edges are checked
+// against the sample's sphere list when the tile hands its hits to the buckets (tile_edge_flags) and
+// the two booleans travel in the record's spare word.
 template <int D>
+__device__ __forceinline__ int tile_edge_flags(const ExtendDev &x, const TileLds<D> &sm, bool h, int cl, int id,
+                                               double d2) {
+  // Most samples have no sphere within reach of their ball (sok: finite, moderate coordinates): an
+  // edge inside the ball then collides with nothing and needs neither the node's coordinates nor a
+  // test.  (d2 finite and the sample finite => the node is finite; len <= r_bound => the list covers it.)
+  const double len = sqrt_rn(d2);
+  const bool quick = sm.snl[cl] == 0 && sm.sok[cl] != 0 && len > 0.0 && len <= x.r_bound && len < 1e29;
+  const bool need = h && !quick && x.m > 0;
+  if (__ballot(need) == 0ull) return 0;
+  double tx = 0, ty = 0, tz = 0;
+  if (need) { const double4 nd = x.naos[id]; tx = nd.x; ty = nd.y; tz = nd.z; }
+  const typename QRecT<D>::type c = sm.cp[cl];
+  bool ho, hi;
+  edge_flags(x, need, c.x, c.y, c.z, tx, ty, tz, len, sm.snl[cl], sm.ssl[cl], ho, hi);
+  return (ho ? 1 : 0) | (hi ? 2 : 0);
+}
+
+template <int D, bool EXT>
 struct TileEmit {
   static constexpr bool kNeedsOwner = false;
   TileLds<D> &sm;
   const HitSink &hs;
   const int2 *meta;
+  const ExtendDev &x;
   int q0;
   __device__ __forceinline__ void operator()(bool h, int q, int /*owner*/, int id, double d2) const {
+    const int cl = h ? q - q0 : 0;
     int slot = 0;
-    const int cl = q - q0;
     if (h) slot = atomicAdd(&sm.lcnt[cl], 1);
     const bool in_lds = h && slot < kTbLcap;
     if (in_lds) {
@@ -445,20 +476,23 @@ struct TileEmit {
     }
     const bool spill = h && !in_lds;
     if (__ballot(spill) != 0ull) {
-      int owner = 0;
+      // a dense ball (more than kTbLcap hits of one copy in one tile): straight to the bucket
+      int owner = 0, flags = 0;
       if (spill) owner = meta[q].x;
-      emit_hits_grouped(hs, spill, owner, id, d2);   // at most kTileB queries per wave
+      if constexpr (EXT) flags = tile_edge_flags<D>(x, sm, spill, cl, id, d2);
+      emit_hits_grouped(hs, spill, owner, id, d2, flags);   // at most kTileB queries per wave
     }
   }
 };
 
-template <int D>
+template <int D, bool EXT>
 __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
     const float *__restrict__ fx, const float *__restrict__ fy, const float *__restrict__ fz,
     const float *__restrict__ fw, const float *__restrict__ fpp, int n_nodes, int n_chunks,
     const ChunkExt *__restrict__ chunk_ext, const typename QRecT<D>::type *__restrict__ copies_s, const typename QRecFT<D>::type *__restrict__ copies_f,
     const Scalars *__restrict__ sc, int n_parts, int2 *__restrict__ ev, int slice_cap,
-    const ConfirmArgs a, const ConfirmArgs *__restrict__ ca, const TileGrid tg, int *__restrict__ visits) {
+    const ConfirmArgs a, const ConfirmArgs *__restrict__ ca, const TileGrid tg, const ExtendDev x,
+    int *__restrict__ visits) {
   __shared__ TileLds<D> sm;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -488,6 +522,18 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
       if (q0 + lane < q1) {
         const typename QRecT<D>::type c = copies_s[q0 + lane];
         sm.cp[lane] = c;
+        if constexpr (EXT) {
+          const double rb = x.r_bound >= 0.0 ? x.r_bound : 0.0;
+          const double pmax = fmax(fmax(fabs(c.x), fabs(c.y)), fabs(c.z));
+          // slack for the rounding of the foot point and of this distance; NaN / inf sample: everything is a candidate
+          const double base_b = rb + 1e-12 * (pmax + 1.0);
+          const bool usable = (pmax < 1e29) && (c.x == c.x) && (c.y == c.y) && (c.z == c.z) && (base_b < 1e29);
+          const ReachProbe rp = reach_probe(x, c.x, c.y, c.z, base_b, usable);
+          sm.srp[lane] = make_float4(rp.mx, rp.my, rp.mz, rp.h);
+          sm.sbase[lane] = base_b;
+          sm.sok[lane] = (usable && x.r_bound >= 0.0) ? 1 : 0;
+          sm.snl[lane] = 0; sm.sbad[lane] = 0;
+        }
         // thr NaN / <= 0, x or y NaN or +-inf: the copy can never have a neighbour
         const bool can_hit = (c.thr > 0.0) && (c.x - c.x == 0.0) && (c.y - c.y == 0.0);
         if (can_hit) {
@@ -551,9 +597,39 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
               listed_to = max(listed_to, __shfl(run, 63));
             }
           }
+        } else if (EXT && wave >= 2) {
+          // ---- 1b. sample pass beside the list building (waves 2 and 3): a lane owns a pair of
+          //      spheres (one table read) and walks the tile's samples, whose probes are in LDS ----
+          if (cb == 0) {
+            const int n_pairs = (x.m + 1) / 2;
+            const float4 *tp = reinterpret_cast<const float4 *>(x.reach_f);
+            for (int pr = t - 128; pr < n_pairs; pr += 128) {
+              const float4 u = tp[2 * pr], v = tp[2 * pr + 1];
+              for (int cl = 0; cl < q1 - q0; ++cl) {
+                const float4 pf = sm.srp[cl];
+                ReachProbe rp;
+                rp.mx = pf.x; rp.my = pf.y; rp.mz = pf.z; rp.h = pf.w;
+                // cheap pre-test on the lane's two spheres before touching the sample's fp64 record
+                const float dxa = u.x - rp.mx, dya = u.z - rp.my, dza = v.x - rp.mz;
+                const float dxb = u.y - rp.mx, dyb = u.w - rp.my, dzb = v.y - rp.mz;
+                float da = dxa * dxa; da = __builtin_fmaf(dya, dya, da); da = __builtin_fmaf(dza, dza, da);
+                float db = dxb * dxb; db = __builtin_fmaf(dyb, dyb, db); db = __builtin_fmaf(dzb, dzb, db);
+                const float ba = v.z + rp.h, bb = v.w + rp.h;
+                if (!(da > ba * ba) || !(db > bb * bb)) {
+                  const typename QRecT<D>::type c = sm.cp[cl];
+                  const bool bad = sample_pair(x, pr, u, v, c.x, c.y, c.z, rp, sm.sbase[cl], [&](int j) {
+                    const int at = atomicAdd(&sm.snl[cl], 1);
+                    if (at < kSphListCap) sm.ssl[cl][at] = j;
+                  });
+                  if (bad) sm.sbad[cl] = 1;
+                }
+              }
+            }
+          }
         } else {
           // appended since the last rebuild (and the chunk the sorted part ends in): by extent
-          for (int c = max(cb, tg.n_sorted_chunks) + (t - 64); c < ce; c += kScanThreads - 64) {
+          const int nt = EXT ? 64 : 192;         // wave 1 (and waves 2, 3 unless they run the sample pass)
+          for (int c = max(cb, tg.n_sorted_chunks) + (t - 64); c < ce; c += nt) {
             const ChunkExt cx = chunk_ext[c];
             if (dec_ord(cx.xhi) >= lo && dec_ord(cx.xlo) <= hi && dec_ord(cx.yhi) >= ylo && dec_ord(cx.ylo) <= yhi)
               sm.list[atomicAdd(&sm.n_list, 1)] = c;
@@ -587,7 +663,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
     // not keep written lines): a workgroup-scope fence orders them before the barrier
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
-    const TileEmit<D> emit{sm, a.hs, a.meta, q0};
+    const TileEmit<D, EXT> emit{sm, a.hs, a.meta, x, q0};
     const int c0 = sm.wcnt[0], c1 = c0 + sm.wcnt[1], c2 = c1 + sm.wcnt[2], total = c2 + sm.wcnt[3];
     for (int e0 = 0; e0 < total; e0 += kScanThreads) {
       const int e = e0 + t;
@@ -601,22 +677,43 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
       if (__ballot(has) != 0ull) confirm_entry<D, true>(has, en, n_nodes, a, emit, sm.cp, q0);
     }
     __syncthreads();
-    // ---- 5. hand the collected hits to the buckets ----
-    for (int cl = wave; cl < q1 - q0; cl += kScanThreads / 64) {
-      const int n = min(sm.lcnt[cl], kTbLcap);
-      if (n == 0) continue;
-      const int owner = a.meta[q0 + cl].x;
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&a.hs.count[owner], n);
-      base = __shfl(base, 0);
-      for (int j0 = 0; j0 < n; j0 += 64) {
-        const int j = j0 + lane;
-        const bool h = j < n;
-        BktRec br;
-        br.idx = 0; br.pad = 0; br.d2 = 0.0;
-        if (h) br = sm.hrec[cl][j];
-        place_hit(a.hs, h, owner, base + j, br.idx, br.d2);
+    // ---- 5. hand the collected hits to the buckets: half a wave per copy, two copies per half ----
+    {
+      constexpr int kPerWave = kTileB / (kScanThreads / 64);     // 4 copies per wave
+      const int nc = q1 - q0;
+      // the counter updates of this wave's copies fly together: lane s < 4 owns copy slot s
+      int my_n = 0, my_owner = 0, my_base = 0;
+      if (lane < kPerWave) {
+        const int cl = (lane >> 1) * (kTileB / 2) + wave * 2 + (lane & 1);
+        if (cl < nc) {
+          my_n = min(sm.lcnt[cl], kTbLcap);
+          if (my_n > 0) {
+            my_owner = a.meta[q0 + cl].x;
+            my_base = atomicAdd(&a.hs.count[my_owner], my_n);
+          }
+        }
       }
+      const int half = lane >> 5, hl = lane & 31;
+      for (int i = 0; i < kPerWave / 2; ++i) {
+        const int s = i * 2 + half;                     // this half's copy slot
+        const int cl = i * (kTileB / 2) + wave * 2 + half;
+        const int n = __shfl(my_n, s), owner = __shfl(my_owner, s), base = __shfl(my_base, s);
+        const int nmax = max(n, __shfl_xor(n, 32));
+        for (int j0 = 0; j0 < nmax; j0 += 32) {
+          const int j = j0 + hl;
+          const bool h = j < n;
+          BktRec br;
+          br.idx = 0; br.pad = 0; br.d2 = 0.0;
+          if (h) br = sm.hrec[cl][j];
+          int flags = 0;
+          if constexpr (EXT) flags = tile_edge_flags<D>(x, sm, h, h ? cl : 0, br.idx, br.d2);
+          place_hit(a.hs, h, owner, base + j, br.idx, br.d2, flags);
+        }
+      }
+    }
+    if constexpr (EXT) {
+      // explicitPointCheck of the samples (one part of a tile reports them)
+      if (part == 0 && t < q1 - q0 && x.sample_unsafe) x.sample_unsafe[a.meta[q0 + t].x] = sm.sbad[t] ? 1 : 0;
     }
     __syncthreads();          // LDS is reused by the next tile
   }
@@ -702,10 +799,11 @@ __global__ void nn_scatter_kernel(const HitRec *__restrict__ recs, long long cap
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     HitRec r = recs[i];
-    long long dst = offsets[r.owner] + bcap + atomicAdd(&cursor[r.owner], 1);
+    const int owner = r.owner & 0x3fffffff;            // top bits: edge flags of the fused extend() path
+    long long dst = offsets[owner] + bcap + atomicAdd(&cursor[owner], 1);
     if (dst < out_cap) {
       BktRec br;
-      br.idx = r.idx; br.pad = 0; br.d2 = r.d2;
+      br.idx = r.idx; br.pad = (int)((unsigned)r.owner >> 30); br.d2 = r.d2;
       tmp[dst] = br;
     }
   }
@@ -717,10 +815,12 @@ __global__ void nn_scatter_kernel(const HitRec *__restrict__ recs, long long cap
 int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr_lt, double r_scalar, int nq,
                      int64_t *offsets_dev, int32_t *idx_dev, double *dist_dev, int64_t cap,
                      int64_t *needed_dev, int32_t *owner_dev, int32_t *nearest_idx_dev,
-                     double *nearest_dist_dev, const ExtendFuse *ext) {
+                     double *nearest_dist_dev, ExtendFuse *ext) {
   // r_dev_thr_lt: optional device array of 2*nq thresholds (thr_lt[nq] then thr_gt[nq])
+  if (ext) ext->fused = false;
   if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "radius search on an empty tree");
   if (nq <= 0) return RRTX_OK;
+  if (nq >= (1 << 30)) return fail(ctx, RRTX_E_INVALID, "radius search: at most 2^30 - 1 queries per call");
   const int D = ctx->dim;
   const int n_slots = 1 << ctx->n_wraps;
   hipStream_t st = ctx->stream;
@@ -830,6 +930,24 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   pf.sc_next = sc_next;
   pf.ca_dst = ca_dev;
   pf.nx = ctx->nodes[0]; pf.ny = ctx->nodes[1]; pf.nz = ctx->nodes[2]; pf.nw = ctx->nodes[D == 4 ? 3 : 2];
+  // fused extend() path (sphere list; the caller has synced the tables): only the culled search carries it
+  const bool fuse = ext && use_cull && D == 3 && n_slots == 1;
+  ExtendDev xd;
+  std::memset(&xd, 0, sizeof(xd));
+  xd.r_bound = -1.0;
+  pf.sph = nullptr; pf.m_sph = -1;
+  if (fuse) {
+    xd.sph = ctx->d_sph.as<SphRec>();
+    xd.stab = ctx->d_sph_sample.as<SampleSph>();
+    xd.reach_f = ctx->d_sph_reach_f.as<float>();
+    xd.naos = reinterpret_cast<const double4 *>(ctx->nodes_aos);
+    xd.ox = ctx->origin[0]; xd.oy = ctx->origin[1]; xd.oz = ctx->origin[2];
+    xd.m = ctx->sph_n_active;
+    xd.r_bound = (ext->r >= 0.0 && xd.m > 0) ? ext->r * (1.0 + 1e-12) : -1.0;
+    xd.sample_unsafe = ext->sample_unsafe;
+    pf.sph = xd.sph; pf.m_sph = xd.m;
+    ext->fused = true;
+  }
 
   const double *thr_lt_arr = r_dev_thr_lt;
   const double *thr_gt_arr = r_dev_thr_lt ? r_dev_thr_lt + nq : nullptr;
@@ -918,16 +1036,21 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
       tg.sp = ctx->ws_slab_params.as<SlabParams>();
       tg.cell_start = ctx->ws_slab_start.as<int>();
       tg.n_sorted_chunks = (ctx->ws_slab_params.p && ctx->ws_slab_start.p) ? (int)(ctx->sl_n_sorted / kSlabChunk) : 0;
-      if (D == 4)
-        hipLaunchKernelGGL(nn_tile_kernel<4>, dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
-                           ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, reinterpret_cast<const ChunkExt *>(ctx->chunk_ext),
-                           ctx->ws_copies_s.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(), sc, n_parts,
-                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, ctx->ws_ev_cnt.as<int>());
-      else
-        hipLaunchKernelGGL(nn_tile_kernel<3>, dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
+      if (fuse)
+        hipLaunchKernelGGL((nn_tile_kernel<3, true>), dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
                            ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, reinterpret_cast<const ChunkExt *>(ctx->chunk_ext),
                            ctx->ws_copies_s.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(), sc, n_parts,
-                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, ctx->ws_ev_cnt.as<int>());
+                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, xd, ctx->ws_ev_cnt.as<int>());
+      else if (D == 4)
+        hipLaunchKernelGGL((nn_tile_kernel<4, false>), dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
+                           ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, reinterpret_cast<const ChunkExt *>(ctx->chunk_ext),
+                           ctx->ws_copies_s.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(), sc, n_parts,
+                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, xd, ctx->ws_ev_cnt.as<int>());
+      else
+        hipLaunchKernelGGL((nn_tile_kernel<3, false>), dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
+                           ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, reinterpret_cast<const ChunkExt *>(ctx->chunk_ext),
+                           ctx->ws_copies_s.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(), sc, n_parts,
+                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, xd, ctx->ws_ev_cnt.as<int>());
     } else if (use_filter) {
       // persistent grid: opt_scan_blocks workgroups (multiple of 8) striding over the work
       unsigned pg = (unsigned)ctx->opt_scan_blocks / 8u * 8u;
@@ -996,7 +1119,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
     f.mailbox = ctx->mailbox;
     f.q = q_dev;
     f.r_start = (!r_dev_thr_lt && r_scalar > 0.0) ? 2.0 * r_scalar : 1.0;
-    f.ext = ext;
+    f.hit_out = fuse ? ext->hit_out : nullptr; f.hit_in = fuse ? ext->hit_in : nullptr;
     int rc = launch_nn_finish(ctx, f);
     if (rc) return rc;
   }

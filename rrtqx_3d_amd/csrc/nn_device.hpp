@@ -3,6 +3,7 @@
 // index): per-call scalars, hit sink, copy records, the pack / prefilter-prep kernels both
 // searches launch, the packed fp32 screen.  Everything here has internal linkage.
 #pragma once
+#include "collide_device.hpp"
 #include "exact_math.hpp"
 #include "rrtx_internal.hpp"
 
@@ -29,6 +30,7 @@ struct Scalars {
 // list length either way.
 // one confirmed neighbour in a query's bucket: node index + squared distance in ONE 16-byte store
 // (separate 4- and 8-byte arrays cost a partial cache line write each)
+// (pad: bit 0 / 1 = the edge sample -> node / node -> sample collides, fused extend() path)
 struct alignas(16) BktRec { int32_t idx; int32_t pad; double d2; };
 
 struct HitSink {
@@ -97,6 +99,8 @@ struct PackFused {
   Scalars *sc_next;
   ConfirmArgs *ca_dst;
   const double *nx, *ny, *nz, *nw; // node arrays (the root is node 0)
+  const SphRec *sph;               // fused extend() path: the root entry's two edge flags are decided here
+  int m_sph;                       // active spheres, -1: not the fused path
 };
 
 template <int D>
@@ -144,6 +148,17 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
       if (add) {                               // bcap >= 8: entry 0 of the bucket always exists
         BktRec br;
         br.idx = 0; br.pad = 0; br.d2 = s;
+        if (pf.m_sph > 0) {
+          // explicitEdgeCheck of sample -> root and root -> sample over the whole list (measure-zero case)
+          const double rx = pf.nx[0], ry = pf.ny[0], rz = pf.nz[0], len = sqrt_rn(s);
+          bool ho = false, hi = false;
+          for (int j = 0; j < pf.m_sph; ++j) {
+            const SphRec ob = pf.sph[j];
+            ho = ho || edge_hits_sphere(p[0], p[1], p[2], rx - p[0], ry - p[1], rz - p[2], len, ob);
+            hi = hi || edge_hits_sphere(rx, ry, rz, p[0] - rx, p[1] - ry, p[2] - rz, len, ob);
+          }
+          br.pad = (ho ? 1 : 0) | (hi ? 2 : 0);
+        }
         ca.hs.bkt[(size_t)i * (size_t)ca.hs.bcap] = br;
       }
     }
@@ -222,12 +237,13 @@ __device__ __noinline__ bool seen_by_earlier_slot(const SlotRec *__restrict__ sl
 // Store a hit whose slot in its query's list is already known: bucket if the slot fits, shared
 // overflow list otherwise.  Every lane of the wave calls this together (the overflow branch
 // uses a ballot).
-__device__ __forceinline__ void place_hit(const HitSink &hs, bool hit, int owner, int slot, int id, double d2) {
+__device__ __forceinline__ void place_hit(const HitSink &hs, bool hit, int owner, int slot, int id, double d2,
+                                          int flags = 0) {
   const bool inb = hit && slot < hs.bcap;
   if (inb) {
     const size_t at = (size_t)owner * (size_t)hs.bcap + (size_t)slot;
     BktRec br;
-    br.idx = id; br.pad = 0; br.d2 = d2;
+    br.idx = id; br.pad = flags; br.d2 = d2;
     hs.bkt[at] = br;
   }
   const bool ov = hit && !inb;
@@ -242,7 +258,8 @@ __device__ __forceinline__ void place_hit(const HitSink &hs, bool hit, int owner
       const long long pos = (long long)base + __popcll(m & ((1ull << lane) - 1ull));
       if (pos < hs.cap) {
         HitRec r;
-        r.owner = owner; r.idx = id; r.d2 = d2;
+        r.owner = owner | (flags << 30);     // nq < 2^30 (checked by the launcher): flags ride in the top bits
+        r.idx = id; r.d2 = d2;
         hs.recs[pos] = r;
       }
     }
@@ -258,7 +275,8 @@ __device__ __forceinline__ void emit_hit(const HitSink &hs, bool hit, int owner,
 
 // Many hits of few queries in one wave (dense balls): one counter update per distinct query.
 // Whole wave together.
-__device__ __forceinline__ void emit_hits_grouped(const HitSink &hs, bool hit, int owner, int id, double d2) {
+__device__ __forceinline__ void emit_hits_grouped(const HitSink &hs, bool hit, int owner, int id, double d2,
+                                                  int flags = 0) {
   const int lane = threadIdx.x & 63;
   unsigned long long rem = __ballot(hit);
   while (rem != 0ull) {
@@ -269,7 +287,7 @@ __device__ __forceinline__ void emit_hits_grouped(const HitSink &hs, bool hit, i
     int base = 0;
     if (lane == L) base = atomicAdd(&hs.count[o], __popcll(m));
     base = __builtin_amdgcn_readlane(base, L);
-    place_hit(hs, mine, o, base + __popcll(m & ((1ull << lane) - 1ull)), id, d2);
+    place_hit(hs, mine, o, base + __popcll(m & ((1ull << lane) - 1ull)), id, d2, flags);
     rem &= ~m;
   }
 }

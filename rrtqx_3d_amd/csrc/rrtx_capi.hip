@@ -994,15 +994,21 @@ int rrtx_extend_candidates_dev(rrtx_ctx *ctx, const double *q, int nq, double r,
     return launch_candidate_edges_polygons(ctx, q, nq, offsets, idx, ctx->ws_owner.as<int32_t>(), cap, robot_radius,
                                            hit_out, hit_in, sample_unsafe);
   }
-  // sphere list: the sample pass and both directed edges of every entry ride in the finish kernel of
-  // the search, which holds the lists in registers (no owner array, no sphere lists through memory)
+  // sphere list: in the culled search the sample pass and both directed edges of every neighbour are
+  // decided where the neighbour is found (kernels_nn.hip, TileEmit) and the finish kernel hands out
+  // the flags; the other search paths (small trees, culling off) run the two kernels of their own
   int rc = sync_spheres(ctx, robot_radius);
   if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_owner.ensure(sizeof(int32_t) * (size_t)(cap > 0 ? cap : 1)));
   ExtendFuse ef;
   ef.r = (r >= 0.0) ? r : -1.0;
   ef.hit_out = hit_out; ef.hit_in = hit_in; ef.sample_unsafe = sample_unsafe;
-  return launch_nn_radius(ctx, q, nullptr, r, nq, offsets, idx, cost, cap, needed_dev, nullptr,
-                          want_nearest ? nearest_idx : nullptr, want_nearest ? nearest_dist : nullptr, &ef);
+  ef.fused = false;
+  rc = launch_nn_radius(ctx, q, nullptr, r, nq, offsets, idx, cost, cap, needed_dev, ctx->ws_owner.as<int32_t>(),
+                        want_nearest ? nearest_idx : nullptr, want_nearest ? nearest_dist : nullptr, &ef);
+  if (rc || ef.fused) return rc;
+  return launch_candidate_edges(ctx, q, nq, offsets, idx, ctx->ws_owner.as<int32_t>(), cap, robot_radius, hit_out,
+                                hit_in, (r >= 0.0) ? r : -1.0, sample_unsafe);
 }
 
 int rrtx_extend_candidates(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius, int64_t *offsets,

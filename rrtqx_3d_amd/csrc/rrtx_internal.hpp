@@ -221,9 +221,10 @@ double thr_first_gt(double r);
 double thr_point_clear(double robot_radius, double radius);
 
 // ---- launchers (device pointers, enqueue on ctx->stream) ----------------------
-// Fused extend() work of the finish kernel (sphere list): both directed edges of every list entry and
-// explicitPointCheck of the samples; r = radius the lists were built with
-struct ExtendFuse { double r; uint8_t *hit_out, *hit_in, *sample_unsafe; };
+// Fused extend() work of the range search (sphere list, culled search only): both directed edges of
+// every list entry and explicitPointCheck of the samples; r = radius the lists are built with.
+// `fused` tells the caller whether the search did it (otherwise: launch_candidate_edges).
+struct ExtendFuse { double r; uint8_t *hit_out, *hit_in, *sample_unsafe; bool fused; };
 // the last launch of the range search (kernels_finish.hip); device types passed as void *
 struct FinishLaunch {
   const int *count; int nq; int bcap;
@@ -233,13 +234,13 @@ struct FinishLaunch {
   int32_t *owner; int32_t *nearest_idx; double *nearest_dist;
   int *qhist; int n_qhist; unsigned *mailbox;
   const double *q; double r_start;
-  const ExtendFuse *ext;
+  uint8_t *hit_out, *hit_in;   // fused extend(): the records' edge flags go here (null: not fused)
 };
 int launch_nn_finish(rrtx_ctx *ctx, const FinishLaunch &f);
 int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_or_null, double r_scalar,
                      int nq, int64_t *offsets_dev, int32_t *idx_dev, double *dist_dev, int64_t cap,
                      int64_t *needed_dev, int32_t *owner_dev = nullptr, int32_t *nearest_idx_dev = nullptr,
-                     double *nearest_dist_dev = nullptr, const ExtendFuse *ext = nullptr);
+                     double *nearest_dist_dev = nullptr, ExtendFuse *ext = nullptr);
 int knearest_row(int k, int64_t n_nodes);
 int launch_nn_knearest(rrtx_ctx *ctx, const double *q_dev, int nq, int k, int32_t *idx_dev, double *dist_dev,
                        int32_t *count_dev);
