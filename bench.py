@@ -3,21 +3,26 @@
 
 A step = one pass of the fused extend() preamble over one batch of B synthetic
 samples with every input already resident in HBM:
-    radius-NN (brute force, N nodes)  ->  2*sum(k) directed SimpleEdges: cost +
-    collision check against M sphere obstacles  ->  nearest + sample point check.
+    radius-NN (N nodes)  ->  2*sum(k) directed SimpleEdges: cost + collision check
+    against M sphere obstacles  ->  nearest + sample point check.
+Every step takes a FRESH batch (a ring of pre-generated device batches), so chunk lists,
+bucket histograms and cache contents differ step to step.
 value = directed edges collision-checked per second (whole job, all ranks).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C4|C3] [--scaling weak|strong]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU (weak scaling): node SoA and obstacle list are replicated (4.8 MB and
-8 KB -- trivially small next to 288 GB of HBM), every rank owns its own batch of
-B samples, and the per-edge collision bitmask is exchanged with one RCCL
-all-reduce so every rank (the planner host of every agent) sees all results.
+Multi-GPU: node SoA and obstacle list are replicated (4.8 MB and 8 KB -- trivially small next
+to 288 GB of HBM).  --scaling weak (default): every rank owns its own batches of B samples.
+--scaling strong: ONE global batch of B samples per step, rank r takes samples
+parallel.shard_range(B, r, world).  Either way the per-edge collision bitmask is exchanged with
+one RCCL all-reduce so every rank (the planner host of every agent) sees all results.  With
+N > 1 the line carries both modes (`value` is the one --scaling names, `other_scaling` the other).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,8 +37,28 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s FMA-counted vector fp64 => 39.3 T unfused op/s
 ROBOT_RADIUS = 0.5             # R/experimentsForRRTQX.jl:38
+METRIC = "collision-checked edges/sec + radius-NN queries/sec at N=200k nodes, 256 obs"
+RING = 8                       # pre-generated sample batches per rank
 
 
+def lib_sha16():
+    from rrtqx_3d_amd import _capi
+    with open(_capi.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def source_sha16():
+    """identifies the kernel sources a committed PMC file was taken on (the .so itself is not tracked)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rrtqx_3d_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# --------------------------------------------------------------------- CPU baselines ----
 def cpu_baseline(cfg, pts, Q, sph, r, budget_s=10.0):
     """Oracle (C restatement of the reference's per-sample loop) on one host core."""
     from oracle import oracle as O
@@ -43,9 +68,8 @@ def cpu_baseline(cfg, pts, Q, sph, r, budget_s=10.0):
     nq = Q.shape[0]
     # calibrate on a slice, then run a bounded sample
     t0 = time.perf_counter()
-    e0, _, _, _ = O.extend_batch_spheres(tree, osph, m, Q[:256], r, ROBOT_RADIUS)
-    dt = time.perf_counter() - t0
-    per_q = dt / 256
+    O.extend_batch_spheres(tree, osph, m, Q[:256], r, ROBOT_RADIUS)
+    per_q = (time.perf_counter() - t0) / 256
     n_sample = int(min(nq, max(256, budget_s / max(per_q, 1e-9))))
     t0 = time.perf_counter()
     edges, neigh, hits, _ = O.extend_batch_spheres(tree, osph, m, Q[:n_sample], r, ROBOT_RADIUS)
@@ -94,11 +118,52 @@ def cpu_baseline_all_cores(cfg, pts, Q, sph, r, per_q, budget_s=4.0):
                       "not the reference's (single-threaded) behaviour"}
 
 
+def cpu_baseline_dubins(pts, Q, polys, r, r_min, budget_s=12.0):
+    """Config 3 on one host core: the oracle's per-sample Dubins preamble (wrapped range search, both
+    directed edges steered with calculateTrajectory and checked with the two-stage explicitEdgeCheck)."""
+    import math
+    from oracle import oracle as O
+    tree = O.KDTree(4, wraps=[3], wrap_points=[2.0 * math.pi])
+    tree.insert_many(pts)
+    ps = O.PolygonSet(polys)
+    edges, t0, n = 0, time.perf_counter(), 0
+    for q in Q:
+        idx, _ = tree.within_range(r, q)
+        for j in idx:
+            for s, g in ((q, pts[j]), (pts[j], q)):
+                res = O.dubins_steer(s, g, r_min)
+                O.dubins_edge_check_polygons(ps, s, g, res[-1], ROBOT_RADIUS, r_min)
+                edges += 1
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": edges / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} of {len(Q)} samples: wrapped kd-tree range search + {edges} directed Dubins edges "
+                      f"steered and checked against {len(polys)} polygons, {dt:.1f} s on 1 host core",
+            "nn_queries_per_s": n / dt}
+
+
+# ------------------------------------------------------------------------- helpers ----
+class Buffers:
+    """device outputs of one fused extend() call"""
+
+    def __init__(self, torch, dev, B, cap):
+        self.off = torch.empty(B + 1, dtype=torch.int64, device=dev)
+        self.idx = torch.empty(cap, dtype=torch.int32, device=dev)
+        self.cost = torch.empty(cap, dtype=torch.float64, device=dev)
+        self.hout = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.hin = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.nidx = torch.empty(B, dtype=torch.int32, device=dev)
+        self.ndist = torch.empty(B, dtype=torch.float64, device=dev)
+        self.unsafe = torch.empty(B, dtype=torch.uint8, device=dev)
+        self.cap = cap
+
+
 def concurrent_agents(k, torch, dev, pts, sph, r, B, cap, N, rounds=20):
     """Side measurement, never `value`: k independent planners (the reference drives 4 agents, each
     with its own tree and obstacle list, R/rrtqx.jl:29-31) share the GPU, one context and one HIP
-    stream per agent, every agent stepping its own batch.  Shows how much of the step is launch
-    latency that other agents' kernels can fill."""
+    stream per agent, every agent stepping its own batch."""
     from rrtqx_3d_amd import synth
     from rrtqx_3d_amd.context import Context
     agents = []
@@ -109,24 +174,19 @@ def concurrent_agents(k, torch, dev, pts, sph, r, B, cap, N, rounds=20):
         c.spheres_set(sph)
         c.nodes_append(pts)
         q = torch.from_numpy(synth.queries(B, 3, seed=synth.SEED + 77 + a)).to(dev)
-        buf = dict(off=torch.empty(B + 1, dtype=torch.int64, device=dev), idx=torch.empty(cap, dtype=torch.int32, device=dev),
-                   cost=torch.empty(cap, dtype=torch.float64, device=dev), ho=torch.empty(cap, dtype=torch.uint8, device=dev),
-                   hi=torch.empty(cap, dtype=torch.uint8, device=dev), need=torch.zeros(1, dtype=torch.int64, device=dev),
-                   ni=torch.empty(B, dtype=torch.int32, device=dev), nd=torch.empty(B, dtype=torch.float64, device=dev),
-                   un=torch.empty(B, dtype=torch.uint8, device=dev))
-        agents.append((c, st, q, buf))
+        agents.append((c, st, q, Buffers(torch, dev, B, cap), torch.zeros(1, dtype=torch.int64, device=dev)))
 
     def step(ag):
-        c, st, q, b = ag
-        c.extend_candidates_dev(q.data_ptr(), B, r, ROBOT_RADIUS, b["off"].data_ptr(), b["idx"].data_ptr(),
-                                b["cost"].data_ptr(), b["ho"].data_ptr(), b["hi"].data_ptr(), cap, b["need"].data_ptr(),
-                                b["ni"].data_ptr(), b["nd"].data_ptr(), b["un"].data_ptr())
+        c, st, q, b, need = ag
+        c.extend_candidates_dev(q.data_ptr(), B, r, ROBOT_RADIUS, b.off.data_ptr(), b.idx.data_ptr(),
+                                b.cost.data_ptr(), b.hout.data_ptr(), b.hin.data_ptr(), cap, need.data_ptr(),
+                                b.nidx.data_ptr(), b.ndist.data_ptr(), b.unsafe.data_ptr())
 
     for _ in range(3):
         for ag in agents:
             step(ag)
     torch.cuda.synchronize()
-    edges = sum(2 * int(ag[3]["need"].item()) for ag in agents)
+    edges = sum(2 * int(ag[4].item()) for ag in agents)
     t0 = time.perf_counter()
     for _ in range(rounds):
         for ag in agents:
@@ -139,13 +199,108 @@ def concurrent_agents(k, torch, dev, pts, sph, r, B, cap, N, rounds=20):
             "note": "k contexts on k streams, each stepping its own batch of the same config; not `value`"}
 
 
+def bench_c3(args, torch, dist, dev, rank, world):
+    """--config C3: the fused Dubins preamble (BASELINE config 3).  Not the driver's default line."""
+    import math
+    from rrtqx_3d_amd import _capi, parallel, synth
+    from rrtqx_3d_amd.context import Context
+    cfg = synth.CONFIGS["C3"]
+    N, M, B = cfg.n_nodes, cfg.n_obstacles, cfg.batch
+    r = synth.ball_radius(N, 4, gamma=100.0, delta=10.0)       # R/dubinsExperimentsForPaper.jl:102
+    r_min = 1.0
+    pts, polys = synth.nodes(N, 4), synth.polygons(M)
+    Q = synth.queries(B, 4, seed=synth.SEED + 1 + 1000 * rank)
+    ctx = Context(4, device=dev.index or 0, node_capacity=N)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    ctx.set_wrap(3, 2.0 * math.pi)
+    ctx.polygons_set(polys)
+    ctx.nodes_append_dev(torch.from_numpy(pts).to(dev).data_ptr(), N)
+    d_q = torch.from_numpy(Q).to(dev)
+    cap = 2048 * B
+    f64 = lambda m: torch.empty(m, dtype=torch.float64, device=dev)
+    u8 = lambda m: torch.empty(m, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    d_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_key, d_co, d_ci = f64(cap), f64(cap), f64(cap)
+    d_ho, d_hi, d_un = u8(cap), u8(cap), u8(B)
+    d_need = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_ni = torch.empty(B, dtype=torch.int32, device=dev)
+    d_nd = f64(B)
+
+    def compute():
+        ctx.extend_candidates_dubins_dev(d_q.data_ptr(), B, r, ROBOT_RADIUS, r_min, d_off.data_ptr(), d_idx.data_ptr(),
+                                         d_key.data_ptr(), d_co.data_ptr(), d_ci.data_ptr(), None, None, d_ho.data_ptr(),
+                                         d_hi.data_ptr(), cap, d_need.data_ptr(), d_ni.data_ptr(), d_nd.data_ptr(),
+                                         d_un.data_ptr())
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        compute()
+    fence()
+    k_total = int(d_need.item())
+    if k_total > cap:
+        raise SystemExit(f"candidate capacity too small: {k_total} > {cap}")
+    steps = args.steps
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        compute()
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.profile(2)
+    for _ in range(2):
+        compute()
+    fence()
+    st = ctx.stats()
+    ctx.profile(0)
+    e_sum, t_max = parallel.reduce_throughput(2 * k_total * steps, dt, device=dev)
+    if rank == 0:
+        dub_ms = st.ms_dubins / max(st.launches_dubins, 1)
+        # Dubins steering + two-stage check is fp64 arithmetic: ~400 flops per steer (SURVEY 8d) plus, per
+        # polyline piece that reaches stage 2, the polygon test.  The steering figure alone is a floor.
+        steer_flops = 2 * k_total * 400
+        out = {
+            "metric": METRIC, "value": e_sum / t_max, "unit": "edges/s", "n_gpus": world, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * t_max / steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg.name + " (fused Dubins preamble, wrapped theta)", "n_nodes": N, "n_obstacles": M,
+                       "batch_per_gpu": B, "radius": r, "edge": "DubinsEdge", "min_turning_radius": r_min,
+                       "directed_edges_per_step_per_gpu": 2 * k_total},
+            "nn_queries_per_s": B * world * steps / t_max,
+            "kernel_ms": {"nn_scan": st.ms_nn_scan / max(st.launches_nn_scan, 1),
+                          "nn_finish": st.ms_nn_finish / 2, "dubins": dub_ms,
+                          "points": st.ms_points / max(st.launches_points, 1)},
+            "roofline": {"kernel": "dubins edge kernels (steer + two-stage check)", "bound": "valu_fp64", "unit": "TFLOP/s",
+                         "achieved": steer_flops / (dub_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TOPS,
+                         "frac": steer_flops / (dub_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS, "traffic": None,
+                         "note": "compute bound (fp64 VALU issue), not HBM: achieved counts only the ~400 flops of each "
+                                 "steer (SURVEY 8d); the stage-2 polyline tests dominate the instruction count "
+                                 "(DESIGN.md 4.6, profiles/*pmc_dubins_fused*)"},
+            "hip_runtime": _capi.hip_runtime(), "lib_sha16": lib_sha16(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_dubins(pts, Q, polys, r, r_min)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C4")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed line (no steady-state, polygon, host-path passes)")
     ap.add_argument("--nn-filter", type=int, default=1, help="1: fp32 prefilter + exact fp64 confirm (default); 0: exact scan")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsal)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: all ranks on cuda:0")
@@ -160,7 +315,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from rrtqx_3d_amd import synth
+    from rrtqx_3d_amd import _capi, parallel, synth
     from rrtqx_3d_amd.context import Context
 
     rank = int(os.environ.get("RANK", "0"))
@@ -181,19 +336,19 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if args.config == "C3":
+        return bench_c3(args, torch, dist, dev, rank, world)
     cfg = synth.CONFIGS[args.config]
-    assert cfg.dim == 3, "the bench line is the SimpleEdge path"
+    assert cfg.dim == 3, "the bench line is the SimpleEdge path (--config C3 for the Dubins preamble)"
     N, M, B = cfg.n_nodes, cfg.n_obstacles, cfg.batch
     r = synth.ball_radius(N, 3)
     pts = synth.nodes(N, 3)
     sph = synth.spheres(M)
-    Q = synth.queries(B, 3, seed=synth.SEED + 1 + 1000 * rank)   # every rank its own batch
-
+    steady_steps = 0 if args.no_extras else args.steps
     ctx = Context(3, device=local_rank, node_capacity=N)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)          # kernels, events and torch share one stream
     ctx.spheres_set(sph)
-    from rrtqx_3d_amd import _capi
     ctx.set_option(_capi.RRTX_OPT_NN_FILTER, args.nn_filter)
     if args.scan_blocks:
         ctx.set_option(_capi.RRTX_OPT_SCAN_BLOCKS, args.scan_blocks)
@@ -208,197 +363,289 @@ def main():
     # ---- inputs resident in HBM before the timed region -----------------------
     d_pts = torch.from_numpy(pts).to(dev)
     ctx.nodes_append_dev(d_pts.data_ptr(), N)
-    d_q = torch.from_numpy(Q).to(dev)
     cap = 96 * B                                 # expected sum(k) ~ 26 B; generous head room
-    d_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
-    d_idx = torch.empty(cap, dtype=torch.int32, device=dev)
-    d_cost = torch.empty(cap, dtype=torch.float64, device=dev)
-    d_hout = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    d_hin = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    d_needed = torch.zeros(1, dtype=torch.int64, device=dev)
-    d_nidx = torch.empty(B, dtype=torch.int32, device=dev)
-    d_ndist = torch.empty(B, dtype=torch.float64, device=dev)
-    d_unsafe = torch.empty(B, dtype=torch.uint8, device=dev)
-    from rrtqx_3d_amd import parallel
-
-    def compute():
-        ctx.extend_candidates_dev(d_q.data_ptr(), B, r, ROBOT_RADIUS, d_off.data_ptr(), d_idx.data_ptr(),
-                                  d_cost.data_ptr(), d_hout.data_ptr(), d_hin.data_ptr(), cap,
-                                  d_needed.data_ptr(), d_nidx.data_ptr(), d_ndist.data_ptr(), d_unsafe.data_ptr())
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # sizing pass (part of the warm-up): number of candidate entries of this rank's batch
-    compute()
-    fence()
-    k_total = int(d_needed.item())
-    if k_total > cap:
-        raise SystemExit(f"candidate capacity too small: {k_total} > {cap}")
-    edges_per_step = 2 * k_total
+    def make_mode(mode):
+        """weak: this rank's own ring of B-sample batches; strong: a ring of GLOBAL batches (same seed on
+        every rank), of which this rank takes its shard_range."""
+        if mode == "weak" or world == 1:
+            lo, hi = 0, B
+            batches = [synth.queries(B, 3, seed=synth.SEED + 1 + 1000 * rank + 17 * j) for j in range(RING)]
+        else:
+            lo, hi = parallel.shard_range(B, rank, world)
+            batches = [synth.queries(B, 3, seed=synth.SEED + 1 + 17 * j)[lo:hi] for j in range(RING)]
+        nb = hi - lo
+        d_q = [torch.from_numpy(np.ascontiguousarray(b)).to(dev) for b in batches]
+        buf = Buffers(torch, dev, max(nb, 1), cap)
+        d_need = torch.zeros(RING, dtype=torch.int64, device=dev)
+        return {"mode": mode, "nb": nb, "host_q": batches, "q": d_q, "buf": buf, "need": d_need}
 
-    # exchange buffers sized for the largest shard: 2 bits (out, in) per candidate entry and rank
-    k_max = k_total
-    if world > 1:
-        t = torch.tensor([k_total], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        k_max = int(t.item())
-    bit_cap = (k_max + 4095) // 4096 * 4096
-    words_per_rank = parallel.words_for(bit_cap)
-    d_bits = [torch.zeros(world * words_per_rank, dtype=torch.int64, device=dev) for _ in range(2)]
-    pending = [None, None]
+    def compute(m, j):
+        b = m["buf"]
+        ctx.extend_candidates_dev(m["q"][j].data_ptr(), m["nb"], r, ROBOT_RADIUS, b.off.data_ptr(), b.idx.data_ptr(),
+                                  b.cost.data_ptr(), b.hout.data_ptr(), b.hin.data_ptr(), cap,
+                                  m["need"].data_ptr() + 8 * j, b.nidx.data_ptr(), b.ndist.data_ptr(),
+                                  b.unsafe.data_ptr())
 
-    def step(i):
-        compute()
+    def run_mode(m, steps, warmup, profile):
+        """times `steps` steps of mode m; returns (directed edges of this rank over the steps, seconds, stats, ...)"""
+        # sizing pass (part of the warm-up): candidate entries of every batch of the ring
+        for j in range(RING):
+            compute(m, j)
+        fence()
+        k_ring = [int(v) for v in m["need"].tolist()]
+        if max(k_ring) > cap:
+            raise SystemExit(f"candidate capacity too small: {max(k_ring)} > {cap}")
+        # exchange buffers sized for the largest shard: 2 bits (out, in) per candidate entry and rank
+        k_max = max(k_ring)
         if world > 1:
-            # per-edge collision bitmask exchange: each rank fills its slice, one RCCL all-reduce
-            # (disjoint slices: SUM == OR).  Double-buffered and asynchronous: the exchange of step i
-            # runs on RCCL's stream while step i+1 computes.
-            b = i & 1
-            if pending[b] is not None:
-                pending[b].wait()
-            ctx.pack_hits_dev(d_hout.data_ptr(), d_hin.data_ptr(), d_off.data_ptr() + 8 * B, bit_cap,
-                              d_bits[b].data_ptr() + 8 * rank * words_per_rank)
-            pending[b] = parallel.exchange_hit_bitmasks(d_bits[b], rank, world, words_per_rank, async_op=True)
+            t = torch.tensor([k_max], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            k_max = int(t.item())
+        bit_cap = (k_max + 4095) // 4096 * 4096
+        wpr = parallel.words_for(bit_cap)
+        d_bits = [torch.zeros(world * wpr, dtype=torch.int64, device=dev) for _ in range(2)]
+        pending = [None, None]
+        b = m["buf"]
 
-    def drain():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        def step(i):
+            j = i % RING
+            compute(m, j)
+            if world > 1:
+                # per-edge collision bitmask exchange: each rank fills its slice, one RCCL all-reduce
+                # (disjoint slices: SUM == OR).  Double-buffered and asynchronous: the exchange of step i
+                # runs on RCCL's stream while step i+1 computes.
+                s = i & 1
+                if pending[s] is not None:
+                    pending[s].wait()
+                ctx.pack_hits_dev(b.hout.data_ptr(), b.hin.data_ptr(), b.off.data_ptr() + 8 * m["nb"], bit_cap,
+                                  d_bits[s].data_ptr() + 8 * rank * wpr)
+                pending[s] = parallel.exchange_hit_bitmasks(d_bits[s], rank, world, wpr, async_op=True)
 
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    fence()
+        def drain():
+            for s in range(2):
+                if pending[s] is not None:
+                    pending[s].wait()
+                    pending[s] = None
 
-    # HIP events around the dominant kernel only, and only on every 4th step: two event records drain
-    # the pipeline for ~10 us, a tenth of the step
-    sample_every = 4 if args.steps >= 8 else 1
-    ctx.set_option(_capi.RRTX_OPT_PROFILE_EVERY, sample_every)
-    ctx.profile(1)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    fence()
-    dt = time.perf_counter() - t0
-    st = ctx.stats()
-    ctx.set_option(_capi.RRTX_OPT_PROFILE_EVERY, 1)
-    # the other kernel families are timed in a short pass of their own: an event record between two
-    # kernels costs ~10 us of pipeline drain, which must not sit inside the timed region
-    ctx.profile(2)
-    for i in range(5):
-        compute()
-    fence()
-    st_all = ctx.stats()
-    # the brute-force form of the search (every tile of 64 copies streams every node, north_star's
-    # kernel) is measured beside the default culled form: a short pass with culling switched off
-    bf = None
-    if args.nn_filter and args.nn_cull and st.last_scan_units > 0:
-        ctx.set_option(_capi.RRTX_OPT_NN_CULL, 0)
-        compute()
+        for i in range(warmup):
+            step(i)
+        drain()
         fence()
-        ctx.profile(1)
+        sample_every = 4 if steps >= 8 else 1
+        if profile:
+            # HIP events around the dominant kernel only, and only on every 4th step: two event records
+            # drain the pipeline for ~10 us
+            ctx.set_option(_capi.RRTX_OPT_PROFILE_EVERY, sample_every)
+            ctx.profile(1)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        drain()
+        fence()
+        dt = time.perf_counter() - t0
+        st = ctx.stats() if profile else None
+        if profile:
+            ctx.set_option(_capi.RRTX_OPT_PROFILE_EVERY, 1)
+            ctx.profile(0)
+        edges = sum(2 * k_ring[i % RING] for i in range(steps))
+        return edges, dt, st, k_ring, sample_every
+
+    modes = [args.scaling] + ([("strong" if args.scaling == "weak" else "weak")] if world > 1 else [])
+    results = {}
+    for mode in modes:
+        m = make_mode(mode)
+        edges, dt, st, k_ring, sample_every = run_mode(m, args.steps, args.warmup, profile=(mode == modes[0]))
+        e_sum, t_max = parallel.reduce_throughput(edges, dt, device=dev)
+        results[mode] = {"m": m, "edges": edges, "dt": dt, "st": st, "k_ring": k_ring, "e_sum": e_sum, "t_max": t_max,
+                         "sample_every": sample_every}
+    main_r = results[modes[0]]
+    m = main_r["m"]
+    st = main_r["st"]
+    k_ring = main_r["k_ring"]
+    k_mean = sum(k_ring) / len(k_ring)
+
+    extras = {}
+    if not args.no_extras:
+        # per-family device time in a short pass of its own (an event record between two kernels costs
+        # ~10 us of pipeline drain, which must not sit inside the timed region)
+        ctx.profile(2)
         for i in range(5):
-            compute()
+            compute(m, i % RING)
         fence()
-        st_bf = ctx.stats()
-        bf = {"scan_ms": st_bf.ms_nn_scan / max(st_bf.launches_nn_scan, 1), "tile_q": int(st_bf.last_tile_q)}
-        ctx.set_option(_capi.RRTX_OPT_NN_CULL, args.nn_cull)
-        compute()
-        fence()
-    ctx.profile(0)
+        st_all = ctx.stats()
+        ctx.profile(0)
+        extras["kernel_ms_all"] = {"nn_pack_place_finish": st_all.ms_nn_finish / 5}
+        # the brute-force form of the search (every tile of 64 copies streams every node, north_star's
+        # kernel) measured beside the default culled form: a short pass with culling switched off
+        if args.nn_filter and args.nn_cull and st.last_scan_units > 0:
+            ctx.set_option(_capi.RRTX_OPT_NN_CULL, 0)
+            compute(m, 0)
+            fence()
+            ctx.profile(1)
+            for i in range(5):
+                compute(m, 0)
+            fence()
+            st_bf = ctx.stats()
+            extras["bf"] = {"scan_ms": st_bf.ms_nn_scan / max(st_bf.launches_nn_scan, 1), "tile_q": int(st_bf.last_tile_q)}
+            ctx.set_option(_capi.RRTX_OPT_NN_CULL, args.nn_cull)
+            ctx.profile(0)
+            compute(m, 0)
+            fence()
 
-    # ---- aggregate over ranks ----------------------------------------------------
-    e_sum, t_max = parallel.reduce_throughput(edges_per_step, dt, device=dev)
-    q_sum = B * world
+    # ---- steady state: the tree grows by the batch after every step (kdInsert of every sample, R/DRRT_Q.jl:2575)
+    #      and the ball shrinks with it (R/rrtqx.jl:382), so index tails and rebuilds are inside the timing ----
+    steady = None
+    if steady_steps > 0 and modes[0] == "weak":
+        d_need_s = torch.zeros(steady_steps + 1, dtype=torch.int64, device=dev)
+        sctx = Context(3, device=local_rank, node_capacity=N + (steady_steps + 2) * B)
+        sctx.set_stream(stream.cuda_stream)
+        sctx.spheres_set(sph)
+        sctx.nodes_append_dev(d_pts.data_ptr(), N)
+        bufs = m["buf"]
+
+        def sstep(i, slot):
+            n_now = N + i * B
+            rr = synth.ball_radius(n_now, 3)
+            sctx.extend_candidates_dev(m["q"][i % RING].data_ptr(), B, rr, ROBOT_RADIUS, bufs.off.data_ptr(),
+                                       bufs.idx.data_ptr(), bufs.cost.data_ptr(), bufs.hout.data_ptr(), bufs.hin.data_ptr(),
+                                       cap, d_need_s.data_ptr() + 8 * slot, bufs.nidx.data_ptr(), bufs.ndist.data_ptr(),
+                                       bufs.unsafe.data_ptr())
+            sctx.nodes_append_dev(m["q"][i % RING].data_ptr(), B)
+
+        sstep(0, steady_steps)       # warm-up (buffers, index build); the tree keeps the batch
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steady_steps):
+            sstep(i + 1, i)
+        fence()
+        dts = time.perf_counter() - t0
+        ks = d_need_s[:steady_steps].tolist()
+        e_s, t_s = parallel.reduce_throughput(int(2 * sum(ks)), dts, device=dev)
+        steady = {"value_steady": e_s / t_s, "ms_per_step": 1e3 * t_s / steady_steps, "steps": steady_steps,
+                  "n_nodes_start": N + B, "n_nodes_end": N + (steady_steps + 1) * B,
+                  "neighbors_per_step_first_last": [int(ks[0]), int(ks[-1])],
+                  "note": "every step: fused extend() preamble on a fresh batch with r = min(delta, gamma (ln(1+n)/n)^(1/3)) "
+                          "for the current n, then rrtx_nodes_append_dev of the whole batch (every sample inserted: upper "
+                          "bound on the reference's accepted samples); index tail growth and slab-index rebuilds are inside "
+                          "the timed loop"}
+        sctx.close()
 
     if rank == 0:
+        e_sum, t_max = main_r["e_sum"], main_r["t_max"]
+        nb = m["nb"]
         ms_step = 1e3 * t_max / args.steps
         scan_ms = st.ms_nn_scan / max(st.launches_nn_scan, 1)
         tile_q = int(st.last_tile_q)   # query copies sharing one streamed pass of the node arrays
-        n_tiles = (B + tile_q - 1) // tile_q
-        units = int(st.last_scan_units)  # slab-culled scan: (tile, 512-node chunk) pairs actually streamed
+        n_tiles = (nb + tile_q - 1) // tile_q
+        units = int(st.last_scan_units)  # slab-culled scan: (tile, 512-node chunk) pairs actually streamed (last call)
+        k_last = k_ring[(args.steps - 1) % RING]
         node_visits = units * 512 if units > 0 else n_tiles * N
-        bytes_streamed = node_visits * 24 + B * 32 + k_total * 16      # node passes + queries + hit records
-        achieved = bytes_streamed / (scan_ms * 1e-3) / 1e9
-        valu_ops = B * N * 9                                           # 3 sub, 3 mul, 2 add, 1 cmp per (query, node)
-        # HBM-side bytes per launch of this kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE,
-        # rocprofv3 --pmc, scripts_gpu_pmc.sh); PMC counters cannot be read inside this process.
+        # SURVEY 8(d) contract figure: node passes x 24 B (fp64 x, y, z of every node visit) + queries + hit records
+        bytes_alg = node_visits * 24 + nb * 32 + k_last * 16
+        # what the kernel really requests: the fp32 screen record of a node is 16 B (x, y, z, |p|^2); each entry the
+        # screen leaves over re-reads the fp64 rows of its lane's 8 nodes (3 x 64 B); 16-B hit records out
         culled = units > 0
-        kernel = ("nn_tile_kernel<3>" if culled else "nn_scan_f32_kernel<3> + nn_confirm_kernel<3>") if args.nn_filter \
+        kernel = ("nn_tile_kernel<3, true>" if culled else "nn_scan_f32_kernel<3> + nn_confirm_kernel<3>") if args.nn_filter \
             else "nn_scan_kernel<3>"
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if args.config == "C4" and args.nn_filter and os.path.exists(tpath):
+        bytes_req = node_visits * 16 + nb * 48 + k_last * (192 + 16 + 8)
+        alg_gbs = bytes_alg / (scan_ms * 1e-3) / 1e9
+        traffic, traffic_src, frac_traffic, hbm_gbs = None, None, None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        if args.config == "C4" and args.nn_filter and os.path.exists(tpath) and world == 1:
             tj = json.load(open(tpath))
-            if tj.get("kernel") == kernel:
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 PMC passes)"
+            # counters cannot be read inside this process; the committed PMC passes count only when they were
+            # taken on these kernel sources
+            if tj.get("kernel") == kernel and tj.get("source_sha16") == source_sha16():
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = f"profiles/r02_traffic.json (rocprofv3 PMC passes, sources {tj['source_sha16']})"
+                hbm_gbs = traffic / (scan_ms * 1e-3) / 1e9
+                frac_traffic = hbm_gbs / HBM_PEAK_GBS
         roof_bf = None
+        bf = extras.get("bf")
         if bf:
-            nt = (B + bf["tile_q"] - 1) // bf["tile_q"]
-            by = nt * N * 24 + B * 32 + k_total * 16
+            nt = (nb + bf["tile_q"] - 1) // bf["tile_q"]
+            by = nt * N * 24 + nb * 32 + k_ring[0] * 16
             ach = by / (bf["scan_ms"] * 1e-3) / 1e9
             roof_bf = {"kernel": "nn_scan_f32_kernel<3> + nn_confirm_kernel<3> (RRTX_OPT_NN_CULL=0)", "bound": "hbm",
                        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                        "algorithmic_bytes_per_launch": by, "tile_q": bf["tile_q"], "ms": bf["scan_ms"],
-                       "pairs_per_s": B * N / (bf["scan_ms"] * 1e-3)}
+                       "pairs_per_s": nb * N / (bf["scan_ms"] * 1e-3)}
         out = {
-            "metric": "collision-checked edges/sec + radius-NN queries/sec at N=200k nodes, 256 obs",
-            "value": e_sum * args.steps / t_max,
+            "metric": METRIC,
+            "value": e_sum / t_max,
             "unit": "edges/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": modes[0],
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": cfg.name, "n_nodes": N, "n_obstacles": M, "batch_per_gpu": B,
-                       "radius": r, "edge": "SimpleEdge", "directed_edges_per_step_per_gpu": edges_per_step,
-                       "neighbors_per_step_per_gpu": k_total, "sharding": "samples+edges sharded, nodes/obstacles replicated"},
-            "nn_queries_per_s": q_sum * args.steps / t_max,
-            "kernel_ms": {
-                "nn_scan": scan_ms,
-                "nn_finish": st_all.ms_nn_finish / 5,
-                "edges": st_all.ms_edges / 5,
-                "points": st_all.ms_points / 5,
-            },
+            "config": {"workload": cfg.name, "n_nodes": N, "n_obstacles": M,
+                       "batch_per_gpu": nb, "global_batch": nb * world if modes[0] == "weak" else B,
+                       "radius": r, "edge": "SimpleEdge", "directed_edges_per_step_per_gpu": 2 * k_mean,
+                       "neighbors_per_step_per_gpu": k_mean, "fresh_batch_every_step": True, "batch_ring": RING,
+                       "sharding": "samples+edges sharded, nodes/obstacles replicated"},
+            "nn_queries_per_s": (nb * world if modes[0] == "weak" else B) * args.steps / t_max,
+            "launches_per_step": 4,
+            "kernel_ms": {"nn_scan": scan_ms, **extras.get("kernel_ms_all", {})},
             "roofline": {
-                "kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                "kernel": kernel, "bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": bytes_streamed, "tile_q": tile_q,
-                "kernel_ms": scan_ms, "timed_launches": int(st.launches_nn_scan),
-                "timing": f"HIP events around every {sample_every}th launch inside the timed region",
+                "algorithmic_GBps": alg_gbs, "algorithmic_bytes_per_launch": bytes_alg,
+                "requested_bytes_per_launch": bytes_req, "frac_requested": bytes_req / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "hbm_GBps": hbm_gbs, "frac_traffic": frac_traffic,
+                "tile_q": tile_q, "kernel_ms": scan_ms, "timed_launches": int(st.launches_nn_scan),
+                "timing": f"HIP events around every {main_r['sample_every']}th launch inside the timed region",
                 "culled_units": units, "node_visits_per_launch": node_visits,
                 "node_visits_unculled": n_tiles * N,
-                "pairs_per_s": B * N / (scan_ms * 1e-3),
-                "valu_fp64_frac": (valu_ops / (scan_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS) if not args.nn_filter else None,
-                "note": ("culled search: bytes = chunks actually streamed x 512 nodes x 24 B (SURVEY 8d figure per node "
-                         "visit, T_q = tile_q); the kernel is latency / issue bound and its working set is L2-resident, "
-                         "see DESIGN.md 4.1") if culled else
+                "pairs_per_s": nb * N / (scan_ms * 1e-3),
+                "valu_fp64_frac": (nb * N * 9 / (scan_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS) if not args.nn_filter else None,
+                "note": ("`achieved` / `frac` are the SURVEY 8(d) CONTRACT figure (chunks streamed x 512 nodes x 24 B per node "
+                         "visit at T_q = tile_q, / kernel time) -- algorithmic bytes, not bytes moved from HBM.  The kernel "
+                         "streams the 16-B fp32 screen record of a node (`frac_requested`), its working set is L2-resident "
+                         "and the counters (`traffic`, `frac_traffic`) are the HBM-side truth; the kernel is issue / latency "
+                         "bound, see DESIGN.md 4.1.  The same kernel also decides both collision flags of every neighbour "
+                         "(fused extend path).") if culled else
                         "VALU-issue bound, node arrays are L2-resident; see DESIGN.md",
             },
             "roofline_bruteforce": roof_bf,
+            "hip_runtime": _capi.hip_runtime(),
+            "lib_sha16": lib_sha16(),
+            "source_sha16": source_sha16(),
         }
-        if world == 1:
+        if len(modes) > 1:
+            o = results[modes[1]]
+            out["other_scaling"] = {"scaling": modes[1], "value": o["e_sum"] / o["t_max"],
+                                    "ms_per_step": 1e3 * o["t_max"] / args.steps, "batch_per_gpu": o["m"]["nb"],
+                                    "note": ("strong: ONE global batch of B samples per step split with parallel.shard_range; "
+                                             "at B = 16384 a step is four dependent launch-bound kernels, so the per-step "
+                                             "floor bounds the speed-up") if modes[1] == "strong" else
+                                            "weak: every rank its own B-sample batches"}
+        if steady:
+            out["steady_state"] = steady
+            out["value_steady"] = steady["value_steady"]
+        if world == 1 and not args.no_extras:
             # the same step through the host-pointer entry point (what a ccall from Julia pays):
             # H2D of the samples, kernels, D2H of lists/costs/flags.  Reported, never `value`.
             ctx.set_stream(None)
-            ctx.extend_candidates(Q, r, ROBOT_RADIUS, cap=cap)
+            Q0 = m["host_q"][0]
+            ctx.extend_candidates(Q0, r, ROBOT_RADIUS, cap=cap)
             t1 = time.perf_counter()
             for _ in range(5):
-                ctx.extend_candidates(Q, r, ROBOT_RADIUS, cap=cap)
-            out["host_buffer_path"] = {"edges_per_s": edges_per_step * 5 / (time.perf_counter() - t1),
+                ctx.extend_candidates(Q0, r, ROBOT_RADIUS, cap=cap)
+            out["host_buffer_path"] = {"edges_per_s": 2 * k_ring[0] * 5 / (time.perf_counter() - t1),
                                        "note": "PCIe-inclusive: host numpy in/out through rrtx_extend_candidates"}
-        if world == 1:
             # BASELINE.json's config text says "polygon obstacles": the reference's 3-D planner checks
             # spheres (explicitEdgeCheck3D) and `value` above is that; this is the same step against 256
             # random polygons in the (x, y) projection (explicitEdgeCheck2D), device-resident, reported only.
@@ -406,22 +653,42 @@ def main():
             ctx.polygons_set(synth.polygons(M))
             ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 1)
             for _ in range(3):
-                compute()
+                compute(m, 0)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(20):
-                compute()
+            for i in range(20):
+                compute(m, i % RING)
             torch.cuda.synchronize()
             dtp = (time.perf_counter() - t1) / 20
-            out["polygon_obstacles"] = {"edges_per_s": edges_per_step / dtp, "ms_per_step": dtp * 1e3, "n_polygons": M,
-                                        "colliding_fraction": float((d_hout[:k_total].sum() + d_hin[:k_total].sum()).item()) / edges_per_step,
-                                        "note": "same samples and tree, candidate edges and samples checked against the polygon list"}
+            ctx.profile(2)
+            for i in range(5):
+                compute(m, 0)
+            torch.cuda.synchronize()
+            stp = ctx.stats()
+            ctx.profile(0)
+            b = m["buf"]
+            kt = k_ring[0]
+            coll = float((b.hout[:kt].sum() + b.hin[:kt].sum()).item()) / (2 * kt)
+            edges_ms = stp.ms_edges / 5
+            # a directed edge against the polygon list = 32 B of edge + M (24 B centre/radius + P x 16 B)
+            pbar = 3.5
+            by_poly = 2 * kt * 32 + 2 * kt * M * (24 + pbar * 16)
+            out["polygon_obstacles"] = {
+                "edges_per_s": 2 * k_mean / dtp, "ms_per_step": dtp * 1e3, "n_polygons": M, "colliding_fraction": coll,
+                "roofline": {"kernel": "edges_polygons_kernel", "bound": "hbm", "unit": "GB/s",
+                             "achieved": by_poly / (edges_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "frac": by_poly / (edges_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "kernel_ms": edges_ms, "algorithmic_bytes_per_launch": by_poly,
+                             "note": "contract bytes = E (32 + M (24 + Pbar 16)); the obstacle table (22 KB) lives in LDS / L2, "
+                                     "the kernel is VALU-issue bound (fp64 polygon tests of the pairs the box screen leaves), "
+                                     "see DESIGN.md 4.6 and profiles/"},
+                "note": "same samples and tree, candidate edges and samples checked against the polygon list"}
             ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 0)
             ctx.set_stream(None)
         if world == 1 and args.agents > 1:
             out["concurrent_agents"] = concurrent_agents(args.agents, torch, dev, pts, sph, r, B, cap, N)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, pts, Q, sph, r)
+            out["cpu_baseline"] = cpu_baseline(cfg, pts, m["host_q"][0], sph, r)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -113,6 +113,65 @@ SYMBOLS = [
 ]
 
 _lib = None
+_runtime = None
+
+
+def mapped_hip_runtimes():
+    """Real paths of every libamdhip64 image mapped into this process (/proc/self/maps)."""
+    found = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(" ", 1)[-1].strip()
+                if "libamdhip64.so" in os.path.basename(path):
+                    rp = os.path.realpath(path)
+                    if rp not in found:
+                        found.append(rp)
+    except OSError:
+        pass
+    return found
+
+
+def hip_runtime() -> dict:
+    """Which HIP runtime serves this process: librrtx_hip.so is built against the system ROCm while a
+    PyTorch wheel bundles its own libamdhip64 under the same SONAME, so whichever image is loaded first
+    serves both (stream handles and device pointers cross between torch and this library).  That is
+    fine as long as it is ONE image; two different images in one process is refused."""
+    load()
+    _pin_runtime()          # look again: torch may have been imported since
+    return dict(_runtime)
+
+
+_verified_with_torch = False
+
+
+def verify_runtime():
+    """Called when a context is created: once torch is in the process, make sure it did not bring a
+    second runtime image with it (it does when it is imported AFTER this library)."""
+    global _verified_with_torch
+    if _verified_with_torch or "torch" not in sys.modules:
+        return
+    _pin_runtime()
+    _verified_with_torch = True
+
+
+def _pin_runtime():
+    global _runtime
+    images = mapped_hip_runtimes()
+    if len(images) > 1:
+        raise RuntimeError("two different HIP runtimes are mapped into this process: " + ", ".join(images) +
+                           " -- device pointers and streams would cross between them; import torch before "
+                           "rrtqx_3d_amd (or not at all) so that one image serves both")
+    info = {"path": images[0] if images else None, "version": None}
+    if images:
+        try:
+            rt = C.CDLL(images[0])
+            v = C.c_int(0)
+            if rt.hipRuntimeGetVersion(C.byref(v)) == 0:
+                info["version"] = int(v.value)
+        except (OSError, AttributeError):
+            pass
+    _runtime = info
 
 
 def load() -> C.CDLL:
@@ -136,6 +195,7 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = L
+    _pin_runtime()
     return L
 
 

@@ -18,6 +18,7 @@ from ._capi import RrtxError, Stats, f64
 class Context:
     def __init__(self, dim: int = 3, device: int = 0, node_capacity: int = 1024):
         self._lib = _capi.load()
+        _capi.verify_runtime()      # one HIP runtime image per process, or refuse
         self.dim = dim
         self.device = device
         h = C.c_void_p()

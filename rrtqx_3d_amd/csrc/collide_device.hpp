@@ -127,34 +127,19 @@ __device__ __forceinline__ void edge_flags(const ExtendDev &x, bool act, double 
   }
 }
 
-// Sample pass for one (sample, pair of spheres): explicitPointCheck's per-sphere terms
-// (R/DRRT_Q.jl:1402-1415, 1463-1487 as thresholds on the squared distance) and membership in the
-// sample's sphere list.  Spheres the fp32 screen rules out are farther than reach + ball radius from
-// the sample: neither inside, nor closer than the robot radius, nor touchable by an edge in the ball.
-// Returns true if one of the two spheres makes the sample unsafe; listed spheres go to `on_list`.
-// (u, v) = the pair's two table rows {cxA,cxB,cyA,cyB} {czA,czB,RA,RB}, loaded by the caller.
-template <class OnList>
-__device__ __forceinline__ bool sample_pair(const ExtendDev &x, int pr, const float4 u, const float4 v, double px,
-                                            double py, double pz, const ReachProbe &rp, double base_b,
-                                            const OnList &on_list) {
-  const float dxa = u.x - rp.mx, dya = u.z - rp.my, dza = v.x - rp.mz;
-  const float dxb = u.y - rp.mx, dyb = u.w - rp.my, dzb = v.y - rp.mz;
-  float da = dxa * dxa; da = __builtin_fmaf(dya, dya, da); da = __builtin_fmaf(dza, dza, da);
-  float db = dxb * dxb; db = __builtin_fmaf(dyb, dyb, db); db = __builtin_fmaf(dzb, dzb, db);
-  const float ba = v.z + rp.h, bb = v.w + rp.h;
-  const unsigned near = (!(da > ba * ba) ? 1u : 0u) | (!(db > bb * bb) ? 2u : 0u);
-  bool bad = false;
-  for (int h2 = 0; h2 < 2; ++h2) {
-    const int j = 2 * pr + h2;
-    if (((near >> h2) & 1u) && j < x.m) {
-      const SampleSph sp = x.stab[j];
-      const double s = sq3(sp.cx, sp.cy, sp.cz, px, py, pz);
-      bad = bad | !(s >= sp.thr_in) | (s < sp.thr_pt);
-      const double B = base_b + sp.reach;
-      if (x.r_bound >= 0.0 && !(s > B * B * (1.0 + 1e-12))) on_list(j);
-    }
-  }
-  return bad;
+// Sample pass, exact part for one (sample, sphere) the fp32 screen could not rule out:
+// explicitPointCheck's per-sphere terms (R/DRRT_Q.jl:1402-1415, 1463-1487 as thresholds on the squared
+// distance) and membership in the sample's sphere list.  Spheres the screen rules out are farther
+// than reach + ball radius from the sample: neither inside, nor closer than the robot radius, nor
+// touchable by an edge in the ball.  Returns true if the sphere makes the sample unsafe; *listed says
+// whether it belongs on the list.
+__device__ __forceinline__ bool sample_exact(const ExtendDev &x, int j, double px, double py, double pz, double base_b,
+                                             bool *listed) {
+  const SampleSph sp = x.stab[j];
+  const double s = sq3(sp.cx, sp.cy, sp.cz, px, py, pz);
+  const double B = base_b + sp.reach;
+  *listed = x.r_bound >= 0.0 && !(s > B * B * (1.0 + 1e-12));
+  return !(s >= sp.thr_in) | (s < sp.thr_pt);
 }
 
 }  // namespace

@@ -168,57 +168,63 @@ __device__ __forceinline__ void confirm_entry(bool has, int2 en, int n_nodes, co
     // (owner, slot): the slot matters only with ghosts; emitters that want the owner for every hit say so
     if (Emit::kNeedsOwner || a.n_slots > 1) m = a.meta[en.x];
   }
-  double ex[kScanFU], ey[kScanFU], ez[kScanFU], ew[kScanFU];
-  if constexpr (LM) {
-    // node arrays are allocated in whole chunks: the 64-byte rows are always readable
-    const double2 *rx = reinterpret_cast<const double2 *>(a.nx + p0);
-    const double2 *ry = reinterpret_cast<const double2 *>(a.ny + p0);
-    const double2 *rz = reinterpret_cast<const double2 *>(a.nz + p0);
-    const double2 *rw = reinterpret_cast<const double2 *>(a.nw + p0);
+  // the lane's eight nodes in two halves of four: half the registers, and the exact part is a fraction
+  // of the kernel's instructions anyway
+  constexpr int kH = kScanFU / 2;
+#pragma unroll 1
+  for (int hv = 0; hv < 2; ++hv) {
+    double ex[kH], ey[kH], ez[kH], ew[kH];
+    if constexpr (LM) {
+      // node arrays are allocated in whole chunks: the 32-byte rows are always readable
+      const double2 *rx = reinterpret_cast<const double2 *>(a.nx + p0 + kH * hv);
+      const double2 *ry = reinterpret_cast<const double2 *>(a.ny + p0 + kH * hv);
+      const double2 *rz = reinterpret_cast<const double2 *>(a.nz + p0 + kH * hv);
+      const double2 *rw = reinterpret_cast<const double2 *>(a.nw + p0 + kH * hv);
 #pragma unroll
-    for (int v = 0; v < kScanFU / 2; ++v) {
-      const double2 vx = rx[v], vy = ry[v], vz = rz[v];
-      ex[2 * v] = vx.x; ex[2 * v + 1] = vx.y;
-      ey[2 * v] = vy.x; ey[2 * v + 1] = vy.y;
-      ez[2 * v] = vz.x; ez[2 * v + 1] = vz.y;
-      if constexpr (D == 4) { const double2 vw = rw[v]; ew[2 * v] = vw.x; ew[2 * v + 1] = vw.y; }
-      else { ew[2 * v] = 0.0; ew[2 * v + 1] = 0.0; }
+      for (int v = 0; v < kH / 2; ++v) {
+        const double2 vx = rx[v], vy = ry[v], vz = rz[v];
+        ex[2 * v] = vx.x; ex[2 * v + 1] = vx.y;
+        ey[2 * v] = vy.x; ey[2 * v + 1] = vy.y;
+        ez[2 * v] = vz.x; ez[2 * v + 1] = vz.y;
+        if constexpr (D == 4) { const double2 vw = rw[v]; ew[2 * v] = vw.x; ew[2 * v + 1] = vw.y; }
+        else { ew[2 * v] = 0.0; ew[2 * v + 1] = 0.0; }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kH; ++u) {
+        const int pos = p0 + 64 * (kH * hv + u);
+        const int pc = (pos < n_nodes) ? pos : 0;
+        ex[u] = a.nx[pc]; ey[u] = a.ny[pc]; ez[u] = a.nz[pc];
+        if constexpr (D == 4) ew[u] = a.nw[pc]; else ew[u] = 0.0;
+      }
     }
-  } else {
+    double s[kH];
+    unsigned hm = 0u;
 #pragma unroll
-    for (int u = 0; u < kScanFU; ++u) {
-      const int pos = p0 + 64 * u;
-      const int pc = (pos < n_nodes) ? pos : 0;
-      ex[u] = a.nx[pc]; ey[u] = a.ny[pc]; ez[u] = a.nz[pc];
-      if constexpr (D == 4) ew[u] = a.nw[pc]; else ew[u] = 0.0;
+    for (int u = 0; u < kH; ++u) {
+      const int pos = LM ? p0 + kH * hv + u : p0 + 64 * (kH * hv + u);
+      if constexpr (D == 4) s[u] = sq4(ce.x, ce.y, ce.z, ce.w, ex[u], ey[u], ez[u], ew[u]);
+      else s[u] = sq3(ce.x, ce.y, ce.z, ex[u], ey[u], ez[u]);
+      bool hu = has && pos < n_nodes && (s[u] < ce.thr);
+      if (m.y > 0 && hu) {
+        const int id = a.pos_id ? a.pos_id[pos] : pos;
+        hu = !seen_by_earlier_slot<D>(a.slots, a.n_slots, m.x, m.y, id, ex[u], ey[u], ez[u], ew[u]);
+      }
+      hm |= (hu ? 1u : 0u) << u;
     }
-  }
-  double s[kScanFU];
-  unsigned hm = 0u;
+    // normally one of the eight is a neighbour; emit them one per round
+    while (__ballot(hm != 0u) != 0ull) {
+      const bool h = hm != 0u;
+      const int uu = h ? (__ffs((int)hm) - 1) : 0;
+      hm &= hm - 1u;
+      double hs2 = s[0];
 #pragma unroll
-  for (int u = 0; u < kScanFU; ++u) {
-    const int pos = LM ? p0 + u : p0 + 64 * u;
-    if constexpr (D == 4) s[u] = sq4(ce.x, ce.y, ce.z, ce.w, ex[u], ey[u], ez[u], ew[u]);
-    else s[u] = sq3(ce.x, ce.y, ce.z, ex[u], ey[u], ez[u]);
-    bool hu = has && pos < n_nodes && (s[u] < ce.thr);
-    if (m.y > 0 && hu) {
-      const int id = a.pos_id ? a.pos_id[pos] : pos;
-      hu = !seen_by_earlier_slot<D>(a.slots, a.n_slots, m.x, m.y, id, ex[u], ey[u], ez[u], ew[u]);
+      for (int u = 1; u < kH; ++u) hs2 = (uu == u) ? s[u] : hs2;
+      const int pos = LM ? p0 + kH * hv + uu : p0 + 64 * (kH * hv + uu);
+      int hid = pos;
+      if (h && a.pos_id) hid = a.pos_id[pos];
+      emit(h, en.x, m.x, hid, hs2);
     }
-    hm |= (hu ? 1u : 0u) << u;
-  }
-  // normally one of the eight is a neighbour; emit them one per round
-  while (__ballot(hm != 0u) != 0ull) {
-    const bool h = hm != 0u;
-    const int uu = h ? (__ffs((int)hm) - 1) : 0;
-    hm &= hm - 1u;
-    double hs2 = s[0];
-#pragma unroll
-    for (int u = 1; u < kScanFU; ++u) hs2 = (uu == u) ? s[u] : hs2;
-    const int pos = LM ? p0 + uu : p0 + 64 * uu;
-    int hid = pos;
-    if (h && a.pos_id) hid = a.pos_id[pos];
-    emit(h, en.x, m.x, hid, hs2);
   }
 }
 
@@ -425,6 +431,8 @@ struct TileLds {
   int sok[kTileB];             // the sample's coordinates are finite and moderate (screens apply)
   float4 srp[kTileB];          // the sample's probe of the fp32 reach table (centre, inflated ball radius)
   double sbase[kTileB];        // ball radius + slack of the exact list test
+  int sqn[2];                  // (sample, sphere) pairs the screen left over, one queue per sample-pass wave
+  int sq[2][64];
   int ssl[kTileB][kSphListCap];
 };
 
@@ -438,22 +446,33 @@ struct TileGrid {
 // EXT: every confirmed neighbour is a candidate edge of extend().  Both directed edges are checked
 // against the sample's sphere list when the tile hands its hits to the buckets (tile_edge_flags) and
 // the two booleans travel in the record's spare word.
+// Most samples have no sphere within reach of their ball (sok: finite, moderate coordinates): an
+// edge inside the ball then collides with nothing and needs neither the node's coordinates nor a
+// test.  (d2 finite and the sample finite => the node is finite; len <= r_bound => the list covers it.)
+template <int D>
+__device__ __forceinline__ bool tile_edge_needed(const ExtendDev &x, const TileLds<D> &sm, int cl, double d2) {
+  const double len = sqrt_rn(d2);
+  const bool quick = sm.snl[cl] == 0 && sm.sok[cl] != 0 && len > 0.0 && len <= x.r_bound && len < 1e29;
+  return !quick && x.m > 0;
+}
+// the two flags of one neighbour whose node record nd has been fetched; all lanes of the wave together
+template <int D>
+__device__ __forceinline__ int tile_edge_eval(const ExtendDev &x, const TileLds<D> &sm, bool need, int cl,
+                                              const double4 nd, double d2) {
+  if (__ballot(need) == 0ull) return 0;
+  const typename QRecT<D>::type c = sm.cp[cl];
+  bool ho, hi;
+  edge_flags(x, need, c.x, c.y, c.z, nd.x, nd.y, nd.z, sqrt_rn(d2), sm.snl[cl], sm.ssl[cl], ho, hi);
+  return (ho ? 1 : 0) | (hi ? 2 : 0);
+}
 template <int D>
 __device__ __forceinline__ int tile_edge_flags(const ExtendDev &x, const TileLds<D> &sm, bool h, int cl, int id,
                                                double d2) {
-  // Most samples have no sphere within reach of their ball (sok: finite, moderate coordinates): an
-  // edge inside the ball then collides with nothing and needs neither the node's coordinates nor a
-  // test.  (d2 finite and the sample finite => the node is finite; len <= r_bound => the list covers it.)
-  const double len = sqrt_rn(d2);
-  const bool quick = sm.snl[cl] == 0 && sm.sok[cl] != 0 && len > 0.0 && len <= x.r_bound && len < 1e29;
-  const bool need = h && !quick && x.m > 0;
+  const bool need = h && tile_edge_needed<D>(x, sm, cl, d2);
   if (__ballot(need) == 0ull) return 0;
-  double tx = 0, ty = 0, tz = 0;
-  if (need) { const double4 nd = x.naos[id]; tx = nd.x; ty = nd.y; tz = nd.z; }
-  const typename QRecT<D>::type c = sm.cp[cl];
-  bool ho, hi;
-  edge_flags(x, need, c.x, c.y, c.z, tx, ty, tz, len, sm.snl[cl], sm.ssl[cl], ho, hi);
-  return (ho ? 1 : 0) | (hi ? 2 : 0);
+  double4 nd = make_double4(0.0, 0.0, 0.0, 0.0);
+  if (need) nd = x.naos[id];
+  return tile_edge_eval<D>(x, sm, need, cl, nd, d2);
 }
 
 template <int D, bool EXT>
@@ -552,7 +571,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
         ylo = fmin(ylo, __shfl_xor(ylo, off));
         yhi = fmax(yhi, __shfl_xor(yhi, off));
       }
-      if (lane == 0) { sm.lo = lo; sm.hi = hi; sm.ylo = ylo; sm.yhi = yhi; sm.n_list = 0; }
+      if (lane == 0) { sm.lo = lo; sm.hi = hi; sm.ylo = ylo; sm.yhi = yhi; sm.n_list = 0; sm.sqn[0] = 0; sm.sqn[1] = 0; }
     }
     __syncthreads();
     const double lo = sm.lo, hi = sm.hi, ylo = sm.ylo, yhi = sm.yhi;
@@ -603,27 +622,47 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
           if (cb == 0) {
             const int n_pairs = (x.m + 1) / 2;
             const float4 *tp = reinterpret_cast<const float4 *>(x.reach_f);
-            for (int pr = t - 128; pr < n_pairs; pr += 128) {
-              const float4 u = tp[2 * pr], v = tp[2 * pr + 1];
+            const int qw = wave - 2;
+            // exact part for one left-over pair
+            auto exact = [&](int cl, int j) {
+              const typename QRecT<D>::type c = sm.cp[cl];
+              bool listed;
+              if (sample_exact(x, j, c.x, c.y, c.z, sm.sbase[cl], &listed)) sm.sbad[cl] = 1;
+              if (listed) {
+                const int at = atomicAdd(&sm.snl[cl], 1);
+                if (at < kSphListCap) sm.ssl[cl][at] = j;
+              }
+            };
+            for (int pr0 = 0; pr0 < n_pairs; pr0 += 128) {
+              const int pr = pr0 + (t - 128);
+              float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = make_float4(0.f, 0.f, 0.f, 0.f);
+              const bool pv = pr < n_pairs;
+              if (pv) { u = tp[2 * pr]; v = tp[2 * pr + 1]; }
               for (int cl = 0; cl < q1 - q0; ++cl) {
                 const float4 pf = sm.srp[cl];
-                ReachProbe rp;
-                rp.mx = pf.x; rp.my = pf.y; rp.mz = pf.z; rp.h = pf.w;
-                // cheap pre-test on the lane's two spheres before touching the sample's fp64 record
-                const float dxa = u.x - rp.mx, dya = u.z - rp.my, dza = v.x - rp.mz;
-                const float dxb = u.y - rp.mx, dyb = u.w - rp.my, dzb = v.y - rp.mz;
+                const float dxa = u.x - pf.x, dya = u.z - pf.y, dza = v.x - pf.z;
+                const float dxb = u.y - pf.x, dyb = u.w - pf.y, dzb = v.y - pf.z;
                 float da = dxa * dxa; da = __builtin_fmaf(dya, dya, da); da = __builtin_fmaf(dza, dza, da);
                 float db = dxb * dxb; db = __builtin_fmaf(dyb, dyb, db); db = __builtin_fmaf(dzb, dzb, db);
-                const float ba = v.z + rp.h, bb = v.w + rp.h;
-                if (!(da > ba * ba) || !(db > bb * bb)) {
-                  const typename QRecT<D>::type c = sm.cp[cl];
-                  const bool bad = sample_pair(x, pr, u, v, c.x, c.y, c.z, rp, sm.sbase[cl], [&](int j) {
-                    const int at = atomicAdd(&sm.snl[cl], 1);
-                    if (at < kSphListCap) sm.ssl[cl][at] = j;
-                  });
-                  if (bad) sm.sbad[cl] = 1;
+                const float ba = v.z + pf.w, bb = v.w + pf.w;
+                // the left-over pairs are queued (no load in this loop) and evaluated one per lane below
+                for (int h2 = 0; h2 < 2; ++h2) {
+                  const int j = 2 * pr + h2;
+                  const bool near = pv && j < x.m && (h2 == 0 ? !(da > ba * ba) : !(db > bb * bb));
+                  if (near) {
+                    const int at = atomicAdd(&sm.sqn[qw], 1);
+                    if (at < 64) sm.sq[qw][at] = cl | (j << 4);
+                    else exact(cl, j);               // queue full (dense obstacle field): right away
+                  }
                 }
               }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int nq_ev = min(sm.sqn[qw], 64);
+            if (lane < nq_ev) {
+              const int ev = sm.sq[qw][lane];
+              exact(ev & 15, ev >> 4);
             }
           }
         } else {
@@ -882,7 +921,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   int *qhist = nullptr;
   int2 *cbk = nullptr;
   if (use_cull) {
-    int rc = slab_refresh(ctx);
+    int rc = slab_refresh(ctx, (long long)((n_copies_max + 15) / 16));
     if (rc) return rc;
     n_buckets = 1;                          // side * side cells, about 16 copies each
     while (n_buckets < (long long)(n_copies_max / 16) && n_buckets < kMaxQBuckets) n_buckets *= 4;

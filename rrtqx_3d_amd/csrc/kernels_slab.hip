@@ -115,11 +115,24 @@ __global__ __launch_bounds__(256) void chunk_range_kernel(const double *__restri
 
 }  // namespace
 
-int slab_refresh(rrtx_ctx *ctx) {
+// When to rebuild: a search pays for every chunk of the appended tail (its nodes are in arrival order,
+// so each tail chunk spans the world and every tile screens it: ~0.2 us per (tile in flight, chunk)),
+// a rebuild costs ~30 us of launches + ~0.6 ns per node.  The searches since the last rebuild run up a
+// debt of what the tail has cost them; the index is rebuilt when the debt exceeds the price of a
+// rebuild (and always before the tail outgrows half the tree).  Single appends between single queries
+// thus rebuild rarely, whole batches appended between batched searches every handful of calls.  Only
+// the moment changes; no result depends on it.
+int slab_refresh(rrtx_ctx *ctx, long long n_tiles) {
   const int64_t n = ctx->n_nodes;
   const int64_t tail = n - ctx->sl_n_sorted;
-  const int64_t limit = n / 128 > 1024 ? n / 128 : 1024;
-  if (tail <= limit) return RRTX_OK;
+  const int64_t floor_tail = n / 128 > 1024 ? n / 128 : 1024;
+  if (tail <= floor_tail) return RRTX_OK;
+  const double tail_chunks = (double)((tail + kSlabChunk - 1) / kSlabChunk);
+  const double rounds = n_tiles > 1024 ? (double)n_tiles / 1024.0 : 1.0;
+  ctx->sl_debt_us += 0.2 * tail_chunks * rounds;
+  const double rebuild_us = 30.0 + 0.6e-3 * (double)n;
+  if (ctx->sl_n_sorted > 0 && tail <= n / 2 && ctx->sl_debt_us < rebuild_us) return RRTX_OK;
+  ctx->sl_debt_us = 0.0;
   hipStream_t st = ctx->stream;
   // about one cell per chunk: cells of ~512 nodes, laid out as a square grid over (x, y)
   int side = (int)std::sqrt((double)n / (double)kSlabChunk);

@@ -1,13 +1,13 @@
 #!/bin/bash
 # PMC passes for the bench (separate passes; --kernel-trace only, as the pool requires).
-# usage: scripts_gpu_pmc.sh <tag>   -> gpurun_out/<tag>/pN_per_kernel_avg.csv
+# usage: scripts_gpu_pmc.sh <tag>   -> gpurun_out/<tag>/pN_per_kernel_avg.csv + traffic.json
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-tag=${1:-pmc_r1}
+tag=${1:-r02_pmc}
 out=gpurun_out/$tag
 mkdir -p $out
 run() { # name counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/$name.json 2> $out/$name.err
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $out/$name.json 2> $out/$name.err
   echo "pass $name rc=$?"
   python3 tools/pmc_summary.py $out/$name > $out/${name}_per_kernel_avg.csv
   rm -rf $out/$name
@@ -17,4 +17,5 @@ run p2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_AC
 run p3 FETCH_SIZE
 run p4 WRITE_SIZE
 run p5 TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
-ls $out
+python3 tools/pmc_traffic.py $out "nn_tile_kernel<3, true>" > $out/traffic.json
+cat $out/traffic.json
