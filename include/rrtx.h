@@ -118,6 +118,15 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
 #define RRTX_OPT_BUCKET_MULT 10
 /*   RRTX_OPT_TUNE (default 0): bit mask of kernel variants under measurement; results are identical. */
 #define RRTX_OPT_TUNE 11
+/*   RRTX_OPT_SPACE_HAS_TIME (default 0; dim = 4 only): CSpace.spaceHasTime (R/DRRT_data_structures.jl:330) for the
+ *   Dubins entry points.  The third coordinate of [x y t theta] is then time (planning runs in reverse time:
+ *   an edge's start node is LATER than its end node): edge.dist = sqrt(Wdist^2 + dt^2), edge.velocity =
+ *   Wdist / dt and edge.trajectory carries a time column (R/DRRT_DubinsEdge_functions.jl:660-697), validMove
+ *   wants start time > end time and a velocity within rrtx_set_dubins_velocity's bounds (:115-121), and the two-stage
+ *   edge check hands its chord and its pieces to explicitEdgeCheck2D with their times, so polygons that move
+ *   in time (kinds 6 / 7) are tested where they are when the robot passes (:750-774, R/DRRT.jl:1579-1651).
+ *   This one DOES select behaviour: it says which space the caller plans in. */
+#define RRTX_OPT_SPACE_HAS_TIME 12
 int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value);
 
 /* Host-only helper (no GPU needed): the exact thresholds on SQUARED distances the kernels
@@ -163,8 +172,8 @@ int rrtx_polygons_set(rrtx_ctx *ctx, const int32_t *vert_off, const double *vxy,
  * (startPoint[3], R/DRRT_Q.jl:1703; point[3], :1369): edges are tested at the closest approach of
  * the two centres against the bounding circle (:1699-1771), points against the polygon moved to its
  * place at that time (R/DRRT.jl:1289-1305, 1395-1420).  A moving obstacle without a path, and Dubins
- * edge checks against moving obstacles (which need the time-stamped trajectory of
- * R/DRRT_DubinsEdge_functions.jl:660-697), fail with RRTX_E_STATE. */
+ * edge checks against moving obstacles in a space WITHOUT time (their pieces carry no time stamp; see
+ * RRTX_OPT_SPACE_HAS_TIME), fail with RRTX_E_STATE. */
 int rrtx_polygon_paths_set(rrtx_ctx *ctx, const int32_t *path_off, const double *path_xyt, int m);
 /* obstacleAugmentation / expiry (R/obstacleAugmentation.jl:106-114,
  * R/DRRT_Q.jl:3301): change radius and/or active flag of sphere `which`. */
@@ -244,6 +253,14 @@ int rrtx_simple_steer(rrtx_ctx *ctx, const double *s, const double *g, int64_t n
  * ("rsl","rsr","rlr","lsr","lsl","lrl","xxx").  s, g are ne x 4 [x y t theta]. */
 int rrtx_dubins_steer(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min,
                       double *cost, uint8_t *word /* ne x 3 */);
+/* S.dubinsMinVelocity / S.dubinsMaxVelocity (R/DRRT_data_structures.jl:354-355), read by validMove in a space
+ * with time.  Default: no bounds. */
+int rrtx_set_dubins_velocity(rrtx_ctx *ctx, double v_min, double v_max);
+/* calculateTrajectory's scalar results in full: dist = edge.dist (== Wdist without time, sqrt(Wdist^2 + dt^2)
+ * with), wdist = edge.Wdist, velocity = edge.velocity (0 without time), valid_move = validMove(S, edge)
+ * (always 1 without time).  Any output may be NULL. */
+int rrtx_dubins_steer_full(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min, double *dist,
+                           double *wdist, double *velocity, uint8_t *word /* ne x 3 */, uint8_t *valid_move);
 /* Same, plus the discretised trajectory (:506-701) and the two-stage Dubins
  * collision check against the polygon list (:750-774).  traj_len[i] = number of
  * polyline rows the reference builds (may be NULL). */
@@ -252,8 +269,9 @@ int rrtx_dubins_edges_check(rrtx_ctx *ctx, const double *s, const double *g, int
                             uint8_t *hit, int32_t *traj_len);
 
 /* edge.trajectory of calculateTrajectory(S, ::DubinsEdge) (:506-701): the discretised polyline
- * (0.1 rad arc steps, Julia float-range length rule), P_i rows of (x, y) per edge, CSR layout:
- * traj_off[ne+1] (rows), traj_xy[2 * total rows].  Two-call pattern: if the total exceeds
+ * (0.1 rad arc steps, Julia float-range length rule), P_i rows of (x, y) per edge -- rows of (x, y, t) with
+ * RRTX_OPT_SPACE_HAS_TIME, the last row being the end node's (x, y, t) (:684-696) -- CSR layout:
+ * traj_off[ne+1] (rows), traj_xy[(2 or 3) * total rows].  Two-call pattern: if the total exceeds
  * cap_rows the call returns RRTX_E_CAPACITY with *needed_rows set (traj_off is still valid). */
 int rrtx_dubins_trajectory(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min,
                            int64_t *traj_off, double *traj_xy, int64_t cap_rows, int64_t *needed_rows);
@@ -274,6 +292,9 @@ int rrtx_extend_candidates(rrtx_ctx *ctx, const double *q, int nq, double r, dou
  * [x y t theta] with theta wrapped (rrtx_set_wrap), polygon obstacle list.  Per neighbour entry:
  * key = the KDdist the range search stores, Dubins cost and word for sample->near (out) and
  * near->sample (in), and the two-stage Dubins collision flags (R/DRRT_DubinsEdge_functions.jl:750-774).
+ * With RRTX_OPT_SPACE_HAS_TIME the costs are edge.dist in [x y t theta] and a flag byte also carries
+ * bit 1 (value 2) = !validMove(S, edge): findBestParent blocks an edge on either (R/DRRT_Q.jl:1960), so the
+ * caller's test is simply hit != 0.
  * word_out / word_in (3 bytes per entry) and nearest_* / sample_unsafe may be NULL. */
 int rrtx_extend_candidates_dubins(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius,
                                   double r_min, int64_t *offsets, int32_t *idx, double *key, double *cost_out,

@@ -110,6 +110,13 @@ def lib() -> C.CDLL:
     L.orc_dubins_edge_check_polygons.restype = C.c_int
     L.orc_dubins_edge_check_polygons.argtypes = [C.POINTER(Polygon), C.c_int, c_double_p, c_double_p,
                                                  c_double_p, C.c_int, C.c_double, C.c_double, c_int32_p]
+    L.orc_dubins_steer_time.argtypes = [c_double_p, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p,
+                                        C.c_char_p, c_double_p, C.c_int, C.POINTER(C.c_int)]
+    L.orc_dubins_valid_move_time.restype = C.c_int
+    L.orc_dubins_valid_move_time.argtypes = [c_double_p, c_double_p, C.c_double, C.c_double, C.c_double]
+    L.orc_dubins_edge_check_polygons_time.restype = C.c_int
+    L.orc_dubins_edge_check_polygons_time.argtypes = [C.POINTER(Polygon), C.c_int, c_double_p, c_double_p,
+                                                      c_double_p, C.c_int, C.c_double, C.c_double, c_int32_p]
     L.orc_julia_range_len.restype = C.c_int64
     L.orc_julia_range_len.argtypes = [C.c_double] * 3
     L.orc_kd_insert_many.restype = None
@@ -390,6 +397,33 @@ def dubins_edge_check_polygons(ps: PolygonSet, s, g, traj, robot_radius, r_min):
     fh = C.c_int32()
     hit = lib().orc_dubins_edge_check_polygons(ps.arr, ps.m, _dp(s), _dp(g), _dp(traj), traj.shape[0],
                                                robot_radius, r_min, C.byref(fh))
+    return bool(hit), fh.value
+
+
+def dubins_steer_time(s, g, r_min: float):
+    """calculateTrajectory(S, ::DubinsEdge) with S.spaceHasTime: (dist, Wdist, velocity, word, traj[P,3])."""
+    s, g = _vec(s), _vec(g)
+    dist, wdist, vel = C.c_double(), C.c_double(), C.c_double()
+    word = C.create_string_buffer(4)
+    cap = 1024
+    traj = np.zeros((cap, 3), dtype=np.float64)
+    n = C.c_int()
+    lib().orc_dubins_steer_time(_dp(s), _dp(g), r_min, C.byref(dist), C.byref(wdist), C.byref(vel), word, _dp(traj),
+                                cap, C.byref(n))
+    return dist.value, wdist.value, vel.value, word.value.decode(), traj[: n.value].copy()
+
+
+def dubins_valid_move_time(s, g, velocity: float, v_min: float, v_max: float) -> bool:
+    s, g = _vec(s), _vec(g)
+    return bool(lib().orc_dubins_valid_move_time(_dp(s), _dp(g), velocity, v_min, v_max))
+
+
+def dubins_edge_check_polygons_time(ps: "PolygonSet", s, g, traj3, robot_radius, r_min):
+    s, g = _vec(s), _vec(g)
+    traj3 = np.ascontiguousarray(traj3, dtype=np.float64).reshape(-1, 3)
+    fh = C.c_int32()
+    hit = lib().orc_dubins_edge_check_polygons_time(ps.arr, ps.m, _dp(s), _dp(g), _dp(traj3), traj3.shape[0],
+                                                    robot_radius, r_min, C.byref(fh))
     return bool(hit), fh.value
 
 

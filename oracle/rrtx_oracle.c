@@ -1174,6 +1174,73 @@ int orc_dubins_edge_check_polygons(const orc_polygon *obs, int m, const double *
   return 0;
 }
 
+/* calculateTrajectory(S, edge::DubinsEdge) with S.spaceHasTime (R/DRRT_DubinsEdge_functions.jl:660-697):
+ * the same six-word steering in (x, y); edge.Wdist = bestDist, edge.dist = sqrt(bestDist^2 + dt^2)
+ * (:667, `^2` on a Float64 is x*x), edge.velocity = Wdist / dt with dt = start time - end time (:682;
+ * planning runs in reverse time, the start of an edge is LATER than its end), and the trajectory gets a
+ * third column: row 1 carries the start time, rows 2 .. P-1 the start time minus the distance walked
+ * so far (sum of the straight pieces between stored rows, accumulated left to right, :691-695) over the
+ * velocity, and the last row is overwritten with the end node's (x, y, t) (:696).  traj3 (may be NULL)
+ * receives up to traj_cap rows of (x, y, t). */
+void orc_dubins_steer_time(const double *s, const double *g, double r_min, double *dist, double *wdist,
+                           double *velocity, char *word, double *traj3, int traj_cap, int *traj_len) {
+  double best;
+  int n = 0;
+  double *xy = (double *)malloc(sizeof(double) * 2 * (size_t)(traj_cap > 0 ? traj_cap : 1));
+  orc_dubins_steer(s, g, r_min, &best, word, xy, traj_cap, &n);
+  *wdist = best;
+  if (best == INFINITY) {                 /* :661-662: no trajectory, no velocity */
+    *dist = INFINITY;
+    if (velocity) *velocity = NAN;
+    if (traj_len) *traj_len = 0;
+    free(xy);
+    return;
+  }
+  const double dt = s[2] - g[2];
+  *dist = sqrt(best * best + dt * dt);
+  const double vel = best / dt;
+  if (velocity) *velocity = vel;
+  if (traj_len) *traj_len = n;
+  if (traj3 && n > 0) {
+    const int rows = n < traj_cap ? n : traj_cap;
+    for (int i = 0; i < rows; ++i) { traj3[3 * i] = xy[2 * i]; traj3[3 * i + 1] = xy[2 * i + 1]; traj3[3 * i + 2] = 0.0; }
+    traj3[2] = s[2];
+    double cumulative = 0.0;
+    for (int i = 1; i < rows - 1; ++i) {
+      cumulative += orc_euclid(xy + 2 * (i - 1), xy + 2 * i, 2);
+      traj3[3 * i + 2] = s[2] - cumulative / vel;
+    }
+    if (n <= traj_cap) { traj3[3 * (n - 1)] = g[0]; traj3[3 * (n - 1) + 1] = g[1]; traj3[3 * (n - 1) + 2] = g[2]; }
+  }
+  free(xy);
+}
+
+/* validMove(S, edge::DubinsEdge) with S.spaceHasTime, R/DRRT_DubinsEdge_functions.jl:115-121 */
+int orc_dubins_valid_move_time(const double *s, const double *g, double velocity, double v_min, double v_max) {
+  return (s[2] > g[2]) && (v_min <= velocity && velocity <= v_max);
+}
+
+/* explicitEdgeCheck(S, edge::DubinsEdge, obstacle) over the list in a space with time (:750-774):
+ * stage 1 the chord start -> end ([x y t theta]: the moving kinds read time from [3]) with
+ * robotRadius + 2 minTurningRadius, stage 2 every stored piece trajectory[i-1, :] -> [i, :] (rows of
+ * x, y, t) with robotRadius. */
+int orc_dubins_edge_check_polygons_time(const orc_polygon *obs, int m, const double *s, const double *g,
+                                        const double *traj3, int traj_len, double robot_radius, double r_min,
+                                        int32_t *first_hit) {
+  for (int i = 0; i < m; ++i) {
+    const orc_polygon *ob = &obs[i];
+    if (!orc_edge_check_polygon(ob, s, g, robot_radius + 2 * r_min)) continue;
+    for (int k = 1; k < traj_len; ++k) {
+      if (orc_edge_check_polygon(ob, traj3 + 3 * (k - 1), traj3 + 3 * k, robot_radius)) {
+        if (first_hit) *first_hit = i;
+        return 1;
+      }
+    }
+  }
+  if (first_hit) *first_hit = -1;
+  return 0;
+}
+
 /* ------------------------------------------------------------------------ */
 /* CPU baseline: the per-sample inner loop of extend/findBestParent          */
 /* R/rrtqx.jl:926 (kdFindNearest), R/DRRT_Q.jl:2551 (kdFindWithinRange),     */

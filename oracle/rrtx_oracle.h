@@ -132,6 +132,15 @@ void orc_dubins_steer(const double *s, const double *g, double r_min, double *co
 int orc_dubins_edge_check_polygons(const orc_polygon *obs, int m, const double *s, const double *g,
                                    const double *traj, int traj_len, double robot_radius,
                                    double r_min, int32_t *first_hit);
+/* The same with S.spaceHasTime (R/DRRT_DubinsEdge_functions.jl:660-697, 115-121, 750-774): edge.dist,
+ * edge.Wdist, edge.velocity, the trajectory with its time column (rows of x, y, t), validMove, and the
+ * two-stage edge check whose pieces carry time (kinds 6 / 7 are tested at their time stamps). */
+void orc_dubins_steer_time(const double *s, const double *g, double r_min, double *dist, double *wdist,
+                           double *velocity, char *word, double *traj3, int traj_cap, int *traj_len);
+int orc_dubins_valid_move_time(const double *s, const double *g, double velocity, double v_min, double v_max);
+int orc_dubins_edge_check_polygons_time(const orc_polygon *obs, int m, const double *s, const double *g,
+                                        const double *traj3, int traj_len, double robot_radius, double r_min,
+                                        int32_t *first_hit);
 /* Julia float range length for start:step:stop in the literal fallback branch */
 int64_t orc_julia_range_len(double start, double step, double stop);
 

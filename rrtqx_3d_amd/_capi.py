@@ -31,6 +31,7 @@ RRTX_OPT_EXTEND_OBSTACLES = 8
 RRTX_OPT_NEAREST_REC_CAP = 9
 RRTX_OPT_BUCKET_MULT = 10
 RRTX_OPT_TUNE = 11
+RRTX_OPT_SPACE_HAS_TIME = 12
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -93,6 +94,8 @@ SYMBOLS = [
     ("rrtx_points_check", C.c_int, [_VP, C.c_int, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP]),
     ("rrtx_simple_steer", C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP]),
     ("rrtx_dubins_steer", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP]),
+    ("rrtx_set_dubins_velocity", C.c_int, [_VP, C.c_double, C.c_double]),
+    ("rrtx_dubins_steer_full", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP, _VP, _VP, _VP]),
     ("rrtx_dubins_edges_check", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_double, _VP, _VP, _VP, _VP]),
     ("rrtx_dubins_trajectory", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP, C.c_int64, c_int64_p]),
     ("rrtx_extend_candidates", C.c_int, [_VP, _VP, C.c_int, C.c_double, C.c_double, _VP, _VP, _VP, _VP, _VP,

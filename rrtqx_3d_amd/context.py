@@ -218,6 +218,30 @@ class Context:
                                                 _capi._ptr(word)))
         return cost, word.view("S3").ravel()      # numpy bytes array: b"rsl", b"rsr", ...
 
+    def set_space_has_time(self, has_time: bool):
+        """CSpace.spaceHasTime for the Dubins entry points (dim = 4: [x y t theta])."""
+        self.space_has_time = bool(has_time)
+        self.set_option(_capi.RRTX_OPT_SPACE_HAS_TIME, 1 if has_time else 0)
+
+    def set_dubins_velocity(self, v_min: float, v_max: float):
+        """S.dubinsMinVelocity / S.dubinsMaxVelocity (validMove in a space with time)."""
+        self._check(self._lib.rrtx_set_dubins_velocity(self._h, float(v_min), float(v_max)))
+
+    def dubins_steer_full(self, s, g, r_min: float):
+        """calculateTrajectory's scalars: dict(dist, wdist, velocity, word, valid_move)."""
+        s = f64(s, (-1, 4))
+        g = f64(g, (-1, 4))
+        ne = s.shape[0]
+        dist = np.empty(ne, dtype=np.float64)
+        wdist = np.empty(ne, dtype=np.float64)
+        vel = np.empty(ne, dtype=np.float64)
+        word = np.empty((ne, 3), dtype=np.uint8)
+        valid = np.empty(ne, dtype=np.uint8)
+        self._check(self._lib.rrtx_dubins_steer_full(self._h, _capi._ptr(s), _capi._ptr(g), ne, r_min, _capi._ptr(dist),
+                                                     _capi._ptr(wdist), _capi._ptr(vel), _capi._ptr(word),
+                                                     _capi._ptr(valid)))
+        return dict(dist=dist, wdist=wdist, velocity=vel, word=word.view("S3").ravel(), valid_move=valid)
+
     def dubins_edges_check(self, s, g, r_min: float, robot_radius: float):
         s = f64(s, (-1, 4))
         g = f64(g, (-1, 4))
@@ -232,14 +256,16 @@ class Context:
         return cost, word.view("S3").ravel(), hit, tl
 
     def dubins_trajectory(self, s, g, r_min: float):
-        """edge.trajectory of every Dubins edge: (traj_off[ne+1] in rows, traj_xy[rows, 2])."""
+        """edge.trajectory of every Dubins edge: (traj_off[ne+1] in rows, traj[rows, 2]) -- rows of
+        (x, y, t) in a space with time (set_space_has_time)."""
         s = f64(s, (-1, 4))
         g = f64(g, (-1, 4))
         ne = s.shape[0]
         off = np.empty(ne + 1, dtype=np.int64)
         cap = max(64 * ne, 64)
+        cols = 3 if getattr(self, "space_has_time", False) else 2
         while True:
-            xy = np.empty((cap, 2), dtype=np.float64)
+            xy = np.empty((cap, cols), dtype=np.float64)
             needed = C.c_int64()
             rc = self._lib.rrtx_dubins_trajectory(self._h, _capi._ptr(s), _capi._ptr(g), ne, r_min, _capi._ptr(off),
                                                   _capi._ptr(xy), cap, C.byref(needed))

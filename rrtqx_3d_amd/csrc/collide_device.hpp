@@ -21,6 +21,63 @@ __device__ __forceinline__ bool edge_hits_sphere(double p0x, double p0y, double 
   return !(s >= ob.thr);
 }
 
+// ---- polygons moving in time (kinds 6 and 7) ------------------------------------------------
+// findIndexBeforeTime, R/DRRT_Q.jl:1351-1362: 1-based row count with path[i, 3] < t
+__device__ __forceinline__ int index_before_time(const double *__restrict__ path, int rows, double t) {
+  if (rows < 1) return -1;
+  int i = 0;
+  while (i + 1 <= rows && path[3 * i + 2] < t) i += 1;
+  return i;
+}
+
+// findTransformObsToTimeOfPoint, R/DRRT_Q.jl:1367-1391
+__device__ __forceinline__ void transform_obs_to_time(const double *__restrict__ path, int rows, double t,
+                                                      double &dx, double &dy) {
+  const int before = index_before_time(path, rows, t);
+  if (before < 1) { dx = path[0]; dy = path[1]; return; }
+  if (before == rows) { dx = path[3 * (before - 1)]; dy = path[3 * (before - 1) + 1]; return; }
+  const double *b = path + 3 * (before - 1), *a = path + 3 * before;
+  const double along = (t - b[2]) / (a[2] - b[2]);
+  dx = b[0] + along * (a[0] - b[0]);
+  dy = b[1] + along * (a[1] - b[1]);
+}
+
+// explicitEdgeCheck2D, kinds 6 and 7 (R/DRRT_Q.jl:1699-1771 = R/DRRT.jl:1579-1651): robot edge in
+// (x, y, time) against the obstacle's bounding circle carried along its path; every path segment that
+// overlaps the edge in time is tested at the time of closest approach of the two centres.
+__device__ bool edge_hits_moving(double sx, double sy, double st, double ex, double ey, double et,
+                                 double robot_radius, double cx, double cy, double rad,
+                                 const double *__restrict__ path, int rows) {
+  double x_1, y_1, T_1, lx, ly, lt;
+  if (st < et) { x_1 = sx; y_1 = sy; T_1 = st; lx = ex; ly = ey; lt = et; }
+  else { lx = sx; ly = sy; lt = st; x_1 = ex; y_1 = ey; T_1 = et; }
+  int first = index_before_time(path, rows, T_1);
+  if (first < 1) first = 1;
+  int last = 1 + index_before_time(path, rows, lt);
+  if (last > rows) last = rows;
+  if (last <= first) return false;
+  const double m_x1 = (lx - x_1) / (lt - T_1);
+  const double m_y1 = (ly - y_1) / (lt - T_1);
+  const double rr = rad + robot_radius;
+  for (int is = first; is <= last - 1; ++is) {
+    const double *pa = path + 3 * (is - 1), *pb = path + 3 * is;
+    const double x_2 = pa[0] + cx, y_2 = pa[1] + cy, T_2 = pa[2];
+    const double m_x2 = ((pb[0] + cx) - x_2) / (pb[2] - T_2);
+    const double m_y2 = ((pb[1] + cy) - y_2) / (pb[2] - T_2);
+    const double num = (((m_x1 * m_x1) * T_1 + m_x2 * (((m_x2 * T_2) + x_1) - x_2)) -
+                        m_x1 * (((m_x2 * (T_1 + T_2)) + x_1) - x_2)) +
+                       (m_y1 - m_y2) * ((((m_y1 * T_1) - (m_y2 * T_2)) - y_1) + y_2);
+    const double den = (m_x1 - m_x2) * (m_x1 - m_x2) + (m_y1 - m_y2) * (m_y1 - m_y2);
+    double T_c = num / den;
+    if (T_c < jl_max(T_1, T_2)) T_c = jl_max(T_1, T_2);
+    else if (T_c > jl_min(lt, pb[2])) T_c = jl_min(lt, pb[2]);
+    const double r_x = m_x1 * (T_c - T_1) + x_1, r_y = m_y1 * (T_c - T_1) + y_1;
+    const double o_x = m_x2 * (T_c - T_2) + x_2, o_y = m_y2 * (T_c - T_2) + y_2;
+    if ((r_x - o_x) * (r_x - o_x) + (r_y - o_y) * (r_y - o_y) < rr * rr) return true;
+  }
+  return false;
+}
+
 // Per-sample sphere lists of the fused extend path (sample_spheres_kernel / nn_finish_kernel):
 // everything the sample pass needs about one active sphere, one 64-byte record:
 //   thr_in  : quickCheck, inside the sphere            <=> !(s >= thr_in)   (R/DRRT_Q.jl:1410)

@@ -2,11 +2,14 @@
 // two-stage Dubins edge check against polygon obstacles.  Replaces
 // calculateTrajectory(S, ::DubinsEdge) and explicitEdgeCheck(S, ::DubinsEdge, ob)
 // (R/DRRT_DubinsEdge_functions.jl:329-709, 750-774; helpers
-// R/DRRT_distance_functions.jl:62-80), space without time.  gfx950 only.
+// R/DRRT_distance_functions.jl:62-80), in a space without time and -- template TIME,
+// CSpace.spaceHasTime -- in [x y t theta] with the time-stamped trajectory of :660-697, validMove of
+// :115-121 and obstacles that move in time (kinds 6 / 7, R/DRRT.jl:1579-1651).  gfx950 only.
 //
 // Transcendentals come from the ROCm device library, not Julia's libm, so edge
 // costs carry the 1e-6 relative tolerance north_star allows; everything else
 // keeps the reference's operation order (no FMA contraction).
+#include "collide_device.hpp"
 #include "exact_math.hpp"
 #include "rrtx_internal.hpp"
 
@@ -249,6 +252,84 @@ __device__ __forceinline__ void piece_point(const Piece &p, int k, double r_min,
   }
 }
 
+// Time column of edge.trajectory (R/DRRT_DubinsEdge_functions.jl:682-696): row 1 = the start node's
+// time, rows 2 .. P-1 = start time - (distance walked along the stored polyline) / velocity, last
+// row = the end node's (x, y, t).  The reference adds the straight pieces up one by one; here the
+// distance at a row is (distance at the first row of its piece) + (rows into the piece) x (the
+// piece's step): inside an arc every step is the same chord, and the three junctions are measured
+// once.  The two sums differ by rounding only (~1e-15 relative), which is inside the tolerance
+// north_star gives Dubins edge costs; only a collision test on a knife edge can tell.
+struct TimeInfo {
+  double st, et, vel;      // start / end time, edge.velocity = Wdist / (st - et)
+  double gx, gy;           // end node (the last row is made exact)
+  double cum[3], chord[3];
+  int P;
+};
+
+__device__ __forceinline__ TimeInfo time_info(const Steer &st, const double *__restrict__ s,
+                                              const double *__restrict__ g, double r_min) {
+  TimeInfo ti;
+  ti.st = s[2]; ti.et = g[2];
+  ti.vel = st.cost / (s[2] - g[2]);
+  ti.gx = g[0]; ti.gy = g[1];
+  ti.P = st.pc[0].len + st.pc[1].len + st.pc[2].len;
+  double run = 0.0, lx = 0.0, ly = 0.0;
+  bool have_last = false;
+#pragma unroll
+  for (int pi = 0; pi < 3; ++pi) {
+    const Piece &p = st.pc[pi];
+    ti.cum[pi] = run; ti.chord[pi] = 0.0;
+    if (p.len <= 0) continue;
+    double x0, y0;
+    piece_point(p, 0, r_min, x0, y0);
+    if (have_last) { run = run + seg_len2(lx, ly, x0, y0); ti.cum[pi] = run; }
+    if (p.len > 1) {
+      double x1, y1;
+      piece_point(p, 1, r_min, x1, y1);
+      ti.chord[pi] = seg_len2(x0, y0, x1, y1);
+      run = run + (double)(p.len - 1) * ti.chord[pi];
+      piece_point(p, p.len - 1, r_min, lx, ly);
+    } else {
+      lx = x0; ly = y0;
+    }
+    have_last = true;
+  }
+  return ti;
+}
+
+// row `row` of the stored polyline with its time stamp
+__device__ __forceinline__ void polyline_point_t(const Piece *pc, const TimeInfo &ti, int row, double r_min, double &x,
+                                                 double &y, double &t) {
+  int pi = 0, k = row;
+  if (k >= pc[0].len) { k -= pc[0].len; pi = 1; }
+  if (pi == 1 && k >= pc[1].len) { k -= pc[1].len; pi = 2; }
+  piece_point(pc[pi], k, r_min, x, y);
+  if (row == 0) t = ti.st;
+  else if (row == ti.P - 1) { x = ti.gx; y = ti.gy; t = ti.et; }
+  else t = ti.st - (ti.cum[pi] + (double)k * ti.chord[pi]) / ti.vel;
+}
+
+// edge.dist with S.spaceHasTime: sqrt(bestDist^2 + (start time - end time)^2), Inf stays Inf (:661-667)
+__device__ __forceinline__ double dist_with_time(double best, double st, double et) {
+  if (best == __builtin_inf()) return best;
+  const double dt = st - et;
+  return sqrt_rn(best * best + dt * dt);
+}
+// validMove with S.spaceHasTime (:115-121)
+__device__ __forceinline__ bool valid_move_time(double st, double et, double vel, double vmin, double vmax) {
+  return (st > et) && (vmin <= vel) && (vel <= vmax);
+}
+
+// the polygon list as the Dubins kernels read it
+struct PolyTab {
+  const double *meta;        // per active obstacle {cx, cy, radius, kind}
+  const int32_t *off;        // vertex CSR
+  const double *vxy;
+  const int32_t *poff;       // path CSR (kinds 6 / 7)
+  const double *path;        // rows (dx, dy, t)
+  int m;
+};
+
 __device__ __forceinline__ void write_word(uint8_t *__restrict__ word, long long i, int w) {
   const char *tab = "rslrsrrlrlsrlsllrlxxx";
   word[3 * i + 0] = (uint8_t)tab[3 * w + 0];
@@ -256,15 +337,24 @@ __device__ __forceinline__ void write_word(uint8_t *__restrict__ word, long long
   word[3 * i + 2] = (uint8_t)tab[3 * w + 2];
 }
 
+// calculateTrajectory's scalar results.  has_time: edge.dist = sqrt(Wdist^2 + dt^2), edge.velocity and
+// validMove (R/DRRT_DubinsEdge_functions.jl:661-682, 115-121); otherwise dist = Wdist and every move is valid.
 __global__ __launch_bounds__(256) void dubins_steer_kernel(const double *__restrict__ s,
                                                            const double *__restrict__ g, long long ne,
-                                                           double r_min, double *__restrict__ cost,
-                                                           uint8_t *__restrict__ word) {
+                                                           double r_min, int has_time, double vmin, double vmax,
+                                                           double *__restrict__ cost, double *__restrict__ wdist,
+                                                           double *__restrict__ velocity,
+                                                           uint8_t *__restrict__ word, uint8_t *__restrict__ valid) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ne) return;
   Steer st;
   dubins_steer<false>(s + 4 * i, g + 4 * i, r_min, st);
-  cost[i] = st.cost;
+  const double t0 = s[4 * i + 2], t1 = g[4 * i + 2];
+  const double vel = st.cost / (t0 - t1);
+  if (cost) cost[i] = has_time ? dist_with_time(st.cost, t0, t1) : st.cost;
+  if (wdist) wdist[i] = st.cost;
+  if (velocity) velocity[i] = has_time ? vel : 0.0;
+  if (valid) valid[i] = (!has_time || valid_move_time(t0, t1, vel, vmin, vmax)) ? 1 : 0;
   if (word) write_word(word, i, st.word);
 }
 
@@ -356,15 +446,17 @@ __device__ bool seg_hits_polygon_past_circle(double ax, double ay, double bx, do
 //     whatever the lengths of the individual polylines are, and an edge that has collided drops
 //     out of the numbering.
 // Same set of tests, same arithmetic in each.  Every lane of the wave calls this together.
-struct WaveDubins {
+template <bool TIME>
+struct WaveDubinsT {
   Piece pc[64][3];
   unsigned long long mask[64];
   unsigned long long cand[64];    // stage 1: obstacles the chord's box reaches; stage 2: those a piece reaches
-  double chord[4][64];            // stage 1: the edges' chords; stage 2: end points of the round's 64 pieces
+  double chord[TIME ? 6 : 4][64]; // stage 1: the edges' chords; stage 2: end points (and times) of the round's 64 pieces
   int piece_edge[64];
   int pstart[65];
   int pairs[65];
   int done[64];
+  TimeInfo ti[TIME ? 64 : 1];
 };
 
 __device__ __forceinline__ void polyline_point(const Piece *pc, int row, double r_min, double &x, double &y) {
@@ -374,11 +466,18 @@ __device__ __forceinline__ void polyline_point(const Piece *pc, int row, double 
   piece_point(pc[pi], row, r_min, x, y);
 }
 
-__device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st, double sx, double sy, double gx,
-                                     double gy, double r_min, double robot_radius, const double *__restrict__ meta,
-                                     const int32_t *__restrict__ off, const double *__restrict__ vxy, int m) {
+template <bool TIME>
+__device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Steer &st, const double *__restrict__ sp,
+                                     const double *__restrict__ gp, double r_min, double robot_radius,
+                                     const PolyTab &tab) {
+  const double *__restrict__ meta = tab.meta;
+  const int32_t *__restrict__ off = tab.off;
+  const double *__restrict__ vxy = tab.vxy;
+  const int m = tab.m;
+  const double sx = sp[0], sy = sp[1], gx = gp[0], gy = gp[1];
   const int lane = threadIdx.x & 63;
   w.pc[lane][0] = st.pc[0]; w.pc[lane][1] = st.pc[1]; w.pc[lane][2] = st.pc[2];
+  if constexpr (TIME) w.ti[lane] = time_info(st, sp, gp, r_min);
   w.done[lane] = 0;
   const int rows = st.pc[0].len + st.pc[1].len + st.pc[2].len;
   for (int j0 = 0; j0 < m; j0 += 64) {
@@ -387,6 +486,7 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
     // chord's box cannot reach fail that test for certain (box widened by 1e-9 against ~1e-15 of
     // rounding; NaN / overflow keep the obstacle)
     w.chord[0][lane] = sx; w.chord[1][lane] = sy; w.chord[2][lane] = gx; w.chord[3][lane] = gy;   // (stage 2 reuses it)
+    if constexpr (TIME) { w.chord[4][lane] = sp[2]; w.chord[5][lane] = gp[2]; }
     unsigned long long cand = 0ull;
     if (valid && !w.done[lane]) {
       // (NaN-propagating min / max: a chord with a NaN coordinate keeps every obstacle)
@@ -396,7 +496,8 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
         const double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
         const double R = fabs((robot_radius + 2 * r_min) + meta[4 * j + 2]) * (1.0 + 1e-9) +
                          1e-9 * (1.0 + fabs(cx) + fabs(cy)) + cslack;
-        const bool c = !(cxmax < cx - R || cxmin > cx + R || cymax < cy - R || cymin > cy + R);
+        bool c = !(cxmax < cx - R || cxmin > cx + R || cymax < cy - R || cymin > cy + R);
+        if constexpr (TIME) c = c || meta[4 * j + 3] >= 6.0;     // a moving obstacle is not where its record says
         cand |= (c ? 1ull : 0ull) << (j - j0);
       }
     }
@@ -420,9 +521,16 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
       unsigned long long bits = w.cand[e];
       for (int r = p - w.pstart[e]; r > 0; --r) bits &= bits - 1ull;
       const int b = __ffsll((long long)bits) - 1;
-      if (seg_hits_polygon(w.chord[0][e], w.chord[1][e], w.chord[2][e], w.chord[3][e], robot_radius + 2 * r_min, meta,
-                           off, vxy, j0 + b))
-        atomicOr(&w.mask[e], 1ull << b);
+      const int j = j0 + b;
+      bool h1;
+      if (TIME && meta[4 * j + 3] >= 6.0)
+        h1 = edge_hits_moving(w.chord[0][e], w.chord[1][e], w.chord[TIME ? 4 : 0][e], w.chord[2][e], w.chord[3][e],
+                              w.chord[TIME ? 5 : 0][e], robot_radius + 2 * r_min, meta[4 * j + 0], meta[4 * j + 1],
+                              meta[4 * j + 2], tab.path + 3 * (size_t)tab.poff[j], tab.poff[j + 1] - tab.poff[j]);
+      else
+        h1 = seg_hits_polygon(w.chord[0][e], w.chord[1][e], w.chord[2][e], w.chord[3][e], robot_radius + 2 * r_min, meta,
+                              off, vxy, j);
+      if (h1) atomicOr(&w.mask[e], 1ull << b);
     }
     __builtin_amdgcn_wave_barrier();
     const unsigned long long mask = w.mask[lane];
@@ -450,7 +558,7 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
         const int i = i0 + lane;
         unsigned long long near = 0ull;
         int e = 0;
-        double px = 0.0, py = 0.0, x = 0.0, y = 0.0;
+        double px = 0.0, py = 0.0, x = 0.0, y = 0.0, pt = 0.0, t = 0.0;
         if (i < total) {
           int lo = 0, hi = 64;                     // edge e with pstart[e] <= i < pstart[e + 1]
           while (hi - lo > 1) {
@@ -460,17 +568,24 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
           e = lo;
           if (!w.done[e]) {
             const int row = base + (i - w.pstart[e]) + 1;
-            polyline_point(w.pc[e], row - 1, r_min, px, py);
-            polyline_point(w.pc[e], row, r_min, x, y);
+            if constexpr (TIME) {
+              polyline_point_t(w.pc[e], w.ti[e], row - 1, r_min, px, py, pt);
+              polyline_point_t(w.pc[e], w.ti[e], row, r_min, x, y, t);
+            } else {
+              polyline_point(w.pc[e], row - 1, r_min, px, py);
+              polyline_point(w.pc[e], row, r_min, x, y);
+            }
             unsigned long long mm = w.mask[e];
             while (mm != 0ull) {
               const int b = __ffsll((long long)mm) - 1;
               mm &= mm - 1ull;
-              if (!seg_outside_circle(px, py, x, y, robot_radius, meta, j0 + b)) near |= 1ull << b;
+              const bool moving = TIME && meta[4 * (j0 + b) + 3] >= 6.0;   // no bounding-circle step for those (:1579)
+              if (moving || !seg_outside_circle(px, py, x, y, robot_radius, meta, j0 + b)) near |= 1ull << b;
             }
           }
         }
         w.chord[0][lane] = px; w.chord[1][lane] = py; w.chord[2][lane] = x; w.chord[3][lane] = y;
+        if constexpr (TIME) { w.chord[4][lane] = pt; w.chord[5][lane] = t; }
         w.cand[lane] = near;
         w.piece_edge[lane] = e;
         int pin = __popcll(near);
@@ -493,9 +608,15 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
           unsigned long long bits = w.cand[it];
           for (int r = p - w.pairs[it]; r > 0; --r) bits &= bits - 1ull;
           const int j = j0 + __ffsll((long long)bits) - 1;
-          if (seg_hits_polygon_past_circle(w.chord[0][it], w.chord[1][it], w.chord[2][it], w.chord[3][it], robot_radius,
-                                           meta, off, vxy, j))
-            w.done[ee] = 1;
+          bool h2;
+          if (TIME && meta[4 * j + 3] >= 6.0)
+            h2 = edge_hits_moving(w.chord[0][it], w.chord[1][it], w.chord[TIME ? 4 : 0][it], w.chord[2][it], w.chord[3][it],
+                                  w.chord[TIME ? 5 : 0][it], robot_radius, meta[4 * j + 0], meta[4 * j + 1], meta[4 * j + 2],
+                                  tab.path + 3 * (size_t)tab.poff[j], tab.poff[j + 1] - tab.poff[j]);
+          else
+            h2 = seg_hits_polygon_past_circle(w.chord[0][it], w.chord[1][it], w.chord[2][it], w.chord[3][it], robot_radius,
+                                              meta, off, vxy, j);
+          if (h2) w.done[ee] = 1;
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -508,17 +629,18 @@ __device__ bool wave_dubins_collides(WaveDubins &w, bool valid, const Steer &st,
 
 // Candidate Dubins edges of extend(): CSR entry e = (sample qi, node idx[e]); both directed edges
 // sample->near and near->sample are steered and checked (R/DRRT_Q.jl:1951-1963, 2600-2602 with
-// Edge = DubinsEdge).
-__global__ __launch_bounds__(256, 3) void candidate_dubins_kernel(
+// Edge = DubinsEdge).  TIME: costs are edge.dist in [x y t theta], the pieces carry time, and bit 1 of
+// a hit byte says !validMove (findBestParent blocks an edge on explicitEdgeCheck || !validMove, :1960).
+template <bool TIME>
+__global__ __launch_bounds__(256, TIME ? 2 : 3) void candidate_dubins_kernel(
     const double *__restrict__ q, const int64_t *__restrict__ offsets, int nq, const int32_t *__restrict__ idx,
     const int32_t *__restrict__ owner, const double *__restrict__ nx, const double *__restrict__ ny,
     const double *__restrict__ nz, const double *__restrict__ nw, int n_nodes, long long cap, double r_min,
-    double robot_radius, const double *__restrict__ meta, const int32_t *__restrict__ off,
-    const double *__restrict__ vxy, int m, double *__restrict__ cost_out, double *__restrict__ cost_in,
-    uint8_t *__restrict__ word_out, uint8_t *__restrict__ word_in, uint8_t *__restrict__ hit_out,
-    uint8_t *__restrict__ hit_in) {
-  __shared__ WaveDubins wd[4];
-  WaveDubins &w = wd[threadIdx.x >> 6];
+    double robot_radius, double vmin, double vmax, const PolyTab tab, double *__restrict__ cost_out,
+    double *__restrict__ cost_in, uint8_t *__restrict__ word_out, uint8_t *__restrict__ word_in,
+    uint8_t *__restrict__ hit_out, uint8_t *__restrict__ hit_in) {
+  __shared__ WaveDubinsT<TIME> wd[4];
+  WaveDubinsT<TIME> &w = wd[threadIdx.x >> 6];
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = offsets[nq];
   if (total > cap) return;      // capacity overflow: the CSR arrays are only partly written
@@ -537,31 +659,35 @@ __global__ __launch_bounds__(256, 3) void candidate_dubins_kernel(
   }
   Steer st;
   dubins_steer<true>(s, g, r_min, st);
+  int bad_move = 0;
   if (valid) {
-    cost_out[e] = st.cost;
+    cost_out[e] = TIME ? dist_with_time(st.cost, s[2], g[2]) : st.cost;
     if (word_out) write_word(word_out, e, st.word);
+    if (TIME && !valid_move_time(s[2], g[2], st.cost / (s[2] - g[2]), vmin, vmax)) bad_move = 2;
   }
-  const bool ho = wave_dubins_collides(w, valid, st, s[0], s[1], g[0], g[1], r_min, robot_radius, meta, off, vxy, m);
-  if (valid) hit_out[e] = ho ? 1 : 0;
+  const bool ho = wave_dubins_collides<TIME>(w, valid, st, s, g, r_min, robot_radius, tab);
+  if (valid) hit_out[e] = (ho ? 1 : 0) | bad_move;
   dubins_steer<true>(g, s, r_min, st);
+  bad_move = 0;
   if (valid) {
-    cost_in[e] = st.cost;
+    cost_in[e] = TIME ? dist_with_time(st.cost, g[2], s[2]) : st.cost;
     if (word_in) write_word(word_in, e, st.word);
+    if (TIME && !valid_move_time(g[2], s[2], st.cost / (g[2] - s[2]), vmin, vmax)) bad_move = 2;
   }
-  const bool hi = wave_dubins_collides(w, valid, st, g[0], g[1], s[0], s[1], r_min, robot_radius, meta, off, vxy, m);
-  if (valid) hit_in[e] = hi ? 1 : 0;
+  const bool hi = wave_dubins_collides<TIME>(w, valid, st, g, s, r_min, robot_radius, tab);
+  if (valid) hit_in[e] = (hi ? 1 : 0) | bad_move;
 }
 
 // explicitEdgeCheck(S, ::DubinsEdge, ob) over the polygon list (:750-774):
 // stage 1 = straight chord with radius robotRadius + 2*minTurningRadius,
 // stage 2 = every stored polyline piece with robotRadius.
+template <bool TIME>
 __global__ __launch_bounds__(256) void dubins_edges_check_kernel(
     const double *__restrict__ s, const double *__restrict__ g, long long ne, double r_min,
-    double robot_radius, const double *__restrict__ meta, const int32_t *__restrict__ off,
-    const double *__restrict__ vxy, int m, double *__restrict__ cost, uint8_t *__restrict__ word,
+    double robot_radius, const PolyTab tab, double *__restrict__ cost, uint8_t *__restrict__ word,
     uint8_t *__restrict__ hit, int32_t *__restrict__ traj_len) {
-  __shared__ WaveDubins wd[4];
-  WaveDubins &w = wd[threadIdx.x >> 6];
+  __shared__ WaveDubinsT<TIME> wd[4];
+  WaveDubinsT<TIME> &w = wd[threadIdx.x >> 6];
   // Edges arrive grouped by their sample, and the cost of an edge is decided by where its sample
   // lies (near a polygon every polyline has to be walked, elsewhere none): a wave therefore takes
   // every n_waves-th edge instead of 64 neighbours, so that all waves get the same mix.
@@ -574,21 +700,22 @@ __global__ __launch_bounds__(256) void dubins_edges_check_kernel(
   dubins_steer<true>(s + 4 * ic, g + 4 * ic, r_min, st);
   const int P = st.pc[0].len + st.pc[1].len + st.pc[2].len;
   if (valid) {
-    if (cost) cost[i] = st.cost;
+    if (cost) cost[i] = TIME ? dist_with_time(st.cost, s[4 * ic + 2], g[4 * ic + 2]) : st.cost;
     if (word) write_word(word, i, st.word);
     if (traj_len) traj_len[i] = P;
   }
-  const double sx = s[4 * ic], sy = s[4 * ic + 1], gx = g[4 * ic], gy = g[4 * ic + 1];
-  const bool h = wave_dubins_collides(w, valid, st, sx, sy, gx, gy, r_min, robot_radius, meta, off, vxy, m);
+  const bool h = wave_dubins_collides<TIME>(w, valid, st, s + 4 * ic, g + 4 * ic, r_min, robot_radius, tab);
   if (valid) hit[i] = h ? 1 : 0;
 }
 
-// edge.trajectory (R/DRRT_DubinsEdge_functions.jl:699-701): the P x 2 polyline of every edge,
-// written at traj_off[i] (row units); mode 0 only reports P per edge.
+// edge.trajectory (R/DRRT_DubinsEdge_functions.jl:684-701): the polyline of every edge, written at
+// traj_off[i] (row units), rows of (x, y) -- with has_time rows of (x, y, t); traj == null only
+// reports P per edge.
 __global__ __launch_bounds__(256) void dubins_trajectory_kernel(const double *__restrict__ s,
                                                                 const double *__restrict__ g, long long ne,
-                                                                double r_min, const int64_t *__restrict__ traj_off,
-                                                                double *__restrict__ traj_xy, long long cap_rows,
+                                                                double r_min, int has_time,
+                                                                const int64_t *__restrict__ traj_off,
+                                                                double *__restrict__ traj, long long cap_rows,
                                                                 int32_t *__restrict__ traj_len) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ne) return;
@@ -596,14 +723,42 @@ __global__ __launch_bounds__(256) void dubins_trajectory_kernel(const double *__
   dubins_steer<true>(s + 4 * i, g + 4 * i, r_min, st);
   const int P = st.pc[0].len + st.pc[1].len + st.pc[2].len;
   if (traj_len) traj_len[i] = P;
-  if (!traj_xy) return;
+  if (!traj) return;
   long long row = traj_off[i];
+  if (has_time) {
+    const TimeInfo ti = time_info(st, s + 4 * i, g + 4 * i, r_min);
+    for (int k = 0; k < P; ++k, ++row) {
+      double x, y, t;
+      polyline_point_t(st.pc, ti, k, r_min, x, y, t);
+      if (row < cap_rows) { traj[3 * row] = x; traj[3 * row + 1] = y; traj[3 * row + 2] = t; }
+    }
+    return;
+  }
   for (int pi = 0; pi < 3; ++pi)
     for (int k = 0; k < st.pc[pi].len; ++k, ++row) {
       double x, y;
       piece_point(st.pc[pi], k, r_min, x, y);
-      if (row < cap_rows) { traj_xy[2 * row] = x; traj_xy[2 * row + 1] = y; }
+      if (row < cap_rows) { traj[2 * row] = x; traj[2 * row + 1] = y; }
     }
+}
+
+PolyTab poly_tab(rrtx_ctx *ctx) {
+  PolyTab t;
+  t.meta = ctx->d_poly_meta.as<double>();
+  t.off = ctx->d_poly_off.as<int32_t>();
+  t.vxy = ctx->d_poly_vxy.as<double>();
+  t.poff = ctx->d_poly_path_off.as<int32_t>();
+  t.path = ctx->d_poly_path.as<double>();
+  t.m = ctx->poly_n_active;
+  return t;
+}
+
+// obstacles that move in time are tested at the pieces' time stamps: only a space with time has them
+int check_space(rrtx_ctx *ctx) {
+  if (ctx->poly_has_moving && !ctx->opt_space_has_time)
+    return fail(ctx, RRTX_E_STATE, "Dubins edges against moving obstacles (kind 6/7) need the time-parameterised "
+                                   "trajectory: set RRTX_OPT_SPACE_HAS_TIME (CSpace.spaceHasTime)");
+  return RRTX_OK;
 }
 
 }  // namespace
@@ -616,42 +771,48 @@ int launch_candidate_dubins(rrtx_ctx *ctx, const double *q_dev, int nq, const in
   if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
   int rc = sync_polygons(ctx);
   if (rc) return rc;
-  // kinds 6 / 7 test each trajectory piece at its time stamp (R/DRRT_DubinsEdge_functions.jl:660-697 builds
-  // the time-parameterised polyline); this library steers in a space without time
-  if (ctx->poly_has_moving)
-    return fail(ctx, RRTX_E_STATE, "Dubins edges against moving obstacles (kind 6/7) need time-parameterised trajectories");
+  if ((rc = check_space(ctx))) return rc;
+  const PolyTab tab = poly_tab(ctx);
   span_begin(ctx, KF_DUBINS);
-  hipLaunchKernelGGL(candidate_dubins_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, q_dev,
-                     offsets_dev, nq, idx_dev, owner_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[3],
-                     (int)ctx->n_nodes, (long long)cap, r_min, robot_radius, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
-                     ctx->d_poly_vxy.as<double>(), ctx->poly_n_active, cost_out, cost_in, word_out, word_in, hit_out,
-                     hit_in);
+  const dim3 grid((unsigned)((cap + 255) / 256)), block(256);
+  if (ctx->opt_space_has_time)
+    hipLaunchKernelGGL(candidate_dubins_kernel<true>, grid, block, 0, ctx->stream, q_dev, offsets_dev, nq, idx_dev,
+                       owner_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[3], (int)ctx->n_nodes,
+                       (long long)cap, r_min, robot_radius, ctx->dubins_vmin, ctx->dubins_vmax, tab, cost_out, cost_in,
+                       word_out, word_in, hit_out, hit_in);
+  else
+    hipLaunchKernelGGL(candidate_dubins_kernel<false>, grid, block, 0, ctx->stream, q_dev, offsets_dev, nq, idx_dev,
+                       owner_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[3], (int)ctx->n_nodes,
+                       (long long)cap, r_min, robot_radius, ctx->dubins_vmin, ctx->dubins_vmax, tab, cost_out, cost_in,
+                       word_out, word_in, hit_out, hit_in);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
 }
 
 int launch_dubins_trajectory(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
-                             const int64_t *traj_off_dev, double *traj_xy_dev, int64_t cap_rows,
+                             const int64_t *traj_off_dev, double *traj_dev, int64_t cap_rows,
                              int32_t *traj_len_dev) {
   if (ne <= 0) return RRTX_OK;
   if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
   span_begin(ctx, KF_DUBINS);
   hipLaunchKernelGGL(dubins_trajectory_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream,
-                     s_dev, g_dev, (long long)ne, r_min, traj_off_dev, traj_xy_dev, (long long)cap_rows,
-                     traj_len_dev);
+                     s_dev, g_dev, (long long)ne, r_min, ctx->opt_space_has_time ? 1 : 0, traj_off_dev, traj_dev,
+                     (long long)cap_rows, traj_len_dev);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
 }
 
 int launch_dubins_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
-                        double *cost_dev, uint8_t *word_dev) {
+                        double *cost_dev, uint8_t *word_dev, double *wdist_dev, double *velocity_dev,
+                        uint8_t *valid_dev) {
   if (ne <= 0) return RRTX_OK;
   if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
   span_begin(ctx, KF_DUBINS);
   hipLaunchKernelGGL(dubins_steer_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, s_dev,
-                     g_dev, (long long)ne, r_min, cost_dev, word_dev);
+                     g_dev, (long long)ne, r_min, ctx->opt_space_has_time ? 1 : 0, ctx->dubins_vmin, ctx->dubins_vmax,
+                     cost_dev, wdist_dev, velocity_dev, word_dev, valid_dev);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
@@ -664,15 +825,16 @@ int launch_dubins_edges_check(rrtx_ctx *ctx, const double *s_dev, const double *
   if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
   int rc = sync_polygons(ctx);
   if (rc) return rc;
-  // kinds 6 / 7 test each trajectory piece at its time stamp (R/DRRT_DubinsEdge_functions.jl:660-697 builds
-  // the time-parameterised polyline); this library steers in a space without time
-  if (ctx->poly_has_moving)
-    return fail(ctx, RRTX_E_STATE, "Dubins edges against moving obstacles (kind 6/7) need time-parameterised trajectories");
+  if ((rc = check_space(ctx))) return rc;
+  const PolyTab tab = poly_tab(ctx);
   span_begin(ctx, KF_DUBINS);
-  hipLaunchKernelGGL(dubins_edges_check_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream,
-                     s_dev, g_dev, (long long)ne, r_min, robot_radius, ctx->d_poly_meta.as<double>(),
-                     ctx->d_poly_off.as<int32_t>(), ctx->d_poly_vxy.as<double>(), ctx->poly_n_active, cost_dev,
-                     word_dev, hit_dev, traj_len_dev);
+  const dim3 grid((unsigned)((ne + 255) / 256)), block(256);
+  if (ctx->opt_space_has_time)
+    hipLaunchKernelGGL(dubins_edges_check_kernel<true>, grid, block, 0, ctx->stream, s_dev, g_dev, (long long)ne, r_min,
+                       robot_radius, tab, cost_dev, word_dev, hit_dev, traj_len_dev);
+  else
+    hipLaunchKernelGGL(dubins_edges_check_kernel<false>, grid, block, 0, ctx->stream, s_dev, g_dev, (long long)ne, r_min,
+                       robot_radius, tab, cost_dev, word_dev, hit_dev, traj_len_dev);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;

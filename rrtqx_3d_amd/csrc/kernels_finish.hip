@@ -23,7 +23,8 @@ namespace {
 
 constexpr int kFinThreads = 512;
 constexpr int kFinQ = kFinThreads / 32;   // queries per workgroup
-constexpr int kBigSort = 2048;
+constexpr int kBigSort = 2048;      // LDS sort of the normal build of the kernel
+constexpr int kHugeSort = 8192;     // ... of the build for calls with long lists (dense balls: Dubins spaces, sweeps)
 
 struct FinishArgs {
   const int *count;
@@ -52,6 +53,7 @@ struct FinishArgs {
   NearestIndex ni;
 };
 
+template <int KSORT>
 struct FinLds {
   long long red[kFinThreads / 64];
   long long off[kFinQ + 1];
@@ -59,9 +61,9 @@ struct FinLds {
   int todo[kFinQ];             // the list needs the whole workgroup
   int empty[kFinQ];
   int gcnt;
-  int s_idx[kBigSort];
-  double s_d2[kBigSort];
-  unsigned char s_fl[kBigSort];   // the records' edge flags travel with the sort
+  int s_idx[KSORT];
+  double s_d2[KSORT];
+  unsigned char s_fl[KSORT];   // the records' edge flags travel with the sort
   double r_best[kFinThreads / 64];
   int r_besti[kFinThreads / 64];
   NearestScratch ns;
@@ -83,9 +85,9 @@ __device__ __forceinline__ BktRec load_rec(const FinishArgs &a, int q, long long
 
 // D: coordinates per query point.  Eight waves per SIMD = four workgroups per CU: the 1024 workgroups of
 // a 16384-query batch are then resident at once and the kernel is one pass of their dependency chain.
-template <int D>
-__global__ __launch_bounds__(kFinThreads, 8) void nn_finish_kernel(FinishArgs a) {
-  __shared__ FinLds sm;
+template <int D, int KSORT>
+__global__ __launch_bounds__(kFinThreads, KSORT > kBigSort ? 2 : 8) void nn_finish_kernel(FinishArgs a) {
+  __shared__ FinLds<KSORT> sm;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int hl = t & 31, hw = t >> 5;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(kFinThreads, 8) void nn_finish_kernel(FinishArgs a)
     }
     double best = __builtin_inf();
     int best_i = 0x7fffffff;
-    if (gk <= kBigSort) {
+    if (gk <= KSORT) {
       int n2 = 64;
       while (n2 < gk) n2 <<= 1;
       for (int i = t; i < n2; i += kFinThreads) {
@@ -383,8 +385,16 @@ int launch_nn_finish(rrtx_ctx *ctx, const FinishLaunch &f) {
   a.ni.n_chunks = (int)((ctx->n_nodes + kSlabChunk - 1) / kSlabChunk);
   a.hit_out = f.hit_out; a.hit_in = f.hit_in;
   const dim3 grid((unsigned)((f.nq + kFinQ - 1) / kFinQ)), block(kFinThreads);
-  if (D == 4) hipLaunchKernelGGL(nn_finish_kernel<4>, grid, block, 0, ctx->stream, a);
-  else hipLaunchKernelGGL(nn_finish_kernel<3>, grid, block, 0, ctx->stream, a);
+  // lists of hundreds of entries and more (the caller made room for them): the build that sorts up to
+  // kHugeSort entries in LDS (one workgroup per CU) instead of counting ranks over global memory
+  const bool huge = f.out_cap / (f.nq > 0 ? f.nq : 1) >= 2048;
+  if (D == 4) {
+    if (huge) hipLaunchKernelGGL((nn_finish_kernel<4, kHugeSort>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((nn_finish_kernel<4, kBigSort>), grid, block, 0, ctx->stream, a);
+  } else {
+    if (huge) hipLaunchKernelGGL((nn_finish_kernel<3, kHugeSort>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((nn_finish_kernel<3, kBigSort>), grid, block, 0, ctx->stream, a);
+  }
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
 }

@@ -935,10 +935,10 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
     qhist = ctx->ws_qhist.as<int>();
     cbk = ctx->ws_cb.as<int2>();
   }
-  // ---- hit sink: per-query buckets (bkt_mult x the average the caller made room for, at most 2 GiB
-  //      in all) + overflow list ----
+  // ---- hit sink: per-query buckets (bkt_mult x the average the caller made room for, at most 16 GiB
+  //      in all -- there are 288) + overflow list ----
   long long bcap_ll = (rec_cap + nq - 1) / nq * ctx->bkt_mult;
-  while (bcap_ll > 16 && bcap_ll * nq > (1ll << 27)) bcap_ll /= 2;
+  while (bcap_ll > 16 && bcap_ll * nq > (1ll << 30)) bcap_ll /= 2;
   bcap_ll = (bcap_ll + 7) / 8 * 8;
   if (bcap_ll < 8) bcap_ll = 8;
   if (bcap_ll > (1ll << 24)) bcap_ll = 1ll << 24;

@@ -418,6 +418,10 @@ int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value) {
     case RRTX_OPT_KNN_LISTS: ctx->opt_knn_lists = value != 0; return RRTX_OK;
     case RRTX_OPT_EXTEND_OBSTACLES: ctx->opt_extend_polygons = value == 1; return RRTX_OK;
     case RRTX_OPT_TUNE: ctx->opt_tune = (int)value; return RRTX_OK;
+    case RRTX_OPT_SPACE_HAS_TIME:
+      if (value != 0 && ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "a space with time is [x y t theta]: dim = 4");
+      ctx->opt_space_has_time = value != 0;
+      return RRTX_OK;
     case RRTX_OPT_NEAREST_REC_CAP: ctx->opt_nearest_rec_cap = value > 0 ? (long long)value : 0; return RRTX_OK;
     case RRTX_OPT_BUCKET_MULT: {
       int m = 2;
@@ -924,6 +928,39 @@ int rrtx_dubins_steer(rrtx_ctx *ctx, const double *s, const double *g, int64_t n
   return dubins_common(ctx, s, g, ne, r_min, 0.0, false, cost, word, nullptr, nullptr);
 }
 
+int rrtx_set_dubins_velocity(rrtx_ctx *ctx, double v_min, double v_max) {
+  CHECK_CTX(ctx);
+  ctx->dubins_vmin = v_min;
+  ctx->dubins_vmax = v_max;
+  return RRTX_OK;
+}
+
+int rrtx_dubins_steer_full(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min, double *dist,
+                           double *wdist, double *velocity, uint8_t *word, uint8_t *valid_move) {
+  CHECK_CTX(ctx);
+  if (ne < 0 || (ne > 0 && (!s || !g))) return fail(ctx, RRTX_E_INVALID, "dubins_steer_full: bad arguments");
+  if (ne == 0) return RRTX_OK;
+  if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
+  const size_t pb = sizeof(double) * (size_t)ne * 4;
+  int rc = stage_in(ctx, ctx->ws_q, s, pb);
+  if (rc) return rc;
+  rc = stage_in(ctx, ctx->ws_q2, g, pb);
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_dist.ensure(sizeof(double) * 3 * (size_t)ne));
+  RRTX_HIP(ctx, ctx->ws_out_u8a.ensure(4 * (size_t)ne));
+  double *d_dist = ctx->ws_out_dist.as<double>(), *d_w = d_dist + ne, *d_v = d_w + ne;
+  uint8_t *d_word = ctx->ws_out_u8a.as<uint8_t>(), *d_valid = d_word + 3 * (size_t)ne;
+  rc = launch_dubins_steer(ctx, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>(), ne, r_min, d_dist, d_word, d_w, d_v, d_valid);
+  if (rc) return rc;
+  if (dist) RRTX_HIP(ctx, hipMemcpyAsync(dist, d_dist, sizeof(double) * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  if (wdist) RRTX_HIP(ctx, hipMemcpyAsync(wdist, d_w, sizeof(double) * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  if (velocity) RRTX_HIP(ctx, hipMemcpyAsync(velocity, d_v, sizeof(double) * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  if (word) RRTX_HIP(ctx, hipMemcpyAsync(word, d_word, 3 * (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  if (valid_move) RRTX_HIP(ctx, hipMemcpyAsync(valid_move, d_valid, (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
 int rrtx_dubins_edges_check(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min,
                             double robot_radius, double *cost, uint8_t *word, uint8_t *hit, int32_t *traj_len) {
   CHECK_CTX(ctx);
@@ -959,11 +996,12 @@ int rrtx_dubins_trajectory(rrtx_ctx *ctx, const double *s, const double *g, int6
   // pass 2: write the polylines
   rc = stage_in(ctx, ctx->ws_out_off, traj_off, sizeof(int64_t) * ((size_t)ne + 1));
   if (rc) return rc;
-  RRTX_HIP(ctx, ctx->ws_out_f64.ensure(sizeof(double) * 2 * (size_t)total));
+  const size_t cols = ctx->opt_space_has_time ? 3 : 2;      // (x, y) or, in a space with time, (x, y, t)
+  RRTX_HIP(ctx, ctx->ws_out_f64.ensure(sizeof(double) * cols * (size_t)total));
   rc = launch_dubins_trajectory(ctx, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>(), ne, r_min,
                                 ctx->ws_out_off.as<int64_t>(), ctx->ws_out_f64.as<double>(), total, nullptr);
   if (rc) return rc;
-  RRTX_HIP(ctx, hipMemcpyAsync(traj_xy, ctx->ws_out_f64.p, sizeof(double) * 2 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipMemcpyAsync(traj_xy, ctx->ws_out_f64.p, sizeof(double) * cols * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RRTX_OK;
 }

@@ -109,6 +109,8 @@ struct rrtx_ctx {
   int opt_tile_q = 0;               // query copies per workgroup tile (0 = kernel default)
   int opt_nn_cull = 1;              // 0 off, 1 auto (trees of >= 8192 nodes), 2 always
   long long opt_nearest_rec_cap = 0; // testing: candidate record capacity of the screened nearest scan (0 = default)
+  int opt_space_has_time = 0;       // CSpace.spaceHasTime for the Dubins entry points ([x y t theta], R/DRRT_data_structures.jl:330)
+  double dubins_vmin = 0.0, dubins_vmax = 1e300;   // S.dubinsMinVelocity / dubinsMaxVelocity (validMove)
   int opt_tune = 0;                 // experiment switches (RRTX_OPT_TUNE), never change a result
   int opt_profile_every = 1;        // profiling level 1 times every n-th launch of the search kernel
   long long span_tick = 0;
@@ -264,7 +266,8 @@ int launch_points_polygons(rrtx_ctx *ctx, const double *p_dev, int64_t np, doubl
 int launch_simple_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne,
                         double *dist_dev, double *wdist_dev);
 int launch_dubins_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
-                        double *cost_dev, uint8_t *word_dev);
+                        double *cost_dev, uint8_t *word_dev, double *wdist_dev = nullptr,
+                        double *velocity_dev = nullptr, uint8_t *valid_dev = nullptr);
 int launch_dubins_edges_check(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne,
                               double r_min, double robot_radius, double *cost_dev, uint8_t *word_dev,
                               uint8_t *hit_dev, int32_t *traj_len_dev);

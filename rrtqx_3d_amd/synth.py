@@ -28,13 +28,23 @@ class Config:
     dubins: bool = False
 
 
-# BASELINE.json configs 2-4 (config 1 is the CPU plumbing case, config 5 the 8-GPU scenario)
+# BASELINE.json configs 2-5 (config 1 is the CPU plumbing case).  C5 is what BASELINE.json says: DubinsEdge in
+# [x y t theta] with dynamic / discoverable obstacles at N = 500k (see dynamic_polygons and nodes_time below);
+# C5s is the plain 3-D search at C5's node count.
 CONFIGS = {
     "C2": Config("C2: 3D SimpleEdge N=10k M=32 B=1024", 10_000, 32, 1024),
     "C3": Config("C3: Dubins N=50k M=64 B=4096", 50_000, 64, 4096, dim=4, dubins=True),
     "C4": Config("C4: 3D SimpleEdge N=200k M=256 B=16384", 200_000, 256, 16384),
-    "C5": Config("C5: N=500k M=256 B=16384", 500_000, 256, 16384),
+    "C5": Config("C5: DubinsEdge + time, dynamic discoverable obstacles, N=500k M=256 B=16384", 500_000, 256, 16384,
+                 dim=4, dubins=True),
+    "C5s": Config("C5s: 3D SimpleEdge search at N=500k M=256 B=16384", 500_000, 256, 16384),
 }
+
+# the Dubins-with-time scenes of R/dubinsExperimentsForPaper.jl:193-236: time spans [minTime, maxTime],
+# velocities 5 .. 30, minTurningRadius 2, delta 20 / ballConstant 400 in the script (SURVEY 8d uses 10 / 100)
+T_MIN, T_MAX = 10.0, 35.0
+V_MIN, V_MAX = 5.0, 30.0
+R_MIN_TIME = 2.0
 
 
 def ball_radius(n: int, d: int, gamma: float = 80.0, delta: float = 8.0) -> float:
@@ -53,6 +63,41 @@ def nodes(n: int, dim: int = 3, seed: int = SEED) -> np.ndarray:
 
 def queries(b: int, dim: int = 3, seed: int = SEED + 1) -> np.ndarray:
     return nodes(b, dim, seed)
+
+
+def nodes_time(n: int, seed: int = SEED) -> np.ndarray:
+    """[x y t theta] with the time coordinate uniform over [T_MIN, T_MAX] (the bounds of the space,
+    R/dubinsExperimentsForPaper.jl:209-210)."""
+    p = nodes(n, 4, seed)
+    rng = np.random.default_rng(seed + 9)
+    p[:, 2] = rng.uniform(T_MIN, T_MAX, n)
+    return p
+
+
+def dynamic_polygons(m: int, seed: int = SEED + 4, moving_frac: float = 0.25, hidden_frac: float = 0.125):
+    """BASELINE config 5's obstacle list: m polygons by the recipe of polygons(); the first
+    moving_frac * m move in time (kinds 6 and 7 alternating) along piecewise-linear paths of 2 .. 12 rows
+    (dx, dy, t), t ascending over [0, 45] (the path grammar of readTimeObstaclesFromfile,
+    R/DRRT_Q.jl:1022-1061); the last hidden_frac * m are "discoverable": static polygons the robot has not
+    seen yet (active = 0 until they appear, R/generate2DRandomDiscoverableObstacles.m).
+    Returns (polys, kinds, paths, active, hidden_indices)."""
+    rng = np.random.default_rng(seed)
+    polys = polygons(m, seed)
+    n_mov, n_hid = int(m * moving_frac), int(m * hidden_frac)
+    kinds = np.full(m, 3, dtype=np.uint8)
+    paths = [None] * m
+    for i in range(n_mov):
+        kinds[i] = 6 if i % 2 == 0 else 7
+        rows = int(rng.integers(2, 13))
+        t = np.sort(rng.uniform(0.0, 45.0, rows))
+        t[0] = 0.0
+        step = rng.normal(0.0, 6.0, (rows, 2))
+        step[0] = 0.0
+        paths[i] = np.concatenate([np.cumsum(step, axis=0), t[:, None]], axis=1)
+    active = np.ones(m, dtype=np.uint8)
+    hidden = np.arange(m - n_hid, m)
+    active[hidden] = 0
+    return polys, kinds, paths, active, hidden
 
 
 def spheres(m: int, seed: int = SEED + 2) -> np.ndarray:

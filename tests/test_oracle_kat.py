@@ -310,3 +310,51 @@ def test_reference_env_files_as_inputs(oracle):
     assert b2.shape == (31, 4) and (b2[:, 3] == 3.5).all()
     rs = env["rand_Static_polygons"]
     assert len(rs) == 35 and all(len(p) == 4 for p in rs)
+
+
+# ---- Dubins in a space with time (R/DRRT_DubinsEdge_functions.jl:115-121, 660-697, 750-774), hand-derived ----
+def test_T1_dubins_time_straight_ahead(oracle):
+    """s = (0, 0, t=10, theta=0) -> g = (10, 0, t=0, theta=0), r_min = 1: Wdist = 10 (K10), dt = 10 - 0, so
+    edge.dist = sqrt(10^2 + 10^2), edge.velocity = 10 / 10 = 1; trajectory: row 1 carries the start time, the
+    last row IS the end node (x, y, t), rows between carry start time - distance walked / velocity."""
+    dist, wdist, vel, word, traj = oracle.dubins_steer_time([0, 0, 10, 0], [10, 0, 0, 0], 1.0)
+    assert abs(wdist - 10.0) < 1e-12 and abs(dist - np.sqrt(200.0)) < 1e-12 and abs(vel - 1.0) < 1e-12
+    assert traj.shape[1] == 3 and traj[0, 2] == 10.0
+    assert np.array_equal(traj[-1], [10.0, 0.0, 0.0])            # made exact, :696
+    walked = np.concatenate([[0.0], np.cumsum(np.hypot(*np.diff(traj[:, :2], axis=0).T))])
+    assert np.allclose(traj[1:-1, 2], 10.0 - walked[1:-1] / vel, atol=1e-12)
+    assert (np.diff(traj[:, 2]) <= 0).all()                      # reverse time: the robot moves toward t = 0
+    # no route (word xxx never happens for finite input, but Wdist = Inf must stay Inf): dist of an Inf cost
+    # is Inf; here: the non-time cost equals Wdist
+    c, w, t2 = oracle.dubins_steer([0, 0, 10, 0], [10, 0, 0, 0], 1.0)
+    assert c == wdist and w == word and np.array_equal(t2[:-1], traj[:-1, :2])
+
+
+def test_T2_dubins_time_valid_move(oracle):
+    """validMove: start time > end time AND dubinsMinVelocity <= velocity <= dubinsMaxVelocity (:120)"""
+    s, g = [0, 0, 10, 0], [10, 0, 0, 0]
+    assert not oracle.dubins_valid_move_time(s, g, 1.0, 5.0, 30.0)          # too slow
+    assert oracle.dubins_valid_move_time(s, g, 10.0, 5.0, 30.0)
+    assert oracle.dubins_valid_move_time(s, g, 5.0, 5.0, 30.0) and oracle.dubins_valid_move_time(s, g, 30.0, 5.0, 30.0)
+    assert not oracle.dubins_valid_move_time(s, g, 30.000001, 5.0, 30.0)
+    assert not oracle.dubins_valid_move_time(g, s, 10.0, 5.0, 30.0)         # forward in time: never
+    assert not oracle.dubins_valid_move_time(s, [10, 0, 10, 0], 10.0, 5.0, 30.0)   # no duration
+    assert not oracle.dubins_valid_move_time(s, g, float("nan"), 5.0, 30.0)
+
+
+def test_T3_dubins_time_moving_obstacle(oracle):
+    """A unit square (bounding radius sqrt(.5)) drifting up the line x = 5 crosses the x axis at time 5; the
+    robot of T1 is at x = 5 at time 5 (x = 10 - t): the centres meet -> hit.  The same square held below
+    y = -4 until t = 8 and only then rushed across: in [8, 10] the robot is at x <= 2, at least 3 from the
+    line x = 5, farther than robotRadius + sqrt(.5) = 1.21 (stage 2) and than the inflated 3.21 of the
+    chord test when the square passes y = 0 at t = 8.9 (robot at x = 1.1: 3.9 away) -> no hit."""
+    sq = np.array([[-0.5, -0.5], [0.5, -0.5], [0.5, 0.5], [-0.5, 0.5]]) + [5.0, -5.0]
+    s, g = [0, 0, 10, 0], [10, 0, 0, 0]
+    _, _, _, _, traj = oracle.dubins_steer_time(s, g, 1.0)
+    meet = oracle.PolygonSet([sq], kinds=[6], paths=[np.array([[0, 0, 0.0], [0, 10, 10.0]])])
+    assert oracle.dubins_edge_check_polygons_time(meet, s, g, traj, 0.5, 1.0) == (True, 0)
+    late = oracle.PolygonSet([sq], kinds=[6], paths=[np.array([[0, 0, 0.0], [0, 1, 8.0], [0, 10, 10.0]])])
+    assert oracle.dubins_edge_check_polygons_time(late, s, g, traj, 0.5, 1.0) == (False, -1)
+    # a static polygon sitting on the route is hit whatever the times are
+    static = oracle.PolygonSet([sq + [0.0, 5.0]])
+    assert oracle.dubins_edge_check_polygons_time(static, s, g, traj, 0.5, 1.0) == (True, 0)

@@ -32,7 +32,7 @@ def timed(ctx, fn, reps=5):
 
 
 def main():
-    for name in ("C2", "C4", "C5"):
+    for name in ("C2", "C4", "C5s"):
         cfg = synth.CONFIGS[name]
         pts, Q, sph = synth.nodes(cfg.n_nodes, 3), synth.queries(cfg.batch, 3), synth.spheres(cfg.n_obstacles)
         r = synth.ball_radius(cfg.n_nodes, 3)
