@@ -206,12 +206,14 @@ function syncObstacles(tree::HipTree, S::TS) where {TS}
     cxyzr[1:3, i] = ob.position[1:3]
     cxyzr[4, i] = ob.radius
     active[i] = (ob.obstacleUnused || ob.lifeSpan <= 0) ? 0x00 : 0x01   # R/DRRT_Q.jl:1777
-    sig = hash((objectid(ob), ob.radius, active[i]), sig)
+    # (position included: the planner moves dynamic spheres in place, R/rrtqx.jl:453-584)
+    sig = hash((objectid(ob), ob.position[1], ob.position[2], ob.position[3], ob.radius, active[i]), sig)
     ptr = ptr.child
   end
+  # extend_candidates checks against the sphere list (RRTX_OPT_EXTEND_OBSTACLES = 8, value 0), whatever a
+  # syncPolygonObstacles call in between has selected
+  rrtx_check(tree, ccall((:rrtx_set_option, LIBRRTX), Cint, (Ptr{Cvoid}, Cint, Int64), tree.ctx, 8, 0))
   if sig != tree.obsSig
-    # extend_candidates checks against the sphere list (RRTX_OPT_EXTEND_OBSTACLES = 8, value 0)
-    rrtx_check(tree, ccall((:rrtx_set_option, LIBRRTX), Cint, (Ptr{Cvoid}, Cint, Int64), tree.ctx, 8, 0))
     GC.@preserve cxyzr active rrtx_check(tree, ccall((:rrtx_spheres_set, LIBRRTX), Cint,
         (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{UInt8}, Cint), tree.ctx, cxyzr, active, m))
     tree.obsSig = sig
@@ -310,6 +312,40 @@ function explicitPointCheck(S::CSpace{T}, point::Array{Float64}) where {T}
   return (unsafe[] != 0x00, clr[])
 end
 
+# explicitPointCheck3D (R/DRRT_Q.jl:1558-1590): the root check of the 3-D driver, no quick pass
+function explicitPointCheck3D(S::CSpace{T}, point::Array{Float64}) where {T}
+  if S.inWarmupTime
+    return (false, Inf)
+  end
+  tree = HIP_TREE_OF[S]
+  syncObstacles(tree, S)
+  p = vec(point)
+  unsafe = Ref{UInt8}(0); clr = Ref{Float64}(0.0)
+  GC.@preserve p rrtx_check(tree, ccall((:rrtx_points_check, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Int64, Cdouble, Cint, Ref{UInt8}, Ref{Float64}),
+      tree.ctx, 0, p, 1, S.robotRadius, 0, unsafe, clr))
+  return (unsafe[] != 0x00, clr[])
+end
+
+# explicitNodeCheck / explicitNodeCheck3D (R/DRRT_Q.jl:1594-1595)
+explicitNodeCheck(S::CSpace{T}, node::RRTNode{T}) where {T} = explicitPointCheck(S, node.position)
+explicitNodeCheck3D(S::CSpace{T}, node::RRTNode{T}) where {T} = explicitPointCheck3D(S, node.position)
+
+# explicitPointCheck for a space whose obstacles are polygon Obstacles (R/DRRT.jl:1434-1470): call
+# syncPolygonObstacles(tree, S) after every change of the list, then this
+function explicitPointCheckPolygons(S::TS, point::Array{Float64}) where {TS}
+  if S.inWarmupTime
+    return (false, Inf)
+  end
+  tree = HIP_TREE_OF[S]
+  p = vec(point)
+  unsafe = Ref{UInt8}(0); clr = Ref{Float64}(0.0)
+  GC.@preserve p rrtx_check(tree, ccall((:rrtx_points_check, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Int64, Cdouble, Cint, Ref{UInt8}, Ref{Float64}),
+      tree.ctx, 1, p, 1, S.robotRadius, 1, unsafe, clr))
+  return (unsafe[] != 0x00, clr[])
+end
+
 # calculateTrajectory(S, ::SimpleEdge) (R/DRRT_SimpleEdge_functions.jl:177-181)
 function calculateTrajectory(S::TS, edge::SimpleEdge) where {TS}
   tree = HIP_TREE_OF[S]
@@ -404,5 +440,162 @@ function obstacleSweep(tree::HipTree, S::TS, ob::SphereObstacle) where {TS}
     end
     rrtx_check(tree, rc)
     return ids[1:Int(needed[])]
+  end
+end
+
+
+# ---------------------------------------------------------------------------
+# Edge = DubinsEdge (R/DRRT_DubinsEdge.jl, R/DRRT_DubinsEdge_functions.jl; README's per-edge-type
+# contract, R/README.txt:85-99).  The tree is a HipTree{RRTNode{Float64}}(4, KDdist, [4], [2pi]) and the
+# obstacle list a List{Obstacle} (syncPolygonObstacles).  Call syncDubinsSpace(tree, S) once after the
+# CSpace is configured (and again when spaceHasTime or the velocity bounds change).
+function syncDubinsSpace(tree::HipTree, S::TS) where {TS}
+  # RRTX_OPT_SPACE_HAS_TIME = 12: CSpace.spaceHasTime (R/DRRT_data_structures.jl:330)
+  rrtx_check(tree, ccall((:rrtx_set_option, LIBRRTX), Cint, (Ptr{Cvoid}, Cint, Int64), tree.ctx, 12, S.spaceHasTime ? 1 : 0))
+  rrtx_check(tree, ccall((:rrtx_set_dubins_velocity, LIBRRTX), Cint, (Ptr{Cvoid}, Cdouble, Cdouble),
+      tree.ctx, S.dubinsMinVelocity, S.dubinsMaxVelocity))
+end
+
+# calculateTrajectory(S, ::DubinsEdge) (R/DRRT_DubinsEdge_functions.jl:329-709): dubinsType, Wdist, dist,
+# distOriginal, velocity (space with time) and the discretised trajectory (P x 2, or P x 3 with time)
+function calculateTrajectory(S::TS, edge::DubinsEdge) where {TS}
+  tree = HIP_TREE_OF[S]
+  s = vec(convert(Array{Float64}, edge.startNode.position)); g = vec(convert(Array{Float64}, edge.endNode.position))
+  d = Ref{Float64}(0.0); w = Ref{Float64}(0.0); v = Ref{Float64}(0.0)
+  word = Vector{UInt8}(undef, 3); ok = Ref{UInt8}(0)
+  GC.@preserve s g word rrtx_check(tree, ccall((:rrtx_dubins_steer_full, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Ref{Float64}, Ref{Float64}, Ref{Float64}, Ptr{UInt8}, Ref{UInt8}),
+      tree.ctx, s, g, 1, S.minTurningRadius, d, w, v, word, ok))
+  edge.dubinsType = String(copy(word))
+  edge.Wdist = w[]
+  edge.dist = d[]
+  edge.distOriginal = edge.dist
+  if S.spaceHasTime
+    edge.velocity = v[]
+  end
+  if edge.Wdist == Inf                           # no trajectory is built (:661-662)
+    return
+  end
+  cols = S.spaceHasTime ? 3 : 2
+  off = Vector{Int64}(undef, 2)
+  cap = 256
+  while true
+    rows = Array{Float64}(undef, cols, cap)      # column-major cols x cap == row-major cap x cols on the C side
+    needed = Ref{Int64}(0)
+    rc = GC.@preserve s g off rows ccall((:rrtx_dubins_trajectory, LIBRRTX), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Ptr{Int64}, Ptr{Cdouble}, Int64, Ref{Int64}),
+        tree.ctx, s, g, 1, S.minTurningRadius, off, rows, cap, needed)
+    if rc == RRTX_E_CAPACITY
+      cap = Int(needed[])
+      continue
+    end
+    rrtx_check(tree, rc)
+    edge.trajectory = copy(transpose(rows[:, 1:Int(needed[])]))
+    return
+  end
+end
+
+# validMove(S, ::DubinsEdge) (R/DRRT_DubinsEdge_functions.jl:115-125): host arithmetic on what
+# calculateTrajectory stored, exactly the reference's expression
+function validMove(S::TS, edge::DubinsEdge) where {TS}
+  if S.spaceHasTime
+    return ((edge.startNode.position[3] > edge.endNode.position[3]) && (S.dubinsMinVelocity <= edge.velocity <= S.dubinsMaxVelocity))
+  end
+  return true
+end
+
+# explicitEdgeCheck(C, edge) over the whole obstacle list (R/DRRT.jl:1660-1678 with the two-stage test of
+# R/DRRT_DubinsEdge_functions.jl:750-774 per obstacle): one call steers and checks
+function explicitEdgeCheck(S::CSpace{T}, edge::DubinsEdge, verbose::Bool = false) where {T}
+  if S.inWarmupTime
+    return false
+  end
+  tree = HIP_TREE_OF[S]
+  s = vec(convert(Array{Float64}, edge.startNode.position)); g = vec(convert(Array{Float64}, edge.endNode.position))
+  cost = Ref{Float64}(0.0); hit = Ref{UInt8}(0)
+  GC.@preserve s g rrtx_check(tree, ccall((:rrtx_dubins_edges_check, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble, Ref{Float64}, Ptr{UInt8}, Ref{UInt8}, Ptr{Int32}),
+      tree.ctx, s, g, 1, S.minTurningRadius, S.robotRadius, cost, C_NULL, hit, C_NULL))
+  return hit[] != 0x00
+end
+
+# explicitEdgeCheck(S, edge::DubinsEdge, obstacle) (R/DRRT_DubinsEdge_functions.jl:750-774) against ONE
+# obstacle of the list: the inflated chord test, then every stored piece of edge.trajectory, each through
+# explicitEdgeCheck2D on the device (rrtx_edges_check, kind = 1, obstacle = list position)
+function explicitEdgeCheck(S::CSpace{T}, edge::DubinsEdge, obstacle::Obstacle) where {T}
+  tree = HIP_TREE_OF[S]
+  which = -1
+  ptr = S.obstacles.front
+  for i = 1:S.obstacles.length
+    if ptr.data === obstacle
+      which = i - 1
+      break
+    end
+    ptr = ptr.child
+  end
+  which >= 0 || error("obstacle is not in CSpace.obstacles")
+  s = vec(convert(Array{Float64}, edge.startNode.position)); g = vec(convert(Array{Float64}, edge.endNode.position))
+  hit = Ref{UInt8}(0)
+  GC.@preserve s g rrtx_check(tree, ccall((:rrtx_edges_check, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cint, Ref{UInt8}, Ptr{Int32}),
+      tree.ctx, 1, s, g, 1, S.robotRadius + 2 * S.minTurningRadius, which, hit, C_NULL))
+  if hit[] == 0x00
+    return false
+  end
+  P = size(edge.trajectory, 1)
+  if P < 2
+    return false
+  end
+  cols = size(edge.trajectory, 2)               # 2, or 3 with time (the moving kinds read it)
+  p0 = zeros(Float64, 4, P - 1); p1 = zeros(Float64, 4, P - 1)
+  for i = 2:P
+    p0[1:cols, i - 1] = edge.trajectory[i - 1, :]
+    p1[1:cols, i - 1] = edge.trajectory[i, :]
+  end
+  hits = Vector{UInt8}(undef, P - 1)
+  GC.@preserve p0 p1 hits rrtx_check(tree, ccall((:rrtx_edges_check, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cint, Ptr{UInt8}, Ptr{Int32}),
+      tree.ctx, 1, p0, p1, P - 1, S.robotRadius, which, hits, C_NULL))
+  return any(h -> h != 0x00, hits)
+end
+
+# Batched preamble of extend()/findBestParent for Edge = DubinsEdge (BASELINE configs 3 and 5): per sample
+# the wrapped range search, both directed edges steered and checked; in a space with time a flag byte
+# also carries bit 1 = !validMove, so `hit != 0` is findBestParent's whole blocking test (R/DRRT_Q.jl:1960).
+struct ExtendCandidatesDubins
+  offsets::Vector{Int64}
+  idx::Vector{Int32}
+  key::Vector{Float64}        # KDdist of the range search
+  costOut::Vector{Float64}    # edge.dist newNode -> near
+  costIn::Vector{Float64}     # edge.dist near -> newNode
+  hitOut::Vector{UInt8}
+  hitIn::Vector{UInt8}
+  nearestIdx::Vector{Int32}
+  nearestDist::Vector{Float64}
+  sampleUnsafe::Vector{UInt8}
+end
+
+function extend_candidates_dubins(tree::HipTree, S::TS, positions::Array{Float64,2}, hyberBallRad::Float64) where {TS}
+  nq = size(positions, 2)                     # 4 x nq
+  offsets = Vector{Int64}(undef, nq + 1)
+  nidx = Vector{Int32}(undef, nq); ndist = Vector{Float64}(undef, nq); unsafe = Vector{UInt8}(undef, nq)
+  cap = 2048 * nq
+  while true
+    idx = Vector{Int32}(undef, cap); key = Vector{Float64}(undef, cap)
+    cout = Vector{Float64}(undef, cap); cin = Vector{Float64}(undef, cap)
+    hout = Vector{UInt8}(undef, cap); hin = Vector{UInt8}(undef, cap)
+    needed = Ref{Int64}(0)
+    rc = GC.@preserve positions offsets idx key cout cin hout hin nidx ndist unsafe ccall((:rrtx_extend_candidates_dubins, LIBRRTX), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cdouble, Cdouble, Cdouble, Ptr{Int64}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble},
+         Ptr{Cdouble}, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Int64, Ref{Int64}, Ptr{Int32}, Ptr{Cdouble}, Ptr{UInt8}),
+        tree.ctx, positions, nq, hyberBallRad, S.robotRadius, S.minTurningRadius, offsets, idx, key, cout, cin,
+        C_NULL, C_NULL, hout, hin, cap, needed, nidx, ndist, unsafe)
+    if rc == RRTX_E_CAPACITY
+      cap = Int(needed[])
+      continue
+    end
+    rrtx_check(tree, rc)
+    n = Int(needed[])
+    return ExtendCandidatesDubins(offsets, idx[1:n], key[1:n], cout[1:n], cin[1:n], hout[1:n], hin[1:n], nidx, ndist, unsafe)
   end
 end

@@ -2,6 +2,8 @@
 // context lifetime, node/obstacle tables, host-buffer staging around the kernel
 // launchers.  gfx950 only; no CPU fallback: every compute entry point runs HIP
 // kernels or fails with RRTX_E_DEVICE.
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <mutex>
 
@@ -18,6 +20,37 @@ int fail(rrtx_ctx *ctx, int code, const char *fmt, ...) {
   va_end(ap);
   if (ctx) ctx->err = buf;
   return code;
+}
+
+// ---- roctx ranges around the C-ABI calls (tracing hook) ---------------------------------
+// A rocprofv3 --marker-trace of a Julia-hosted run then shows which planner call every kernel belongs
+// to.  The marker library is looked up at run time (rocprofiler-sdk's roctx, else the legacy one) so the
+// library carries no link dependency on it; without it the ranges are no-ops.
+namespace {
+typedef int (*roctx_push_fn)(const char *);
+typedef int (*roctx_pop_fn)(void);
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+std::once_flag g_roctx_once;
+void roctx_resolve() {
+  const char *names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+  for (const char *n : names) {
+    void *h = dlopen(n, RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) continue;
+    roctx_push_fn push = reinterpret_cast<roctx_push_fn>(dlsym(h, "roctxRangePushA"));
+    roctx_pop_fn pop = reinterpret_cast<roctx_pop_fn>(dlsym(h, "roctxRangePop"));
+    if (push && pop) { g_roctx_push = push; g_roctx_pop = pop; return; }
+  }
+}
+}  // namespace
+
+ApiRange::ApiRange(const char *name) {
+  std::call_once(g_roctx_once, roctx_resolve);
+  active = g_roctx_push != nullptr;
+  if (active) (void)g_roctx_push(name);
+}
+ApiRange::~ApiRange() {
+  if (active) (void)g_roctx_pop();
 }
 
 // ---- exact thresholds on squared distances ------------------------------------
@@ -287,6 +320,7 @@ std::mutex g_create_mu;
 using namespace rrtx;
 
 #define CHECK_CTX(ctx)                 \
+  ::rrtx::ApiRange _rrtx_api_range(__func__); \
   do {                                 \
     if (!(ctx)) return RRTX_E_INVALID; \
     hipError_t _sd = hipSetDevice((ctx)->device); \

@@ -204,6 +204,13 @@ namespace rrtx {
 
 int fail(rrtx_ctx *ctx, int code, const char *fmt, ...);
 
+// roctx range for the duration of one C-ABI call (rrtx_capi.hip); a no-op without a marker library
+struct ApiRange {
+  explicit ApiRange(const char *name);
+  ~ApiRange();
+  bool active;
+};
+
 #define RRTX_HIP(ctx, expr)                                                               \
   do {                                                                                    \
     hipError_t _e = (expr);                                                               \
