@@ -127,6 +127,10 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
  *   in time (kinds 6 / 7) are tested where they are when the robot passes (:750-774, R/DRRT.jl:1579-1651).
  *   This one DOES select behaviour: it says which space the caller plans in. */
 #define RRTX_OPT_SPACE_HAS_TIME 12
+/*   RRTX_OPT_ROOT_RULE (default 1): node 0 of this context is the kd-tree's root, which the range search takes
+ *   with <= (R/kdTree_general.jl:896).  0 for a context that holds a LATER index range of a tree sharded over
+ *   several GPUs (rrtqx_3d_amd/parallel.py): its node 0 is an ordinary node. */
+#define RRTX_OPT_ROOT_RULE 13
 int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value);
 
 /* Host-only helper (no GPU needed): the exact thresholds on SQUARED distances the kernels

@@ -32,6 +32,7 @@ RRTX_OPT_NEAREST_REC_CAP = 9
 RRTX_OPT_BUCKET_MULT = 10
 RRTX_OPT_TUNE = 11
 RRTX_OPT_SPACE_HAS_TIME = 12
+RRTX_OPT_ROOT_RULE = 13
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

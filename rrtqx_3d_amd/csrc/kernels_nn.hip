@@ -975,6 +975,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   std::memset(&xd, 0, sizeof(xd));
   xd.r_bound = -1.0;
   pf.sph = nullptr; pf.m_sph = -1;
+  pf.root_rule = ctx->opt_root_rule;
   if (fuse) {
     xd.sph = ctx->d_sph.as<SphRec>();
     xd.stab = ctx->d_sph_sample.as<SampleSph>();

@@ -101,6 +101,7 @@ struct PackFused {
   const double *nx, *ny, *nz, *nw; // node arrays (the root is node 0)
   const SphRec *sph;               // fused extend() path: the root entry's two edge flags are decided here
   int m_sph;                       // active spheres, -1: not the fused path
+  int root_rule;                   // 0: node 0 of this context is not the tree's root (node-range shard)
 };
 
 template <int D>
@@ -143,7 +144,7 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
     if (pf.count) {
       const double s = (D == 4) ? sq4(p[0], p[1], p[2], p[3], pf.nx[0], pf.ny[0], pf.nz[0], pf.nw[0])
                                 : sq3(p[0], p[1], p[2], pf.nx[0], pf.ny[0], pf.nz[0]);
-      const bool add = s >= tlt && s < tgt;
+      const bool add = pf.root_rule && s >= tlt && s < tgt;
       pf.count[i] = add ? 1 : 0;
       if (add) {                               // bcap >= 8: entry 0 of the bucket always exists
         BktRec br;
@@ -188,7 +189,7 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
       SlotRec sr;
       sr.x = g[0]; sr.y = g[1]; sr.z = g[2]; sr.w = g[3];
       sr.thr_lt = valid ? tlt : -1.0;
-      sr.thr_gt = tgt;
+      sr.thr_gt = (pf.count && !pf.root_rule) ? tlt : tgt;   // (the root's <= in seen_by_earlier_slot)
       sr.pad0 = 0.0; sr.pad1 = 0.0;
       if (n_wraps > 0) slots[(size_t)i * n_slots + k] = sr;   // only the ghost rules read the table
       if (valid) {

@@ -452,6 +452,7 @@ int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value) {
     case RRTX_OPT_KNN_LISTS: ctx->opt_knn_lists = value != 0; return RRTX_OK;
     case RRTX_OPT_EXTEND_OBSTACLES: ctx->opt_extend_polygons = value == 1; return RRTX_OK;
     case RRTX_OPT_TUNE: ctx->opt_tune = (int)value; return RRTX_OK;
+    case RRTX_OPT_ROOT_RULE: ctx->opt_root_rule = value != 0; return RRTX_OK;
     case RRTX_OPT_SPACE_HAS_TIME:
       if (value != 0 && ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "a space with time is [x y t theta]: dim = 4");
       ctx->opt_space_has_time = value != 0;

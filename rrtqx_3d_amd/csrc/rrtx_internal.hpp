@@ -111,6 +111,7 @@ struct rrtx_ctx {
   long long opt_nearest_rec_cap = 0; // testing: candidate record capacity of the screened nearest scan (0 = default)
   int opt_space_has_time = 0;       // CSpace.spaceHasTime for the Dubins entry points ([x y t theta], R/DRRT_data_structures.jl:330)
   double dubins_vmin = 0.0, dubins_vmax = 1e300;   // S.dubinsMinVelocity / dubinsMaxVelocity (validMove)
+  int opt_root_rule = 1;            // 0: node 0 is not the tree's root (this context holds a later node range)
   int opt_tune = 0;                 // experiment switches (RRTX_OPT_TUNE), never change a result
   int opt_profile_every = 1;        // profiling level 1 times every n-th launch of the search kernel
   long long span_tick = 0;

@@ -11,7 +11,18 @@ What shards and what does not ("Multi-GPU"):
     (RCCL has no bitwise-OR reduction).  The message is (2*cap/8) bytes per rank -- tens of KB,
     latency-bound on xGMI.
 
-The functions below hold only the index arithmetic and the collective, so they run unchanged on
+Second mode, for trees that should not be replicated: the node SoA is partitioned by index
+range -- rank g holds nodes [lo_g, hi_g) in a context of its own (local index = global - lo_g; only
+rank 0's context holds the root, the others switch the root's <= rule off with RRTX_OPT_ROOT_RULE = 0),
+every rank searches ALL queries against its shard, and the per-shard results are merged:
+  - range search: all-gather of the per-query counts, then of the (index, distance) payloads padded to
+    the largest shard; shard order is index order, so concatenating the shards' lists per query keeps
+    every list ascending in node index -- the unsharded CSR, entry for entry;
+  - nearest: all-gather of (distance, index) per query and the lexicographic minimum (RCCL has no
+    arg-min reduction).
+Both are latency-bound exchanges of a few MB at C4 / C5 sizes.
+
+The functions below hold only the index arithmetic and the collectives, so they run unchanged on
 CPU tensors with the gloo backend (tests/test_parallel_gloo.py) and on GPU tensors with nccl.
 """
 from __future__ import annotations
@@ -65,3 +76,69 @@ def reduce_throughput(local_units: int, local_seconds: float, device=None, group
     c = torch.tensor([local_units], dtype=torch.int64, device=device)
     dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
     return int(c.item()), float(t.item())
+
+
+def _all_gather_padded(x: torch.Tensor, n_max: int, world: int, group=None):
+    """all_gather of 1-D tensors of different lengths: pad to n_max (the collectives want equal sizes)"""
+    buf = torch.zeros(n_max, dtype=x.dtype, device=x.device)
+    buf[: x.numel()] = x
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return out
+
+
+def merge_sharded_radius(offsets: torch.Tensor, idx_global: torch.Tensor, dist_: torch.Tensor, group=None):
+    """Node-range-sharded range search: every rank holds the CSR lists of ALL B queries against ITS node
+    shard (offsets int64[B+1]; idx_global = shard base + local index, ascending inside each list; dist_ the
+    stored keys).  Returns the unsharded CSR (offsets, idx, dist) on every rank: per query the shards' lists
+    in rank order, which is ascending node index."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return offsets, idx_global, dist_
+    B = offsets.numel() - 1
+    counts = (offsets[1:] - offsets[:-1]).contiguous()
+    all_counts = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    C = torch.stack(all_counts)                                   # [world, B]
+    totals = C.sum(dim=1)
+    n_max = max(int(totals.max().item()), 1)
+    g_idx = _all_gather_padded(idx_global.to(torch.int64), n_max, world, group)
+    g_dist = _all_gather_padded(dist_, n_max, world, group)
+    per_q = C.sum(dim=0)
+    out_off = torch.zeros(B + 1, dtype=torch.int64, device=offsets.device)
+    out_off[1:] = torch.cumsum(per_q, dim=0)
+    total = int(out_off[-1].item())
+    out_idx = torch.empty(total, dtype=torch.int64, device=offsets.device)
+    out_dist = torch.empty(total, dtype=dist_.dtype, device=offsets.device)
+    before = torch.zeros(B, dtype=torch.int64, device=offsets.device)     # entries of lower ranks per query
+    ar = torch.arange(B, device=offsets.device)
+    for r in range(world):
+        cr = C[r]
+        k_r = int(totals[r].item())
+        if k_r:
+            off_r = torch.cumsum(cr, dim=0) - cr
+            owner = torch.repeat_interleave(ar, cr)
+            dest = out_off[:-1][owner] + before[owner] + (torch.arange(k_r, device=offsets.device) - off_r[owner])
+            out_idx[dest] = g_idx[r][:k_r]
+            out_dist[dest] = g_dist[r][:k_r]
+        before = before + cr
+    return out_off, out_idx.to(idx_global.dtype), out_dist
+
+
+def merge_sharded_nearest(idx_global: torch.Tensor, dist_: torch.Tensor, group=None):
+    """Node-range-sharded kdFindNearest: every rank's (index, distance) of its shard's nearest node per
+    query -> the global nearest: smallest distance, lowest index among equals (a shard with no answer
+    reports distance +inf)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return idx_global, dist_
+    gi = [torch.empty_like(idx_global) for _ in range(world)]
+    gd = [torch.empty_like(dist_) for _ in range(world)]
+    dist.all_gather(gi, idx_global.contiguous(), group=group)
+    dist.all_gather(gd, dist_.contiguous(), group=group)
+    I = torch.stack(gi).to(torch.int64)                           # [world, B]
+    D = torch.stack(gd)
+    dmin = D.min(dim=0).values
+    big = torch.iinfo(torch.int64).max
+    cand = torch.where(D == dmin.unsqueeze(0), I, torch.full_like(I, big))
+    return cand.min(dim=0).values.to(idx_global.dtype), dmin

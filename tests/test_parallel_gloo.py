@@ -77,3 +77,133 @@ def test_bitmask_exchange_world2():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+# ---- one batch shared by the ranks: node-range sharding and strong-scaling sample shards, oracle-produced ----
+def _spawn(target, world, *args):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+def _node_shard_worker(rank, world, port, q):
+    """every rank holds an index range of the tree (its own oracle kd-tree), searches ALL queries against it and
+    the merged result must be the unsharded oracle's, entry for entry"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from rrtqx_3d_amd import synth
+        n, nq, r = 3001, 97, 9.0                      # ragged shards (3001 = 1001 + 1000 + 1000 at world 3)
+        pts, Q = synth.nodes(n, 3), synth.queries(nq, 3)
+        Q[5] = pts[0] + [r, 0.0, 0.0]                 # exactly at the range from the ROOT: taken (<=) -- by rank 0 only
+        lo, hi = parallel.shard_range(n, rank, world)
+        # a shard's local node 0 is the root only on rank 0: the naive scan below applies the reference's rule
+        # (root <=, others <) to global indices
+        def shard_lists(q):
+            d = pts[lo:hi] - q
+            dd = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+            keep = dd < r
+            if lo == 0:
+                keep[0] = dd[0] <= r
+            loc = np.nonzero(keep)[0]
+            return loc + lo, dd[loc]
+        offs, idxs, dists = [0], [], []
+        n_idx = np.zeros(nq, dtype=np.int64)
+        n_dist = np.zeros(nq)
+        for i in range(nq):
+            gi, gd = shard_lists(Q[i])
+            idxs.append(gi); dists.append(gd); offs.append(offs[-1] + len(gi))
+            d = pts[lo:hi] - Q[i]
+            s = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            k = int(np.argmin(s))
+            n_idx[i], n_dist[i] = k + lo, np.sqrt(s[k])
+        off_t = torch.tensor(offs, dtype=torch.int64)
+        idx_t = torch.from_numpy(np.concatenate(idxs).astype(np.int64))
+        dist_t = torch.from_numpy(np.concatenate(dists))
+        m_off, m_idx, m_dist = parallel.merge_sharded_radius(off_t, idx_t, dist_t)
+        g_idx, g_dist = parallel.merge_sharded_nearest(torch.from_numpy(n_idx), torch.from_numpy(n_dist))
+        # the unsharded oracle (the reference's kd-tree)
+        tree = O.KDTree(3)
+        tree.insert_many(pts)
+        ok = True
+        for i in range(nq):
+            ri, rk = tree.within_range(r, Q[i])
+            o = np.argsort(ri)
+            a, b = int(m_off[i]), int(m_off[i + 1])
+            ok &= np.array_equal(m_idx[a:b].numpy(), ri[o].astype(np.int64)) and np.array_equal(m_dist[a:b].numpy(), rk[o])
+            ni, nd = tree.nearest(Q[i], naive=True)
+            ok &= int(g_idx[i]) == ni and float(g_dist[i]) == nd
+        ok &= 0 in m_idx[int(m_off[5]):int(m_off[6])].tolist()          # the root at exactly the range
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_node_range_sharded_search_world2_and_3():
+    assert _spawn(_node_shard_worker, 2) == [(0, True), (1, True)]
+    assert _spawn(_node_shard_worker, 3) == [(0, True), (1, True), (2, True)]
+
+
+def _strong_worker(rank, world, port, q):
+    """strong scaling: ONE global batch, rank r checks the candidate edges of samples shard_range(B, r, world)
+    (oracle here, the HIP path in bench.py --scaling strong); after the bitmask exchange every rank holds the
+    collision flags of the WHOLE batch, identical to the unsharded oracle's"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from rrtqx_3d_amd import synth
+        n, B, r, rr = 4000, 301, 8.0, 0.5
+        pts, Q, sph = synth.nodes(n, 3), synth.queries(B, 3), synth.spheres(24)
+        tree = O.KDTree(3)
+        tree.insert_many(pts)
+        osph, m = O.make_spheres(sph)
+
+        def flags(qs):
+            ho, hi = [], []
+            for qq in qs:
+                ri, _ = tree.within_range(r, qq)
+                for j in np.sort(ri):
+                    ho.append(O.edge_check_spheres(osph, m, qq, pts[j], rr)[0])
+                    hi.append(O.edge_check_spheres(osph, m, pts[j], qq, rr)[0])
+            return np.array(ho, dtype=np.uint8), np.array(hi, dtype=np.uint8)
+
+        lo, hi_ = parallel.shard_range(B, rank, world)
+        my_out, my_in = flags(Q[lo:hi_])
+        counts = torch.zeros(world, dtype=torch.int64)
+        counts[rank] = len(my_out)
+        dist.all_reduce(counts)
+        cap = int(counts.max().item())
+        wpr = parallel.words_for(cap)
+        bits = torch.zeros(world * wpr, dtype=torch.int64)
+        parallel.rank_slice(bits, rank, wpr).copy_(torch.from_numpy(_pack(my_out, my_in, cap)))
+        parallel.exchange_hit_bitmasks(bits, rank, world, wpr)
+        # unpack every rank's slice and compare with the unsharded run over the whole batch
+        all_out, all_in = flags(Q)
+        got_out, got_in = [], []
+        for rk in range(world):
+            w = parallel.rank_slice(bits, rk, wpr).numpy().view(np.uint8)
+            b = np.unpackbits(w, bitorder="little")
+            k = int(counts[rk].item())
+            got_out.append(b[:k]); got_in.append(b[cap:cap + k])
+        ok = np.array_equal(np.concatenate(got_out), all_out) and np.array_equal(np.concatenate(got_in), all_in)
+        q.put((rank, bool(ok and all_out.sum() > 0)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_strong_scaling_batch_shards_world2():
+    assert _spawn(_strong_worker, 2) == [(0, True), (1, True)]
