@@ -39,10 +39,18 @@ __device__ __forceinline__ double seg_len2(double ax, double ay, double bx, doub
 // segment given by its two end points
 struct Piece {
   double cx, cy;      // arc centre | line p1
-  double a, b;        // arc phi_start, step | line p2
+  double a, b;        // arc cos(phi_start), sin(phi_start) | line p2
   int len;            // number of polyline rows
-  int is_line;
+  int kind;           // 0 arc with step +0.1, 2 arc with step -0.1, 1 line
 };
+
+// cos / sin of k * 0.1: row k of an arc is at phi_start -+ k * 0.1 (StepRangeLen element of
+// collect(phi_start:-+0.1:phi_end)), so its point is one angle addition on the arc's own cos / sin of
+// phi_start instead of a cos and a sin per row (the polyline walk is most of the Dubins edge check).
+// The two forms differ by an ulp or two in the coordinates -- as device and Julia libm do anyway.
+constexpr int kArcTab = 72;           // an arc spans less than 2 pi: at most 63 rows
+__device__ const double kArcCos[kArcTab] = {1.0, 0.9950041652780258, 0.9800665778412416, 0.955336489125606, 0.9210609940028851, 0.8775825618903728, 0.8253356149096782, 0.7648421872844884, 0.6967067093471654, 0.6216099682706644, 0.5403023058681398, 0.4535961214255773, 0.3623577544766734, 0.26749882862458735, 0.16996714290024081, 0.0707372016677029, -0.029199522301288815, -0.12884449429552486, -0.2272020946930871, -0.3232895668635036, -0.4161468365471424, -0.5048461045998576, -0.5885011172553458, -0.6662760212798244, -0.7373937155412458, -0.8011436155469337, -0.8568887533689473, -0.9040721420170612, -0.9422223406686583, -0.9709581651495907, -0.9899924966004454, -0.9991351502732795, -0.9982947757947531, -0.9874797699088649, -0.9667981925794609, -0.9364566872907963, -0.896758416334147, -0.848100031710408, -0.7909677119144165, -0.7259323042001399, -0.6536436208636119, -0.5748239465332685, -0.4902608213406994, -0.40079917207997545, -0.30733286997841935, -0.2107957994307797, -0.11215252693505398, -0.01238866346289056, 0.08749898343944727, 0.18651236942257576, 0.28366218546322625, 0.37797774271298107, 0.4685166713003771, 0.5543743361791615, 0.6346928759426347, 0.70866977429126, 0.7755658785102502, 0.8347127848391598, 0.8855195169413194, 0.9274784307440359, 0.960170286650366, 0.9832684384425847, 0.9965420970232175, 0.9998586363834151, 0.9931849187581926, 0.9765876257280235, 0.9502325919585293, 0.9143831482353194, 0.8693974903498248, 0.8157251001253568, 0.7539022543433046, 0.6845466664428059};
+__device__ const double kArcSin[kArcTab] = {0.0, 0.09983341664682815, 0.19866933079506122, 0.2955202066613396, 0.3894183423086505, 0.479425538604203, 0.5646424733950355, 0.6442176872376911, 0.7173560908995228, 0.7833269096274834, 0.8414709848078965, 0.8912073600614354, 0.9320390859672264, 0.963558185417193, 0.9854497299884603, 0.9974949866040544, 0.9995736030415051, 0.9916648104524686, 0.9738476308781951, 0.9463000876874145, 0.9092974268256817, 0.8632093666488737, 0.8084964038195901, 0.74570521217672, 0.6754631805511506, 0.5984721441039565, 0.5155013718214642, 0.4273798802338298, 0.33498815015590466, 0.23924932921398198, 0.1411200080598672, 0.04158066243329049, -0.058374143427580086, -0.15774569414324865, -0.25554110202683167, -0.35078322768961984, -0.44252044329485246, -0.5298361409084934, -0.6118578909427193, -0.6877661591839741, -0.7568024953079282, -0.8182771110644108, -0.8715757724135882, -0.9161659367494549, -0.951602073889516, -0.977530117665097, -0.9936910036334645, -0.9999232575641008, -0.9961646088358406, -0.9824526126243325, -0.9589242746631385, -0.9258146823277321, -0.8834546557201531, -0.8322674422239008, -0.7727644875559871, -0.7055403255703919, -0.6312666378723208, -0.5506855425976376, -0.4646021794137566, -0.373876664830236, -0.27941549819892586, -0.18216250427209502, -0.0830894028174964, 0.0168139004843506, 0.11654920485049364, 0.21511998808781552, 0.3115413635133787, 0.4048499206165983, 0.49411335113860894, 0.5784397643882001, 0.6569865987187891, 0.7289690401258765};
 
 struct Steer {
   double cost;
@@ -63,13 +71,13 @@ __device__ __forceinline__ int julia_range_len(double start, double step, double
 
 __device__ __forceinline__ Piece make_arc(double cx, double cy, double phi_start, double phi_end, double step) {
   Piece p;
-  p.cx = cx; p.cy = cy; p.a = phi_start; p.b = step; p.is_line = 0;
+  p.cx = cx; p.cy = cy; p.a = cos(phi_start); p.b = sin(phi_start); p.kind = step < 0.0 ? 2 : 0;
   p.len = (phi_end == phi_start) ? 1 : julia_range_len(phi_start, step, phi_end);
   return p;
 }
 __device__ __forceinline__ Piece make_line(double x1, double y1, double x2, double y2) {
   Piece p;
-  p.cx = x1; p.cy = y1; p.a = x2; p.b = y2; p.is_line = 1; p.len = 2;
+  p.cx = x1; p.cy = y1; p.a = x2; p.b = y2; p.kind = 1; p.len = 2;
   return p;
 }
 
@@ -242,13 +250,17 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
 }
 
 __device__ __forceinline__ void piece_point(const Piece &p, int k, double r_min, double &x, double &y) {
-  if (p.is_line) {
+  if (p.kind == 1) {
     x = (k == 0) ? p.cx : p.a;
     y = (k == 0) ? p.cy : p.b;
   } else {
-    double phi = p.a + (double)k * p.b;   // phi_start + i*step (StepRangeLen element)
-    x = p.cx + r_min * cos(phi);
-    y = p.cy + r_min * sin(phi);
+    // phi = phi_start -+ k * 0.1
+    const int kc = k < kArcTab ? k : kArcTab - 1;
+    double ck = kArcCos[kc], sk = kArcSin[kc];
+    if (k >= kArcTab) { ck = cos((double)k * .1); sk = sin((double)k * .1); }     // (cannot happen: an arc is < 2 pi)
+    if (p.kind == 2) sk = -sk;
+    x = p.cx + r_min * (p.a * ck - p.b * sk);
+    y = p.cy + r_min * (p.b * ck + p.a * sk);
   }
 }
 
@@ -451,11 +463,16 @@ struct WaveDubinsT {
   Piece pc[64][3];
   unsigned long long mask[64];
   unsigned long long cand[64];    // stage 1: obstacles the chord's box reaches; stage 2: those a piece reaches
-  double chord[TIME ? 6 : 4][64]; // stage 1: the edges' chords; stage 2: end points (and times) of the round's 64 pieces
-  int piece_edge[64];
+  union {
+    double chord[TIME ? 6 : 4][64];              // stage 1: the edges' chords
+    unsigned int pq[(TIME ? 6 : 4) * 128];       // stage 2: queue of (edge, row, obstacle) pairs awaiting the full test
+  };
+  unsigned long long pm[3][64];   // per piece of the edge: the marked obstacles that piece can touch at all (arc screen)
+  unsigned char piece_edge[64];
+  unsigned char lc[2][64];        // rows to walk in piece 0 / piece 1 of the edge (0: that piece touches nothing)
   int pstart[65];
-  int pairs[65];
-  int done[64];
+  int pqn;
+  unsigned char done[64];
   TimeInfo ti[TIME ? 64 : 1];
 };
 
@@ -534,32 +551,137 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
     }
     __builtin_amdgcn_wave_barrier();
     const unsigned long long mask = w.mask[lane];
-    const int segs = (mask != 0ull && rows > 1) ? rows - 1 : 0;
-    // ---- stage 2 (lane = one polyline piece of one edge), kPieceWin pieces of every live edge at a
-    // time: an edge that has collided leaves the numbering at the next window, so its remaining pieces
-    // stop taking up lanes (most candidate edges do collide somewhere along the polyline) ----
-    constexpr int kPieceWin = 8;
-    for (int base = 0;; base += kPieceWin) {
-      const bool live = segs > base && !w.done[lane];
-      if (__ballot(live) == 0ull) break;
-      incl = live ? min(kPieceWin, segs - base) : 0;
+    // ---- arc screen (lane = edge): every stored row of an arc lies on its circle (centre c, radius r_min),
+    // so a piece of the arc -- and the short piece that joins it to the next one, whose far end is the
+    // tangent point on the same circle -- stays inside that disk.  A static polygon whose every edge is
+    // farther than r_min + robotRadius (+ slack) from c, or a ball whose centre is farther than that plus
+    // its radius, cannot be hit by any of them: most stage-1 survivors are near misses of the inflated
+    // chord, and this spares their ~60 pieces per arc the full test.  Moving obstacles are kept.
+    {
+      unsigned long long pm[3] = {mask, mask, mask};
+      if (mask != 0ull) {
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
+        for (int pi = 0; pi < 3; ++pi) {
+          const Piece &pc = st.pc[pi];
+          if (pc.kind == 1 || pc.len <= 0) continue;
+          const double reach = (r_min + robot_radius) * (1.0 + 1e-9) + 1e-9 * (1.0 + fabs(pc.cx) + fabs(pc.cy));
+          unsigned long long keep = 0ull, mm = mask;
+          while (mm != 0ull) {
+            const int b = __ffsll((long long)mm) - 1;
+            mm &= mm - 1ull;
+            const int j = j0 + b;
+            const int kind = (int)meta[4 * j + 3];
+            bool touch = true;
+            if (kind == 3) {
+              const int vb = off[j], ve = off[j + 1];
+              double d2min = __builtin_inf();
+              if (ve - vb >= 2) {
+                double Ax = vxy[2 * (ve - 1)], Ay = vxy[2 * (ve - 1) + 1];
+                for (int v = vb; v < ve; ++v) {
+                  const double Bx = vxy[2 * v], By = vxy[2 * v + 1];
+                  d2min = jl_min(d2min, dspts(pc.cx, pc.cy, Ax, Ay, Bx, By));
+                  Ax = Bx; Ay = By;
+                }
+              }
+              touch = !(d2min > reach * reach);
+            } else if (kind == 1) {
+              const double dx = pc.cx - meta[4 * j + 0], dy = pc.cy - meta[4 * j + 1];
+              const double R = reach + fabs(meta[4 * j + 2]) * (1.0 + 1e-9);
+              touch = !(dx * dx + dy * dy > R * R);
+            }
+            if (touch) keep |= 1ull << b;
+          }
+          pm[pi] = keep;
+        }
       }
-      w.pstart[lane + 1] = incl;
-      if (lane == 0) w.pstart[0] = 0;
-      __builtin_amdgcn_wave_barrier();
-      const int total = __shfl(incl, 63);
-      for (int i0 = 0; i0 < total; i0 += 64) {
+      w.pm[0][lane] = pm[0]; w.pm[1][lane] = pm[1]; w.pm[2][lane] = pm[2];
+    }
+    // Which stored pieces are walked at all: piece k of the polyline (row k-1 -> row k) belongs to the arc its
+    // first row lies on, else to the arc its second row starts (the two short joins), else it is the straight
+    // middle piece; the rows of one arc are contiguous, so an edge walks up to three row ranges, and only
+    // those whose arc (or line) can touch one of the marked obstacles.
+    int segs = 0;
+    {
+      const int la = st.pc[0].len, lb = st.pc[1].len;
+      const bool line1 = st.pc[1].kind == 1;
+      const int last = rows - 1;
+      int c0 = min(la, last); c0 = c0 > 0 ? c0 : 0;                                   // rows 1 .. la
+      int c1 = line1 ? ((last >= la + 1) ? 1 : 0) : (min(la + lb, last) - la);        // row la+1 | rows la+1 .. la+lb
+      c1 = c1 > 0 ? c1 : 0;
+      int c2 = last - (line1 ? la + lb : la + lb + 1) + 1;                            // the rest
+      c2 = c2 > 0 ? c2 : 0;
+      const bool l1 = line1 ? (mask != 0ull) : (w.pm[1][lane] != 0ull);
+      if (w.pm[0][lane] == 0ull) c0 = 0;
+      if (!l1) c1 = 0;
+      if (w.pm[2][lane] == 0ull) c2 = 0;
+      w.lc[0][lane] = (unsigned char)c0;
+      w.lc[1][lane] = (unsigned char)c1;
+      if (mask != 0ull && rows > 1) segs = c0 + c1 + c2;
+    }
+    // ---- stage 2 (lane = one polyline piece of one edge), a window of rows of every live edge at a
+    // time: an edge that has collided leaves the numbering at the next window, so its remaining pieces
+    // stop taking up lanes (most candidate edges do collide somewhere along the polyline).  The window is
+    // 8 rows, more when few edges are left so that a round still fills the wave.  Step a) gives every
+    // piece the obstacles whose bounding circle it reaches; those (piece, obstacle) pairs are QUEUED and the
+    // full polygon test -- by far the longest part -- runs on 64 queued pairs at a time, whatever round
+    // they came from, so its lanes are full too. ----
+    constexpr int kPqCap = (TIME ? 6 : 4) * 128;
+    if (lane == 0) w.pqn = 0;
+    __builtin_amdgcn_wave_barrier();
+    // b) lane = one queued (piece, obstacle) pair that got past the bounding circle: the full test
+    auto test_pair = [&](unsigned int ent) {
+      const int ee = (int)(ent & 63u), row = (int)((ent >> 6) & 255u), j = j0 + (int)(ent >> 14);
+      if (w.done[ee]) return;
+      double px, py, x, y, pt = 0.0, t = 0.0;
+      if constexpr (TIME) {
+        polyline_point_t(w.pc[ee], w.ti[ee], row - 1, r_min, px, py, pt);
+        polyline_point_t(w.pc[ee], w.ti[ee], row, r_min, x, y, t);
+      } else {
+        polyline_point(w.pc[ee], row - 1, r_min, px, py);
+        polyline_point(w.pc[ee], row, r_min, x, y);
+      }
+      bool h2;
+      if (TIME && meta[4 * j + 3] >= 6.0)
+        h2 = edge_hits_moving(px, py, pt, x, y, t, robot_radius, meta[4 * j + 0], meta[4 * j + 1], meta[4 * j + 2],
+                              tab.path + 3 * (size_t)tab.poff[j], tab.poff[j + 1] - tab.poff[j]);
+      else
+        h2 = seg_hits_polygon_past_circle(px, py, x, y, robot_radius, meta, off, vxy, j);
+      if (h2) w.done[ee] = 1;
+    };
+    // (one copy of the round body and ONE site of the drain loop: the polygon test is long, and every
+    //  inlined copy of it costs registers)
+    bool finishing = false;
+    int base = 0;
+    for (;;) {
+      int total = 0, win = 8;
+      if (!finishing) {
+        const bool live = segs > base && !w.done[lane];
+        const unsigned long long lm = __ballot(live);
+        if (lm == 0ull) {
+          finishing = true;
+        } else {
+          const int n_live = __popcll(lm);
+          if (n_live * win < 64) win = (64 + n_live - 1) / n_live;
+          incl = live ? min(win, segs - base) : 0;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+          }
+          w.pstart[lane + 1] = incl;
+          if (lane == 0) w.pstart[0] = 0;
+          __builtin_amdgcn_wave_barrier();
+          total = __shfl(incl, 63);
+        }
+      }
+      const int n_rounds = finishing ? 1 : (total + 63) / 64;
+      for (int rd = 0; rd < n_rounds; ++rd) {
         // a) lane = piece: its end points, and which of the edge's marked obstacles it can touch at all
         //    (the polygon test's own first step, :1536-1539: outside the bounding circle => no hit)
-        const int i = i0 + lane;
-        unsigned long long near = 0ull;
-        int e = 0;
-        double px = 0.0, py = 0.0, x = 0.0, y = 0.0, pt = 0.0, t = 0.0;
-        if (i < total) {
+        const int i = rd * 64 + lane;
+        unsigned long long pending = 0ull;
+        int e = 0, row = 0;
+        if (!finishing && i < total) {
           int lo = 0, hi = 64;                     // edge e with pstart[e] <= i < pstart[e + 1]
           while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -567,60 +689,73 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
           }
           e = lo;
           if (!w.done[e]) {
-            const int row = base + (i - w.pstart[e]) + 1;
+            // live piece number -> row and the piece it belongs to
+            int tt = base + (i - w.pstart[e]);
+            const int la = w.pc[e][0].len, lb = w.pc[e][1].len;
+            const bool line1 = w.pc[e][1].kind == 1;
+            const int c0 = w.lc[0][e], c1 = w.lc[1][e];
+            int own;
+            if (tt < c0) { row = 1 + tt; own = 0; }
+            else if (tt - c0 < c1) { row = la + 1 + (tt - c0); own = 1; }
+            else { row = (line1 ? la + lb : la + lb + 1) + (tt - c0 - c1); own = 2; }
+            double px, py, x, y;
+            polyline_point(w.pc[e], row - 1, r_min, px, py);
+            polyline_point(w.pc[e], row, r_min, x, y);
             if constexpr (TIME) {
-              polyline_point_t(w.pc[e], w.ti[e], row - 1, r_min, px, py, pt);
-              polyline_point_t(w.pc[e], w.ti[e], row, r_min, x, y, t);
-            } else {
-              polyline_point(w.pc[e], row - 1, r_min, px, py);
-              polyline_point(w.pc[e], row, r_min, x, y);
+              if (row == w.ti[e].P - 1) { x = w.ti[e].gx; y = w.ti[e].gy; }    // the last row is the end node itself
             }
-            unsigned long long mm = w.mask[e];
+            // the obstacles this piece can touch: those of the arc it belongs to (the straight piece: all marked)
+            unsigned long long mm = (own == 1 && line1) ? w.mask[e] : w.pm[own][e];
             while (mm != 0ull) {
               const int b = __ffsll((long long)mm) - 1;
               mm &= mm - 1ull;
               const bool moving = TIME && meta[4 * (j0 + b) + 3] >= 6.0;   // no bounding-circle step for those (:1579)
-              if (moving || !seg_outside_circle(px, py, x, y, robot_radius, meta, j0 + b)) near |= 1ull << b;
+              if (moving || !seg_outside_circle(px, py, x, y, robot_radius, meta, j0 + b)) pending |= 1ull << b;
             }
           }
         }
-        w.chord[0][lane] = px; w.chord[1][lane] = py; w.chord[2][lane] = x; w.chord[3][lane] = y;
-        if constexpr (TIME) { w.chord[4][lane] = pt; w.chord[5][lane] = t; }
-        w.cand[lane] = near;
-        w.piece_edge[lane] = e;
-        int pin = __popcll(near);
+        // queue the pairs (whatever does not fit waits for the drain below), then drain
+        for (;;) {
+          const int cnt = __popcll(pending);
+          int pin = cnt;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int v = __shfl_up(pin, o);
-          if (lane >= o) pin += v;
+          for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(pin, o);
+            if (lane >= o) pin += v;
+          }
+          const int n_new = __shfl(pin, 63);
+          const int qb = w.pqn;
+          int at = qb + pin - cnt;
+          unsigned long long nb = pending;
+          while (nb != 0ull) {
+            const int b = __ffsll((long long)nb) - 1;
+            nb &= nb - 1ull;
+            if (at < kPqCap) {
+              w.pq[at] = (unsigned)e | ((unsigned)row << 6) | ((unsigned)b << 14);
+              pending &= ~(1ull << b);
+            }
+            ++at;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) w.pqn = (qb + n_new < kPqCap) ? qb + n_new : kPqCap;
+          __builtin_amdgcn_wave_barrier();
+          const bool more = __ballot(pending != 0ull) != 0ull;
+          // between windows what is known about collisions decides who walks on: drain down to 32 there
+          const int at_least = (more || finishing) ? 1 : ((rd == n_rounds - 1) ? 32 : 64);
+          for (;;) {
+            const int n = w.pqn;                       // wave-uniform
+            if (n < at_least || n == 0) break;
+            const int take = n < 64 ? n : 64;
+            if (lane < take) test_pair(w.pq[n - take + lane]);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) w.pqn = n - take;
+            __builtin_amdgcn_wave_barrier();
+          }
+          if (!more) break;
         }
-        w.pairs[lane + 1] = pin;
-        if (lane == 0) w.pairs[0] = 0;
-        __builtin_amdgcn_wave_barrier();
-        const int n_pairs = __shfl(pin, 63);
-        // b) lane = one (piece, obstacle) pair that got past the bounding circle: the full test
-        for (int p = lane; p < n_pairs; p += 64) {
-          int it = 0;
-          for (int step = 32; step > 0; step >>= 1)
-            if (w.pairs[it + step] <= p) it += step;
-          const int ee = w.piece_edge[it];
-          if (w.done[ee]) continue;
-          unsigned long long bits = w.cand[it];
-          for (int r = p - w.pairs[it]; r > 0; --r) bits &= bits - 1ull;
-          const int j = j0 + __ffsll((long long)bits) - 1;
-          bool h2;
-          if (TIME && meta[4 * j + 3] >= 6.0)
-            h2 = edge_hits_moving(w.chord[0][it], w.chord[1][it], w.chord[TIME ? 4 : 0][it], w.chord[2][it], w.chord[3][it],
-                                  w.chord[TIME ? 5 : 0][it], robot_radius, meta[4 * j + 0], meta[4 * j + 1], meta[4 * j + 2],
-                                  tab.path + 3 * (size_t)tab.poff[j], tab.poff[j + 1] - tab.poff[j]);
-          else
-            h2 = seg_hits_polygon_past_circle(w.chord[0][it], w.chord[1][it], w.chord[2][it], w.chord[3][it], robot_radius,
-                                              meta, off, vxy, j);
-          if (h2) w.done[ee] = 1;
-        }
-        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
+      if (finishing) break;
+      base += win;
     }
     __builtin_amdgcn_wave_barrier();
   }

@@ -387,7 +387,7 @@ int launch_nn_finish(rrtx_ctx *ctx, const FinishLaunch &f) {
   const dim3 grid((unsigned)((f.nq + kFinQ - 1) / kFinQ)), block(kFinThreads);
   // lists of hundreds of entries and more (the caller made room for them): the build that sorts up to
   // kHugeSort entries in LDS (one workgroup per CU) instead of counting ranks over global memory
-  const bool huge = f.out_cap / (f.nq > 0 ? f.nq : 1) >= 2048;
+  const bool huge = f.out_cap / (f.nq > 0 ? f.nq : 1) > 2048;
   if (D == 4) {
     if (huge) hipLaunchKernelGGL((nn_finish_kernel<4, kHugeSort>), grid, block, 0, ctx->stream, a);
     else hipLaunchKernelGGL((nn_finish_kernel<4, kBigSort>), grid, block, 0, ctx->stream, a);
