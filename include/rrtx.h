@@ -241,6 +241,21 @@ int64_t rrtx_graph_edges_count(rrtx_ctx *ctx);
 int rrtx_graph_edges_clear(rrtx_ctx *ctx);
 int rrtx_obstacle_sweep(rrtx_ctx *ctx, int obstacle, double search_range, double robot_radius, int32_t *edge_ids,
                         int64_t cap, int64_t *needed);
+/* Cost propagation over the edge mirror: the fixed point that rewire / reduceInconsistency /
+ * propogateDescendants (R/DRRT_Q.jl:2490-2541, 2647-2817) drive rrtLMC to when changeThresh = 0 and the queue
+ * runs dry -- lmc(root) = 0, lmc(v) = min over mirrored edges v -> u with finite dist of lmc(u) + dist (one
+ * rounded addition per edge, the value the reference's heap order also ends at), Inf for a node that cannot
+ * reach the root (an orphan).  Every mirrored edge carries edge.dist: the SimpleEdge cost of its two nodes when
+ * appended, overwritten with rrtx_graph_edges_set_dist (Dubins costs, costs in a space with time), set to Inf
+ * with rrtx_graph_edges_block for the ids rrtx_obstacle_sweep returned (addNewObstacle: `dist = Inf`,
+ * R/DRRT_Q.jl:3249).  parent_edge[v] (may be NULL) = the id of the mirrored edge v -> rrtParent(v): the lowest id
+ * among the edges that attain the minimum (-1: the root, or an orphan).  passes (may be NULL) = relaxation
+ * passes run.  A positive changeThresh makes the reference's result depend on its pop order; that variant is
+ * not offered. */
+int rrtx_graph_edges_set_dist(rrtx_ctx *ctx, int64_t first_id, const double *dist, int64_t n);
+int rrtx_graph_edges_block(rrtx_ctx *ctx, const int32_t *edge_ids, int64_t n);
+int rrtx_graph_cost_to_root(rrtx_ctx *ctx, int root_idx, double *lmc /* n_nodes */, int32_t *parent_edge /* n_nodes */,
+                            int32_t *passes);
 /* explicitPointCheck (R/DRRT_Q.jl:1520-1556; quick=0: explicitPointCheck3D,
  * :1558-1590).  unsafe[i] in {0,1}; clearance[i] = the returned certificate
  * (0.0 when unsafe). kind as above. */
@@ -337,6 +352,10 @@ int rrtx_extend_candidates_dubins_dev(rrtx_ctx *ctx, const double *q, int nq, do
 /* Per-edge collision bitmask for the multi-GPU exchange (RCCL all-reduce over
  * xGMI): bit e (e < cap) = hit_out[e], bit cap+e = hit_in[e]; entries at or
  * beyond *n_valid_dev read as 0.  words has (2*cap+63)/64 uint64 entries. */
+/* device-pointer form of rrtx_graph_cost_to_root (waits on the stream between groups of passes to learn whether
+ * the fixed point is reached) */
+int rrtx_graph_cost_to_root_dev(rrtx_ctx *ctx, int root_idx, double *lmc_dev, int32_t *parent_edge_dev);
+
 int rrtx_pack_hits_dev(rrtx_ctx *ctx, const uint8_t *hit_out, const uint8_t *hit_in,
                        const int64_t *n_valid_dev, int64_t cap, uint64_t *words);
 

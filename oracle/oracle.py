@@ -34,9 +34,10 @@ class Polygon(C.Structure):
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (seconds). Returns the .so path."""
     src = os.path.join(_HERE, "rrtx_oracle.c")
+    src2 = os.path.join(_HERE, "rrtx_oracle_graph.c")
     hdr = os.path.join(_HERE, "rrtx_oracle.h")
     stale = (not os.path.exists(_LIB_PATH)
-             or any(os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr)))
+             or any(os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, src2, hdr)))
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _LIB_PATH
@@ -117,6 +118,29 @@ def lib() -> C.CDLL:
     L.orc_dubins_edge_check_polygons_time.restype = C.c_int
     L.orc_dubins_edge_check_polygons_time.argtypes = [C.POINTER(Polygon), C.c_int, c_double_p, c_double_p,
                                                       c_double_p, C.c_int, C.c_double, C.c_double, c_int32_p]
+    L.orc_graph_create.restype = C.c_void_p
+    L.orc_graph_create.argtypes = [C.c_int64]
+    L.orc_graph_destroy.argtypes = [C.c_void_p]
+    L.orc_graph_add_edge.restype = C.c_int64
+    L.orc_graph_add_edge.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_int, C.c_int]
+    L.orc_graph_set_node.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double]
+    L.orc_graph_set_move_goal.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    L.orc_graph_set_edge_dist.argtypes = [C.c_void_p, C.c_int64, C.c_double]
+    for f in (L.orc_graph_lmc, L.orc_graph_tree_cost):
+        f.restype = C.c_double
+        f.argtypes = [C.c_void_p, C.c_int64]
+    L.orc_graph_parent_edge.restype = C.c_int64
+    L.orc_graph_parent_edge.argtypes = [C.c_void_p, C.c_int64]
+    L.orc_graph_queue_length.restype = C.c_int64
+    L.orc_graph_queue_length.argtypes = [C.c_void_p]
+    L.orc_graph_n_edges.restype = C.c_int64
+    L.orc_graph_n_edges.argtypes = [C.c_void_p]
+    L.orc_graph_verify_in_queue.argtypes = [C.c_void_p, C.c_int64]
+    L.orc_graph_verify_in_os.argtypes = [C.c_void_p, C.c_int64]
+    L.orc_graph_make_parent_of.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    L.orc_graph_reduce_inconsistency.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_double]
+    L.orc_graph_block_edge.argtypes = [C.c_void_p, C.c_int64]
+    L.orc_graph_propagate_descendants.argtypes = [C.c_void_p]
     L.orc_julia_range_len.restype = C.c_int64
     L.orc_julia_range_len.argtypes = [C.c_double] * 3
     L.orc_kd_insert_many.restype = None
@@ -425,6 +449,67 @@ def dubins_edge_check_polygons_time(ps: "PolygonSet", s, g, traj3, robot_radius,
     hit = lib().orc_dubins_edge_check_polygons_time(ps.arr, ps.m, _dp(s), _dp(g), _dp(traj3), traj3.shape[0],
                                                     robot_radius, r_min, C.byref(fh))
     return bool(hit), fh.value
+
+
+class Graph:
+    """The reference's cost propagation on an index graph (rrtx_oracle_graph.c): rrtLMC / rrtTreeCost per node,
+    edges with dist, the rrtXQueue heap and the orphan stack; methods carry the reference's names."""
+
+    def __init__(self, n: int):
+        self.n = n
+        self._h = C.c_void_p(lib().orc_graph_create(n))
+
+    def __del__(self):
+        try:
+            lib().orc_graph_destroy(self._h)
+        except Exception:
+            pass
+
+    def add_edge(self, start: int, end: int, dist: float, initial: bool = False, valid_move: bool = True) -> int:
+        return lib().orc_graph_add_edge(self._h, start, end, dist, 1 if initial else 0, 1 if valid_move else 0)
+
+    def set_node(self, v: int, lmc: float, tree_cost: float):
+        lib().orc_graph_set_node(self._h, v, lmc, tree_cost)
+
+    def set_move_goal(self, v: int, flag: bool = True):
+        lib().orc_graph_set_move_goal(self._h, v, 1 if flag else 0)
+
+    def set_edge_dist(self, e: int, dist: float):
+        lib().orc_graph_set_edge_dist(self._h, e, dist)
+
+    def lmc(self):
+        L = lib()
+        return np.array([L.orc_graph_lmc(self._h, v) for v in range(self.n)])
+
+    def tree_cost(self):
+        L = lib()
+        return np.array([L.orc_graph_tree_cost(self._h, v) for v in range(self.n)])
+
+    def parent_edge(self):
+        L = lib()
+        return np.array([L.orc_graph_parent_edge(self._h, v) for v in range(self.n)], dtype=np.int64)
+
+    def queue_length(self) -> int:
+        return lib().orc_graph_queue_length(self._h)
+
+    def verifyInQueue(self, v: int):
+        lib().orc_graph_verify_in_queue(self._h, v)
+
+    def verifyInOSQueue(self, v: int):
+        lib().orc_graph_verify_in_os(self._h, v)
+
+    def makeParentOf(self, new_parent: int, node: int, edge: int):
+        lib().orc_graph_make_parent_of(self._h, new_parent, node, edge)
+
+    def reduceInconsistency(self, goal: int, root: int, hyberBallRad: float = float("inf"), changeThresh: float = 0.0):
+        lib().orc_graph_reduce_inconsistency(self._h, goal, root, hyberBallRad, changeThresh)
+
+    def blockEdge(self, e: int):
+        """addNewObstacle's handling of one edge the new obstacle hits (R/DRRT_Q.jl:3248-3268)"""
+        lib().orc_graph_block_edge(self._h, e)
+
+    def propogateDescendants(self):
+        lib().orc_graph_propagate_descendants(self._h)
 
 
 def julia_range_len(start, step, stop) -> int:

@@ -154,6 +154,27 @@ int64_t orc_extend_batch_spheres(orc_kd *t, const orc_sphere *obs, int m, const 
                                  int64_t *nearest_idx, int64_t *n_neighbors_total,
                                  int64_t *n_hits_total);
 
+/* ---- N4: cost propagation (rrtx_oracle_graph.c): rewire / reduceInconsistency / propogateDescendants with the
+ * reference's BinaryHeap and list orders, R/DRRT_Q.jl:2052-2077, 2364-2541, 2647-2817, 3244-3268, R/heap.jl:138-273 */
+typedef struct orc_graph orc_graph;
+orc_graph *orc_graph_create(int64_t n_nodes);
+void orc_graph_destroy(orc_graph *g);
+int64_t orc_graph_add_edge(orc_graph *g, int64_t start, int64_t end, double dist, int initial, int valid_move);
+void orc_graph_set_node(orc_graph *g, int64_t v, double lmc, double tree_cost);
+void orc_graph_set_move_goal(orc_graph *g, int64_t v, int flag);
+void orc_graph_set_edge_dist(orc_graph *g, int64_t e, double dist);
+double orc_graph_lmc(const orc_graph *g, int64_t v);
+double orc_graph_tree_cost(const orc_graph *g, int64_t v);
+int64_t orc_graph_parent_edge(const orc_graph *g, int64_t v);
+int64_t orc_graph_queue_length(const orc_graph *g);
+int64_t orc_graph_n_edges(const orc_graph *g);
+void orc_graph_verify_in_queue(orc_graph *g, int64_t v);
+void orc_graph_verify_in_os(orc_graph *g, int64_t v);
+void orc_graph_make_parent_of(orc_graph *g, int64_t new_parent, int64_t node, int64_t edge);
+void orc_graph_reduce_inconsistency(orc_graph *g, int64_t goal, int64_t root, double ball, double change_thresh);
+void orc_graph_block_edge(orc_graph *g, int64_t e);
+void orc_graph_propagate_descendants(orc_graph *g);
+
 #ifdef __cplusplus
 }
 #endif

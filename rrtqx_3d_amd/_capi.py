@@ -95,6 +95,10 @@ SYMBOLS = [
     ("rrtx_points_check", C.c_int, [_VP, C.c_int, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP]),
     ("rrtx_simple_steer", C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP]),
     ("rrtx_dubins_steer", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP]),
+    ("rrtx_graph_edges_set_dist", C.c_int, [_VP, C.c_int64, _VP, C.c_int64]),
+    ("rrtx_graph_edges_block", C.c_int, [_VP, _VP, C.c_int64]),
+    ("rrtx_graph_cost_to_root", C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
+    ("rrtx_graph_cost_to_root_dev", C.c_int, [_VP, C.c_int, _VP, _VP]),
     ("rrtx_set_dubins_velocity", C.c_int, [_VP, C.c_double, C.c_double]),
     ("rrtx_dubins_steer_full", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP, _VP, _VP, _VP]),
     ("rrtx_dubins_edges_check", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_double, _VP, _VP, _VP, _VP]),

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "librrtx_hip.so")
 
-SOURCES = ["rrtx_capi.hip", "kernels_nn.hip", "kernels_finish.hip", "kernels_nearest.hip", "kernels_slab.hip", "kernels_sweep.hip", "kernels_collide.hip",
+SOURCES = ["rrtx_capi.hip", "kernels_nn.hip", "kernels_finish.hip", "kernels_nearest.hip", "kernels_slab.hip", "kernels_sweep.hip", "kernels_graph.hip", "kernels_collide.hip",
            "kernels_dubins.hip"]
 HEADERS = ["rrtx_internal.hpp", "exact_math.hpp", "nn_device.hpp", "collide_device.hpp", os.path.join("..", "..", "include", "rrtx.h")]
 

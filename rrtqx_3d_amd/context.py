@@ -395,6 +395,27 @@ class Context:
     def graph_edges_clear(self):
         self._check(self._lib.rrtx_graph_edges_clear(self._h))
 
+    def graph_edges_set_dist(self, first_id: int, dist):
+        """edge.dist of mirrored edges [first_id, first_id + len(dist)) (Inf = blocked)"""
+        d = np.ascontiguousarray(dist, dtype=np.float64).reshape(-1)
+        self._check(self._lib.rrtx_graph_edges_set_dist(self._h, int(first_id), _capi._ptr(d), d.shape[0]))
+
+    def graph_edges_block(self, edge_ids):
+        """addNewObstacle's `edge.dist = Inf` for the ids an obstacle sweep returned"""
+        ids = np.ascontiguousarray(edge_ids, dtype=np.int32).reshape(-1)
+        self._check(self._lib.rrtx_graph_edges_block(self._h, _capi._ptr(ids), ids.shape[0]))
+
+    def graph_cost_to_root(self, root_idx: int, want_parent: bool = True):
+        """rrtLMC of every node at the fixed point of rewire / reduceInconsistency (changeThresh = 0) over the
+        edge mirror, and the id of each node's parent edge (-1: root or orphan).  Returns (lmc, parent_edge, passes)."""
+        n = self.n_nodes
+        lmc = np.empty(n, dtype=np.float64)
+        par = np.empty(n, dtype=np.int32) if want_parent else None
+        passes = C.c_int32()
+        self._check(self._lib.rrtx_graph_cost_to_root(self._h, int(root_idx), _capi._ptr(lmc),
+                                                      _capi._ptr(par) if want_parent else None, C.byref(passes)))
+        return lmc, par, passes.value
+
     def obstacle_sweep(self, obstacle: int, search_range: float, robot_radius: float, cap: Optional[int] = None):
         """addNewObstacle's edge loop: ids (ascending) of the registered edges that start within
         search_range of sphere `obstacle` and collide with it."""

@@ -404,10 +404,12 @@ int rrtx_destroy(rrtx_ctx *ctx) {
                     &ctx->ws_slab_hist, &ctx->ws_slab_start, &ctx->ws_slab_sr, &ctx->ws_slab_params, &ctx->ws_copies_s,
                     &ctx->ws_meta_s, &ctx->ws_cb, &ctx->ws_qhist, &ctx->ws_bkt,
                     &ctx->ws_ev_a, &ctx->ws_ev_cnt, &ctx->ws_confirm_args, &ctx->ws_sph_lists, &ctx->d_sph_sample,
-                    &ctx->ws_sweep_mark, &ctx->ws_sweep_flag, &ctx->ws_sweep_cnt, &ctx->ws_sweep_start};
+                    &ctx->ws_sweep_mark, &ctx->ws_sweep_flag, &ctx->ws_sweep_cnt, &ctx->ws_sweep_start,
+                    &ctx->ws_graph_lmc, &ctx->ws_graph_stamp, &ctx->ws_graph_parent, &ctx->ws_graph_flags};
   for (auto b : bufs) b->release();
   if (ctx->ge_start) (void)hipFree(ctx->ge_start);
   if (ctx->ge_end) (void)hipFree(ctx->ge_end);
+  if (ctx->ge_dist) (void)hipFree(ctx->ge_dist);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -833,13 +835,66 @@ int rrtx_graph_edges_append(rrtx_ctx *ctx, const int32_t *start_idx, const int32
     int rc;
     if ((rc = regrow(ctx, ctx->ge_start, nc, ctx->ge_n))) return rc;
     if ((rc = regrow(ctx, ctx->ge_end, nc, ctx->ge_n))) return rc;
+    if ((rc = regrow(ctx, ctx->ge_dist, nc, ctx->ge_n))) return rc;
     ctx->ge_cap = nc;
   }
   RRTX_HIP(ctx, hipMemcpyAsync(ctx->ge_start + ctx->ge_n, start_idx, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   RRTX_HIP(ctx, hipMemcpyAsync(ctx->ge_end + ctx->ge_n, end_idx, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  // edge.dist defaults to the SimpleEdge cost of the edge (rrtx_graph_edges_set_dist overrides it)
+  int rc2 = launch_graph_edge_dist(ctx, ctx->ge_n, n);
+  if (rc2) return rc2;
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->ge_n += n;
   return RRTX_OK;
+}
+
+int rrtx_graph_edges_set_dist(rrtx_ctx *ctx, int64_t first_id, const double *dist, int64_t n) {
+  CHECK_CTX(ctx);
+  if (n < 0 || first_id < 0 || first_id + n > ctx->ge_n || (n > 0 && !dist))
+    return fail(ctx, RRTX_E_INVALID, "graph_edges_set_dist: edges [%lld, %lld) of %lld", (long long)first_id,
+                (long long)(first_id + n), (long long)ctx->ge_n);
+  if (n == 0) return RRTX_OK;
+  RRTX_HIP(ctx, hipMemcpyAsync(ctx->ge_dist + first_id, dist, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
+int rrtx_graph_edges_block(rrtx_ctx *ctx, const int32_t *edge_ids, int64_t n) {
+  CHECK_CTX(ctx);
+  if (n < 0 || (n > 0 && !edge_ids)) return fail(ctx, RRTX_E_INVALID, "graph_edges_block: bad arguments");
+  const double inf = INFINITY;
+  for (int64_t i = 0; i < n; ++i) {
+    if (edge_ids[i] < 0 || edge_ids[i] >= ctx->ge_n) return fail(ctx, RRTX_E_INVALID, "graph_edges_block: edge id %d out of range", edge_ids[i]);
+    RRTX_HIP(ctx, hipMemcpyAsync(ctx->ge_dist + edge_ids[i], &inf, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
+int rrtx_graph_cost_to_root(rrtx_ctx *ctx, int root_idx, double *lmc, int32_t *parent_edge, int32_t *passes) {
+  CHECK_CTX(ctx);
+  if (!lmc) return fail(ctx, RRTX_E_INVALID, "graph_cost_to_root: lmc is NULL");
+  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "graph_cost_to_root on an empty tree");
+  if (root_idx < 0 || root_idx >= ctx->n_nodes) return fail(ctx, RRTX_E_INVALID, "graph_cost_to_root: root %d out of range", root_idx);
+  const size_t n = (size_t)ctx->n_nodes;
+  RRTX_HIP(ctx, ctx->ws_out_f64.ensure(sizeof(double) * n));
+  RRTX_HIP(ctx, ctx->ws_out_i32.ensure(sizeof(int32_t) * n));
+  int np = 0;
+  int rc = launch_graph_cost_to_root(ctx, root_idx, ctx->ws_out_f64.as<double>(), parent_edge ? ctx->ws_out_i32.as<int32_t>() : nullptr, &np);
+  if (rc) return rc;
+  RRTX_HIP(ctx, hipMemcpyAsync(lmc, ctx->ws_out_f64.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (parent_edge) RRTX_HIP(ctx, hipMemcpyAsync(parent_edge, ctx->ws_out_i32.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (passes) *passes = np;
+  return RRTX_OK;
+}
+
+int rrtx_graph_cost_to_root_dev(rrtx_ctx *ctx, int root_idx, double *lmc_dev, int32_t *parent_edge_dev) {
+  CHECK_CTX(ctx);
+  if (!lmc_dev) return fail(ctx, RRTX_E_INVALID, "graph_cost_to_root: lmc is NULL");
+  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "graph_cost_to_root on an empty tree");
+  if (root_idx < 0 || root_idx >= ctx->n_nodes) return fail(ctx, RRTX_E_INVALID, "graph_cost_to_root: root %d out of range", root_idx);
+  return launch_graph_cost_to_root(ctx, root_idx, lmc_dev, parent_edge_dev, nullptr);
 }
 
 int rrtx_obstacle_sweep(rrtx_ctx *ctx, int obstacle, double search_range, double robot_radius, int32_t *edge_ids,

@@ -182,6 +182,8 @@ struct rrtx_ctx {
 
   // device mirror of the planner's directed edges (obstacle sweeps, kernels_sweep.hip)
   int32_t *ge_start = nullptr, *ge_end = nullptr;
+  double *ge_dist = nullptr;        // edge.dist of every mirrored edge (Inf = blocked); SimpleEdge cost by default
+  rrtx::DevBuf ws_graph_lmc, ws_graph_stamp, ws_graph_parent, ws_graph_flags;   // cost propagation (kernels_graph.hip)
   int64_t ge_n = 0, ge_cap = 0;
   rrtx::DevBuf ws_sweep_mark, ws_sweep_flag, ws_sweep_cnt, ws_sweep_start;
 
@@ -301,6 +303,9 @@ int launch_nearest_from_lists(rrtx_ctx *ctx, const double *q_dev, int nq, const 
 
 int launch_obstacle_sweep(rrtx_ctx *ctx, const double centre[3], double thr_lt, double thr_gt, const SphRec &ob,
                           int active, int32_t *out_dev, int64_t cap, long long **total_dev);
+
+int launch_graph_edge_dist(rrtx_ctx *ctx, long long first, long long n);
+int launch_graph_cost_to_root(rrtx_ctx *ctx, int root, double *lmc_dev, int32_t *parent_dev, int *passes_out);
 
 int launch_pack_hits(rrtx_ctx *ctx, const uint8_t *hit_out, const uint8_t *hit_in, const int64_t *n_valid_dev,
                      int64_t cap, uint64_t *words);
