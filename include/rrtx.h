@@ -251,11 +251,18 @@ int rrtx_obstacle_sweep(rrtx_ctx *ctx, int obstacle, double search_range, double
  * R/DRRT_Q.jl:3249).  parent_edge[v] (may be NULL) = the id of the mirrored edge v -> rrtParent(v): the lowest id
  * among the edges that attain the minimum (-1: the root, or an orphan).  passes (may be NULL) = relaxation
  * passes run.  A positive changeThresh makes the reference's result depend on its pop order; that variant is
- * not offered. */
+ * not offered.
+ * rrtx_graph_cost_update gives the same answer starting from the state the previous call (either function, same
+ * root) left on the device: nodes and edges appended since then, costs changed with set_dist / block.  This is
+ * the replanning step: edges whose cost was touched and that were parent edges orphan their subtrees
+ * (propogateDescendants, R/DRRT_Q.jl:2760-2817), orphans restart at Inf, and only the region that changes is
+ * relaxed again.  Without a previous solve for this root it is rrtx_graph_cost_to_root. */
 int rrtx_graph_edges_set_dist(rrtx_ctx *ctx, int64_t first_id, const double *dist, int64_t n);
 int rrtx_graph_edges_block(rrtx_ctx *ctx, const int32_t *edge_ids, int64_t n);
 int rrtx_graph_cost_to_root(rrtx_ctx *ctx, int root_idx, double *lmc /* n_nodes */, int32_t *parent_edge /* n_nodes */,
                             int32_t *passes);
+int rrtx_graph_cost_update(rrtx_ctx *ctx, int root_idx, double *lmc /* n_nodes */, int32_t *parent_edge /* n_nodes */,
+                           int32_t *passes);
 /* explicitPointCheck (R/DRRT_Q.jl:1520-1556; quick=0: explicitPointCheck3D,
  * :1558-1590).  unsafe[i] in {0,1}; clearance[i] = the returned certificate
  * (0.0 when unsafe). kind as above. */
@@ -352,9 +359,10 @@ int rrtx_extend_candidates_dubins_dev(rrtx_ctx *ctx, const double *q, int nq, do
 /* Per-edge collision bitmask for the multi-GPU exchange (RCCL all-reduce over
  * xGMI): bit e (e < cap) = hit_out[e], bit cap+e = hit_in[e]; entries at or
  * beyond *n_valid_dev read as 0.  words has (2*cap+63)/64 uint64 entries. */
-/* device-pointer form of rrtx_graph_cost_to_root (waits on the stream between groups of passes to learn whether
+/* device-pointer forms of rrtx_graph_cost_to_root / _update (they wait on the stream between groups of passes to learn whether
  * the fixed point is reached) */
 int rrtx_graph_cost_to_root_dev(rrtx_ctx *ctx, int root_idx, double *lmc_dev, int32_t *parent_edge_dev);
+int rrtx_graph_cost_update_dev(rrtx_ctx *ctx, int root_idx, double *lmc_dev, int32_t *parent_edge_dev);
 
 int rrtx_pack_hits_dev(rrtx_ctx *ctx, const uint8_t *hit_out, const uint8_t *hit_in,
                        const int64_t *n_valid_dev, int64_t cap, uint64_t *words);

@@ -443,6 +443,33 @@ function obstacleSweep(tree::HipTree, S::TS, ob::SphereObstacle) where {TS}
   end
 end
 
+# edge.dist of registered edges first_id, first_id+1, ... (ids from registerEdges); registerEdges itself
+# gives every edge the SimpleEdge cost of its two nodes.
+function syncEdgeCosts(tree::HipTree, first_id::Int, edges::Vector{TE}) where {TE}
+  d = Float64[e.dist for e in edges]
+  GC.@preserve d rrtx_check(tree, ccall((:rrtx_graph_edges_set_dist, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Int64), tree.ctx, first_id, d, length(d)))
+end
+
+# addNewObstacle's `edge.dist = Inf` (R/DRRT_Q.jl:3249) for the ids obstacleSweep returned
+function blockEdges(tree::HipTree, ids::Vector{Int32})
+  GC.@preserve ids rrtx_check(tree, ccall((:rrtx_graph_edges_block, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Ptr{Int32}, Int64), tree.ctx, ids, length(ids)))
+end
+
+# The state propogateDescendants + reduceInconsistency (R/DRRT_Q.jl:2703-2817) reach with changeThresh = 0.0
+# once the queue is empty: rrtLMC of every node, and the registered id of its parent edge (-1: root / orphan).
+# The caller writes them back: node.rrtLMC = node.rrtTreeCost = lmc[i+1]; makeParentOf along edge parent[i+1].
+function costToRoot(tree::HipTree, root)
+  n = length(tree.nodes)
+  lmc = Vector{Float64}(undef, n)
+  parent = Vector{Int32}(undef, n)
+  passes = Ref{Int32}(0)
+  GC.@preserve lmc parent rrtx_check(tree, ccall((:rrtx_graph_cost_to_root, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Int32}, Ref{Int32}), tree.ctx, tree.indexOf[root], lmc, parent, passes))
+  return lmc, parent
+end
+
 
 # ---------------------------------------------------------------------------
 # Edge = DubinsEdge (R/DRRT_DubinsEdge.jl, R/DRRT_DubinsEdge_functions.jl; README's per-edge-type

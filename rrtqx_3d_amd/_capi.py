@@ -99,6 +99,8 @@ SYMBOLS = [
     ("rrtx_graph_edges_block", C.c_int, [_VP, _VP, C.c_int64]),
     ("rrtx_graph_cost_to_root", C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
     ("rrtx_graph_cost_to_root_dev", C.c_int, [_VP, C.c_int, _VP, _VP]),
+    ("rrtx_graph_cost_update", C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
+    ("rrtx_graph_cost_update_dev", C.c_int, [_VP, C.c_int, _VP, _VP]),
     ("rrtx_set_dubins_velocity", C.c_int, [_VP, C.c_double, C.c_double]),
     ("rrtx_dubins_steer_full", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP, _VP, _VP, _VP]),
     ("rrtx_dubins_edges_check", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_double, _VP, _VP, _VP, _VP]),

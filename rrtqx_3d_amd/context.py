@@ -405,16 +405,20 @@ class Context:
         ids = np.ascontiguousarray(edge_ids, dtype=np.int32).reshape(-1)
         self._check(self._lib.rrtx_graph_edges_block(self._h, _capi._ptr(ids), ids.shape[0]))
 
-    def graph_cost_to_root(self, root_idx: int, want_parent: bool = True):
+    def graph_cost_to_root(self, root_idx: int, want_parent: bool = True, update: bool = False):
         """rrtLMC of every node at the fixed point of rewire / reduceInconsistency (changeThresh = 0) over the
-        edge mirror, and the id of each node's parent edge (-1: root or orphan).  Returns (lmc, parent_edge, passes)."""
+        edge mirror, and the id of each node's parent edge (-1: root or orphan).  Returns (lmc, parent_edge, passes).
+        update=True continues from the previous solve (rrtx_graph_cost_update): same answer, less work."""
         n = self.n_nodes
         lmc = np.empty(n, dtype=np.float64)
         par = np.empty(n, dtype=np.int32) if want_parent else None
         passes = C.c_int32()
-        self._check(self._lib.rrtx_graph_cost_to_root(self._h, int(root_idx), _capi._ptr(lmc),
-                                                      _capi._ptr(par) if want_parent else None, C.byref(passes)))
+        fn = self._lib.rrtx_graph_cost_update if update else self._lib.rrtx_graph_cost_to_root
+        self._check(fn(self._h, int(root_idx), _capi._ptr(lmc), _capi._ptr(par) if want_parent else None, C.byref(passes)))
         return lmc, par, passes.value
+
+    def graph_cost_update(self, root_idx: int, want_parent: bool = True):
+        return self.graph_cost_to_root(root_idx, want_parent, update=True)
 
     def obstacle_sweep(self, obstacle: int, search_range: float, robot_radius: float, cap: Optional[int] = None):
         """addNewObstacle's edge loop: ids (ascending) of the registered edges that start within

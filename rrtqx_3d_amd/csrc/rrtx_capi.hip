@@ -405,11 +405,14 @@ int rrtx_destroy(rrtx_ctx *ctx) {
                     &ctx->ws_meta_s, &ctx->ws_cb, &ctx->ws_qhist, &ctx->ws_bkt,
                     &ctx->ws_ev_a, &ctx->ws_ev_cnt, &ctx->ws_confirm_args, &ctx->ws_sph_lists, &ctx->d_sph_sample,
                     &ctx->ws_sweep_mark, &ctx->ws_sweep_flag, &ctx->ws_sweep_cnt, &ctx->ws_sweep_start,
-                    &ctx->ws_graph_lmc, &ctx->ws_graph_stamp, &ctx->ws_graph_parent, &ctx->ws_graph_flags};
+                    &ctx->gc.lmc, &ctx->gc.parent, &ctx->gc.stamp, &ctx->gc.flags, &ctx->gc.orph, &ctx->gc.anc, &ctx->gc.ids,
+                    &ctx->gc.in_cnt, &ctx->gc.in_start, &ctx->gc.in_cursor, &ctx->gc.in_tiles, &ctx->gc.in_src, &ctx->gc.in_w,
+                    &ctx->gc.in_pos};
   for (auto b : bufs) b->release();
   if (ctx->ge_start) (void)hipFree(ctx->ge_start);
   if (ctx->ge_end) (void)hipFree(ctx->ge_end);
   if (ctx->ge_dist) (void)hipFree(ctx->ge_dist);
+  if (ctx->ge_dirty) (void)hipFree(ctx->ge_dirty);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -814,6 +817,7 @@ int64_t rrtx_graph_edges_count(rrtx_ctx *ctx) { return ctx ? ctx->ge_n : 0; }
 int rrtx_graph_edges_clear(rrtx_ctx *ctx) {
   CHECK_CTX(ctx);
   ctx->ge_n = 0;
+  graph_cost_forget(ctx);
   return RRTX_OK;
 }
 
@@ -836,6 +840,7 @@ int rrtx_graph_edges_append(rrtx_ctx *ctx, const int32_t *start_idx, const int32
     if ((rc = regrow(ctx, ctx->ge_start, nc, ctx->ge_n))) return rc;
     if ((rc = regrow(ctx, ctx->ge_end, nc, ctx->ge_n))) return rc;
     if ((rc = regrow(ctx, ctx->ge_dist, nc, ctx->ge_n))) return rc;
+    if ((rc = regrow(ctx, ctx->ge_dirty, nc, ctx->ge_n))) return rc;
     ctx->ge_cap = nc;
   }
   RRTX_HIP(ctx, hipMemcpyAsync(ctx->ge_start + ctx->ge_n, start_idx, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
@@ -855,6 +860,8 @@ int rrtx_graph_edges_set_dist(rrtx_ctx *ctx, int64_t first_id, const double *dis
                 (long long)(first_id + n), (long long)ctx->ge_n);
   if (n == 0) return RRTX_OK;
   RRTX_HIP(ctx, hipMemcpyAsync(ctx->ge_dist + first_id, dist, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  int rc = launch_graph_touch(ctx, first_id, n);
+  if (rc) return rc;
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RRTX_OK;
 }
@@ -862,25 +869,21 @@ int rrtx_graph_edges_set_dist(rrtx_ctx *ctx, int64_t first_id, const double *dis
 int rrtx_graph_edges_block(rrtx_ctx *ctx, const int32_t *edge_ids, int64_t n) {
   CHECK_CTX(ctx);
   if (n < 0 || (n > 0 && !edge_ids)) return fail(ctx, RRTX_E_INVALID, "graph_edges_block: bad arguments");
-  const double inf = INFINITY;
-  for (int64_t i = 0; i < n; ++i) {
+  for (int64_t i = 0; i < n; ++i)
     if (edge_ids[i] < 0 || edge_ids[i] >= ctx->ge_n) return fail(ctx, RRTX_E_INVALID, "graph_edges_block: edge id %d out of range", edge_ids[i]);
-    RRTX_HIP(ctx, hipMemcpyAsync(ctx->ge_dist + edge_ids[i], &inf, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  }
-  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return RRTX_OK;
+  return launch_graph_block(ctx, edge_ids, n);
 }
 
-int rrtx_graph_cost_to_root(rrtx_ctx *ctx, int root_idx, double *lmc, int32_t *parent_edge, int32_t *passes) {
-  CHECK_CTX(ctx);
-  if (!lmc) return fail(ctx, RRTX_E_INVALID, "graph_cost_to_root: lmc is NULL");
-  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "graph_cost_to_root on an empty tree");
-  if (root_idx < 0 || root_idx >= ctx->n_nodes) return fail(ctx, RRTX_E_INVALID, "graph_cost_to_root: root %d out of range", root_idx);
+namespace {
+int graph_cost_host(rrtx_ctx *ctx, const char *fn, int root_idx, bool update, double *lmc, int32_t *parent_edge, int32_t *passes) {
+  if (!lmc) return fail(ctx, RRTX_E_INVALID, "%s: lmc is NULL", fn);
+  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "%s on an empty tree", fn);
+  if (root_idx < 0 || root_idx >= ctx->n_nodes) return fail(ctx, RRTX_E_INVALID, "%s: root %d out of range", fn, root_idx);
   const size_t n = (size_t)ctx->n_nodes;
   RRTX_HIP(ctx, ctx->ws_out_f64.ensure(sizeof(double) * n));
   RRTX_HIP(ctx, ctx->ws_out_i32.ensure(sizeof(int32_t) * n));
   int np = 0;
-  int rc = launch_graph_cost_to_root(ctx, root_idx, ctx->ws_out_f64.as<double>(), parent_edge ? ctx->ws_out_i32.as<int32_t>() : nullptr, &np);
+  int rc = launch_graph_cost(ctx, root_idx, update, ctx->ws_out_f64.as<double>(), parent_edge ? ctx->ws_out_i32.as<int32_t>() : nullptr, &np);
   if (rc) return rc;
   RRTX_HIP(ctx, hipMemcpyAsync(lmc, ctx->ws_out_f64.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   if (parent_edge) RRTX_HIP(ctx, hipMemcpyAsync(parent_edge, ctx->ws_out_i32.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -889,12 +892,32 @@ int rrtx_graph_cost_to_root(rrtx_ctx *ctx, int root_idx, double *lmc, int32_t *p
   return RRTX_OK;
 }
 
+int graph_cost_dev(rrtx_ctx *ctx, const char *fn, int root_idx, bool update, double *lmc_dev, int32_t *parent_edge_dev) {
+  if (!lmc_dev) return fail(ctx, RRTX_E_INVALID, "%s: lmc is NULL", fn);
+  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "%s on an empty tree", fn);
+  if (root_idx < 0 || root_idx >= ctx->n_nodes) return fail(ctx, RRTX_E_INVALID, "%s: root %d out of range", fn, root_idx);
+  return launch_graph_cost(ctx, root_idx, update, lmc_dev, parent_edge_dev, nullptr);
+}
+}  // namespace
+
+int rrtx_graph_cost_to_root(rrtx_ctx *ctx, int root_idx, double *lmc, int32_t *parent_edge, int32_t *passes) {
+  CHECK_CTX(ctx);
+  return graph_cost_host(ctx, "graph_cost_to_root", root_idx, false, lmc, parent_edge, passes);
+}
+
+int rrtx_graph_cost_update(rrtx_ctx *ctx, int root_idx, double *lmc, int32_t *parent_edge, int32_t *passes) {
+  CHECK_CTX(ctx);
+  return graph_cost_host(ctx, "graph_cost_update", root_idx, true, lmc, parent_edge, passes);
+}
+
 int rrtx_graph_cost_to_root_dev(rrtx_ctx *ctx, int root_idx, double *lmc_dev, int32_t *parent_edge_dev) {
   CHECK_CTX(ctx);
-  if (!lmc_dev) return fail(ctx, RRTX_E_INVALID, "graph_cost_to_root: lmc is NULL");
-  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "graph_cost_to_root on an empty tree");
-  if (root_idx < 0 || root_idx >= ctx->n_nodes) return fail(ctx, RRTX_E_INVALID, "graph_cost_to_root: root %d out of range", root_idx);
-  return launch_graph_cost_to_root(ctx, root_idx, lmc_dev, parent_edge_dev, nullptr);
+  return graph_cost_dev(ctx, "graph_cost_to_root", root_idx, false, lmc_dev, parent_edge_dev);
+}
+
+int rrtx_graph_cost_update_dev(rrtx_ctx *ctx, int root_idx, double *lmc_dev, int32_t *parent_edge_dev) {
+  CHECK_CTX(ctx);
+  return graph_cost_dev(ctx, "graph_cost_update", root_idx, true, lmc_dev, parent_edge_dev);
 }
 
 int rrtx_obstacle_sweep(rrtx_ctx *ctx, int obstacle, double search_range, double robot_radius, int32_t *edge_ids,

@@ -58,6 +58,18 @@ struct DevBuf {
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// cost propagation over the edge mirror (kernels_graph.hip): the state of the last solve stays on the device
+struct GraphCost {
+  DevBuf lmc, parent, stamp, flags, orph, anc, ids;
+  DevBuf in_cnt, in_start, in_cursor, in_tiles;     // CSR of in-edges: per end node, ...
+  DevBuf in_src, in_w, in_pos;                      // ... start node and cost of every in-edge; slot of every edge id
+  int64_t in_ne = 0;                                // edges the CSR holds ([in_ne, ge_n) is the tail)
+  int in_nn = 0;                                    // nodes the CSR holds
+  int solved_root = -1;
+  int64_t solved_nodes = 0, solved_edges = 0;
+  bool touched_old = false;                         // set_dist / block since the last solve
+};
+
 enum KernelFamily { KF_NN_SCAN = 0, KF_NN_FINISH, KF_NN_NEAREST, KF_EDGES, KF_POINTS, KF_DUBINS, KF_COUNT };
 
 struct TimedSpan { hipEvent_t a, b; int family; };
@@ -183,7 +195,8 @@ struct rrtx_ctx {
   // device mirror of the planner's directed edges (obstacle sweeps, kernels_sweep.hip)
   int32_t *ge_start = nullptr, *ge_end = nullptr;
   double *ge_dist = nullptr;        // edge.dist of every mirrored edge (Inf = blocked); SimpleEdge cost by default
-  rrtx::DevBuf ws_graph_lmc, ws_graph_stamp, ws_graph_parent, ws_graph_flags;   // cost propagation (kernels_graph.hip)
+  uint8_t *ge_dirty = nullptr;      // edge cost touched since the last cost solve (set_dist / block)
+  rrtx::GraphCost gc;               // cost propagation state (kernels_graph.hip)
   int64_t ge_n = 0, ge_cap = 0;
   rrtx::DevBuf ws_sweep_mark, ws_sweep_flag, ws_sweep_cnt, ws_sweep_start;
 
@@ -305,7 +318,10 @@ int launch_obstacle_sweep(rrtx_ctx *ctx, const double centre[3], double thr_lt, 
                           int active, int32_t *out_dev, int64_t cap, long long **total_dev);
 
 int launch_graph_edge_dist(rrtx_ctx *ctx, long long first, long long n);
-int launch_graph_cost_to_root(rrtx_ctx *ctx, int root, double *lmc_dev, int32_t *parent_dev, int *passes_out);
+int launch_graph_touch(rrtx_ctx *ctx, long long first, long long n);
+int launch_graph_block(rrtx_ctx *ctx, const int32_t *ids_host, long long n);
+int launch_graph_cost(rrtx_ctx *ctx, int root, bool update, double *lmc_dev, int32_t *parent_dev, int *passes_out);
+void graph_cost_forget(rrtx_ctx *ctx);
 
 int launch_pack_hits(rrtx_ctx *ctx, const uint8_t *hit_out, const uint8_t *hit_in, const int64_t *n_valid_dev,
                      int64_t cap, uint64_t *words);

@@ -640,3 +640,22 @@ def obstacleSweep(S: CSpace, KD: HipTree, ob) -> np.ndarray:
     S.bind(KD)
     _sync_obstacles(S)
     return KD.ctx.obstacle_sweep(_list_position(S, ob), S.robotRadius + S.delta + ob.radius, S.robotRadius)
+
+
+def syncEdgeCosts(KD: HipTree, first_id: int, edges: Sequence[SimpleEdge]):
+    """edge.dist of registered edges first_id, first_id + 1, ... (registerEdges gives every edge the
+    SimpleEdge cost of its two nodes; Dubins costs and costs in a space with time are sent with this)."""
+    KD.ctx.graph_edges_set_dist(first_id, [e.dist for e in edges])
+
+
+def blockEdges(KD: HipTree, ids):
+    """addNewObstacle's `edge.dist = Inf` (R/DRRT_Q.jl:3249) for the ids obstacleSweep returned."""
+    KD.ctx.graph_edges_block(ids)
+
+
+def costToRoot(KD: HipTree, root: RRTNode) -> Tuple[np.ndarray, np.ndarray]:
+    """The state propogateDescendants + reduceInconsistency (R/DRRT_Q.jl:2703-2817) reach with
+    changeThresh = 0.0 once rrtXQueue is empty, computed over the registered edges: (rrtLMC per node in
+    insertion order, registered id of each node's rrtParentEdge or -1 for the root and for orphans)."""
+    lmc, parent, _ = KD.ctx.graph_cost_to_root(root.index)
+    return lmc, parent

@@ -165,3 +165,116 @@ def test_cost_to_root_edges_of_the_domain():
             ctx.graph_edges_set_dist(2, [1.0, 2.0])      # past the last edge
         with pytest.raises(_capi.RrtxError):
             ctx.graph_edges_block([3])
+
+
+def test_update_follows_a_replanning_sequence(oracle):
+    """rrtx_graph_cost_update through what a planner does between solves: the tree grows (nodes + edges appended),
+    obstacles appear (sweep + block), costs are re-priced (set_dist up and down).  After every step the update must
+    equal the oracle's reduceInconsistency on the same graph, and a full solve in a second context."""
+    rng = np.random.default_rng(11)
+    n_total, r, root = 12_000, 3.2, 5
+    pts = rng.uniform(-20, 20, (n_total, 3))
+    s_all, e_all = _geometric_graph(oracle, pts, r)
+    w_all = _edge_dist(pts, s_all, e_all)
+    # the tree grows in index order: an edge exists once both its nodes do
+    born = np.maximum(s_all, e_all)
+    order = np.argsort(born, kind="stable")
+    s_all, e_all, w_all, born = s_all[order], e_all[order], w_all[order], born[order]
+    stages = [6000, 6001, 6500, 9000, 12_000]
+    with Context(3) as ctx, Context(3) as fresh:
+        have_n = have_e = 0
+        w_now = np.zeros(0)
+        for step, n in enumerate(stages):
+            ne = int(np.searchsorted(born, n))                 # edges among the first n nodes
+            ctx.nodes_append(pts[have_n:n])
+            ctx.graph_edges_append(s_all[have_e:ne], e_all[have_e:ne])
+            w_now = np.concatenate([w_now, w_all[have_e:ne]])
+            have_n, have_e = n, ne
+            if step == 2:
+                # an obstacle appears next to the root: blocked edges orphan a region
+                sph = np.array([[pts[root, 0] + 2.5, pts[root, 1], pts[root, 2], 3.0]])
+                ctx.spheres_set(sph, np.ones(1, dtype=np.uint8))
+                ids = ctx.obstacle_sweep(0, RR + r + 3.0, RR)
+                assert len(ids) > 10
+                ctx.graph_edges_block(ids)
+                w_now[ids] = INF
+            if step == 3:
+                # re-pricing: some edges get cheaper, some dearer, some blocked, some unblocked
+                pick = rng.choice(ne, 4000, replace=False)
+                new = w_now[pick].copy()
+                new[:1500] *= 0.25
+                new[1500:3000] *= 3.0
+                new[3000:3500] = INF
+                new[3500:] = w_all[pick[3500:]]
+                w_now[pick] = new
+                runs = np.split(np.sort(pick), np.nonzero(np.diff(np.sort(pick)) != 1)[0] + 1)
+                for run in runs:
+                    ctx.graph_edges_set_dist(int(run[0]), w_now[run])
+            lmc, par, passes = ctx.graph_cost_update(root)
+            want, _ = _oracle_solve(oracle, n, s_all[:ne], e_all[:ne], w_now, root)
+            assert np.array_equal(lmc, want), step
+            _check_parents(lmc, par, s_all[:ne], e_all[:ne], w_now, root)
+            if step > 0:
+                assert passes < 60
+        # the same graph solved from nothing
+        fresh.nodes_append(pts)
+        fresh.graph_edges_append(s_all, e_all)
+        fresh.graph_edges_set_dist(0, w_now)
+        lmc_f, par_f, _ = fresh.graph_cost_to_root(root)
+        assert np.array_equal(lmc_f, lmc) and np.array_equal(par_f, par)
+        # update with nothing new is the identity; a different root solves in full
+        lmc_i, par_i, p_i = ctx.graph_cost_update(root)
+        assert np.array_equal(lmc_i, lmc) and np.array_equal(par_i, par) and p_i <= 9
+        lmc_o, _, _ = ctx.graph_cost_update(77)
+        want_o, _ = _oracle_solve(oracle, n_total, s_all, e_all, w_now, 77)
+        assert np.array_equal(lmc_o, want_o)
+
+
+def test_update_after_blocking_matches_block_propagate_reduce(oracle):
+    # the reference's own sequence on the oracle: blockEdge per edge, propogateDescendants, reduceInconsistency
+    rng = np.random.default_rng(21)
+    n, r, root = 8000, 3.6, 0
+    pts = rng.uniform(-20, 20, (n, 3))
+    s, e = _geometric_graph(oracle, pts, r)
+    w = _edge_dist(pts, s, e)
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        ctx.graph_edges_append(s, e)
+        lmc0, par0, _ = ctx.graph_cost_to_root(root)
+        # block the parent edges of 200 nodes (every one orphans a subtree) and 300 other edges
+        victims = rng.choice(np.nonzero(par0 >= 0)[0], 200, replace=False)
+        blocked = np.unique(np.concatenate([par0[victims], rng.choice(len(s), 300, replace=False)])).astype(np.int32)
+        ctx.graph_edges_block(blocked)
+        lmc1, par1, passes = ctx.graph_cost_update(root)
+        want, _ = _oracle_solve(oracle, n, s, e, w, root, blocked)
+        assert np.array_equal(lmc1, want)
+        assert np.all(lmc1 >= lmc0) and (lmc1 != lmc0).sum() > 200
+        w1 = w.copy()
+        w1[blocked] = INF
+        _check_parents(lmc1, par1, s, e, w1, root)
+        # unblock everything again: back to the first answer
+        ctx.graph_edges_set_dist(0, w)
+        lmc2, par2, _ = ctx.graph_cost_update(root)
+        assert np.array_equal(lmc2, lmc0) and np.array_equal(par2, par0)
+
+
+def test_update_with_free_edges_falls_back_to_a_full_solve(oracle):
+    # parent edges of cost 0 need not form a forest; the update then solves in full and still agrees
+    rng = np.random.default_rng(4)
+    n = 600
+    pts = rng.uniform(-5, 5, (n, 3))
+    pts[100:110] = pts[100]                                   # ten nodes on one spot: cost-0 edges among them
+    s, e = _geometric_graph(oracle, pts, 2.0)
+    w = _edge_dist(pts, s, e)
+    assert (w == 0).sum() >= 90
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        ctx.graph_edges_append(s, e)
+        lmc0, par0, _ = ctx.graph_cost_to_root(3)
+        blocked = np.unique(par0[100:110][par0[100:110] >= 0]).astype(np.int32)
+        ctx.graph_edges_block(blocked)
+        lmc1, _, _ = ctx.graph_cost_update(3)
+        w1 = w.copy()
+        w1[blocked] = INF
+        want, _ = _oracle_solve(oracle, n, s, e, w1, 3)
+        assert np.array_equal(lmc1, want)
