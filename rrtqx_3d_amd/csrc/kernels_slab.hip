@@ -113,11 +113,119 @@ __global__ __launch_bounds__(256) void chunk_range_kernel(const double *__restri
   }
 }
 
+// ---- sorted runs: a batch appended between two rebuilds is laid out in cell order inside its own range of
+// positions, so that its chunks are short strips of the grid instead of samples of the whole world and a
+// tile's extent test skips most of them.  (Position -> node index stays sl_id; only the order inside the
+// batch's range changes.)
+constexpr int kRunMaxCells = 4096;
+constexpr int kRunLdsChunks = 512;
+
+__global__ void run_rank_kernel(const double *__restrict__ nx, const double *__restrict__ ny, long long base, int n,
+                                const SlabParams *__restrict__ sp, int *__restrict__ hist, int2 *__restrict__ sr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = cell_of(nx[base + i], ny[base + i], sp->x0, sp->inv_wx, sp->Kx, sp->y0, sp->inv_wy, sp->Ky);
+  sr[i] = make_int2(b, atomicAdd(&hist[b], 1));
+}
+
+// every workgroup scans the cell histogram itself (at most kRunMaxCells counters: cheaper than a launch)
+__global__ __launch_bounds__(256) void run_place_kernel(
+    long long base, int n, int K, const int2 *__restrict__ sr, const int *__restrict__ hist, const float *__restrict__ fx,
+    const float *__restrict__ fy, const float *__restrict__ fz, const float *__restrict__ fw, const float *__restrict__ fpp,
+    int dim, float *__restrict__ sx, float *__restrict__ sy, float *__restrict__ sz, float *__restrict__ sw,
+    float *__restrict__ spp, int32_t *__restrict__ sid, const double *__restrict__ nx, const double *__restrict__ ny,
+    const double *__restrict__ nz, const double *__restrict__ nw, double *__restrict__ dx, double *__restrict__ dy,
+    double *__restrict__ dz, double *__restrict__ dw, ChunkExt *__restrict__ chunk_ext) {
+  __shared__ int start[kRunMaxCells];
+  __shared__ int wsum[4];
+  __shared__ unsigned long long ext[kRunLdsChunks][4];      // the workgroup's share of the run's chunk extents
+  const long long ch0 = base / kSlabChunk;
+  const int n_run_chunks = (int)((base + n - 1) / kSlabChunk - ch0 + 1);
+  const bool lds_ext = n_run_chunks <= kRunLdsChunks;
+  if (lds_ext)
+    for (int k = threadIdx.x; k < n_run_chunks; k += 256) { ext[k][0] = ~0ull; ext[k][1] = 0ull; ext[k][2] = ~0ull; ext[k][3] = 0ull; }
+  {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (K + 255) / 256;
+    const int b0 = min(t * per, K), b1 = min(b0 + per, K);
+    int local = 0;
+    for (int k = b0; k < b1; ++k) local += hist[k];
+    int v = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(v, off);
+      if (lane >= off) v += o;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int prefix = v - local;
+    for (int w = 0; w < wave; ++w) prefix += wsum[w];
+    for (int k = b0; k < b1; ++k) { start[k] = prefix; prefix += hist[k]; }
+    __syncthreads();
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int2 r = sr[i];
+    const int off = start[r.x] + r.y;
+    if ((unsigned)off < (unsigned)n) {                 // always, with a consistent histogram; never write outside
+      const long long p = base + off, src = base + i;
+      const double x = nx[src], y = ny[src];
+      sx[p] = fx[src]; sy[p] = fy[src]; sz[p] = fz[src];
+      dx[p] = x; dy[p] = y; dz[p] = nz[src];
+      if (dim == 4) { sw[p] = fw[src]; dw[p] = nw[src]; }
+      spp[p] = fpp[src];
+      sid[p] = (int32_t)src;
+      // chunk extents: through LDS first (the 512 nodes of a chunk would otherwise queue up on four addresses)
+      const long long ch = p / kSlabChunk;
+      unsigned long long *e4 = lds_ext ? ext[ch - ch0] : &chunk_ext[ch].xlo;
+      if (x == x) { const unsigned long long e = enc_ord(x); atomicMin(&e4[0], e); atomicMax(&e4[1], e); }
+      if (y == y) { const unsigned long long e = enc_ord(y); atomicMin(&e4[2], e); atomicMax(&e4[3], e); }
+    }
+  }
+  if (lds_ext) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_run_chunks; k += 256) {
+      ChunkExt *g = &chunk_ext[ch0 + k];
+      if (ext[k][0] != ~0ull) { atomicMin(&g->xlo, ext[k][0]); atomicMax(&g->xhi, ext[k][1]); }
+      if (ext[k][2] != ~0ull) { atomicMin(&g->ylo, ext[k][2]); atomicMax(&g->yhi, ext[k][3]); }
+    }
+  }
+}
+
 }  // namespace
+
+// can the batch [base, base + n) be appended as a sorted run?  (an index exists, its grid fits the place kernel,
+// the batch is worth two more launches)
+bool slab_run_wanted(const rrtx_ctx *ctx, int64_t n) {
+  return ctx->sl_n_sorted > 0 && ctx->ws_slab_params.p && ctx->sl_cells > 0 && ctx->sl_cells <= kRunMaxCells && n >= 1024;
+}
+
+// the slab arrays of nodes [base, base + n) (index-order arrays already written) in cell order
+int slab_append_run(rrtx_ctx *ctx, int64_t base, int64_t n) {
+  hipStream_t st = ctx->stream;
+  const int K = ctx->sl_cells;
+  RRTX_HIP(ctx, ctx->ws_run_hist.ensure(sizeof(int) * (size_t)(K + 1)));
+  RRTX_HIP(ctx, ctx->ws_run_sr.ensure(sizeof(int2) * (size_t)n));
+  RRTX_HIP(ctx, hipMemsetAsync(ctx->ws_run_hist.p, 0, sizeof(int) * (size_t)(K + 1), st));
+  const int wi = ctx->dim == 4 ? 3 : 2;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipLaunchKernelGGL(run_rank_kernel, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], (long long)base, (int)n,
+                     ctx->ws_slab_params.as<SlabParams>(), ctx->ws_run_hist.as<int>(), ctx->ws_run_sr.as<int2>());
+  hipLaunchKernelGGL(run_place_kernel, grid, block, 0, st, (long long)base, (int)n, K, ctx->ws_run_sr.as<int2>(),
+                     ctx->ws_run_hist.as<int>(), ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[wi],
+                     ctx->nodes_pp, ctx->dim, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[wi], ctx->sl_pp, ctx->sl_id,
+                     ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[wi], ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2],
+                     ctx->sl_d[wi], reinterpret_cast<ChunkExt *>(ctx->chunk_ext));
+  RRTX_HIP(ctx, hipGetLastError());
+  // chunks of the run (a chunk shared with the batch before counts once)
+  ctx->sl_run_chunks += (double)((base + n + kSlabChunk - 1) / kSlabChunk - (base + kSlabChunk - 1) / kSlabChunk);
+  return RRTX_OK;
+}
 
 // When to rebuild: a search pays for every chunk of the appended tail (its nodes are in arrival order,
 // so each tail chunk spans the world and every tile screens it: ~0.2 us per (tile in flight, chunk)),
-// a rebuild costs ~30 us of launches + ~0.6 ns per node.  The searches since the last rebuild run up a
+// a rebuild costs ~30 us of launches + ~0.6 ns per node.  Chunks of a sorted run (slab_append_run) are strips of
+// the grid, of which a tile's reach touches about one in six.  The searches since the last rebuild run up a
 // debt of what the tail has cost them; the index is rebuilt when the debt exceeds the price of a
 // rebuild (and always before the tail outgrows half the tree).  Single appends between single queries
 // thus rebuild rarely, whole batches appended between batched searches every handful of calls.  Only
@@ -128,11 +236,13 @@ int slab_refresh(rrtx_ctx *ctx, long long n_tiles) {
   const int64_t floor_tail = n / 128 > 1024 ? n / 128 : 1024;
   if (tail <= floor_tail) return RRTX_OK;
   const double tail_chunks = (double)((tail + kSlabChunk - 1) / kSlabChunk);
+  const double run_chunks = ctx->sl_run_chunks < tail_chunks ? ctx->sl_run_chunks : tail_chunks;
   const double rounds = n_tiles > 1024 ? (double)n_tiles / 1024.0 : 1.0;
-  ctx->sl_debt_us += 0.2 * tail_chunks * rounds;
+  ctx->sl_debt_us += 0.2 * ((tail_chunks - run_chunks) + run_chunks / 6.0) * rounds;
   const double rebuild_us = 30.0 + 0.6e-3 * (double)n;
   if (ctx->sl_n_sorted > 0 && tail <= n / 2 && ctx->sl_debt_us < rebuild_us) return RRTX_OK;
   ctx->sl_debt_us = 0.0;
+  ctx->sl_run_chunks = 0.0;
   hipStream_t st = ctx->stream;
   // about one cell per chunk: cells of ~512 nodes, laid out as a square grid over (x, y)
   int side = (int)std::sqrt((double)n / (double)kSlabChunk);
@@ -164,6 +274,7 @@ int slab_refresh(rrtx_ctx *ctx, long long n_tiles) {
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   ctx->sl_n_sorted = n;
+  ctx->sl_cells = K;
   return RRTX_OK;
 }
 

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
                                                          double *__restrict__ dz, double *__restrict__ dw,
                                                          double *__restrict__ aos,
                                                          ChunkExt *__restrict__ chunk_ext,
-                                                         unsigned long long *__restrict__ xrange) {
+                                                         unsigned long long *__restrict__ xrange, int slab_later) {
+  // slab_later: the batch's slab entries and chunk extents are written in cell order by slab_append_run
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long m = 0ull;
   unsigned long long xlo = ~0ull, xhi = 0ull, ylo = ~0ull, yhi = 0ull;
@@ -190,9 +191,11 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
     xf[base + i] = fa; yf[base + i] = fb; zf[base + i] = fc;
     // slab index: a new node sits at position == index until the next rebuild; its chunk's
     // x extent grows accordingly (a NaN x can never be within range of anything: not tracked)
-    sx[base + i] = fa; sy[base + i] = fb; sz[base + i] = fc;
-    dx[base + i] = a; dy[base + i] = b; dz[base + i] = c;
-    sid[base + i] = (int32_t)(base + i);
+    if (!slab_later) {
+      sx[base + i] = fa; sy[base + i] = fb; sz[base + i] = fc;
+      dx[base + i] = a; dy[base + i] = b; dz[base + i] = c;
+      sid[base + i] = (int32_t)(base + i);
+    }
     if (a == a) xlo = xhi = enc_ord(a);
     if (b == b) ylo = yhi = enc_ord(b);
     double pp = (double)fa * (double)fa + (double)fb * (double)fb + (double)fc * (double)fc;
@@ -204,13 +207,12 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
       const double sd = d - ow;
       const float fd = (float)sd;
       wf[base + i] = fd;
-      sw[base + i] = fd;
-      dw[base + i] = d;
+      if (!slab_later) { sw[base + i] = fd; dw[base + i] = d; }
       pp += (double)fd * (double)fd;
       m = max(m, (unsigned long long)__double_as_longlong(fabs(sd)));
     }
     ppf[base + i] = (float)pp;
-    spp[base + i] = (float)pp;
+    if (!slab_later) spp[base + i] = (float)pp;
     reinterpret_cast<double4 *>(aos)[base + i] = make_double4(a, b, c, dim == 4 ? pos[i * dim + 3] : 0.0);
   }
   // chunk extents: the 64 positions of a wave lie in one chunk unless they straddle a chunk
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
   const long long ch = (base + i) / kSlabChunk;
   const long long ch_first = (base + ((long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63))) / kSlabChunk;
   const bool one_chunk = __ballot(i < n && ch != ch_first) == 0ull;
-  if (!one_chunk && i < n) {
+  if (!one_chunk && i < n && !slab_later) {
     if (xlo != ~0ull) { atomicMin(&chunk_ext[ch].xlo, xlo); atomicMax(&chunk_ext[ch].xhi, xhi); }
     if (ylo != ~0ull) { atomicMin(&chunk_ext[ch].ylo, ylo); atomicMax(&chunk_ext[ch].yhi, yhi); }
   }
@@ -235,13 +237,20 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
     yhi = max(yhi, o);
   }
   if ((threadIdx.x & 63) == 0) {
-    if (one_chunk) {
+    if (one_chunk && !slab_later) {
       if (xlo != ~0ull) { atomicMin(&chunk_ext[ch_first].xlo, xlo); atomicMax(&chunk_ext[ch_first].xhi, xhi); }
       if (ylo != ~0ull) { atomicMin(&chunk_ext[ch_first].ylo, ylo); atomicMax(&chunk_ext[ch_first].yhi, yhi); }
     }
-    if (m != 0ull) atomicMax(absmax, m);
-    if (xlo != ~0ull) { atomicMin(&xrange[0], xlo); atomicMax(&xrange[1], xhi); }
-    if (ylo != ~0ull) { atomicMin(&xrange[2], ylo); atomicMax(&xrange[3], yhi); }
+    // the bounds of the whole tree rarely move: look first (a stale look only costs an atomic that changes nothing)
+    if (m != 0ull && m > *absmax) atomicMax(absmax, m);
+    if (xlo != ~0ull) {
+      if (xlo < xrange[0]) atomicMin(&xrange[0], xlo);
+      if (xhi > xrange[1]) atomicMax(&xrange[1], xhi);
+    }
+    if (ylo != ~0ull) {
+      if (ylo < xrange[2]) atomicMin(&xrange[2], ylo);
+      if (yhi > xrange[3]) atomicMax(&xrange[3], yhi);
+    }
   }
 }
 
@@ -401,7 +410,8 @@ int rrtx_destroy(rrtx_ctx *ctx) {
                     &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_bsum, &ctx->ws_scalars, &ctx->ws_scalars_nn, &ctx->ws_tmp,
                     &ctx->ws_owner, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
                     &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr, &ctx->ws_mask, &ctx->ws_i32a, &ctx->ws_i32b,
-                    &ctx->ws_slab_hist, &ctx->ws_slab_start, &ctx->ws_slab_sr, &ctx->ws_slab_params, &ctx->ws_copies_s,
+                    &ctx->ws_slab_hist, &ctx->ws_slab_start, &ctx->ws_slab_sr, &ctx->ws_slab_params, &ctx->ws_run_hist, &ctx->ws_run_sr,
+                    &ctx->ws_copies_s,
                     &ctx->ws_meta_s, &ctx->ws_cb, &ctx->ws_qhist, &ctx->ws_bkt,
                     &ctx->ws_ev_a, &ctx->ws_ev_cnt, &ctx->ws_confirm_args, &ctx->ws_sph_lists, &ctx->d_sph_sample,
                     &ctx->ws_sweep_mark, &ctx->ws_sweep_flag, &ctx->ws_sweep_cnt, &ctx->ws_sweep_start,
@@ -518,6 +528,7 @@ int rrtx_nodes_append_dev(rrtx_ctx *ctx, const double *pos_dev, int64_t n) {
     for (int k = 0; k < ctx->dim; ++k) ctx->origin[k] = std::isfinite(first[k]) ? first[k] : 0.0;
     ctx->origin_set = true;
   }
+  const bool as_run = slab_run_wanted(ctx, n);
   hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev,
                      ctx->dim, (long long)n, (long long)ctx->n_nodes, ctx->origin[0], ctx->origin[1], ctx->origin[2],
                      ctx->origin[3], ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
@@ -525,8 +536,12 @@ int rrtx_nodes_append_dev(rrtx_ctx *ctx, const double *pos_dev, int64_t n) {
                      ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->d_absmax.as<unsigned long long>(),
                      ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp, ctx->sl_id,
                      ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2], ctx->sl_d[ctx->dim == 4 ? 3 : 2], ctx->nodes_aos,
-                     reinterpret_cast<ChunkExt *>(ctx->chunk_ext), ctx->d_xrange.as<unsigned long long>());
+                     reinterpret_cast<ChunkExt *>(ctx->chunk_ext), ctx->d_xrange.as<unsigned long long>(), as_run ? 1 : 0);
   RRTX_HIP(ctx, hipGetLastError());
+  if (as_run) {
+    rc = slab_append_run(ctx, ctx->n_nodes, n);
+    if (rc) return rc;
+  }
   ctx->n_nodes += n;
   return RRTX_OK;
 }

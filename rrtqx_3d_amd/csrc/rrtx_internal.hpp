@@ -110,9 +110,11 @@ struct rrtx_ctx {
   rrtx::ChunkExtHost *chunk_ext = nullptr;   // x / y extent of every chunk (enc_ord), see exact_math.hpp ChunkExt
   int64_t cap_chunks = 0;
   int64_t sl_n_sorted = 0;
+  double sl_run_chunks = 0.0;       // chunks of the tail that were appended as sorted runs
+  int sl_cells = 0;                 // cells of the grid of the last rebuild
   double sl_debt_us = 0.0;          // what the appended tail has cost the searches since the last rebuild (estimate)
   rrtx::DevBuf d_xrange;            // uint64[4]: enc_ord of min / max node x, min / max node y
-  rrtx::DevBuf ws_slab_hist, ws_slab_start, ws_slab_sr, ws_slab_params;
+  rrtx::DevBuf ws_slab_hist, ws_slab_start, ws_slab_sr, ws_slab_params, ws_run_hist, ws_run_sr;
 
   // options (rrtx_set_option)
   int opt_nn_filter = 1;            // 1: fp32 prefilter + exact fp64 confirm, 0: exact fp64 scan
@@ -273,7 +275,9 @@ int launch_nn_knearest(rrtx_ctx *ctx, const double *q_dev, int nq, int k, int32_
 int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_dev, double *dist_dev,
                       bool exact = false);
 int scan_units(rrtx_ctx *ctx, int *units);   // (tile, chunk) units of the last culled range scan
-int slab_refresh(rrtx_ctx *ctx, long long n_tiles);   // bring the slab index up to date when it pays (kernels_slab.hip)
+int slab_refresh(rrtx_ctx *ctx, long long n_tiles);
+bool slab_run_wanted(const rrtx_ctx *ctx, int64_t n);
+int slab_append_run(rrtx_ctx *ctx, int64_t base, int64_t n);   // bring the slab index up to date when it pays (kernels_slab.hip)
 constexpr int kSlabChunk = 512;              // node positions per chunk of the slab index
 int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
                          double robot_radius, int obstacle_or_minus1, int obs_begin, int obs_end,

@@ -255,3 +255,54 @@ def test_cull_randomised_scenarios(oracle, seed):
             tree.insert_many(pts[done:upto])
             done = upto
             _both_modes(ctx, Q, r, _oracle_lists(tree, Q, r))
+
+
+def test_cull_sorted_runs_between_rebuilds(oracle):
+    """batches appended after the index exists are laid out in cell order inside their own range of positions
+    (sorted runs: strips of the grid instead of samples of the world).  Range search, nearest (empty balls) and
+    the fused extend() preamble must not notice: same lists as the oracle, same as the unculled scan, and the
+    runs' chunks are indeed skipped by most tiles."""
+    rng = np.random.default_rng(77)
+    n0, nb, steps = 40_000, 6000, 5
+    pts = rng.uniform(-50, 50, (n0 + nb * steps, 3))
+    pts[n0 + 100] = [np.nan, 0.0, 0.0]                    # a node nothing can find, inside a run
+    pts[n0 + 101] = pts[17]                               # a duplicate of an indexed node
+    Q = np.concatenate([rng.uniform(-50, 50, (1500, 3)), rng.uniform(60, 70, (4, 3))])     # the last four: empty balls
+    r = 4.5
+    sph = np.concatenate([rng.uniform(-40, 40, (24, 3)), rng.uniform(1.0, 3.5, (24, 1))], 1)
+    tree = oracle.KDTree(3)
+    tree.insert_many(pts[:n0])
+    pts_o = pts.copy()
+    pts_o[n0 + 100] = 1e9                                 # the oracle's stand-in: as unreachable, keeps indices aligned
+    with Context(3) as ctx:
+        ctx.set_option(_capi.RRTX_OPT_NN_CULL, 2)
+        ctx.spheres_set(sph, np.ones(24, dtype=np.uint8))
+        ctx.nodes_append(pts[:n0])
+        ctx.nn_radius(Q[:8], r)                           # builds the index
+        units_runs = []
+        for s in range(steps):
+            a, b = n0 + s * nb, n0 + (s + 1) * nb
+            ctx.nodes_append(pts[a:b])
+            tree.insert_many(pts_o[a:b])
+            ref = _oracle_lists(tree, Q, r)
+            offsets, idx, dist = ctx.nn_radius(Q, r)
+            _check_csr(offsets, idx, dist, ref)
+            units_runs.append(ctx.stats().last_scan_units)
+            ctx.set_option(_capi.RRTX_OPT_NN_CULL, 0)
+            o2, i2, d2 = ctx.nn_radius(Q, r)
+            ctx.set_option(_capi.RRTX_OPT_NN_CULL, 2)
+            assert np.array_equal(offsets, o2) and np.array_equal(idx, i2) and np.array_equal(dist, d2)
+            near_idx, near_d = ctx.nn_nearest(Q[-4:])
+            for k in range(4):
+                want_i, want_d = tree.nearest(Q[-4 + k])
+                assert near_idx[k] == want_i and near_d[k] == want_d
+        # the fused extend() preamble over the runs == the unfused one over the unculled scan
+        ext = ctx.extend_candidates(Q, r, 0.5)
+        ctx.set_option(_capi.RRTX_OPT_NN_CULL, 0)
+        ext0 = ctx.extend_candidates(Q, r, 0.5)
+        for x, y in zip(ext, ext0):
+            assert np.array_equal(x, y)
+        # a run's chunks are strips: most tiles skip them (unsorted, every tile screens every tail chunk)
+        n_tiles = (len(Q) + 15) // 16
+        tail_chunks = (nb * steps) // 512
+        assert units_runs[-1] < 0.5 * n_tiles * tail_chunks
