@@ -339,6 +339,21 @@ __device__ __forceinline__ void scan_chunk_f32(const float *__restrict__ fx, con
 }
 
 // a wave confirms the entries of its own slice (slice nearly full; same routine as nn_confirm_kernel)
+template <int D, bool LM, class Emit>
+__device__ __forceinline__ void drain_slice_to(const int2 *__restrict__ mine, int &wn, int n_nodes, const ConfirmArgs &a,
+                                               const Emit &emit, const typename QRecT<D>::type *tile_copies, int tile_q0) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // see drain_slice
+  for (int e0 = 0; e0 < wn; e0 += 64) {
+    const int e = e0 + lane;
+    const bool has = e < wn;
+    int2 en = make_int2(0, 0);
+    if (has) en = mine[e];
+    confirm_entry<D, LM>(has, en, n_nodes, a, emit, tile_copies, tile_q0);
+  }
+  wn = 0;
+}
+
 template <int D, bool LM>
 __device__ __forceinline__ void drain_slice(const int2 *__restrict__ mine, int &wn, int n_nodes,
                                             const ConfirmArgs *__restrict__ ca) {
@@ -685,7 +700,12 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
             if (!(dec_ord(cx.xhi) >= lo && dec_ord(cx.xlo) <= hi && dec_ord(cx.yhi) >= ylo && dec_ord(cx.ylo) <= yhi))
               continue;
           }
-          if (wn + 64 * kTileB > slice_cap) drain_slice<D, true>(mine, wn, n_nodes, ca);
+          if (wn + 64 * kTileB > slice_cap) {
+            // the slice is nearly full (a screen that passes almost everything: a non-finite or far-away node makes
+            // the fp32 bounds useless): confirm it now, through the tile's own emitter -- the hits must carry the edge flags
+            const TileEmit<D, EXT> emit_now{sm, a.hs, a.meta, x, q0};
+            drain_slice_to<D, true>(mine, wn, n_nodes, a, emit_now, sm.cp, q0);
+          }
           scan_chunk_f32<D, true>(fx, fy, fz, fw, fpp, chunk * kChunkF, n_nodes, copies_f, q0, q1, mine, wn);
           visited += 1;
         }
