@@ -298,6 +298,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C4")
+    ap.add_argument("--exchange-every", type=int, default=4,
+                    help="multi-GPU: the collision bitmasks of this many steps travel in one all-reduce")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed line (no steady-state, polygon, host-path passes)")
@@ -409,23 +411,27 @@ def main():
             k_max = int(t.item())
         bit_cap = (k_max + 4095) // 4096 * 4096
         wpr = parallel.words_for(bit_cap)
-        d_bits = [torch.zeros(world * wpr, dtype=torch.int64, device=dev) for _ in range(2)]
+        K = max(1, args.exchange_every)
+        d_bits = [torch.zeros((K, world, wpr), dtype=torch.int64, device=dev) for _ in range(2)]
         pending = [None, None]
         b = m["buf"]
 
-        def step(i):
+        def step(i, last=False):
             j = i % RING
             compute(m, j)
             if world > 1:
-                # per-edge collision bitmask exchange: each rank fills its slice, one RCCL all-reduce
-                # (disjoint slices: SUM == OR).  Double-buffered and asynchronous: the exchange of step i
-                # runs on RCCL's stream while step i+1 computes.
-                s = i & 1
-                if pending[s] is not None:
+                # per-edge collision bitmask exchange: each rank packs its slice of the step, and the slices of K
+                # steps travel in ONE RCCL all-reduce (disjoint slices: SUM == OR; xGMI rings are latency bound at
+                # these sizes).  Double-buffered and asynchronous: the exchange of a group of steps runs on RCCL's
+                # stream while the next group computes.
+                s, slot = (i // K) & 1, i % K
+                if slot == 0 and pending[s] is not None:
                     pending[s].wait()
+                    pending[s] = None
                 ctx.pack_hits_dev(b.hout.data_ptr(), b.hin.data_ptr(), b.off.data_ptr() + 8 * m["nb"], bit_cap,
-                                  d_bits[s].data_ptr() + 8 * rank * wpr)
-                pending[s] = parallel.exchange_hit_bitmasks(d_bits[s], rank, world, wpr, async_op=True)
+                                  d_bits[s].data_ptr() + 8 * (slot * world + rank) * wpr)
+                if slot == K - 1 or last:
+                    pending[s] = parallel.exchange_hit_bitmasks_grouped(d_bits[s], rank, async_op=True)
 
         def drain():
             for s in range(2):
@@ -434,8 +440,13 @@ def main():
                     pending[s] = None
 
         for i in range(warmup):
-            step(i)
+            step(i, last=(i == warmup - 1))
         drain()
+        if world > 1:
+            # both exchange buffers have been through the collective once before the clock starts (first use of a
+            # buffer pays registration / staging set-up in the backend)
+            for s in range(2):
+                parallel.exchange_hit_bitmasks_grouped(d_bits[s], rank)
         fence()
         sample_every = 4 if steps >= 8 else 1
         if profile:
@@ -446,7 +457,7 @@ def main():
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(i)
+            step(i, last=(i == steps - 1))
         drain()
         fence()
         dt = time.perf_counter() - t0
@@ -594,7 +605,10 @@ def main():
                        "batch_per_gpu": nb, "global_batch": nb * world if modes[0] == "weak" else B,
                        "radius": r, "edge": "SimpleEdge", "directed_edges_per_step_per_gpu": 2 * k_mean,
                        "neighbors_per_step_per_gpu": k_mean, "fresh_batch_every_step": True, "batch_ring": RING,
-                       "sharding": "samples+edges sharded, nodes/obstacles replicated"},
+                       "sharding": "samples+edges sharded, nodes/obstacles replicated",
+                       "collective": (None if world == 1 else
+                                      "one RCCL all-reduce of the per-edge collision bitmasks of %d steps, asynchronous, double-buffered"
+                                      % max(1, args.exchange_every))},
             "nn_queries_per_s": (nb * world if modes[0] == "weak" else B) * args.steps / t_max,
             "launches_per_step": 4,
             "kernel_ms": {"nn_scan": scan_ms, **extras.get("kernel_ms_all", {})},

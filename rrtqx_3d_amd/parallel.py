@@ -63,6 +63,23 @@ def exchange_hit_bitmasks(bits: torch.Tensor, rank: int, world: int, words_per_r
     return work if async_op else bits
 
 
+def exchange_hit_bitmasks_grouped(bits: torch.Tensor, rank: int, group=None, async_op: bool = False):
+    """The bitmasks of several steps in ONE collective (xGMI rings are latency bound at these sizes: fewer, larger
+    all-reduces).  bits: int64[steps, world, words_per_rank]; this rank has filled bits[:, rank, :].  The other
+    ranks' slices are zeroed, then one all-reduce(SUM) (disjoint slices: SUM == OR) fills them in place.
+    Returns bits, or with async_op=True the work handle (None when world == 1)."""
+    assert bits.dim() == 3 and bits.dtype == torch.int64 and bits.is_contiguous()
+    world = bits.shape[1]
+    if world == 1:
+        return None if async_op else bits
+    if rank > 0:
+        bits[:, :rank].zero_()
+    if rank + 1 < world:
+        bits[:, rank + 1:].zero_()
+    work = dist.all_reduce(bits, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work if async_op else bits
+
+
 def rank_slice(bits: torch.Tensor, r: int, words_per_rank: int) -> torch.Tensor:
     return bits[r * words_per_rank:(r + 1) * words_per_rank]
 

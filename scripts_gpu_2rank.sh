@@ -10,7 +10,7 @@ for mode in weak strong; do
     bench.py --gpus 2 --backend gloo --share-device --scaling $mode --no-cpu-baseline --no-extras > $out/bench_2rank_$mode.json 2> $out/bench_2rank_$mode.err
   echo "$mode rc=$?"
   python3 -c "
-import json; d=json.load(open('$out/bench_2rank_$mode.json'))
+import json; d=json.loads(open('$out/bench_2rank_$mode.json').read().strip().splitlines()[-1])
 print('$mode', 'value %.4g ms/step %.4f batch/gpu %s' % (d['value'], d['ms_per_step'], d['config']['batch_per_gpu']), 'other:', {k: d['other_scaling'][k] for k in ('scaling','value','ms_per_step','batch_per_gpu')})
 "
 done

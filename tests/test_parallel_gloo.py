@@ -56,6 +56,17 @@ def _worker(rank, world, port, cap, q):
         work = parallel.exchange_hit_bitmasks(bits2, rank, world, wpr, async_op=True)
         work.wait()
         ok &= torch.equal(bits2, bits)
+        # several steps' bitmasks in one collective (bench.py --exchange-every): [steps, world, wpr]
+        steps = 3
+        grp = torch.full((steps, world, wpr), 0x3333, dtype=torch.int64)
+        mine = torch.from_numpy(_pack(ho, hi, cap))
+        for k in range(steps):
+            grp[k, rank].copy_(mine ^ k)
+        w3 = parallel.exchange_hit_bitmasks_grouped(grp, rank, async_op=True)
+        w3.wait()
+        for k in range(steps):
+            for r in range(world):
+                ok &= torch.equal(grp[k, r], parallel.rank_slice(bits, r, wpr) ^ k)
         units, tmax = parallel.reduce_throughput(1000 + rank, 0.5 + rank)
         ok &= (units == sum(1000 + r for r in range(world))) and (tmax == 0.5 + world - 1)
         q.put((rank, bool(ok)))
