@@ -347,9 +347,10 @@ int rrtx_extend_candidates_dev(rrtx_ctx *ctx, const double *q, int nq, double r,
                                int32_t *nearest_idx, double *nearest_dist, uint8_t *sample_unsafe);
 
 /* device-pointer form of rrtx_extend_candidates_dubins; *needed_dev receives the number of entries (entries
- * beyond cap are not written).  With wrapped dimensions nearest_* come from the nearest scan (and, like
- * rrtx_nn_nearest_dev, without the host-side fallback for an overflowing candidate buffer); without them
- * samples whose ball is empty get nearest_idx -1. */
+ * beyond cap are not written).  Only enqueues work, never waits on the stream: with wrapped dimensions nearest_*
+ * come from the nearest scan (rrtx_nn_nearest_dev: records a full candidate buffer dropped are re-decided by its
+ * fix-up pass on the device); without them they come off the lists, and a sample whose ball is empty gets
+ * kdFindNearest's answer from the expanding search of the finish kernel -- no -1 leaves the device. */
 int rrtx_extend_candidates_dubins_dev(rrtx_ctx *ctx, const double *q, int nq, double r, double robot_radius,
                                       double r_min, int64_t *offsets, int32_t *idx, double *key, double *cost_out,
                                       double *cost_in, uint8_t *word_out, uint8_t *word_in, uint8_t *hit_out,
