@@ -519,6 +519,22 @@ struct TileEmit {
   }
 };
 
+// Wave shuffles whose source-lane arithmetic is redone where it is used: `l` comes from lane_here(), which the
+// compiler cannot see through, so the twelve bpermute addresses of the xor / up patterns are not hoisted out of
+// the tile loop and kept (or spilled: 13 dwords per lane, written by every wave at kernel start) for the whole kernel.
+__device__ __forceinline__ int lane_here() {
+  int l = (int)(threadIdx.x & 63);
+  asm volatile("" : "+v"(l));
+  return l;
+}
+__device__ __forceinline__ int wshfl_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+__device__ __forceinline__ double wshfl_d(double v, int src_lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffll));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
 template <int D, bool EXT>
 __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
     const float *__restrict__ fx, const float *__restrict__ fy, const float *__restrict__ fz,
@@ -579,12 +595,15 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
           yhi = yb + (fabs(yb) * 4.5e-16 + 1e-300);
         }
       }
+      {
+        const int l = lane_here();
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        lo = fmin(lo, __shfl_xor(lo, off));
-        hi = fmax(hi, __shfl_xor(hi, off));
-        ylo = fmin(ylo, __shfl_xor(ylo, off));
-        yhi = fmax(yhi, __shfl_xor(yhi, off));
+        for (int off = 32; off > 0; off >>= 1) {
+          lo = fmin(lo, wshfl_d(lo, l ^ off));
+          hi = fmax(hi, wshfl_d(hi, l ^ off));
+          ylo = fmin(ylo, wshfl_d(ylo, l ^ off));
+          yhi = fmax(yhi, wshfl_d(yhi, l ^ off));
+        }
       }
       if (lane == 0) { sm.lo = lo; sm.hi = hi; sm.ylo = ylo; sm.yhi = yhi; sm.n_list = 0; sm.sqn[0] = 0; sm.sqn[1] = 0; }
     }
@@ -614,12 +633,13 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
               // rows come in increasing position order: a row starts no earlier than where the rows
               // before it (in this wave instruction and in earlier ones) have already listed
               int run = cb_;
+              const int l = lane_here();
 #pragma unroll
               for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(run, off);
+                const int o = wshfl_i(run, l >= off ? l - off : l);
                 if (lane >= off) run = max(run, o);
               }
-              int before = __shfl_up(run, 1);
+              int before = wshfl_i(run, l >= 1 ? l - 1 : l);
               if (lane == 0) before = listed_to;
               before = max(before, listed_to);
               ca_ = max(ca_, before + 1);
@@ -628,7 +648,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
                 const int at = atomicAdd(&sm.n_list, cnt);
                 for (int j = 0; j < cnt; ++j) sm.list[at + j] = ca_ + j;
               }
-              listed_to = max(listed_to, __shfl(run, 63));
+              listed_to = max(listed_to, __builtin_amdgcn_readlane(run, 63));
             }
           }
         } else if (EXT && wave >= 2) {
@@ -757,7 +777,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
         const int s = i * 2 + half;                     // this half's copy slot
         const int cl = i * (kTileB / 2) + wave * 2 + half;
         const int n = __shfl(my_n, s), owner = __shfl(my_owner, s), base = __shfl(my_base, s);
-        const int nmax = max(n, __shfl_xor(n, 32));
+        const int nmax = max(n, wshfl_i(n, lane_here() ^ 32));
         for (int j0 = 0; j0 < nmax; j0 += 32) {
           const int j = j0 + hl;
           const bool h = j < n;
