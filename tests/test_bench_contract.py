@@ -18,7 +18,7 @@ def test_bench_help_runs_without_gpu():
 
 def test_committed_bench_line_has_the_contract_fields():
     baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_v5_bench.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_v3_bench.json")))
     assert line["metric"] == baseline["metric"]
     for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -32,3 +32,20 @@ def test_committed_bench_line_has_the_contract_fields():
     cb = line["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
     assert line["value"] > 50 * cb["value"]                 # north_star: >= 50x the CPU path
+    # round 2: the honest-roofline keys, the steady-state figure, the launch count, which runtime and sources
+    for k in ("algorithmic_GBps", "requested_bytes_per_launch", "frac_requested", "frac_traffic", "kernel_ms", "timing"):
+        assert k in rf, k
+    assert line["launches_per_step"] == 4 and line["value_steady"] > 0 and line["steady_state"]["steps"] == line["steps"]
+    assert line["hip_runtime"]["path"] and len(line["source_sha16"]) == 16
+    assert line["config"]["fresh_batch_every_step"] is True
+    poly = line["polygon_obstacles"]["roofline"]
+    assert poly["kernel"] == "edges_polygons_kernel" and poly["algorithmic_bytes_per_launch"] > 0
+
+
+def test_committed_c3_line_and_traffic_file():
+    c3 = json.load(open(os.path.join(ROOT, "profiles", "r02_v3_bench_c3.json")))
+    assert c3["config"]["edge"] == "DubinsEdge" and c3["cpu_baseline"]["kind"] == "port" and c3["value"] > 0
+    assert c3["roofline"]["bound"] == "valu_fp64"
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+    assert tr["kernel"].startswith("nn_tile_kernel") and tr["traffic_bytes_per_launch"] > 0 and len(tr["source_sha16"]) == 16
+    assert tr["WRITE_SIZE_bytes_per_launch"] < 15e6        # round-1 verdict: write amplification of the hit records

@@ -2,6 +2,9 @@
 (all three through the C-ABI), plus extend_candidates culled vs unculled.  Prints a summary."""
 import math, sys, time
 import numpy as np
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: F401  (first: one HIP runtime image in the process)
 from rrtqx_3d_amd import _capi
 from rrtqx_3d_amd.context import Context
 
@@ -24,6 +27,9 @@ for sc in range(n_scen):
         pts = base[rng.integers(0, len(base), n)]
     else:
         pts = np.round(rng.uniform(-span, span, (n, d)) / (span / 16)) * (span / 16)
+    if n > 10 and rng.uniform() < 0.25:
+        # a node that ruins the fp32 bounds (the screen then passes everything: slices fill up and are drained mid-screen)
+        pts[int(rng.integers(1, n))] = [np.nan, 0.0, 0.0, 0.0][:d] if rng.uniform() < 0.5 else [1e9] * d
     wrap = d == 4 and rng.uniform() < 0.7
     if d == 4:
         pts[:, 3] = rng.uniform(0, 2 * math.pi, n)
