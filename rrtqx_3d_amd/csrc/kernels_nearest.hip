@@ -401,7 +401,7 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
                          ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
                          ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
                          ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec4>(), ctx->ws_copy_meta.as<int2>(), sc,
-                         (const unsigned long long *)nullptr, 1, (int *)nullptr, (int2 *)nullptr, PackFused{},
+                         (const unsigned long long *)nullptr, 1, 1, (int *)nullptr, (int2 *)nullptr, PackFused{},
                          ConfirmArgs{});
       hipLaunchKernelGGL(nn_filter_prep_kernel<4>, pgrid, block, 0, st, ctx->ws_copies.as<QRec4>(), sc,
                          ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],
@@ -417,7 +417,7 @@ static int launch_nn_nearest_screened(rrtx_ctx *ctx, const double *q_dev, int nq
                          ctx->wrap_dim[2], ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
                          ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
                          ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec3>(), ctx->ws_copy_meta.as<int2>(), sc,
-                         (const unsigned long long *)nullptr, 1, (int *)nullptr, (int2 *)nullptr, PackFused{},
+                         (const unsigned long long *)nullptr, 1, 1, (int *)nullptr, (int2 *)nullptr, PackFused{},
                          ConfirmArgs{});
       hipLaunchKernelGGL(nn_filter_prep_kernel<3>, pgrid, block, 0, st, ctx->ws_copies.as<QRec3>(), sc,
                          ctx->d_absmax.as<unsigned long long>(), (int)n_copies_max, ctx->origin[0], ctx->origin[1],

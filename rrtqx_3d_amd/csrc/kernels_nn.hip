@@ -254,20 +254,24 @@ __global__ __launch_bounds__(256) void nn_confirm_kernel(ConfirmArgs a, const in
 // One chunk of kChunkF nodes (8 per lane, held in VGPRs) against the copies [q0, q1):
 // the hot loop of the range search.  LM selects the lane-major chunk layout of the slab-ordered
 // shadow.  Flagged lanes file (copy, first position) entries at mine[wn...] (see "Rare path").
-template <int D, bool LM>
+// MODE 0: the lane's nodes are base + lane + 64 u (index-order arrays); 1: lane-major chunk of the slab
+// index, positions base + 8 lane .. + 7; 2: lane-major GROUPS, every lane its own eight consecutive
+// positions p_lane .. + 7 (lanes outside the wave mask vm hold nothing and file nothing).
+template <int D, int MODE>
 __device__ __forceinline__ void scan_chunk_f32(const float *__restrict__ fx, const float *__restrict__ fy,
                                                const float *__restrict__ fz, const float *__restrict__ fw,
                                                const float *__restrict__ fpp, const int base, const int node_end,
                                                const typename QRecFT<D>::type *__restrict__ copies_f, const int q0,
-                                               const int q1, int2 *__restrict__ mine, int &wn) {
+                                               const int q1, int2 *__restrict__ mine, int &wn,
+                                               const unsigned p_lane = 0u, const unsigned long long vm = ~0ull) {
   const int lane = threadIdx.x & 63;
   const float kInf = __builtin_inff();
+  constexpr bool LM = MODE != 0;
   float x[kScanFU], y[kScanFU], z[kScanFU], w[kScanFU], pp[kScanFU];
+  const unsigned p0 = (MODE == 2) ? p_lane : (unsigned)(base + 8 * lane);
   if constexpr (LM) {
-    // lane-major chunk: positions base + 8 lane .. + 7, two 16-byte loads per array (the arrays
-    // are allocated in whole chunks, so the rows of the last chunk are readable; what lies
-    // beyond node_end gets pp = +inf)
-    const unsigned p0 = (unsigned)(base + 8 * lane);
+    // lane-major: two 16-byte loads per array (the arrays are allocated in whole chunks, so the
+    // rows of the last chunk are readable; what lies beyond node_end gets pp = +inf)
     const float4 *rx = reinterpret_cast<const float4 *>(fx + p0);
     const float4 *ry = reinterpret_cast<const float4 *>(fy + p0);
     const float4 *rz = reinterpret_cast<const float4 *>(fz + p0);
@@ -321,6 +325,7 @@ __device__ __forceinline__ void scan_chunk_f32(const float *__restrict__ fx, con
       const float m3 = fminf(fminf(t[6], t[7]), m1);
       const float tmin = fminf(m2, m3);
       mk[k] = __ballot(!(tmin > c[k].thr));
+      if constexpr (MODE == 2) mk[k] &= vm;
       anym |= mk[k];
     }
     if (anym != 0ull) {
@@ -331,7 +336,7 @@ __device__ __forceinline__ void scan_chunk_f32(const float *__restrict__ fx, con
         const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(mk[k] >> 32),
                                                           __builtin_amdgcn_mbcnt_lo((unsigned)mk[k], 0u));
         if ((mk[k] >> lane) & 1ull)
-          mine[wn + (int)before] = make_int2(q + k, LM ? base + 8 * lane : base + lane);
+          mine[wn + (int)before] = make_int2(q + k, LM ? (int)p0 : base + lane);
         wn += __popcll(mk[k]);
       }
     }
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
     const int node_end = min(n_nodes, node_begin + seg_len);
     for (int base = node_begin + wave * kChunkF; base < node_end; base += (kScanThreads / 64) * kChunkF) {
       if (wn + 64 * tile_q > slice_cap) drain_slice<D, false>(mine, wn, n_nodes, ca);
-      scan_chunk_f32<D, false>(fx, fy, fz, fw, fpp, base, node_end, copies_f, q0, q1, mine, wn);
+      scan_chunk_f32<D, 0>(fx, fy, fz, fw, fpp, base, node_end, copies_f, q0, q1, mine, wn);
     }
   }
   if (lane == 0) ev_cnt[slice] = wn;
@@ -430,10 +435,14 @@ constexpr int kTbLcap = 96;           // hits per copy collected in LDS (more: s
 constexpr int kTbList = 1024;         // chunk ids per pass of step 2
 constexpr int kTbSlack = 512;
 
+constexpr int kTbGroups = 1024;       // 8-position groups a tile can list (more: whole chunks, step 2)
 template <int D>
 struct TileLds {
   int list[kTbList];
   int n_list;
+  int glist[kTbGroups];
+  int n_groups, gmode;
+  double zlo, zhi;
   int wcnt[kScanThreads / 64];
   double lo, hi, ylo, yhi;
   int lcnt[kTileB];
@@ -454,8 +463,10 @@ struct TileLds {
 // the (x, y) cell structure of the sorted part of the slab index
 struct TileGrid {
   const SlabParams *sp;
-  const int *cell_start;       // [Kx * Ky + 1]
+  const int *cell_start;       // [Kx * Ky * Kz + 1]
   int n_sorted_chunks;         // chunks [0, n_sorted_chunks) hold sorted positions only
+  int kz;                      // bins of the third coordinate per cell (stride of cell_start)
+  int groups;                  // list 8-position groups (cut by the third coordinate too) instead of chunks
 };
 
 // EXT: every confirmed neighbour is a candidate edge of extend().  Both directed edges are checked
@@ -552,7 +563,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
   const int slice = (int)blockIdx.x * (kScanThreads / 64) + wave;
   int2 *__restrict__ mine = ev + (size_t)slice * (size_t)slice_cap;
   const int2 *__restrict__ blk = ev + (size_t)blockIdx.x * (kScanThreads / 64) * (size_t)slice_cap;
-  int visited = 0;                          // chunks this wave screened (statistics)
+  int visited = 0;                          // groups of eight nodes this wave screened (statistics)
 
   // Workgroups are dealt to the 8 XCDs round-robin (b and b + 8 share an XCD and its L2).  Tiles are in
   // cell order, so neighbouring tiles stream the same chunks: give each XCD one contiguous eighth of the
@@ -569,6 +580,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
     if (t < kTileB) sm.lcnt[t] = 0;
     if (wave == 0) {
       double lo = __builtin_inf(), hi = -__builtin_inf(), ylo = __builtin_inf(), yhi = -__builtin_inf();
+      double zlo = __builtin_inf(), zhi = -__builtin_inf();
       if (q0 + lane < q1) {
         const typename QRecT<D>::type c = copies_s[q0 + lane];
         sm.cp[lane] = c;
@@ -585,38 +597,103 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
           sm.snl[lane] = 0; sm.sbad[lane] = 0;
         }
         // thr NaN / <= 0, x or y NaN or +-inf: the copy can never have a neighbour
-        const bool can_hit = (c.thr > 0.0) && (c.x - c.x == 0.0) && (c.y - c.y == 0.0);
+        // (a non-finite third coordinate gives s = NaN or inf, which is never < thr)
+        const bool can_hit = (c.thr > 0.0) && (c.x - c.x == 0.0) && (c.y - c.y == 0.0) && (c.z - c.z == 0.0);
         if (can_hit) {
           const double R = sqrt_rn(c.thr) * (1.0 + 1e-15);         // thr = +inf -> R = +inf
-          const double xa = c.x - R, xb = c.x + R, ya = c.y - R, yb = c.y + R;
+          const double xa = c.x - R, xb = c.x + R, ya = c.y - R, yb = c.y + R, za = c.z - R, zb = c.z + R;
           lo = xa - (fabs(xa) * 4.5e-16 + 1e-300);
           hi = xb + (fabs(xb) * 4.5e-16 + 1e-300);
           ylo = ya - (fabs(ya) * 4.5e-16 + 1e-300);
           yhi = yb + (fabs(yb) * 4.5e-16 + 1e-300);
+          zlo = za - (fabs(za) * 4.5e-16 + 1e-300);
+          zhi = zb + (fabs(zb) * 4.5e-16 + 1e-300);
         }
       }
       {
+        // the copies sit in lanes 0 .. kTileB - 1: four butterfly steps bring their extremes to lane 0
+        static_assert(kTileB == 16, "reach reduction covers lanes 0..15");
         const int l = lane_here();
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
+        for (int off = kTileB / 2; off > 0; off >>= 1) {
           lo = fmin(lo, wshfl_d(lo, l ^ off));
           hi = fmax(hi, wshfl_d(hi, l ^ off));
           ylo = fmin(ylo, wshfl_d(ylo, l ^ off));
           yhi = fmax(yhi, wshfl_d(yhi, l ^ off));
+          zlo = fmin(zlo, wshfl_d(zlo, l ^ off));
+          zhi = fmax(zhi, wshfl_d(zhi, l ^ off));
         }
       }
-      if (lane == 0) { sm.lo = lo; sm.hi = hi; sm.ylo = ylo; sm.yhi = yhi; sm.n_list = 0; sm.sqn[0] = 0; sm.sqn[1] = 0; }
+      if (lane == 0) {
+        sm.lo = lo; sm.hi = hi; sm.ylo = ylo; sm.yhi = yhi; sm.zlo = zlo; sm.zhi = zhi;
+        sm.n_list = 0; sm.sqn[0] = 0; sm.sqn[1] = 0; sm.n_groups = 0; sm.gmode = 0;
+      }
     }
     __syncthreads();
     const double lo = sm.lo, hi = sm.hi, ylo = sm.ylo, yhi = sm.yhi;
+    bool gmode_w0 = false;                  // (wave 0) this tile's sorted part is listed as groups
     if (lo <= hi) {
       for (int cb = 0; cb < n_chunks; cb += kTbList) {
         // ---- 2. chunk list of this pass: chunk ids in [cb, ce) ----
         const int ce = min(cb + kTbList, n_chunks);
         if (wave == 0) {
           const int w_end = min(ce, tg.n_sorted_chunks);
-          if (cb < w_end) {
+          if (cb == 0 && tg.groups && w_end > 0) {
+            // ---- 2a. the sorted part as GROUPS of eight positions (one lane's nodes).  Inside an (x, y)
+            //      cell the positions are ordered by bin of the third coordinate, so the positions of a
+            //      cell that can hold a neighbour are ONE run: bins [cz0, cz1] (a node in another bin has
+            //      |z_q - z_n| > R for every copy of the tile, hence fl(dz dz) >= thr and s >= thr, as for
+            //      x and y: slab_of is monotone).  Lane = cell within reach, in position order; a group
+            //      shared by two runs is listed once (prefix maximum of the runs' last groups).  Groups
+            //      of whole sorted chunks only: the chunk the sorted part ends in goes by extent below.
             const SlabParams sp = *tg.sp;
+            const int Kz = tg.kz;
+            const int cx0 = slab_of(lo, sp.x0, sp.inv_wx, sp.Kx), cx1 = slab_of(hi, sp.x0, sp.inv_wx, sp.Kx);
+            const int cy0 = slab_of(ylo, sp.y0, sp.inv_wy, sp.Ky), cy1 = slab_of(yhi, sp.y0, sp.inv_wy, sp.Ky);
+            const int cz0 = slab_of(sm.zlo, sp.z0, sp.inv_wz, Kz), cz1 = slab_of(sm.zhi, sp.z0, sp.inv_wz, Kz);
+            const int wdt = cx1 - cx0 + 1, nc = wdt * (cy1 - cy0 + 1);
+            const int g_end = tg.n_sorted_chunks * (kChunkF / 8);
+            int listed_to = -1, G = 0;                     // wave-uniform
+            for (int i0 = 0; i0 < nc && G <= kTbGroups; i0 += 64) {
+              const int i = i0 + lane;
+              int g0 = 0, g1 = -1;                         // this cell's groups (empty)
+              if (i < nc) {
+                const int row = i / wdt, col = i - row * wdt;
+                const int cy = cy0 + row;
+                const int c = cy * sp.Kx + ((cy & 1) ? (sp.Kx - 1 - cx1) : cx0) + col;
+                const int p0 = tg.cell_start[c * Kz + cz0], p1 = tg.cell_start[c * Kz + cz1 + 1];
+                if (p1 > p0) { g0 = p0 >> 3; g1 = min((p1 - 1) >> 3, g_end - 1); }
+              }
+              int run = g1, inc;
+              const int l = lane_here();
+#pragma unroll
+              for (int off = 1; off < 64; off <<= 1) {
+                const int o = wshfl_i(run, l >= off ? l - off : l);
+                if (lane >= off) run = max(run, o);
+              }
+              int before = wshfl_i(run, l >= 1 ? l - 1 : l);
+              if (lane == 0) before = listed_to;
+              before = max(before, listed_to);
+              g0 = max(g0, before + 1);
+              const int cnt = max(g1 - g0 + 1, 0);
+              inc = cnt;
+#pragma unroll
+              for (int off = 1; off < 64; off <<= 1) {
+                const int o = wshfl_i(inc, l >= off ? l - off : l);
+                if (lane >= off) inc += o;
+              }
+              const int at = G + inc - cnt;
+              for (int j = 0; j < cnt; ++j)
+                if (at + j < kTbGroups) sm.glist[at + j] = g0 + j;
+              G += __builtin_amdgcn_readlane(inc, 63);
+              listed_to = max(listed_to, __builtin_amdgcn_readlane(run, 63));
+            }
+            gmode_w0 = G <= kTbGroups;                     // more (a dense or spread-out tile): whole chunks
+            if (lane == 0) { sm.n_groups = gmode_w0 ? G : 0; sm.gmode = gmode_w0 ? 1 : 0; }
+          }
+          if (cb < w_end && !gmode_w0) {
+            const SlabParams sp = *tg.sp;
+            const int Kz = tg.kz;
             const int cx0 = slab_of(lo, sp.x0, sp.inv_wx, sp.Kx), cx1 = slab_of(hi, sp.x0, sp.inv_wx, sp.Kx);
             const int cy0 = slab_of(ylo, sp.y0, sp.inv_wy, sp.Ky), cy1 = slab_of(yhi, sp.y0, sp.inv_wy, sp.Ky);
             int listed_to = cb - 1;                        // wave-uniform: highest chunk id listed so far
@@ -627,7 +704,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
                 const int base = cy * sp.Kx;
                 const int c_first = base + ((cy & 1) ? (sp.Kx - 1 - cx1) : cx0);
                 const int c_last = base + ((cy & 1) ? (sp.Kx - 1 - cx0) : cx1);
-                const int p0 = tg.cell_start[c_first], p1 = tg.cell_start[c_last + 1];
+                const int p0 = tg.cell_start[c_first * Kz], p1 = tg.cell_start[(c_last + 1) * Kz];
                 if (p1 > p0) { ca_ = max(p0 / kChunkF, cb); cb_ = min((p1 - 1) / kChunkF, w_end - 1); }
               }
               // rows come in increasing position order: a row starts no earlier than where the rows
@@ -712,6 +789,23 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
         __syncthreads();
         const int nl = sm.n_list;
         // ---- 3. screen ----
+        if (cb == 0 && sm.gmode) {
+          // units of 64 listed groups; part p of a tile takes units p, p + n_parts, ..., dealt to its waves in turn
+          const int G = sm.n_groups, n_gu = (G + 63) >> 6;
+          for (int k = wave;; k += kScanThreads / 64) {
+            const int u = part + n_parts * k;
+            if (u >= n_gu) break;
+            const int gi = 64 * u + lane;
+            const bool valid = gi < G;
+            const unsigned p_lane = valid ? 8u * (unsigned)sm.glist[gi] : 0u;
+            if (wn + 64 * kTileB > slice_cap) {
+              const TileEmit<D, EXT> emit_now{sm, a.hs, a.meta, x, q0};
+              drain_slice_to<D, true>(mine, wn, n_nodes, a, emit_now, sm.cp, q0);
+            }
+            scan_chunk_f32<D, 2>(fx, fy, fz, fw, fpp, 0, n_nodes, copies_f, q0, q1, mine, wn, p_lane, __ballot(valid));
+            visited += min(64, G - 64 * u);
+          }
+        }
         for (int i = wave; i < nl; i += kScanThreads / 64) {
           const int chunk = __builtin_amdgcn_readfirstlane(sm.list[i]);
           if (n_parts > 1 && chunk % n_parts != part) continue;
@@ -726,8 +820,8 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
             const TileEmit<D, EXT> emit_now{sm, a.hs, a.meta, x, q0};
             drain_slice_to<D, true>(mine, wn, n_nodes, a, emit_now, sm.cp, q0);
           }
-          scan_chunk_f32<D, true>(fx, fy, fz, fw, fpp, chunk * kChunkF, n_nodes, copies_f, q0, q1, mine, wn);
-          visited += 1;
+          scan_chunk_f32<D, 1>(fx, fy, fz, fw, fpp, chunk * kChunkF, n_nodes, copies_f, q0, q1, mine, wn);
+          visited += kChunkF / 8;
         }
         if (ce < n_chunks) {  // (trees beyond kTbList chunks) the list is rebuilt by the next pass
           __syncthreads();
@@ -957,14 +1051,20 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   const int n_chunks = (n_nodes + kSlabChunk - 1) / kSlabChunk;
   const bool use_cull = use_filter && (ctx->opt_nn_cull == 2 || (ctx->opt_nn_cull == 1 && n_nodes >= 8192));
   ctx->last_culled = use_cull;
-  int n_buckets = 1;
+  int n_buckets = 1, g2 = 1, g3 = 1;
   int *qhist = nullptr;
   int2 *cbk = nullptr;
   if (use_cull) {
     int rc = slab_refresh(ctx, (long long)((n_copies_max + 15) / 16));
     if (rc) return rc;
-    n_buckets = 1;                          // side * side cells, about 16 copies each
-    while (n_buckets < (long long)(n_copies_max / 16) && n_buckets < kMaxQBuckets) n_buckets *= 4;
+    // square (x, y) grid of about 16 copies per bucket, or (trees with an extent in the third coordinate,
+    // decided by the pack kernel from the node bounds) a cubic grid of about 4: query_grid, nn_device.hpp
+    while (g2 * g2 < (long long)(n_copies_max / 16) && g2 * g2 < kMaxQBuckets) g2 *= 2;
+    g3 = (int)std::lround(std::cbrt((double)n_copies_max / 4.0));
+    if (g3 < 1) g3 = 1;
+    if (g3 > 16) g3 = 16;
+    if (ctx->opt_tune & 1) g3 = 1;          // experiment switch: (x, y) order of the copies
+    n_buckets = g2 * g2 > g3 * g3 * g3 ? g2 * g2 : g3 * g3 * g3;
     if (!ctx->ws_qhist.p) {               // stays all zero between calls (nn_offsets_kernel re-zeroes it)
       RRTX_HIP(ctx, ctx->ws_qhist.ensure(sizeof(int) * (size_t)(kMaxQBuckets + 1)));
       RRTX_HIP(ctx, hipMemsetAsync(ctx->ws_qhist.p, 0, sizeof(int) * (size_t)(kMaxQBuckets + 1), st));
@@ -1041,7 +1141,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
                          ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
                          ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
                          ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec4>(),
-                         ctx->ws_copy_meta.as<int2>(), sc, ctx->d_xrange.as<unsigned long long>(), n_buckets, qhist,
+                         ctx->ws_copy_meta.as<int2>(), sc, ctx->d_xrange.as<unsigned long long>(), g2, g3, qhist,
                          cbk, pf, ca);
     else
       hipLaunchKernelGGL(nn_pack_kernel<3>, grid, block, 0, st, q_dev, nq, thr_lt_arr, thr_gt_arr, tlt, tgt,
@@ -1049,7 +1149,7 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
                          ctx->wrap_period[0], ctx->wrap_period[1], ctx->wrap_period[2],
                          ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->origin[3],
                          ctx->ws_slots.as<SlotRec>(), ctx->ws_copies.as<QRec3>(),
-                         ctx->ws_copy_meta.as<int2>(), sc, ctx->d_xrange.as<unsigned long long>(), n_buckets, qhist,
+                         ctx->ws_copy_meta.as<int2>(), sc, ctx->d_xrange.as<unsigned long long>(), g2, g3, qhist,
                          cbk, pf, ca);
   }
   span_end(ctx);
@@ -1116,6 +1216,8 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
       tg.sp = ctx->ws_slab_params.as<SlabParams>();
       tg.cell_start = ctx->ws_slab_start.as<int>();
       tg.n_sorted_chunks = (ctx->ws_slab_params.p && ctx->ws_slab_start.p) ? (int)(ctx->sl_n_sorted / kSlabChunk) : 0;
+      tg.kz = ctx->sl_kz > 0 ? ctx->sl_kz : 1;
+      tg.groups = (tg.kz > 1 && !(ctx->opt_tune & 2)) ? 1 : 0;     // (experiment switch 2: whole chunks)
       if (fuse)
         hipLaunchKernelGGL((nn_tile_kernel<3, true>), dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
                            ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, reinterpret_cast<const ChunkExt *>(ctx->chunk_ext),
@@ -1216,7 +1318,8 @@ int scan_units(rrtx_ctx *ctx, int *units) {
     RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   long long tot = 0;
-  for (int x : v) tot += x;
+  for (int x : v) tot += x;               // groups of eight node visits; a unit = one wave's worth = 512 visits
+  tot = (tot + kChunkF / 8 - 1) / (kChunkF / 8);
   *units = (int)(tot > 0x7fffffffll ? 0x7fffffffll : tot);
   return RRTX_OK;
 }

@@ -15,23 +15,29 @@ static_assert(kSlabChunk == kChunkF, "the culled scan visits one slab-index chun
 
 // (SlabParams: nn_device.hpp)
 
-__global__ void slab_params_kernel(const unsigned long long *__restrict__ xrange, int Kx, int Ky,
+__global__ void slab_params_kernel(const unsigned long long *__restrict__ xrange, int Kx, int Ky, int Kz,
                                    SlabParams *__restrict__ sp, int *__restrict__ hist) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) {
-    double x0, ix, y0, iy;
+    double x0, ix, y0, iy, z0, iz;
     slab_map(xrange[0], xrange[1], Kx, &x0, &ix);
     slab_map(xrange[2], xrange[3], Ky, &y0, &iy);
-    sp->x0 = x0; sp->inv_wx = ix; sp->y0 = y0; sp->inv_wy = iy; sp->Kx = Kx; sp->Ky = Ky;
+    slab_map(xrange[4], xrange[5], Kz, &z0, &iz);
+    sp->x0 = x0; sp->inv_wx = ix; sp->y0 = y0; sp->inv_wy = iy; sp->z0 = z0; sp->inv_wz = iz;
+    sp->Kx = Kx; sp->Ky = Ky; sp->Kz = Kz; sp->pad = 0;
   }
-  for (int k = i; k <= Kx * Ky; k += gridDim.x * blockDim.x) hist[k] = 0;
+  for (int k = i; k <= Kx * Ky * Kz; k += gridDim.x * blockDim.x) hist[k] = 0;
 }
 
-__global__ void slab_rank_kernel(const double *__restrict__ nx, const double *__restrict__ ny, int n,
-                                 const SlabParams *__restrict__ sp, int *__restrict__ hist, int2 *__restrict__ sr) {
+// sort key of a node: (x, y) cell, then the bin of the third coordinate inside the cell
+__global__ void slab_rank_kernel(const double *__restrict__ nx, const double *__restrict__ ny,
+                                 const double *__restrict__ nz, int n, const SlabParams *__restrict__ sp,
+                                 int *__restrict__ hist, int2 *__restrict__ sr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int b = cell_of(nx[i], ny[i], sp->x0, sp->inv_wx, sp->Kx, sp->y0, sp->inv_wy, sp->Ky);
+  const int Kz = sp->Kz;
+  const int b = cell_of(nx[i], ny[i], sp->x0, sp->inv_wx, sp->Kx, sp->y0, sp->inv_wy, sp->Ky) * Kz +
+                slab_of(nz[i], sp->z0, sp->inv_wz, Kz);
   sr[i] = make_int2(b, atomicAdd(&hist[b], 1));
 }
 
@@ -249,9 +255,11 @@ int slab_refresh(rrtx_ctx *ctx, long long n_tiles) {
   if (side < 2) side = 2;
   if (side > 256) side = 256;
   const int K = side * side;
+  const int Kz = kSlabKz;
+  const int KK = K * Kz;                  // sort keys: (cell, bin of the third coordinate)
   RRTX_HIP(ctx, ctx->ws_slab_params.ensure(sizeof(SlabParams)));
-  RRTX_HIP(ctx, ctx->ws_slab_hist.ensure(sizeof(int) * (size_t)(K + 1)));
-  RRTX_HIP(ctx, ctx->ws_slab_start.ensure(sizeof(int) * (size_t)(K + 1)));
+  RRTX_HIP(ctx, ctx->ws_slab_hist.ensure(sizeof(int) * (size_t)(KK + 1)));
+  RRTX_HIP(ctx, ctx->ws_slab_start.ensure(sizeof(int) * (size_t)(KK + 1)));
   RRTX_HIP(ctx, ctx->ws_slab_sr.ensure(sizeof(int2) * (size_t)n));
   SlabParams *sp = ctx->ws_slab_params.as<SlabParams>();
   int *hist = ctx->ws_slab_hist.as<int>();
@@ -260,10 +268,11 @@ int slab_refresh(rrtx_ctx *ctx, long long n_tiles) {
   const int nb = (int)((n + 255) / 256);
   const int n_chunks = (int)((n + kSlabChunk - 1) / kSlabChunk);
   span_begin(ctx, KF_NN_FINISH);
-  hipLaunchKernelGGL(slab_params_kernel, dim3((K + 256) / 256), dim3(256), 0, st,
-                     ctx->d_xrange.as<unsigned long long>(), side, side, sp, hist);
-  hipLaunchKernelGGL(slab_rank_kernel, dim3(nb), dim3(256), 0, st, ctx->nodes[0], ctx->nodes[1], (int)n, sp, hist, sr);
-  hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, st, hist, start, K);
+  hipLaunchKernelGGL(slab_params_kernel, dim3((KK + 256) / 256), dim3(256), 0, st,
+                     ctx->d_xrange.as<unsigned long long>(), side, side, Kz, sp, hist);
+  hipLaunchKernelGGL(slab_rank_kernel, dim3(nb), dim3(256), 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], (int)n, sp,
+                     hist, sr);
+  hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, st, hist, start, KK);
   hipLaunchKernelGGL(slab_scatter_kernel, dim3(nb), dim3(256), 0, st, (int)n, sr, start, ctx->nodes_f[0],
                      ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->dim,
                      ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp,
@@ -275,6 +284,7 @@ int slab_refresh(rrtx_ctx *ctx, long long n_tiles) {
   RRTX_HIP(ctx, hipGetLastError());
   ctx->sl_n_sorted = n;
   ctx->sl_cells = K;
+  ctx->sl_kz = Kz;
   return RRTX_OK;
 }
 

@@ -104,6 +104,31 @@ struct PackFused {
   int root_rule;                   // 0: node 0 of this context is not the tree's root (node-range shard)
 };
 
+// Bucket of a query copy.  It only ORDERS the copies (no result depends on it): the tiles of the culled
+// search are runs of 16 consecutive copies in bucket order, and a tile's cost is the volume its copies'
+// balls span, so a run should be compact in every coordinate the slab index can cull by -- (x, y) cells
+// and bins of the third coordinate.  g3 = side of the cubic grid, used when the tree has an extent in the
+// third coordinate worth cutting (layers of cells, rows inside a layer and cells inside a row all run
+// alternately forwards and backwards, so consecutive buckets are neighbours); g2 = side of the square
+// (x, y) grid otherwise (planar trees, time = 0).  At most kMaxQBuckets buckets either way.
+struct QGrid { double x0, ix, y0, iy, z0, iz; int sx, sy, sz; };
+__device__ __forceinline__ QGrid query_grid(const unsigned long long *__restrict__ xrange, int g2, int g3) {
+  QGrid g;
+  const double xw = dec_ord(xrange[1]) - dec_ord(xrange[0]), yw = dec_ord(xrange[3]) - dec_ord(xrange[2]);
+  const double zw = dec_ord(xrange[5]) - dec_ord(xrange[4]);
+  const bool use_z = g3 > 1 && zw > 0.125 * fmax(xw, yw) && zw < 1e300;      // NaN extents: false
+  g.sx = use_z ? g3 : g2; g.sy = g.sx; g.sz = use_z ? g3 : 1;
+  slab_map(xrange[0], xrange[1], g.sx, &g.x0, &g.ix);
+  slab_map(xrange[2], xrange[3], g.sy, &g.y0, &g.iy);
+  slab_map(xrange[4], xrange[5], g.sz, &g.z0, &g.iz);
+  return g;
+}
+__device__ __forceinline__ int query_bucket(const QGrid &g, double x, double y, double z) {
+  const int cx = slab_of(x, g.x0, g.ix, g.sx), cy = slab_of(y, g.y0, g.iy, g.sy), cz = slab_of(z, g.z0, g.iz, g.sz);
+  const int row = cz * g.sy + ((cz & 1) ? (g.sy - 1 - cy) : cy);
+  return row * g.sx + ((row & 1) ? (g.sx - 1 - cx) : cx);
+}
+
 template <int D>
 __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const double *__restrict__ thr_lt_arr,
                                const double *__restrict__ thr_gt_arr, double thr_lt_s, double thr_gt_s,
@@ -111,7 +136,7 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
                                double ox, double oy, double oz, double ow,
                                SlotRec *__restrict__ slots, typename QRecT<D>::type *__restrict__ copies,
                                int2 *__restrict__ meta, Scalars *__restrict__ sc,
-                               const unsigned long long *__restrict__ xrange, int n_buckets,
+                               const unsigned long long *__restrict__ xrange, int g2, int g3,
                                int *__restrict__ qhist, int2 *__restrict__ cb, PackFused pf, ConfirmArgs ca) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = i < nq;
@@ -124,15 +149,9 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
   }
   unsigned long long am = 0ull;                // max |copy - origin| feeds the prefilter's rounding bound
   if (act) {
-    // culled scan: copies are bucketed by (x, y) cell over the extent of the node coordinates,
-    // n_buckets = side * side
-    double bx0 = 0.0, bxi = 0.0, by0 = 0.0, byi = 0.0;
-    int side = 1;
-    if (qhist) {
-      while (side * side < n_buckets) side <<= 1;
-      slab_map(xrange[0], xrange[1], side, &bx0, &bxi);
-      slab_map(xrange[2], xrange[3], side, &by0, &byi);
-    }
+    // culled scan: copies are bucketed by grid cell over the extent of the node coordinates
+    QGrid qg;
+    if (qhist) qg = query_grid(xrange, g2, g3);
     double p[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < D; ++k) p[k] = q[(size_t)i * D + k];
@@ -203,7 +222,7 @@ __global__ void nn_pack_kernel(const double *__restrict__ q, int nq, const doubl
         copies[pos] = qr;
         meta[pos] = make_int2(i, k);
         if (qhist) {
-          const int b = cell_of(g[0], g[1], bx0, bxi, side, by0, byi, side);
+          const int b = query_bucket(qg, g[0], g[1], g[2]);
           cb[pos] = make_int2(b, atomicAdd(&qhist[b], 1));
         }
       }
@@ -398,8 +417,10 @@ __device__ __forceinline__ void screen8(const typename QRecFT<D>::type &c, const
 
 // ---------------------------------------------------------- slab index geometry ------
 // written by slab_params_kernel at every rebuild: the (x, y) grid the sorted part of the slab index
-// is ordered by (cell_of); cell_start[c] = first position of cell c, cell_start[Kx * Ky] = sl_n_sorted
-struct SlabParams { double x0, inv_wx, y0, inv_wy; int Kx, Ky; };
+// is ordered by (cell_of), and inside every cell the Kz equal-width bins of the third coordinate;
+// cell_start[c * Kz + b] = first position of bin b of cell c, cell_start[Kx * Ky * Kz] = sl_n_sorted
+struct SlabParams { double x0, inv_wx, y0, inv_wy, z0, inv_wz; int Kx, Ky, Kz, pad; };
+constexpr int kSlabKz = 32;      // bins of the third coordinate inside a cell
 
 // ------------------------------------------------ exact nearest for one point ------
 // kdFindNearest for ONE point by a whole workgroup (NT threads, all call it together): expanding

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
   // slab_later: the batch's slab entries and chunk extents are written in cell order by slab_append_run
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long m = 0ull;
-  unsigned long long xlo = ~0ull, xhi = 0ull, ylo = ~0ull, yhi = 0ull;
+  unsigned long long xlo = ~0ull, xhi = 0ull, ylo = ~0ull, yhi = 0ull, zlo = ~0ull, zhi = 0ull;
   if (i < n) {
     const double a = pos[i * dim + 0], b = pos[i * dim + 1], c = pos[i * dim + 2];
     x[base + i] = a; y[base + i] = b; z[base + i] = c;
@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
     }
     if (a == a) xlo = xhi = enc_ord(a);
     if (b == b) ylo = yhi = enc_ord(b);
+    if (c == c) zlo = zhi = enc_ord(c);
     double pp = (double)fa * (double)fa + (double)fb * (double)fb + (double)fc * (double)fc;
     m = max(max((unsigned long long)__double_as_longlong(fabs(sa)), (unsigned long long)__double_as_longlong(fabs(sb))),
             (unsigned long long)__double_as_longlong(fabs(sc)));
@@ -235,6 +236,10 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
     ylo = min(ylo, o);
     o = __shfl_xor(yhi, off);
     yhi = max(yhi, o);
+    o = __shfl_xor(zlo, off);
+    zlo = min(zlo, o);
+    o = __shfl_xor(zhi, off);
+    zhi = max(zhi, o);
   }
   if ((threadIdx.x & 63) == 0) {
     if (one_chunk && !slab_later) {
@@ -250,6 +255,10 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
     if (ylo != ~0ull) {
       if (ylo < xrange[2]) atomicMin(&xrange[2], ylo);
       if (yhi > xrange[3]) atomicMax(&xrange[3], yhi);
+    }
+    if (zlo != ~0ull) {
+      if (zlo < xrange[4]) atomicMin(&xrange[4], zlo);
+      if (zhi > xrange[5]) atomicMax(&xrange[5], zhi);
     }
   }
 }
@@ -305,7 +314,7 @@ int grow_nodes(rrtx_ctx *ctx, int64_t need) {
   if (!ctx->d_absmax.p) {
     RRTX_HIP(ctx, ctx->d_absmax.ensure(sizeof(unsigned long long)));
     RRTX_HIP(ctx, hipMemset(ctx->d_absmax.p, 0, sizeof(unsigned long long)));
-    const unsigned long long none[4] = {~0ull, 0ull, ~0ull, 0ull};
+    const unsigned long long none[6] = {~0ull, 0ull, ~0ull, 0ull, ~0ull, 0ull};
     RRTX_HIP(ctx, ctx->d_xrange.ensure(sizeof(none)));
     RRTX_HIP(ctx, hipMemcpy(ctx->d_xrange.p, none, sizeof(none), hipMemcpyHostToDevice));
   }

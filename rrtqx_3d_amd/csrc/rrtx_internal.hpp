@@ -112,8 +112,9 @@ struct rrtx_ctx {
   int64_t sl_n_sorted = 0;
   double sl_run_chunks = 0.0;       // chunks of the tail that were appended as sorted runs
   int sl_cells = 0;                 // cells of the grid of the last rebuild
+  int sl_kz = 0;                    // bins of the third coordinate inside a cell (0: no index yet)
   double sl_debt_us = 0.0;          // what the appended tail has cost the searches since the last rebuild (estimate)
-  rrtx::DevBuf d_xrange;            // uint64[4]: enc_ord of min / max node x, min / max node y
+  rrtx::DevBuf d_xrange;            // uint64[6]: enc_ord of min / max node x, min / max node y, min / max of the third coordinate
   rrtx::DevBuf ws_slab_hist, ws_slab_start, ws_slab_sr, ws_slab_params, ws_run_hist, ws_run_sr;
 
   // options (rrtx_set_option)
