@@ -17,6 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "librrtx_hip.so")
+LIB_CLK = os.path.join(HERE, "librrtx_hip_clk.so")
 
 SOURCES = ["rrtx_capi.hip", "kernels_nn.hip", "kernels_finish.hip", "kernels_nearest.hip", "kernels_slab.hip", "kernels_sweep.hip", "kernels_graph.hip", "kernels_collide.hip",
            "kernels_dubins.hip"]
@@ -31,12 +32,14 @@ def _newer(a: str, b: str) -> bool:
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def _compile(src: str, force: bool, save_temps: bool) -> str:
-    obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+def _compile(src: str, force: bool, save_temps: bool, clocks: bool = False) -> str:
+    obj = os.path.join(OBJDIR, src.replace(".hip", ".clk.o" if clocks else ".o"))
     srcp = os.path.join(CSRC, src)
     deps = [srcp] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     if force or any(_newer(d, obj) for d in deps):
         cmd = [HIPCC] + FLAGS + ["-c", srcp, "-o", obj]
+        if clocks:
+            cmd += ["-DRRTX_TILE_CLOCKS"]
         if save_temps:
             cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -48,17 +51,20 @@ def _compile(src: str, force: bool, save_temps: bool) -> str:
     return obj
 
 
-def build(force: bool = False, save_temps: bool = False) -> str:
+def build(force: bool = False, save_temps: bool = False, clocks: bool = False) -> str:
+    """clocks: the measuring build librrtx_hip_clk.so (phase clocks in the tile kernel, tools/tile_clocks.py);
+    never loaded by the product, which always takes librrtx_hip.so."""
     os.makedirs(OBJDIR, exist_ok=True)
+    lib = LIB_CLK if clocks else LIB
     with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, save_temps), SOURCES))
-    if force or any(_newer(o, LIB) for o in objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        objs = list(ex.map(lambda s: _compile(s, force, save_temps, clocks), SOURCES))
+    if force or any(_newer(o, lib) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv))
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, clocks="--clocks" in sys.argv))

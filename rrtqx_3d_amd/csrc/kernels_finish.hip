@@ -59,7 +59,8 @@ struct FinLds {
   long long off[kFinQ + 1];
   int kfull[kFinQ];            // list length as counted
   int todo[kFinQ];             // the list needs the whole workgroup
-  int empty[kFinQ];
+  unsigned todo_mask;          // ... as bits (the two loops over the workgroup's queries below only visit set bits:
+  unsigned empty_mask;         //     sixteen flag reads per wave and loop were a quarter of the kernel's instructions)
   int gcnt;
   int s_idx[KSORT];
   double s_d2[KSORT];
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(kFinThreads, KSORT > kBigSort ? 2 : 8) void nn_fini
   // for the offsets, so the prefix over the preceding counts travels beside them.
   // (No workgroup barrier on the way: a barrier waits for every outstanding load.  Each half wave
   // resets its own LDS words; LDS operations of one wave execute in order.)
-  if (hl == 0) { sm.todo[hw] = 0; sm.empty[hw] = 0; }
+  if (hl == 0) sm.todo[hw] = 0;
+  if (t == 0) sm.empty_mask = 0u;
   int kfull = 0;
   if (qv) kfull = a.count[q];
   const int kInt = 0x7fffffff;
@@ -183,8 +185,10 @@ __global__ __launch_bounds__(kFinThreads, KSORT > kBigSort ? 2 : 8) void nn_fini
     } else {
       for (int w = 0; w < kFinThreads / 64; ++w) p += sm.red[w];
     }
-    for (int k = 0; k < kFinQ; ++k) { sm.off[k] = p; p += sm.kfull[k]; }
+    unsigned tm = 0u;
+    for (int k = 0; k < kFinQ; ++k) { sm.off[k] = p; p += sm.kfull[k]; tm |= sm.todo[k] ? (1u << k) : 0u; }
     sm.off[kFinQ] = p;
+    sm.todo_mask = tm;
   }
   __syncthreads();
   if (!a.prescattered && t <= kFinQ) {
@@ -214,15 +218,15 @@ __global__ __launch_bounds__(kFinThreads, KSORT > kBigSort ? 2 : 8) void nn_fini
     }
     if (a.nearest_idx && qv && small && hl == 0) {
       if (kk > 0) { a.nearest_idx[q] = nbest_i; a.nearest_dist[q] = sqrt_rn(nbest); }
-      else if (a.want_nearest_fix) sm.empty[hw] = 1;
+      else if (a.want_nearest_fix) atomicOr(&sm.empty_mask, 1u << hw);
       else { a.nearest_idx[q] = -1; a.nearest_dist[q] = __builtin_inf(); }
     }
   }
   __syncthreads();
 
   // ---- long or overflowed lists: the whole workgroup, one list at a time ----
-  for (int g = 0; g < kFinQ; ++g) {
-    if (!sm.todo[g]) continue;           // workgroup-uniform
+  for (unsigned tm = sm.todo_mask; tm != 0u; tm &= tm - 1u) {     // workgroup-uniform
+    const int g = __ffs((int)tm) - 1;
     const int qq = q0 + g;
     const long long gb = sm.off[g];
     const int gfull = sm.kfull[g];
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(kFinThreads, KSORT > kBigSort ? 2 : 8) void nn_fini
             best = sm.r_best[w]; best_i = sm.r_besti[w];
           }
         if (gk > 0) { a.nearest_idx[qq] = best_i; a.nearest_dist[qq] = sqrt_rn(best); }
-        else if (a.want_nearest_fix) sm.empty[g] = 1;       // list cut off by the caller's capacity
+        else if (a.want_nearest_fix) atomicOr(&sm.empty_mask, 1u << g);       // list cut off by the caller's capacity
         else { a.nearest_idx[qq] = -1; a.nearest_dist[qq] = __builtin_inf(); }
       }
     }
@@ -342,8 +346,8 @@ __global__ __launch_bounds__(kFinThreads, KSORT > kBigSort ? 2 : 8) void nn_fini
 
   // ---- empty balls: kdFindNearest by expanding search (R/kdTree_general.jl:357-385) ----
   if (a.nearest_idx && a.want_nearest_fix) {
-    for (int g = 0; g < kFinQ; ++g) {
-      if (!sm.empty[g]) continue;          // workgroup-uniform
+    for (unsigned em = sm.empty_mask; em != 0u; em &= em - 1u) {   // workgroup-uniform
+      const int g = __ffs((int)em) - 1;
       const int qq = q0 + g;
       const double ex = a.q[(size_t)qq * D + 0], ey = a.q[(size_t)qq * D + 1], ez = a.q[(size_t)qq * D + 2];
       double ew = 0.0;

@@ -105,10 +105,23 @@ __global__ __launch_bounds__(256) void nn_place_kernel(
   __shared__ int wsum[4];
   {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int per = (n_buckets + 255) / 256;
+    // a thread's share of the counters in registers (the buffer holds kMaxQBuckets + 1 ints, zero beyond the
+    // buckets in use): four 16-byte loads in flight instead of up to sixteen dependent 4-byte ones, read once
+    static_assert(kMaxQBuckets == 256 * 16, "sixteen counters per thread");
+    const int per = (n_buckets + 255) / 256;            // <= 16
     const int b0 = min(t * per, n_buckets), b1 = min(b0 + per, n_buckets);
+    int h[16];
+    if (per == 16) {
+      const int4 *h4 = reinterpret_cast<const int4 *>(qhist + b0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int4 v4 = h4[k]; h[4 * k] = v4.x; h[4 * k + 1] = v4.y; h[4 * k + 2] = v4.z; h[4 * k + 3] = v4.w; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) h[k] = (b0 + k < b1) ? qhist[b0 + k] : 0;
+    }
     int local = 0;
-    for (int k = b0; k < b1; ++k) local += qhist[k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) local += h[k];
     int v = local;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -119,7 +132,9 @@ __global__ __launch_bounds__(256) void nn_place_kernel(
     __syncthreads();
     int prefix = v - local;
     for (int w = 0; w < wave; ++w) prefix += wsum[w];
-    for (int k = b0; k < b1; ++k) { start[k] = prefix; prefix += qhist[k]; }
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (b0 + k < b1) { start[b0 + k] = prefix; prefix += h[k]; }
     __syncthreads();
   }
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,7 +189,15 @@ __device__ __forceinline__ void confirm_entry(bool has, int2 en, int n_nodes, co
 #pragma unroll 1
   for (int hv = 0; hv < 2; ++hv) {
     double ex[kH], ey[kH], ez[kH], ew[kH];
+    int nid[kH];                      // node index of each position, requested with the rows (not per confirmed hit)
     if constexpr (LM) {
+      if (a.pos_id) {
+        const int4 vi = *reinterpret_cast<const int4 *>(a.pos_id + p0 + kH * hv);
+        nid[0] = vi.x; nid[1] = vi.y; nid[2] = vi.z; nid[3] = vi.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < kH; ++u) nid[u] = p0 + kH * hv + u;
+      }
       // node arrays are allocated in whole chunks: the 32-byte rows are always readable
       const double2 *rx = reinterpret_cast<const double2 *>(a.nx + p0 + kH * hv);
       const double2 *ry = reinterpret_cast<const double2 *>(a.ny + p0 + kH * hv);
@@ -196,6 +219,7 @@ __device__ __forceinline__ void confirm_entry(bool has, int2 en, int n_nodes, co
         const int pc = (pos < n_nodes) ? pos : 0;
         ex[u] = a.nx[pc]; ey[u] = a.ny[pc]; ez[u] = a.nz[pc];
         if constexpr (D == 4) ew[u] = a.nw[pc]; else ew[u] = 0.0;
+        nid[u] = pos;                 // (index-order arrays: position = node index)
       }
     }
     double s[kH];
@@ -206,24 +230,26 @@ __device__ __forceinline__ void confirm_entry(bool has, int2 en, int n_nodes, co
       if constexpr (D == 4) s[u] = sq4(ce.x, ce.y, ce.z, ce.w, ex[u], ey[u], ez[u], ew[u]);
       else s[u] = sq3(ce.x, ce.y, ce.z, ex[u], ey[u], ez[u]);
       bool hu = has && pos < n_nodes && (s[u] < ce.thr);
-      if (m.y > 0 && hu) {
-        const int id = a.pos_id ? a.pos_id[pos] : pos;
-        hu = !seen_by_earlier_slot<D>(a.slots, a.n_slots, m.x, m.y, id, ex[u], ey[u], ez[u], ew[u]);
-      }
+      if (m.y > 0 && hu)
+        hu = !seen_by_earlier_slot<D>(a.slots, a.n_slots, m.x, m.y, nid[u], ex[u], ey[u], ez[u], ew[u]);
       hm |= (hu ? 1u : 0u) << u;
     }
-    // normally one of the eight is a neighbour; emit them one per round
-    while (__ballot(hm != 0u) != 0ull) {
-      const bool h = hm != 0u;
-      const int uu = h ? (__ffs((int)hm) - 1) : 0;
-      hm &= hm - 1u;
-      double hs2 = s[0];
+    if constexpr (Emit::kBatch) {
+      // the lane's hits of this half go out together (one slot request per lane)
+      static_assert(kH == 4, "batch emitters take four nodes at a time");
+      emit.batch(en.x, m.x, hm, nid, s);
+    } else {
+      // normally one of the eight is a neighbour; emit them one per round
+      while (__ballot(hm != 0u) != 0ull) {
+        const bool h = hm != 0u;
+        const int uu = h ? (__ffs((int)hm) - 1) : 0;
+        hm &= hm - 1u;
+        double hs2 = s[0];
+        int hid = nid[0];
 #pragma unroll
-      for (int u = 1; u < kH; ++u) hs2 = (uu == u) ? s[u] : hs2;
-      const int pos = LM ? p0 + kH * hv + uu : p0 + 64 * (kH * hv + uu);
-      int hid = pos;
-      if (h && a.pos_id) hid = a.pos_id[pos];
-      emit(h, en.x, m.x, hid, hs2);
+        for (int u = 1; u < kH; ++u) { hs2 = (uu == u) ? s[u] : hs2; hid = (uu == u) ? nid[u] : hid; }
+        emit(h, en.x, m.x, hid, hs2);
+      }
     }
   }
 }
@@ -504,6 +530,39 @@ __device__ __forceinline__ int tile_edge_flags(const ExtendDev &x, const TileLds
 template <int D, bool EXT>
 struct TileEmit {
   static constexpr bool kNeedsOwner = false;
+  static constexpr bool kBatch = true;
+  // up to four hits of one lane (bit u of hm: node id[u] at squared distance d2[u]): ONE slot request for all of
+  // them, then each goes to its slot of the copy's LDS list -- no loop over the busiest lane's hits, no selects
+  __device__ __forceinline__ void batch(int q, int /*owner*/, unsigned hm, const int *id, const double *d2) const {
+    const int cl = hm ? q - q0 : 0;
+    int base = 0;
+    if (hm) base = atomicAdd(&sm.lcnt[cl], __popc(hm));
+    unsigned spill = 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool b = (hm >> u) & 1u;
+      if (__ballot(b) == 0ull) continue;
+      const int slot = base + __popc(hm & ((1u << u) - 1u));
+      if (b && slot < kTbLcap) {
+        BktRec br;
+        br.idx = id[u]; br.pad = 0; br.d2 = d2[u];
+        sm.hrec[cl][slot] = br;
+      }
+      spill |= (b && slot >= kTbLcap) ? (1u << u) : 0u;
+    }
+    if (__ballot(spill != 0u) != 0ull) {
+      // a dense ball (more than kTbLcap hits of one copy in one tile): straight to the bucket
+#pragma unroll 1
+      for (int u = 0; u < 4; ++u) {
+        const bool sp = (spill >> u) & 1u;
+        if (__ballot(sp) == 0ull) continue;
+        int owner = 0, flags = 0;
+        if (sp) owner = meta[q].x;
+        if constexpr (EXT) flags = tile_edge_flags<D>(x, sm, sp, cl, id[u], d2[u]);
+        emit_hits_grouped(hs, sp, owner, id[u], d2[u], flags);   // at most kTileB queries per wave
+      }
+    }
+  }
   TileLds<D> &sm;
   const HitSink &hs;
   const int2 *meta;
@@ -546,6 +605,17 @@ __device__ __forceinline__ double wshfl_d(double v, int src_lane) {
   return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
+// Measuring build (python -m rrtqx_3d_amd.build --clocks -> librrtx_hip_clk.so, tools/tile_clocks.py): thread 0
+// of every workgroup (and the first lane of waves 1, 2 where they finish their part of the list phase) leaves
+// the 100 MHz wall clock at the phase boundaries of its (first) tile.
+#ifdef RRTX_TILE_CLOCKS
+__device__ unsigned long long g_tile_clk[4096 * 16];
+#define RRTX_TILE_CLK_AT(thread, k) do { if (t == (thread)) g_tile_clk[(blockIdx.x & 4095) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define RRTX_TILE_CLK_AT(thread, k) do { } while (0)
+#endif
+#define RRTX_TILE_CLK(k) RRTX_TILE_CLK_AT(0, k)
+
 template <int D, bool EXT>
 __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
     const float *__restrict__ fx, const float *__restrict__ fy, const float *__restrict__ fz,
@@ -577,6 +647,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
     int wn = 0;                             // wave-uniform: entries in the slice
 
     // ---- 1. reach ----
+    RRTX_TILE_CLK(0);
     if (t < kTileB) sm.lcnt[t] = 0;
     if (wave == 0) {
       double lo = __builtin_inf(), hi = -__builtin_inf(), ylo = __builtin_inf(), yhi = -__builtin_inf();
@@ -630,9 +701,13 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
       }
     }
     __syncthreads();
+    RRTX_TILE_CLK(1);
     const double lo = sm.lo, hi = sm.hi, ylo = sm.ylo, yhi = sm.yhi;
     bool gmode_w0 = false;                  // (wave 0) this tile's sorted part is listed as groups
-    if (lo <= hi) {
+    // (no copy of the tile can have a neighbour: nothing to list or screen -- but the fused path's sample pass,
+    // which sits in the list phase, runs all the same: explicitPointCheck of a sample does not depend on its ball;
+    // with lo > hi every range below is empty)
+    if (lo <= hi || EXT) {
       for (int cb = 0; cb < n_chunks; cb += kTbList) {
         // ---- 2. chunk list of this pass: chunk ids in [cb, ce) ----
         const int ce = min(cb + kTbList, n_chunks);
@@ -651,7 +726,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
             const int cx0 = slab_of(lo, sp.x0, sp.inv_wx, sp.Kx), cx1 = slab_of(hi, sp.x0, sp.inv_wx, sp.Kx);
             const int cy0 = slab_of(ylo, sp.y0, sp.inv_wy, sp.Ky), cy1 = slab_of(yhi, sp.y0, sp.inv_wy, sp.Ky);
             const int cz0 = slab_of(sm.zlo, sp.z0, sp.inv_wz, Kz), cz1 = slab_of(sm.zhi, sp.z0, sp.inv_wz, Kz);
-            const int wdt = cx1 - cx0 + 1, nc = wdt * (cy1 - cy0 + 1);
+            const int wdt = cx1 - cx0 + 1, nc = (lo <= hi) ? wdt * (cy1 - cy0 + 1) : 0;
             const int g_end = tg.n_sorted_chunks * (kChunkF / 8);
             int listed_to = -1, G = 0;                     // wave-uniform
             for (int i0 = 0; i0 < nc && G <= kTbGroups; i0 += 64) {
@@ -691,7 +766,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
             gmode_w0 = G <= kTbGroups;                     // more (a dense or spread-out tile): whole chunks
             if (lane == 0) { sm.n_groups = gmode_w0 ? G : 0; sm.gmode = gmode_w0 ? 1 : 0; }
           }
-          if (cb < w_end && !gmode_w0) {
+          if (cb < w_end && !gmode_w0 && lo <= hi) {
             const SlabParams sp = *tg.sp;
             const int Kz = tg.kz;
             const int cx0 = slab_of(lo, sp.x0, sp.inv_wx, sp.Kx), cx1 = slab_of(hi, sp.x0, sp.inv_wx, sp.Kx);
@@ -745,23 +820,41 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
                 if (at < kSphListCap) sm.ssl[cl][at] = j;
               }
             };
+            // the tile's probes: lane cl < 16 of this wave holds sample cl's, the loop below takes them from
+            // there with v_readlane (scalar operands of the packed arithmetic: no LDS read and wait per sample)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            float4 mypf = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < q1 - q0) mypf = sm.srp[lane];
+            const int ipx = __float_as_int(mypf.x), ipy = __float_as_int(mypf.y), ipz = __float_as_int(mypf.z),
+                      ipw = __float_as_int(mypf.w);
+            const int nsamp = q1 - q0;
             for (int pr0 = 0; pr0 < n_pairs; pr0 += 128) {
               const int pr = pr0 + (t - 128);
               float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = make_float4(0.f, 0.f, 0.f, 0.f);
               const bool pv = pr < n_pairs;
               if (pv) { u = tp[2 * pr]; v = tp[2 * pr + 1]; }
-              for (int cl = 0; cl < q1 - q0; ++cl) {
-                const float4 pf = sm.srp[cl];
-                const float dxa = u.x - pf.x, dya = u.z - pf.y, dza = v.x - pf.z;
-                const float dxb = u.y - pf.x, dyb = u.w - pf.y, dzb = v.y - pf.z;
-                float da = dxa * dxa; da = __builtin_fmaf(dya, dya, da); da = __builtin_fmaf(dza, dza, da);
-                float db = dxb * dxb; db = __builtin_fmaf(dyb, dyb, db); db = __builtin_fmaf(dzb, dzb, db);
-                const float ba = v.z + pf.w, bb = v.w + pf.w;
+              const f32x2 ux = {u.x, u.y}, uy = {u.z, u.w}, uz = {v.x, v.y}, ur = {v.z, v.w};
+              const bool va = pv && 2 * pr < x.m, vb = pv && 2 * pr + 1 < x.m;
+#pragma unroll
+              for (int cl = 0; cl < kTileB; ++cl) {
+                if (cl >= nsamp) break;                 // wave-uniform
+                const float px = __int_as_float(__builtin_amdgcn_readlane(ipx, cl));
+                const float py = __int_as_float(__builtin_amdgcn_readlane(ipy, cl));
+                const float pz = __int_as_float(__builtin_amdgcn_readlane(ipz, cl));
+                const float pw = __int_as_float(__builtin_amdgcn_readlane(ipw, cl));
+                // both spheres of the pair at once (v_pk_*): the same operations in the same order as one at a time
+                const f32x2 dx = ux - px, dy = uy - py, dz = uz - pz;
+                f32x2 d = dx * dx;
+                d = __builtin_elementwise_fma(dy, dy, d);
+                d = __builtin_elementwise_fma(dz, dz, d);
+                const f32x2 bnd = ur + pw;
+                const f32x2 b2 = bnd * bnd;
                 // the left-over pairs are queued (no load in this loop) and evaluated one per lane below
+                const bool na = va && !(d.x > b2.x), nb = vb && !(d.y > b2.y);
+                if (__ballot(na || nb) == 0ull) continue;
                 for (int h2 = 0; h2 < 2; ++h2) {
                   const int j = 2 * pr + h2;
-                  const bool near = pv && j < x.m && (h2 == 0 ? !(da > ba * ba) : !(db > bb * bb));
-                  if (near) {
+                  if (h2 == 0 ? na : nb) {
                     const int at = atomicAdd(&sm.sqn[qw], 1);
                     if (at < 64) sm.sq[qw][at] = cl | (j << 4);
                     else exact(cl, j);               // queue full (dense obstacle field): right away
@@ -786,7 +879,11 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
               sm.list[atomicAdd(&sm.n_list, 1)] = c;
           }
         }
+        RRTX_TILE_CLK_AT(0, 8);        // wave 0: list written
+        RRTX_TILE_CLK_AT(64, 9);       // wave 1: tail chunks by extent
+        RRTX_TILE_CLK_AT(128, 10);     // wave 2: sample pass
         __syncthreads();
+        RRTX_TILE_CLK(2);
         const int nl = sm.n_list;
         // ---- 3. screen ----
         if (cb == 0 && sm.gmode) {
@@ -831,11 +928,13 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
       }
     }
     // ---- 4. confirm the workgroup's entries ----
+    RRTX_TILE_CLK(3);
     if (lane == 0) sm.wcnt[wave] = wn;
     // entries were written through to L2 by waves of this workgroup (same CU, same L1, which does
     // not keep written lines): a workgroup-scope fence orders them before the barrier
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
+    RRTX_TILE_CLK(4);
     const TileEmit<D, EXT> emit{sm, a.hs, a.meta, x, q0};
     const int c0 = sm.wcnt[0], c1 = c0 + sm.wcnt[1], c2 = c1 + sm.wcnt[2], total = c2 + sm.wcnt[3];
     for (int e0 = 0; e0 < total; e0 += kScanThreads) {
@@ -850,6 +949,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
       if (__ballot(has) != 0ull) confirm_entry<D, true>(has, en, n_nodes, a, emit, sm.cp, q0);
     }
     __syncthreads();
+    RRTX_TILE_CLK(5);
     // ---- 5. hand the collected hits to the buckets: half a wave per copy, two copies per half ----
     {
       constexpr int kPerWave = kTileB / (kScanThreads / 64);     // 4 copies per wave
@@ -888,7 +988,9 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
       // explicitPointCheck of the samples (one part of a tile reports them)
       if (part == 0 && t < q1 - q0 && x.sample_unsafe) x.sample_unsafe[a.meta[q0 + t].x] = sm.sbad[t] ? 1 : 0;
     }
+    RRTX_TILE_CLK(6);
     __syncthreads();          // LDS is reused by the next tile
+    RRTX_TILE_CLK(7);
   }
   if (lane == 0) visits[slice] = visited;
 }
@@ -1062,6 +1164,8 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
     while (g2 * g2 < (long long)(n_copies_max / 16) && g2 * g2 < kMaxQBuckets) g2 *= 2;
     g3 = (int)std::lround(std::cbrt((double)n_copies_max / 4.0));
     if (g3 < 1) g3 = 1;
+    if (g3 > 16) g3 = 16;
+    if ((ctx->opt_tune >> 16) & 0x1f) g3 = (ctx->opt_tune >> 16) & 0x1f;   // experiment switch: side of the cubic grid
     if (g3 > 16) g3 = 16;
     if (ctx->opt_tune & 1) g3 = 1;          // experiment switch: (x, y) order of the copies
     n_buckets = g2 * g2 > g3 * g3 * g3 ? g2 * g2 : g3 * g3 * g3;
@@ -1309,6 +1413,12 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
 }
+
+#ifdef RRTX_TILE_CLOCKS
+extern "C" int rrtx_debug_tile_clocks(unsigned long long *out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_clk), sizeof(unsigned long long) * (size_t)n_words);
+}
+#endif
 
 int scan_units(rrtx_ctx *ctx, int *units) {
   // node chunks screened by the last culled range search: per-wave counts written by nn_tile_kernel

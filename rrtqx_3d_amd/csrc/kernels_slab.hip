@@ -251,11 +251,13 @@ int slab_refresh(rrtx_ctx *ctx, long long n_tiles) {
   ctx->sl_run_chunks = 0.0;
   hipStream_t st = ctx->stream;
   // about one cell per chunk: cells of ~512 nodes, laid out as a square grid over (x, y)
-  int side = (int)std::sqrt((double)n / (double)kSlabChunk);
+  // (experiment switches, RRTX_OPT_TUNE bits 24-25: smaller cells; bits 8-15: bins of the third coordinate)
+  const int cell_nodes = kSlabChunk >> ((ctx->opt_tune >> 24) & 3);
+  int side = (int)std::sqrt((double)n / (double)cell_nodes);
   if (side < 2) side = 2;
   if (side > 256) side = 256;
   const int K = side * side;
-  const int Kz = kSlabKz;
+  const int Kz = ((ctx->opt_tune >> 8) & 0xff) ? ((ctx->opt_tune >> 8) & 0xff) : kSlabKz;
   const int KK = K * Kz;                  // sort keys: (cell, bin of the third coordinate)
   RRTX_HIP(ctx, ctx->ws_slab_params.ensure(sizeof(SlabParams)));
   RRTX_HIP(ctx, ctx->ws_slab_hist.ensure(sizeof(int) * (size_t)(KK + 1)));

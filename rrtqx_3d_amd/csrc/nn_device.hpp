@@ -315,6 +315,8 @@ __device__ __forceinline__ void emit_hits_grouped(const HitSink &hs, bool hit, i
 // emitters for confirm_entry: what to do with a confirmed neighbour
 struct GlobalEmit {
   static constexpr bool kNeedsOwner = true;
+  static constexpr bool kBatch = false;
+  __device__ __forceinline__ void batch(int, int, unsigned, const int *, const double *) const {}
   const HitSink &hs;
   __device__ __forceinline__ void operator()(bool h, int /*q*/, int owner, int id, double d2) const {
     emit_hit(hs, h, owner, id, d2);

@@ -165,6 +165,27 @@ def test_cull_extend_candidates_same_as_unculled():
         assert len(outs[0]["idx"]) > nq
 
 
+def test_cull_extend_samples_checked_when_no_ball_can_hold_a_node():
+    """explicitPointCheck of a sample does not depend on its ball: whole tiles of samples that cannot have a
+    neighbour (NaN coordinates sort into one bucket; r = 0) still get their collision flag in the fused path."""
+    n, nq = 40_000, 600
+    pts, sph = synth.nodes(n, 3), synth.spheres(64)
+    Q = synth.queries(nq, 3)
+    Q[:200] = sph[np.arange(200) % 64, :3] + 0.01          # inside a sphere
+    Q[200:260, 0] = np.nan                                   # NaN sample: !(s >= thr) holds, so "in collision"
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        ctx.spheres_set(sph)
+        for r in (0.0, synth.ball_radius(n, 3)):
+            outs = []
+            for mode in (2, 0):
+                ctx.set_option(_capi.RRTX_OPT_NN_CULL, mode)
+                outs.append(ctx.extend_candidates(Q, r, 0.5))
+            for k in outs[0]:
+                assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), (r, k)
+            assert outs[0]["sample_unsafe"][:260].all() and not outs[0]["sample_unsafe"].all()
+
+
 def test_cull_every_lane_flagged_and_list_overflow(oracle):
     """balls that swallow the whole tree: every lane of every copy files an entry (the waves must
     confirm their own slices on the way), the per-copy LDS lists and the per-query buckets overflow
