@@ -122,7 +122,8 @@ __device__ __forceinline__ ReachProbe reach_probe(const ExtendDev &x, double cx,
 // this together.  len = sqrt(sq3(sample, node)).
 __device__ __forceinline__ void edge_flags(const ExtendDev &x, bool act, double sx, double sy, double sz, double tx,
                                            double ty, double tz, double len, int nl_in, const int *list, bool &out_hit,
-                                           bool &in_hit) {
+                                           bool &in_hit, const SphRec *list_recs = nullptr) {
+  // list_recs: the listed spheres' records where the caller keeps them at hand (LDS), same order as `list`
   // out: sample -> near ; in: near -> sample.  edgeLen is the same value either way
   const double bx = tx - sx, by = ty - sy, bz = tz - sz;
   const double cx = sx - tx, cy = sy - ty, cz = sz - tz;
@@ -142,7 +143,7 @@ __device__ __forceinline__ void edge_flags(const ExtendDev &x, bool act, double 
     }
     for (int c = 0; __ballot(c < nl) != 0ull; ++c) {
       if (c < nl && !(out_hit && in_hit)) {
-        const SphRec ob = x.sph[list[c]];
+        const SphRec ob = list_recs ? list_recs[c] : x.sph[list[c]];
         if (!out_hit) out_hit = edge_hits_sphere(sx, sy, sz, bx, by, bz, len, ob);
         if (!in_hit) in_hit = edge_hits_sphere(tx, ty, tz, cx, cy, cz, len, ob);
       }

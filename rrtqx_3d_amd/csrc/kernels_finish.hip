@@ -143,27 +143,40 @@ __global__ __launch_bounds__(kFinThreads, KSORT > kBigSort ? 2 : 8) void nn_fini
   int r0 = 0, r1 = 0;
   {
     const int kmax = max(kk, __shfl_xor(kk, 32));      // the two halves of a wave run the same loops
-    for (int j = 0; j < min(kmax, 32); ++j) {
-      const int o = __shfl(m0, j, 32);
-      r0 += (o < m0) ? 1 : 0;
-      r1 += (o < m1) ? 1 : 0;
-    }
-    for (int j = 32; j < kmax; ++j) {
-      const int o = __shfl(m1, j - 32, 32);
-      r0 += (o < m0) ? 1 : 0;
-      r1 += (o < m1) ? 1 : 0;
+    if (kmax <= 32) {
+      // the usual case, no second entry in either half of the wave: half the compares, four entries per round
+      // (slots past a list hold index INT_MAX, which ranks below nothing)
+      const int kr = (kmax + 3) & ~3;
+      for (int j = 0; j < kr; j += 4) {
+        const int o0 = __shfl(m0, j, 32), o1 = __shfl(m0, j + 1, 32), o2 = __shfl(m0, j + 2, 32), o3 = __shfl(m0, j + 3, 32);
+        r0 += ((o0 < m0) ? 1 : 0) + ((o1 < m0) ? 1 : 0) + ((o2 < m0) ? 1 : 0) + ((o3 < m0) ? 1 : 0);
+      }
+    } else {
+      for (int j = 0; j < 32; ++j) {
+        const int o = __shfl(m0, j, 32);
+        r0 += (o < m0) ? 1 : 0;
+        r1 += (o < m1) ? 1 : 0;
+      }
+      for (int j = 32; j < kmax; ++j) {
+        const int o = __shfl(m1, j - 32, 32);
+        r0 += (o < m0) ? 1 : 0;
+        r1 += (o < m1) ? 1 : 0;
+      }
     }
   }
   double nbest = d0;
   int nbest_i = m0;
   if (a.nearest_idx) {
+    // lexicographic minimum of (d2, index) over the half wave: the smallest d2 first (no NaN among confirmed
+    // hits; empty slots hold +inf), then the lowest index among the lanes that attain it
     if ((d1 < nbest) || (d1 == nbest && m1 < nbest_i)) { nbest = d1; nbest_i = m1; }
+    double dm = nbest;
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-      const double ob = __shfl_xor(nbest, off);
-      const int oi = __shfl_xor(nbest_i, off);
-      if ((ob < nbest) || (ob == nbest && oi < nbest_i)) { nbest = ob; nbest_i = oi; }
-    }
+    for (int off = 16; off > 0; off >>= 1) dm = fmin(dm, __shfl_xor(dm, off));
+    int ci = (nbest == dm) ? nbest_i : kInt;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) ci = min(ci, __shfl_xor(ci, off));
+    nbest = dm; nbest_i = ci;
   }
 
   // ---- offsets of this workgroup's queries ----
@@ -178,17 +191,27 @@ __global__ __launch_bounds__(kFinThreads, KSORT > kBigSort ? 2 : 8) void nn_fini
   }
   if (!qv && hl == 0) sm.kfull[hw] = 0;
   __syncthreads();
-  if (t == 0) {
+  if (wave == 0) {
+    // the sixteen list starts: a scan over lanes 0 .. 15 (one thread walking the sixteen lengths kept the other
+    // fifteen half waves waiting at the next barrier)
     long long p = 0;
     if (a.prescattered) {
       p = a.offsets[q0];
     } else {
       for (int w = 0; w < kFinThreads / 64; ++w) p += sm.red[w];
     }
-    unsigned tm = 0u;
-    for (int k = 0; k < kFinQ; ++k) { sm.off[k] = p; p += sm.kfull[k]; tm |= sm.todo[k] ? (1u << k) : 0u; }
-    sm.off[kFinQ] = p;
-    sm.todo_mask = tm;
+    const int kf = lane < kFinQ ? sm.kfull[lane] : 0;
+    const int td = lane < kFinQ ? sm.todo[lane] : 0;
+    long long v = kf;
+#pragma unroll
+    for (int off = 1; off < kFinQ; off <<= 1) {
+      const long long o = __shfl_up(v, off);
+      if (lane >= off) v += o;
+    }
+    if (lane < kFinQ) sm.off[lane] = p + v - kf;
+    if (lane == kFinQ - 1) sm.off[kFinQ] = p + v;
+    const unsigned long long tmb = __ballot(td != 0);
+    if (lane == 0) sm.todo_mask = (unsigned)tmb;
   }
   __syncthreads();
   if (!a.prescattered && t <= kFinQ) {

@@ -484,6 +484,8 @@ struct TileLds {
   int sqn[2];                  // (sample, sphere) pairs the screen left over, one queue per sample-pass wave
   int sq[2][64];
   int ssl[kTileB][kSphListCap];
+  SphRec ssr[kTileB][kSphListCap];   // ... and their records, fetched by the sample pass (the hand-out's edge tests
+                                     //     then wait for the neighbour's coordinates only)
 };
 
 // the (x, y) cell structure of the sorted part of the slab index
@@ -514,7 +516,7 @@ __device__ __forceinline__ int tile_edge_eval(const ExtendDev &x, const TileLds<
   if (__ballot(need) == 0ull) return 0;
   const typename QRecT<D>::type c = sm.cp[cl];
   bool ho, hi;
-  edge_flags(x, need, c.x, c.y, c.z, nd.x, nd.y, nd.z, sqrt_rn(d2), sm.snl[cl], sm.ssl[cl], ho, hi);
+  edge_flags(x, need, c.x, c.y, c.z, nd.x, nd.y, nd.z, sqrt_rn(d2), sm.snl[cl], sm.ssl[cl], ho, hi, sm.ssr[cl]);
   return (ho ? 1 : 0) | (hi ? 2 : 0);
 }
 template <int D>
@@ -814,10 +816,11 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
             auto exact = [&](int cl, int j) {
               const typename QRecT<D>::type c = sm.cp[cl];
               bool listed;
+              const SphRec rec = x.sph[j];          // (requested beside the sample record, used if listed)
               if (sample_exact(x, j, c.x, c.y, c.z, sm.sbase[cl], &listed)) sm.sbad[cl] = 1;
               if (listed) {
                 const int at = atomicAdd(&sm.snl[cl], 1);
-                if (at < kSphListCap) sm.ssl[cl][at] = j;
+                if (at < kSphListCap) { sm.ssl[cl][at] = j; sm.ssr[cl][at] = rec; }
               }
             };
             // the tile's probes: lane cl < 16 of this wave holds sample cl's, the loop below takes them from
@@ -835,9 +838,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
               if (pv) { u = tp[2 * pr]; v = tp[2 * pr + 1]; }
               const f32x2 ux = {u.x, u.y}, uy = {u.z, u.w}, uz = {v.x, v.y}, ur = {v.z, v.w};
               const bool va = pv && 2 * pr < x.m, vb = pv && 2 * pr + 1 < x.m;
-#pragma unroll
-              for (int cl = 0; cl < kTileB; ++cl) {
-                if (cl >= nsamp) break;                 // wave-uniform
+              for (int cl = 0; cl < nsamp; ++cl) {    // (wave-uniform: the probes come by lane number)
                 const float px = __int_as_float(__builtin_amdgcn_readlane(ipx, cl));
                 const float py = __int_as_float(__builtin_amdgcn_readlane(ipy, cl));
                 const float pz = __int_as_float(__builtin_amdgcn_readlane(ipz, cl));

@@ -149,6 +149,63 @@ def test_cull_per_query_radii_on_the_slab_boundary(oracle):
         _both_modes(ctx, Q, r, _oracle_lists(tree, Q, r))
 
 
+def test_cull_third_coordinate_bins(oracle):
+    """the sorted part is also cut by bins of the third coordinate: nodes straight above / below a query at the
+    radius to the ulp (the edge of a tile's reach in z), flat and nearly flat trees, non-finite third coordinates,
+    a tree that is a thin tall column"""
+    rng = np.random.default_rng(12)
+    cases = []
+    n = 24_000
+    pts = rng.uniform(-50, 50, (n, 3))
+    Q = rng.uniform(-50, 50, (400, 3))
+    r = rng.uniform(0.5, 9.0, 400)
+    for k in range(4, 200):
+        rel = rng.choice([0.0, 1e-16, -1e-16, 2e-16, -2e-16, 1e-15, -1e-15])
+        pts[k] = Q[k] + [0.0, 0.0, r[k] * (1.0 + rel) * rng.choice([-1.0, 1.0])]
+    cases.append((pts, Q, r))
+    # flat (one bin), nearly flat (extent far below the (x, y) extent: the copies are ordered in (x, y) only)
+    p = rng.uniform(-50, 50, (n, 3)); p[:, 2] = 3.0
+    cases.append((p, np.concatenate([rng.uniform(-50, 50, (200, 2)), rng.uniform(0, 6, (200, 1))], axis=1), 4.0))
+    p = rng.uniform(-50, 50, (n, 3)); p[:, 2] = rng.uniform(0, 1.0, n)
+    cases.append((p, np.concatenate([rng.uniform(-50, 50, (200, 2)), rng.uniform(-2, 3, (200, 1))], axis=1), 2.5))
+    # inf / NaN / huge third coordinates among nodes and queries
+    p = rng.uniform(-20, 20, (n, 3))
+    p[70, 2] = np.inf; p[80, 2] = np.nan; p[90, 2] = -np.inf; p[100, 2] = 1e300; p[110, 2] = -1e300
+    q = rng.uniform(-20, 20, (300, 3))
+    q[0, 2] = np.nan; q[1, 2] = np.inf; q[2, 2] = 1e300; q[3, 2] = -np.inf
+    cases.append((p, q, 3.0))
+    # a column: tiny (x, y) extent, long in z
+    p = np.concatenate([rng.uniform(-0.5, 0.5, (n, 2)), rng.uniform(-500, 500, (n, 1))], axis=1)
+    cases.append((p, np.concatenate([rng.uniform(-1, 1, (300, 2)), rng.uniform(-520, 520, (300, 1))], axis=1), 1.5))
+    for pts, Q, r in cases:
+        tree = oracle.KDTree(3)
+        tree.insert_many(pts)
+        with Context(3) as ctx:
+            ctx.nodes_append(pts)
+            units = _both_modes(ctx, Q, r, _oracle_lists(tree, Q, r))
+            assert units > 0
+
+
+def test_cull_more_than_1024_chunks():
+    """a tree of more than 1024 chunks (the chunk list of a tile is built in windows) searched with the sorted
+    part listed as groups, before and after an appended batch: culled == brute force"""
+    n, nq = 560_000, 3000
+    rng = np.random.default_rng(13)
+    pts = rng.uniform(-70, 70, (n + 20_000, 3))
+    Q = rng.uniform(-70, 70, (nq, 3))
+    with Context(3) as ctx:
+        ctx.nodes_append(pts[:n])
+        for stage in range(2):
+            outs = []
+            for mode in (2, 0):
+                ctx.set_option(_capi.RRTX_OPT_NN_CULL, mode)
+                outs.append(ctx.nn_radius(Q, 3.0))
+            for a, b in zip(*outs):
+                assert np.array_equal(a, b)
+            assert outs[0][0][-1] > nq
+            ctx.nodes_append(pts[n:])          # a sorted run behind more than 1024 chunks
+
+
 def test_cull_extend_candidates_same_as_unculled():
     n, nq = 40_000, 1500
     pts, Q, sph = synth.nodes(n, 3), synth.queries(nq, 3), synth.spheres(64)
