@@ -413,6 +413,8 @@ __device__ bool edge_hits_polygon(double ax, double ay, double bx, double by, do
 
 // (index_before_time, transform_obs_to_time, edge_hits_moving: collide_device.hpp, shared with kernels_dubins.hip)
 
+constexpr int kPolyWaveCand = 256;     // candidate obstacles a wave lists (more: the whole list is walked)
+constexpr int kPolyWaveSamples = 16;   // ... for at most this many samples per wave
 // per-wave scratch of edges_polygons_kernel: the wave's 64 edges, the survivor masks of the current
 // group of 32 obstacles with their prefix sum, and each edge's first hit (list position)
 struct PolyWave {
@@ -421,6 +423,8 @@ struct PolyWave {
   int pre[65];
   unsigned cand[64];
   int first[64];
+  int jidx[32];        // current group: list position of each of its obstacles
+  short wc[kPolyWaveCand];   // CSR mode: the obstacles any edge of the wave can reach (list positions, ascending)
 };
 
 // Second edge source of edges_polygons_kernel: the candidate edges of extend() straight from the CSR
@@ -486,6 +490,52 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
   __shared__ PolyWave s_w[4];
   PolyWave &w = s_w[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
+  // CSR mode: the 64 edges of a wave belong to a few consecutive samples (the CSR is ordered by sample), and every
+  // point of a candidate edge lies within the edge's length of its sample.  An obstacle whose bounding circle
+  // (inflated by the robot radius, as in the box test below) stays farther than the wave's longest edge from
+  // every one of those samples fails explicitEdgeCheck2D's first test for every edge of the wave: it is left
+  // out of the walk.  What remains (typically a dozen of 256) is walked exactly as before, in list order.
+  int n_walk = m_end - m_begin;
+  bool listed = false;
+  if (csr.q) {
+    const unsigned long long amask = __ballot(act);
+    const int lf = __ffsll((long long)amask) - 1, ll = 63 - __clzll((long long)amask);
+    const int qmine = act ? csr.owner[i >> 1] : 0;
+    const int s0 = __builtin_amdgcn_readlane(qmine, lf), s1 = __builtin_amdgcn_readlane(qmine, ll);
+    double l2 = 0.0;
+    if (act) { const double ex = bx - ax, ey = by - ay; l2 = ex * ex + ey * ey; }
+    const bool fin = (l2 - l2 == 0.0);               // false for NaN / inf lengths
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) l2 = fmax(l2, __shfl_xor(l2, off));
+    double lmax = sqrt_rn(l2) * (1.0 + 1e-9);
+    if (__ballot(!fin) != 0ull) lmax = __builtin_inf();          // a non-finite edge: keep everything
+    if (s1 >= s0 && s1 - s0 < kPolyWaveSamples) {
+      int nc = 0;                                                  // wave-uniform
+      for (int j0 = m_begin; j0 < m_end; j0 += 64) {
+        const int j = j0 + lane;
+        bool keep = false;
+        if (j < m_end) {
+          const int kind = (int)meta[4 * j + 3];
+          if (kind == 6 || kind == 7) keep = true;               // no bounding test for obstacles that move (:1532)
+          else {
+            const double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
+            const double R = fabs(robot_radius + meta[4 * j + 2]) * (1.0 + 1e-9) + 1e-9 * (1.0 + fabs(cx) + fabs(cy));
+            for (int sidx = s0; sidx <= s1; ++sidx) {
+              const double sx = csr.q[(size_t)sidx * stride], sy = csr.q[(size_t)sidx * stride + 1];   // wave-uniform
+              const double ddx = cx - sx, ddy = cy - sy;
+              const double bnd = (R + lmax) * (1.0 + 1e-9) + 1e-9 * (fabs(sx) + fabs(sy));
+              keep = keep || !(ddx * ddx + ddy * ddy > bnd * bnd);   // NaN anywhere: kept
+            }
+          }
+        }
+        const unsigned long long km = __ballot(keep);
+        const int at = nc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+        if (keep && at < kPolyWaveCand) w.wc[at] = (short)(j - m_begin);
+        nc += __popcll(km);
+      }
+      if (nc <= kPolyWaveCand && m_end - m_begin < 32768) { listed = true; n_walk = nc; }
+    }
+  }
   w.e[0][lane] = ax; w.e[1][lane] = ay; w.e[2][lane] = at;
   w.e[3][lane] = bx; w.e[4][lane] = by; w.e[5][lane] = bt;
   w.first[lane] = 0x7fffffff;
@@ -500,13 +550,14 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
   }
   bool done = !act;
   int first = -1;
-  for (int j0 = m_begin; j0 < m_end; j0 += 32) {
-    const int jn = min(32, m_end - j0);
-    // boxes of the group's bounding circles (lane b = obstacle j0 + b), widened the same way and
+  for (int g0 = 0; g0 < n_walk; g0 += 32) {
+    const int jn = min(32, n_walk - g0);
+    // boxes of the group's bounding circles (lane b = b-th obstacle of the group), widened the same way and
     // rounded outward to fp32: a pair whose boxes are disjoint fails the reference's first test for
     // certain.  Kinds 6 / 7 have no bounding test (:1532): unbounded box.
     if (lane < jn) {
-      const int j = j0 + lane;
+      const int j = m_begin + (listed ? (int)w.wc[g0 + lane] : g0 + lane);
+      w.jidx[lane] = j;
       const int kind = (int)meta[4 * j + 3];
       const float inf = __builtin_inff();
       float4 o = {-inf, inf, -inf, inf};
@@ -548,7 +599,7 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
           if (w.pre[owner + step] <= p) owner += step;
         unsigned bits = w.cand[owner];
         for (int r = p - w.pre[owner]; r > 0; --r) bits &= bits - 1;
-        const int j = j0 + __ffs((int)bits) - 1;
+        const int j = w.jidx[__ffs((int)bits) - 1];
         const double eax = w.e[0][owner], eay = w.e[1][owner], ebx = w.e[3][owner], eby = w.e[4][owner];
         const int kind = (int)meta[4 * j + 3];
         bool h;
