@@ -188,13 +188,13 @@ class Context:
                                                obstacle, _capi._ptr(hit), _capi._ptr(first)))
         return hit, first
 
-    def points_check(self, p, robot_radius: float, kind: int = 0, quick: bool = True):
+    def points_check(self, p, robot_radius: float, kind: int = 0, quick: bool = True, want_clearance: bool = True):
         p = f64(p, (-1, self.dim))
         n = p.shape[0]
         unsafe = np.empty(n, dtype=np.uint8)
-        clr = np.empty(n, dtype=np.float64)
+        clr = np.empty(n, dtype=np.float64) if want_clearance else None
         self._check(self._lib.rrtx_points_check(self._h, kind, _capi._ptr(p), n, robot_radius, 1 if quick else 0,
-                                                _capi._ptr(unsafe), _capi._ptr(clr)))
+                                                _capi._ptr(unsafe), _capi._ptr(clr) if want_clearance else None))
         return unsafe, clr
 
     # ---- steering -------------------------------------------------------------------------

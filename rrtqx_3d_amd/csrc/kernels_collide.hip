@@ -771,6 +771,7 @@ __global__ __launch_bounds__(256) void points_polygons_kernel(const double *__re
     const bool valid = j < m;
     double rad = 0.0, dx = 0.0, dy = 0.0, tdc = 0.0;
     int kind = 0;
+    bool near = true;
     if (valid) {
       double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
       rad = meta[4 * j + 2];
@@ -780,8 +781,13 @@ __global__ __launch_bounds__(256) void points_polygons_kernel(const double *__re
         cx = cx + dx; cy = cy + dy;
       }
       tdc = sqrt_rn(sq2(cx, cy, px, py)) - robot_radius;       // distance from the robot boundary to the centre
+      // Only the flag is wanted (no certificate): an obstacle whose bounding circle the robot clears by a margin
+      // far above any rounding can neither be "bad" nor, through the certificate, make the loop skip one that
+      // is (its own distance exceeds the margin, and an obstacle within the margin is skipped only by a
+      // certificate below it) -- so the loop runs over the near obstacles alone, same order, same arithmetic.
+      if (!clearance && (tdc - rad > 1e-6 * (1.0 + fabs(cx) + fabs(cy) + fabs(px) + fabs(py) + fabs(rad)))) near = false;
     }
-    unsigned long long todo = __ballot(valid);
+    unsigned long long todo = __ballot(valid && near);
     for (;;) {
       const unsigned long long c = __ballot(valid && !(tdc - rad > ret_cert)) & todo;
       if (c == 0ull) break;

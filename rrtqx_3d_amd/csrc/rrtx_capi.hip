@@ -993,8 +993,9 @@ int rrtx_points_check(rrtx_ctx *ctx, int kind, const double *p, int64_t np, doub
   if (rc) return rc;
   RRTX_HIP(ctx, ctx->ws_out_u8a.ensure((size_t)np));
   RRTX_HIP(ctx, ctx->ws_out_f64.ensure(sizeof(double) * (size_t)np));
+  // (no certificate wanted: the polygon check then only walks the obstacles near each point)
   rc = rrtx_points_check_dev(ctx, kind, ctx->ws_q.as<double>(), np, robot_radius, quick,
-                             ctx->ws_out_u8a.as<uint8_t>(), ctx->ws_out_f64.as<double>());
+                             ctx->ws_out_u8a.as<uint8_t>(), clearance ? ctx->ws_out_f64.as<double>() : nullptr);
   if (rc) return rc;
   RRTX_HIP(ctx, hipMemcpyAsync(unsafe, ctx->ws_out_u8a.p, (size_t)np, hipMemcpyDeviceToHost, ctx->stream));
   if (clearance)

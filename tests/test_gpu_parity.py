@@ -425,6 +425,54 @@ def test_polygons_edges_and_points(oracle):
         assert np.array_equal(clr, rc)
 
 
+def test_polygon_point_flag_without_certificate_matches_full_check(oracle):
+    """explicitPointCheck with no certificate wanted walks only the obstacles near each point: the flag must be
+    the one the full sequential emulation returns -- random points, points at the robot radius from a polygon
+    edge or a ball to within ulps, points on bounding circles, moving obstacles, non-finite points."""
+    rng = np.random.default_rng(78)
+    polys, kinds, paths = [], [], []
+    for i in range(200):
+        c = rng.uniform(-40, 40, 2)
+        ang = np.sort(rng.uniform(0, 2 * np.pi, rng.integers(3, 7)))
+        polys.append(c + np.c_[np.cos(ang), np.sin(ang)] * rng.uniform(0.5, 6))
+        k = 1 if i % 5 == 0 else (6 if i % 11 == 3 else 3)
+        kinds.append(k)
+        paths.append(np.c_[rng.uniform(-10, 10, (4, 2)), np.sort(rng.uniform(0, 30, 4))] if k == 6 else None)
+    ps = oracle.PolygonSet(polys, kinds=kinds, paths=paths)
+    cr = ps.centre_radius()
+    n = 30_000
+    P = np.zeros((n, 3))
+    P[:, :2] = rng.uniform(-45, 45, (n, 2))
+    P[:, 2] = rng.uniform(0, 30, n)
+    rr = 0.5
+    for i in range(6000):                       # at distance rr (1 +- ulps) from an edge of a static polygon
+        j = i % 200
+        if kinds[j] != 3:
+            continue
+        v = polys[j]
+        a, b = v[i % len(v)], v[(i + 1) % len(v)]
+        t = rng.uniform(0.1, 0.9)
+        e = b - a
+        nrm = np.array([e[1], -e[0]]) / np.hypot(*e)
+        P[i, :2] = a + t * e + nrm * rr * (1.0 + (i % 9 - 4) * 2.0 ** -51) * (1 if i % 2 else -1)
+    for i in range(6000, 9000):                 # on the bounding circle inflated by the robot radius, +- ulps
+        j = i % 200
+        t = rng.uniform(0, 2 * np.pi)
+        P[i, :2] = cr[j, :2] + np.array([np.cos(t), np.sin(t)]) * (cr[j, 2] + rr) * (1.0 + (i % 7 - 3) * 2.0 ** -52)
+    P[9000] = [np.nan, 0, 0]; P[9001] = [np.inf, 1, 2]; P[9002] = [1e300, -1e300, 5]
+    with Context(3) as ctx:
+        ctx.nodes_append(synth.nodes(16, 3))
+        ctx.polygons_set(polys, kinds=kinds, paths=paths)
+        full, clr = ctx.points_check(P, rr, kind=1)
+        flag, none = ctx.points_check(P, rr, kind=1, want_clearance=False)
+        assert none is None
+        assert np.array_equal(full, flag)
+        assert 0 < full.sum() < n
+        for i in list(range(0, 9003, 37)) + [9000, 9001, 9002]:       # and the full check is the oracle's
+            u, c = oracle.point_check_polygons(ps, P[i], rr)
+            assert full[i] == u and (clr[i] == c or (np.isnan(clr[i]) and np.isnan(c)))
+
+
 def test_polygons_edges_degenerate_and_boundary_inputs(oracle):
     """The polygon edge kernel drops far obstacles with a box test before the reference's tests run;
     that shortcut must never change an answer: NaN / inf / huge coordinates, zero-length edges, edges
