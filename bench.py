@@ -567,7 +567,7 @@ def main():
             else "nn_scan_kernel<3>"
         bytes_req = node_visits * 16 + nb * 48 + k_last * (192 + 16 + 8)
         alg_gbs = bytes_alg / (scan_ms * 1e-3) / 1e9
-        traffic, traffic_src, frac_traffic, hbm_gbs = None, None, None, None
+        traffic, traffic_src, frac_traffic, hbm_gbs, issue = None, None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if args.config == "C4" and args.nn_filter and os.path.exists(tpath) and world == 1:
             tj = json.load(open(tpath))
@@ -578,6 +578,17 @@ def main():
                 traffic_src = f"profiles/r02_traffic.json (rocprofv3 PMC passes, sources {tj['source_sha16']})"
                 hbm_gbs = traffic / (scan_ms * 1e-3) / 1e9
                 frac_traffic = hbm_gbs / HBM_PEAK_GBS
+                if tj.get("SQ_INSTS_VALU_per_launch"):
+                    # what bounds this kernel: a SIMD issues about one wave instruction per 4 cycles (MI355X_MICROARCH.md,
+                    # measured in DESIGN.md 4), 1024 SIMDs at 2.4 GHz
+                    insts = tj["SQ_INSTS_VALU_per_launch"] + tj["SQ_INSTS_SALU_per_launch"]
+                    floor_us = insts / 1024.0 * 4.0 / 2.4e3
+                    issue = {"valu_wave_insts_per_launch": tj["SQ_INSTS_VALU_per_launch"],
+                             "salu_wave_insts_per_launch": tj["SQ_INSTS_SALU_per_launch"],
+                             "issue_floor_us": floor_us, "frac_of_kernel_time": floor_us / (scan_ms * 1e3),
+                             "wait_ratio": tj.get("wait_ratio"),
+                             "note": "VALU + SALU wave instructions / 1024 SIMDs x 4 cycles / 2.4 GHz against the kernel's "
+                                     "duration; wait_ratio = SQ_WAIT_ANY / SQ_WAVE_CYCLES (same PMC passes as `traffic`)"}
         roof_bf = None
         bf = extras.get("bf")
         if bf:
@@ -618,19 +629,24 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_GBps": alg_gbs, "algorithmic_bytes_per_launch": bytes_alg,
                 "requested_bytes_per_launch": bytes_req, "frac_requested": bytes_req / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "hbm_GBps": hbm_gbs, "frac_traffic": frac_traffic,
+                "hbm_GBps": hbm_gbs, "frac_traffic": frac_traffic, "issue": issue,
                 "tile_q": tile_q, "kernel_ms": scan_ms, "timed_launches": int(st.launches_nn_scan),
                 "timing": f"HIP events around every {main_r['sample_every']}th launch inside the timed region",
                 "culled_units": units, "node_visits_per_launch": node_visits,
                 "node_visits_unculled": n_tiles * N,
                 "pairs_per_s": nb * N / (scan_ms * 1e-3),
                 "valu_fp64_frac": (nb * N * 9 / (scan_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS) if not args.nn_filter else None,
-                "note": ("`achieved` / `frac` are the SURVEY 8(d) CONTRACT figure (chunks streamed x 512 nodes x 24 B per node "
-                         "visit at T_q = tile_q, / kernel time) -- algorithmic bytes, not bytes moved from HBM.  The kernel "
-                         "streams the 16-B fp32 screen record of a node (`frac_requested`), its working set is L2-resident "
-                         "and the counters (`traffic`, `frac_traffic`) are the HBM-side truth; the kernel is issue / latency "
-                         "bound, see DESIGN.md 4.1.  The same kernel also decides both collision flags of every neighbour "
-                         "(fused extend path).") if culled else
+                "note": ("`achieved` / `frac` are the SURVEY 8(d) CONTRACT figure (node visits x 24 B per visit at T_q = tile_q, "
+                         "/ kernel time; a visit = one node screened against the tile's copies, counted in groups of eight) -- "
+                         "algorithmic bytes, not bytes moved from HBM.  The figure counts work the kernel does NOT avoid: since "
+                         "the tiles are also cut by the third coordinate the kernel visits 3.5x fewer nodes than the build of "
+                         "the middle of round 2 (`culled_units` 11 425 -> ~3 250) and is 1.35x faster, so its contract "
+                         "fraction fell from 0.44 to ~0.19 while the edges/s rose; the brute-force form of the search "
+                         "(`roofline_bruteforce`, north_star's kernel) is the one the contract figure describes.  The kernel "
+                         "streams the 16-B fp32 screen record of a node (`frac_requested`), its working set is L2-resident, "
+                         "the counters (`traffic`, `frac_traffic`) are the HBM-side truth and `issue` says what bounds it "
+                         "(instruction issue + the dependency chain of one workgroup), see DESIGN.md 4.1.  The same kernel "
+                         "also decides both collision flags of every neighbour (fused extend path).") if culled else
                         "VALU-issue bound, node arrays are L2-resident; see DESIGN.md",
             },
             "roofline_bruteforce": roof_bf,

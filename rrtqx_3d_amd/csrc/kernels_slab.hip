@@ -228,14 +228,16 @@ int slab_append_run(rrtx_ctx *ctx, int64_t base, int64_t n) {
   return RRTX_OK;
 }
 
-// When to rebuild: a search pays for every chunk of the appended tail (its nodes are in arrival order,
-// so each tail chunk spans the world and every tile screens it: ~0.2 us per (tile in flight, chunk)),
-// a rebuild costs ~30 us of launches + ~0.6 ns per node.  Chunks of a sorted run (slab_append_run) are strips of
-// the grid, of which a tile's reach touches about one in six.  The searches since the last rebuild run up a
-// debt of what the tail has cost them; the index is rebuilt when the debt exceeds the price of a
-// rebuild (and always before the tail outgrows half the tree).  Single appends between single queries
-// thus rebuild rarely, whole batches appended between batched searches every handful of calls.  Only
-// the moment changes; no result depends on it.
+// When to rebuild: a search pays for every chunk of the appended tail.  An unsorted tail chunk (nodes in arrival
+// order) spans the world, so every tile screens it: one more 512-node unit per tile, ~1 us per search of a
+// 16384-sample batch (1024 tiles in flight).  A chunk of a sorted run (slab_append_run) is a strip of the grid,
+// of which a tile's reach touches about one in six: ~5 units per tile and run of 32 chunks, ~0.16 us per run
+// chunk (tools/steady_probe.py).  A rebuild costs ~40 us of launches + ~0.12 ns per node (the sort keys carry
+// the bin of the third coordinate, so the rank atomics spread over 32 x more counters than in round 1: 83 -> 15 us
+// at 400 k nodes).  The searches since the last rebuild run up a debt of what the tail has cost them; the index
+// is rebuilt when the debt exceeds the price of a rebuild (and always before the tail outgrows half the tree).
+// Single appends between single queries thus rebuild rarely, whole batches appended between batched searches
+// every five or six calls.  Only the moment changes; no result depends on it.
 int slab_refresh(rrtx_ctx *ctx, long long n_tiles) {
   const int64_t n = ctx->n_nodes;
   const int64_t tail = n - ctx->sl_n_sorted;
@@ -243,9 +245,10 @@ int slab_refresh(rrtx_ctx *ctx, long long n_tiles) {
   if (tail <= floor_tail) return RRTX_OK;
   const double tail_chunks = (double)((tail + kSlabChunk - 1) / kSlabChunk);
   const double run_chunks = ctx->sl_run_chunks < tail_chunks ? ctx->sl_run_chunks : tail_chunks;
-  const double rounds = n_tiles > 1024 ? (double)n_tiles / 1024.0 : 1.0;
-  ctx->sl_debt_us += 0.2 * ((tail_chunks - run_chunks) + run_chunks / 6.0) * rounds;
-  const double rebuild_us = 30.0 + 0.6e-3 * (double)n;
+  // (tiles in flight: 1024; a small batch spreads a tile's units over several workgroups)
+  const double rounds = n_tiles > 64 ? (double)n_tiles / 1024.0 : 1.0 / 16.0;
+  ctx->sl_debt_us += (1.0 * (tail_chunks - run_chunks) + 0.16 * run_chunks) * rounds;
+  const double rebuild_us = 40.0 + 0.12e-3 * (double)n;
   if (ctx->sl_n_sorted > 0 && tail <= n / 2 && ctx->sl_debt_us < rebuild_us) return RRTX_OK;
   ctx->sl_debt_us = 0.0;
   ctx->sl_run_chunks = 0.0;

@@ -37,8 +37,16 @@ fetch, n = get("p3_per_kernel_avg.csv", "FETCH_SIZE")
 write, _ = get("p4_per_kernel_avg.csv", "WRITE_SIZE")
 hit, _ = get("p5_per_kernel_avg.csv", "TCC_HIT_sum")
 miss, _ = get("p5_per_kernel_avg.csv", "TCC_MISS_sum")
+valu, _ = get("p1_per_kernel_avg.csv", "SQ_INSTS_VALU")
+salu, _ = get("p1_per_kernel_avg.csv", "SQ_INSTS_SALU")
+wcyc, _ = get("p1_per_kernel_avg.csv", "SQ_WAVE_CYCLES")
+waves, _ = get("p1_per_kernel_avg.csv", "SQ_WAVES")
+wait, _ = get("p2_per_kernel_avg.csv", "SQ_WAIT_ANY")
 out = {
     "kernel": kern, "config": "C4", "launches_averaged": n,
+    "SQ_INSTS_VALU_per_launch": valu, "SQ_INSTS_SALU_per_launch": salu, "SQ_WAVES_per_launch": waves,
+    "SQ_WAVE_CYCLES_per_launch": wcyc, "SQ_WAIT_ANY_per_launch": wait,
+    "wait_ratio": (wait / wcyc) if wait and wcyc else None,
     "FETCH_SIZE_bytes_per_launch": fetch * 1024, "WRITE_SIZE_bytes_per_launch": write * 1024,
     "traffic_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
     "l2_hit_rate": hit / (hit + miss) if hit is not None and hit + miss > 0 else None,
