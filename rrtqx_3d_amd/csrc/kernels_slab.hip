@@ -126,14 +126,6 @@ __global__ __launch_bounds__(256) void chunk_range_kernel(const double *__restri
 constexpr int kRunMaxCells = 4096;
 constexpr int kRunLdsChunks = 512;
 
-__global__ void run_rank_kernel(const double *__restrict__ nx, const double *__restrict__ ny, long long base, int n,
-                                const SlabParams *__restrict__ sp, int *__restrict__ hist, int2 *__restrict__ sr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int b = cell_of(nx[base + i], ny[base + i], sp->x0, sp->inv_wx, sp->Kx, sp->y0, sp->inv_wy, sp->Ky);
-  sr[i] = make_int2(b, atomicAdd(&hist[b], 1));
-}
-
 // every workgroup scans the cell histogram itself (at most kRunMaxCells counters: cheaper than a launch)
 __global__ __launch_bounds__(256) void run_place_kernel(
     long long base, int n, int K, const int2 *__restrict__ sr, const int *__restrict__ hist, const float *__restrict__ fx,
@@ -141,8 +133,10 @@ __global__ __launch_bounds__(256) void run_place_kernel(
     int dim, float *__restrict__ sx, float *__restrict__ sy, float *__restrict__ sz, float *__restrict__ sw,
     float *__restrict__ spp, int32_t *__restrict__ sid, const double *__restrict__ nx, const double *__restrict__ ny,
     const double *__restrict__ nz, const double *__restrict__ nw, double *__restrict__ dx, double *__restrict__ dy,
-    double *__restrict__ dz, double *__restrict__ dw, ChunkExt *__restrict__ chunk_ext) {
+    double *__restrict__ dz, double *__restrict__ dw, ChunkExt *__restrict__ chunk_ext, int *__restrict__ hist_next) {
   __shared__ int start[kRunMaxCells];
+  // the histogram the NEXT run will count in (last read by the run before this one) is cleared on the way
+  for (int k = blockIdx.x * 256 + threadIdx.x; k <= kRunMaxCells; k += gridDim.x * 256) hist_next[k] = 0;
   __shared__ int wsum[4];
   __shared__ unsigned long long ext[kRunLdsChunks][4];      // the workgroup's share of the run's chunk extents
   const long long ch0 = base / kSlabChunk;
@@ -206,22 +200,35 @@ bool slab_run_wanted(const rrtx_ctx *ctx, int64_t n) {
   return ctx->sl_n_sorted > 0 && ctx->ws_slab_params.p && ctx->sl_cells > 0 && ctx->sl_cells <= kRunMaxCells && n >= 1024;
 }
 
-// the slab arrays of nodes [base, base + n) (index-order arrays already written) in cell order
+// before the append kernel of a batch that becomes a sorted run: where that kernel leaves the nodes' (cell, rank)
+int slab_run_prepare(rrtx_ctx *ctx, int64_t n, RunRank *rr) {
+  if (!ctx->ws_run_hist.p) {
+    // two histograms used alternately (a run's place kernel clears the other one), zero from the start
+    RRTX_HIP(ctx, ctx->ws_run_hist.ensure(sizeof(int) * 2 * (size_t)(kRunMaxCells + 1)));
+    RRTX_HIP(ctx, hipMemsetAsync(ctx->ws_run_hist.p, 0, sizeof(int) * 2 * (size_t)(kRunMaxCells + 1), ctx->stream));
+  }
+  RRTX_HIP(ctx, ctx->ws_run_sr.ensure(sizeof(int2) * (size_t)n));
+  rr->sp = ctx->ws_slab_params.as<SlabParams>();
+  rr->hist = ctx->ws_run_hist.as<int>() + (size_t)ctx->run_hist_flip * (kRunMaxCells + 1);
+  rr->sr = ctx->ws_run_sr.as<int2>();
+  return RRTX_OK;
+}
+
+// the slab arrays of nodes [base, base + n) (index-order arrays and (cell, rank) already written by the append
+// kernel) in cell order
 int slab_append_run(rrtx_ctx *ctx, int64_t base, int64_t n) {
   hipStream_t st = ctx->stream;
   const int K = ctx->sl_cells;
-  RRTX_HIP(ctx, ctx->ws_run_hist.ensure(sizeof(int) * (size_t)(K + 1)));
-  RRTX_HIP(ctx, ctx->ws_run_sr.ensure(sizeof(int2) * (size_t)n));
-  RRTX_HIP(ctx, hipMemsetAsync(ctx->ws_run_hist.p, 0, sizeof(int) * (size_t)(K + 1), st));
   const int wi = ctx->dim == 4 ? 3 : 2;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  hipLaunchKernelGGL(run_rank_kernel, grid, block, 0, st, ctx->nodes[0], ctx->nodes[1], (long long)base, (int)n,
-                     ctx->ws_slab_params.as<SlabParams>(), ctx->ws_run_hist.as<int>(), ctx->ws_run_sr.as<int2>());
+  int *hist = ctx->ws_run_hist.as<int>() + (size_t)ctx->run_hist_flip * (kRunMaxCells + 1);
+  int *hist_next = ctx->ws_run_hist.as<int>() + (size_t)(ctx->run_hist_flip ^ 1) * (kRunMaxCells + 1);
+  ctx->run_hist_flip ^= 1;
   hipLaunchKernelGGL(run_place_kernel, grid, block, 0, st, (long long)base, (int)n, K, ctx->ws_run_sr.as<int2>(),
-                     ctx->ws_run_hist.as<int>(), ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[wi],
+                     hist, ctx->nodes_f[0], ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[wi],
                      ctx->nodes_pp, ctx->dim, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[wi], ctx->sl_pp, ctx->sl_id,
                      ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[wi], ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2],
-                     ctx->sl_d[wi], reinterpret_cast<ChunkExt *>(ctx->chunk_ext));
+                     ctx->sl_d[wi], reinterpret_cast<ChunkExt *>(ctx->chunk_ext), hist_next);
   RRTX_HIP(ctx, hipGetLastError());
   // chunks of the run (a chunk shared with the batch before counts once)
   ctx->sl_run_chunks += (double)((base + n + kSlabChunk - 1) / kSlabChunk - (base + kSlabChunk - 1) / kSlabChunk);

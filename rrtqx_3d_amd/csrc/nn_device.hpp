@@ -421,7 +421,7 @@ __device__ __forceinline__ void screen8(const typename QRecFT<D>::type &c, const
 // written by slab_params_kernel at every rebuild: the (x, y) grid the sorted part of the slab index
 // is ordered by (cell_of), and inside every cell the Kz equal-width bins of the third coordinate;
 // cell_start[c * Kz + b] = first position of bin b of cell c, cell_start[Kx * Ky * Kz] = sl_n_sorted
-struct SlabParams { double x0, inv_wx, y0, inv_wy, z0, inv_wz; int Kx, Ky, Kz, pad; };
+// (struct SlabParams: rrtx_internal.hpp)
 constexpr int kSlabKz = 32;      // bins of the third coordinate inside a cell
 
 // ------------------------------------------------ exact nearest for one point ------

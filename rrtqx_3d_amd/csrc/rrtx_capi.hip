@@ -178,8 +178,10 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
                                                          double *__restrict__ dz, double *__restrict__ dw,
                                                          double *__restrict__ aos,
                                                          ChunkExt *__restrict__ chunk_ext,
-                                                         unsigned long long *__restrict__ xrange, int slab_later) {
-  // slab_later: the batch's slab entries and chunk extents are written in cell order by slab_append_run
+                                                         unsigned long long *__restrict__ xrange, int slab_later,
+                                                         const RunRank rr) {
+  // slab_later: the batch's slab entries and chunk extents are written in cell order by slab_append_run, for
+  // which this kernel draws every node's (cell, rank in the cell) on the way (rr; one launch less per batch)
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long m = 0ull;
   unsigned long long xlo = ~0ull, xhi = 0ull, ylo = ~0ull, yhi = 0ull, zlo = ~0ull, zhi = 0ull;
@@ -195,6 +197,10 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const double *__restric
       sx[base + i] = fa; sy[base + i] = fb; sz[base + i] = fc;
       dx[base + i] = a; dy[base + i] = b; dz[base + i] = c;
       sid[base + i] = (int32_t)(base + i);
+    }
+    if (slab_later) {
+      const int cell = cell_of(a, b, rr.sp->x0, rr.sp->inv_wx, rr.sp->Kx, rr.sp->y0, rr.sp->inv_wy, rr.sp->Ky);
+      rr.sr[i] = make_int2(cell, atomicAdd(&rr.hist[cell], 1));
     }
     if (a == a) xlo = xhi = enc_ord(a);
     if (b == b) ylo = yhi = enc_ord(b);
@@ -538,6 +544,12 @@ int rrtx_nodes_append_dev(rrtx_ctx *ctx, const double *pos_dev, int64_t n) {
     ctx->origin_set = true;
   }
   const bool as_run = slab_run_wanted(ctx, n);
+  RunRank rr;
+  rr.sp = nullptr; rr.hist = nullptr; rr.sr = nullptr;
+  if (as_run) {
+    rc = slab_run_prepare(ctx, n, &rr);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev,
                      ctx->dim, (long long)n, (long long)ctx->n_nodes, ctx->origin[0], ctx->origin[1], ctx->origin[2],
                      ctx->origin[3], ctx->nodes[0], ctx->nodes[1], ctx->nodes[2],
@@ -545,7 +557,7 @@ int rrtx_nodes_append_dev(rrtx_ctx *ctx, const double *pos_dev, int64_t n) {
                      ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->d_absmax.as<unsigned long long>(),
                      ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp, ctx->sl_id,
                      ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2], ctx->sl_d[ctx->dim == 4 ? 3 : 2], ctx->nodes_aos,
-                     reinterpret_cast<ChunkExt *>(ctx->chunk_ext), ctx->d_xrange.as<unsigned long long>(), as_run ? 1 : 0);
+                     reinterpret_cast<ChunkExt *>(ctx->chunk_ext), ctx->d_xrange.as<unsigned long long>(), as_run ? 1 : 0, rr);
   RRTX_HIP(ctx, hipGetLastError());
   if (as_run) {
     rc = slab_append_run(ctx, ctx->n_nodes, n);

@@ -116,6 +116,7 @@ struct rrtx_ctx {
   double sl_debt_us = 0.0;          // what the appended tail has cost the searches since the last rebuild (estimate)
   rrtx::DevBuf d_xrange;            // uint64[6]: enc_ord of min / max node x, min / max node y, min / max of the third coordinate
   rrtx::DevBuf ws_slab_hist, ws_slab_start, ws_slab_sr, ws_slab_params, ws_run_hist, ws_run_sr;
+  int run_hist_flip = 0;            // the sorted runs alternate between two cell histograms (each run's place kernel clears the other)
 
   // options (rrtx_set_option)
   int opt_nn_filter = 1;            // 1: fp32 prefilter + exact fp64 confirm, 0: exact fp64 scan
@@ -278,6 +279,11 @@ int launch_nn_nearest(rrtx_ctx *ctx, const double *q_dev, int nq, int32_t *idx_d
 int scan_units(rrtx_ctx *ctx, int *units);   // (tile, chunk) units of the last culled range scan
 int slab_refresh(rrtx_ctx *ctx, long long n_tiles);
 bool slab_run_wanted(const rrtx_ctx *ctx, int64_t n);
+// what the append kernel needs to draw the (cell, rank) of every node of a sorted run (kernels_slab.hip)
+// the grid of the slab index, written on the device at every rebuild (slab_params_kernel)
+struct SlabParams { double x0, inv_wx, y0, inv_wy, z0, inv_wz; int Kx, Ky, Kz, pad; };
+struct RunRank { const SlabParams *sp; int *hist; int2 *sr; };
+int slab_run_prepare(rrtx_ctx *ctx, int64_t n, RunRank *rr);
 int slab_append_run(rrtx_ctx *ctx, int64_t base, int64_t n);   // bring the slab index up to date when it pays (kernels_slab.hip)
 constexpr int kSlabChunk = 512;              // node positions per chunk of the slab index
 int launch_edges_spheres(rrtx_ctx *ctx, const double *p0_dev, const double *p1_dev, int64_t ne,
