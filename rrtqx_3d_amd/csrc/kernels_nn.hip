@@ -600,6 +600,24 @@ __device__ __forceinline__ int lane_here() {
   return l;
 }
 __device__ __forceinline__ int wshfl_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+// Inclusive scans over the 64 lanes of a wave with DPP moves (row shifts 1, 2, 4, 8, then the row broadcasts of
+// GFX9): a few cycles per step where a ds_bpermute step is a trip through the LDS pipe.  All lanes active.
+template <bool MAX>
+__device__ __forceinline__ int wave_scan_incl(int v, const int identity) {
+#define RRTX_SCAN_STEP(ctrl, rows)                                                              \
+  {                                                                                             \
+    const int o = __builtin_amdgcn_update_dpp(identity, v, ctrl, rows, 0xf, false);             \
+    v = MAX ? max(v, o) : v + o;                                                                \
+  }
+  RRTX_SCAN_STEP(0x111, 0xf) RRTX_SCAN_STEP(0x112, 0xf) RRTX_SCAN_STEP(0x114, 0xf) RRTX_SCAN_STEP(0x118, 0xf)
+  RRTX_SCAN_STEP(0x142, 0xa) RRTX_SCAN_STEP(0x143, 0xc)
+#undef RRTX_SCAN_STEP
+  return v;
+}
+// the value of the lane before (lane 0: `first`); wave_shr:1
+__device__ __forceinline__ int wave_prev(int v, const int first) {
+  return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
+}
 __device__ __forceinline__ double wshfl_d(double v, int src_lane) {
   const long long b = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffll));
@@ -741,24 +759,11 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
                 const int p0 = tg.cell_start[c * Kz + cz0], p1 = tg.cell_start[c * Kz + cz1 + 1];
                 if (p1 > p0) { g0 = p0 >> 3; g1 = min((p1 - 1) >> 3, g_end - 1); }
               }
-              int run = g1, inc;
-              const int l = lane_here();
-#pragma unroll
-              for (int off = 1; off < 64; off <<= 1) {
-                const int o = wshfl_i(run, l >= off ? l - off : l);
-                if (lane >= off) run = max(run, o);
-              }
-              int before = wshfl_i(run, l >= 1 ? l - 1 : l);
-              if (lane == 0) before = listed_to;
-              before = max(before, listed_to);
+              const int run = wave_scan_incl<true>(g1, -1);          // last group listed up to and including this lane
+              const int before = max(wave_prev(run, listed_to), listed_to);
               g0 = max(g0, before + 1);
               const int cnt = max(g1 - g0 + 1, 0);
-              inc = cnt;
-#pragma unroll
-              for (int off = 1; off < 64; off <<= 1) {
-                const int o = wshfl_i(inc, l >= off ? l - off : l);
-                if (lane >= off) inc += o;
-              }
+              const int inc = wave_scan_incl<false>(cnt, 0);
               const int at = G + inc - cnt;
               for (int j = 0; j < cnt; ++j)
                 if (at + j < kTbGroups) sm.glist[at + j] = g0 + j;

@@ -1,6 +1,7 @@
 """Where a workgroup of nn_tile_kernel spends its time: runs the fused extend() preamble at C4 on the measuring
 build (python -m rrtqx_3d_amd.build --clocks) and prints, per phase boundary, the mean / median / slowest time
-since the workgroup started (100 MHz wall clock, thread 0 of every workgroup).  Optional argument: RRTX_OPT_TUNE."""
+since the workgroup started (100 MHz wall clock, thread 0 of every workgroup).  Optional arguments: RRTX_OPT_TUNE,
+then the number of 16384-node batches appended (as sorted runs) before the measured searches."""
 import ctypes as C
 import os
 import sys
@@ -23,6 +24,13 @@ with Context(3, node_capacity=cfg.n_nodes) as ctx:
         ctx.set_option(_capi.RRTX_OPT_TUNE, int(sys.argv[1]))
     ctx.nodes_append(pts)
     ctx.spheres_set(synth.spheres(cfg.n_obstacles))
+    n_runs = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if n_runs:
+        ctx.extend_candidates(Q, r, 0.5)            # the index is built by the first search
+        rng = np.random.default_rng(5)
+        for _ in range(n_runs):
+            ctx.nodes_append(rng.uniform(-50, 50, (cfg.batch, 3)))
+        print(f"{n_runs} runs appended, {ctx.n_nodes} nodes")
     for _ in range(3):
         out = ctx.extend_candidates(Q, r, 0.5)
     L = _capi.load()
