@@ -576,6 +576,47 @@ def test_extend_candidates_against_polygon_list(oracle, with_moving):
         assert not out0["hit_out"].any() and not out0["sample_unsafe"].any()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_extend_polygon_path_equals_explicit_edge_and_point_checks(seed):
+    """The fused preamble's polygon checks take shortcuts the stand-alone entry points do not (a wave of candidate
+    edges walks only the obstacles near its samples; the sample check evaluates near obstacles only): on random
+    scenes -- many obstacles, balls, moving and inactive ones, short and long radii, samples on top of nodes
+    (zero-length edges), a NaN sample -- both must give what rrtx_edges_check / rrtx_points_check give for the
+    same edges and points (those walk the whole list and are held to the oracle elsewhere)."""
+    rng = np.random.default_rng(900 + seed)
+    m = int(rng.integers(40, 400))
+    polys, kinds, paths, active = [], [], [], []
+    for i in range(m):
+        c = rng.uniform(-50, 50, 2)
+        ang = np.sort(rng.uniform(0, 2 * np.pi, rng.integers(3, 7)))
+        polys.append(c + np.c_[np.cos(ang), np.sin(ang)] * rng.uniform(0.3, 9))
+        k = 1 if i % 7 == 0 else (6 if (seed % 2 == 1 and i % 9 == 4) else 3)
+        kinds.append(k)
+        paths.append(np.c_[rng.uniform(-15, 15, (4, 2)), np.sort(rng.uniform(0, 30, 4))] if k == 6 else None)
+        active.append(0 if i % 13 == 5 else 1)
+    n, b = 30_000, 2500
+    pts = rng.uniform(-50, 50, (n, 3)); pts[:, 2] = rng.uniform(0, 30, n)
+    Q = rng.uniform(-50, 50, (b, 3)); Q[:, 2] = rng.uniform(0, 30, b)
+    Q[:40] = pts[rng.integers(0, n, 40)]                 # samples on nodes
+    Q[40] = [np.nan, 1.0, 2.0]
+    r = float(rng.choice([1.5, 4.0, 9.0]))
+    rr = float(rng.choice([0.0, 0.5, 2.0]))
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        ctx.polygons_set(polys, kinds=kinds, active=active, paths=paths)
+        ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 1)
+        out = ctx.extend_candidates(Q, r, rr)
+        off, idx = out["offsets"], out["idx"]
+        k = len(idx)
+        assert k > b
+        p0, p1 = synth.candidate_edges(Q, pts, off, idx)
+        hit, _ = ctx.edges_check(p0, p1, rr, kind=1)
+        assert np.array_equal(out["hit_out"], hit[:k]) and np.array_equal(out["hit_in"], hit[k:])
+        unsafe, _ = ctx.points_check(Q, rr, kind=1)
+        assert np.array_equal(out["sample_unsafe"], unsafe)
+        assert 0 < hit.sum() < len(hit)
+
+
 def test_polygon_kat_k7(oracle):
     with Context(3) as ctx:
         ctx.nodes_append([[0, 0, 0]])
