@@ -413,6 +413,7 @@ __device__ bool edge_hits_polygon(double ax, double ay, double bx, double by, do
 
 // (index_before_time, transform_obs_to_time, edge_hits_moving: collide_device.hpp, shared with kernels_dubins.hip)
 
+constexpr int kPolyQueue = 512;        // (edge, polygon segment) tests a wave queues
 constexpr int kPolyWaveCand = 256;     // candidate obstacles a wave lists (more: the whole list is walked)
 constexpr int kPolyWaveSamples = 16;   // ... for at most this many samples per wave
 // per-wave scratch of edges_polygons_kernel: the wave's 64 edges, the survivor masks of the current
@@ -424,6 +425,7 @@ struct PolyWave {
   unsigned cand[64];
   int first[64];
   int jidx[32];        // current group: list position of each of its obstacles
+  unsigned pq[kPolyQueue];         // (edge lane | obstacle slot << 6 | segment << 11) of the segment tests to run
   short wc[kPolyWaveCand];   // CSR mode: the obstacles any edge of the wave can reach (list positions, ascending)
 };
 
@@ -593,24 +595,96 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (int p = lane; p < total; p += 64) {
-        int owner = 0;                                     // largest L with pre[L] <= p
-        for (int step = 32; step > 0; step >>= 1)
-          if (w.pre[owner + step] <= p) owner += step;
-        unsigned bits = w.cand[owner];
-        for (int r = p - w.pre[owner]; r > 0; --r) bits &= bits - 1;
-        const int j = w.jidx[__ffs((int)bits) - 1];
-        const double eax = w.e[0][owner], eay = w.e[1][owner], ebx = w.e[3][owner], eby = w.e[4][owner];
-        const int kind = (int)meta[4 * j + 3];
-        bool h;
-        if (kind == 6 || kind == 7)
-          h = edge_hits_moving(eax, eay, w.e[2][owner], ebx, eby, w.e[5][owner], robot_radius, meta[4 * j + 0],
-                               meta[4 * j + 1], meta[4 * j + 2], path + 3 * (size_t)path_off[j],
-                               path_off[j + 1] - path_off[j]);
-        else
-          h = edge_hits_polygon(eax, eay, ebx, eby, robot_radius, meta, off, vxy, j);
-        if (h) atomicMin(&w.first[owner], j);
+      // The pairs are decided in two stages so that the lanes stay together.  Stage A, lane = pair: the reference's
+      // first test (bounding circle, explicitEdgeCheck2D :1536-1539), which settles balls and the obstacles that
+      // move in time and drops about half of the polygons; for the others every polygon segment whose box comes
+      // within the robot radius of the edge's box is queued.  (A segment farther away than that in x or in y cannot
+      // come out of segmentDistSqrd below robotRadius^2: two segments that far apart do not straddle each other's
+      // lines, not even within rounding -- the crossing point of the lines would have to sit on both -- and their
+      // four point-segment distances are at least the gap.)  Stage B, lane = queued (edge, segment): the
+      // reference's segment test; any segment within the robot radius is a hit (an OR over the segments, their
+      // order does not matter).  Same tests on the pairs that can decide anything, same arithmetic; a hit enters
+      // the edge's first-hit minimum as before.
+      const double rr2 = robot_radius * robot_radius;
+      const double gap_min = fabs(robot_radius) * (1.0 + 1e-9);
+      int nqd = 0;                                          // wave-uniform: tests in the queue
+      auto stage_b = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int q0 = 0; q0 < nqd; q0 += 64) {
+          const int qi = q0 + lane;
+          if (qi < nqd) {
+            const unsigned ent = w.pq[qi];
+            const int owner = (int)(ent & 63u), sg = (int)(ent >> 11);
+            const int j = w.jidx[(ent >> 6) & 31u];
+            const int vb0 = off[j], P = off[j + 1] - vb0;
+            const int va = vb0 + (sg == 0 ? P - 1 : sg - 1), vb = vb0 + sg;
+            if (segment_dist_sqrd(w.e[0][owner], w.e[1][owner], w.e[3][owner], w.e[4][owner], vxy[2 * va], vxy[2 * va + 1],
+                                  vxy[2 * vb], vxy[2 * vb + 1]) < rr2)
+              atomicMin(&w.first[owner], j);
+          }
+        }
+        nqd = 0;
+      };
+      for (int p0 = 0; p0 < total; p0 += 64) {
+        const int p = p0 + lane;
+        int owner = 0, slot = 0, vb0 = 0, P = 0;           // P > 0: a polygon past the bounding circle
+        double elx = 0.0, ehx = 0.0, ely = 0.0, ehy = 0.0, slack = 0.0;
+        if (p < total) {
+          for (int step = 32; step > 0; step >>= 1)            // largest L with pre[L] <= p
+            if (w.pre[owner + step] <= p) owner += step;
+          unsigned bits = w.cand[owner];
+          for (int r = p - w.pre[owner]; r > 0; --r) bits &= bits - 1;
+          slot = __ffs((int)bits) - 1;
+          const int j = w.jidx[slot];
+          const double eax = w.e[0][owner], eay = w.e[1][owner], ebx = w.e[3][owner], eby = w.e[4][owner];
+          const int kind = (int)meta[4 * j + 3];
+          if (kind == 6 || kind == 7) {
+            if (edge_hits_moving(eax, eay, w.e[2][owner], ebx, eby, w.e[5][owner], robot_radius, meta[4 * j + 0],
+                                 meta[4 * j + 1], meta[4 * j + 2], path + 3 * (size_t)path_off[j],
+                                 path_off[j + 1] - path_off[j]))
+              atomicMin(&w.first[owner], j);
+          } else {
+            const double dsq = dist_sqrd_point_to_segment(meta[4 * j + 0], meta[4 * j + 1], eax, eay, ebx, eby);
+            const double rr = robot_radius + meta[4 * j + 2];
+            if (!(dsq > rr * rr)) {
+              if (kind == 1) atomicMin(&w.first[owner], j);
+              else if (kind == 3) {
+                vb0 = off[j];
+                P = off[j + 1] - vb0;
+                if (P < 2) P = 0;                          // (:1551: fewer than two vertices never collide)
+                elx = fmin(eax, ebx); ehx = fmax(eax, ebx); ely = fmin(eay, eby); ehy = fmax(eay, eby);
+                slack = gap_min + 1e-9 * (fabs(elx) + fabs(ehx) + fabs(ely) + fabs(ehy));
+                // (fmin / fmax drop a NaN operand: an edge with a non-finite coordinate keeps every segment)
+                if (!(eax - eax == 0.0 && eay - eay == 0.0 && ebx - ebx == 0.0 && eby - eby == 0.0)) slack = __builtin_inf();
+              }
+            }
+          }
+        }
+        // the polygon's segments, one per round: sg = 0 is (last vertex, first vertex)
+        int pmax = P;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pmax = max(pmax, __shfl_xor(pmax, o));
+        for (int sg = 0; sg < pmax; ++sg) {
+          bool push = false;
+          if (sg < P) {
+            const int va = vb0 + (sg == 0 ? P - 1 : sg - 1), vb = vb0 + sg;
+            const double Ax = vxy[2 * va], Ay = vxy[2 * va + 1], Bx = vxy[2 * vb], By = vxy[2 * vb + 1];
+            const bool apart = (fmin(Ax, Bx) - ehx > slack) || (elx - fmax(Ax, Bx) > slack) ||
+                               (fmin(Ay, By) - ehy > slack) || (ely - fmax(Ay, By) > slack);
+            const bool finite = (Ax - Ax == 0.0) && (Ay - Ay == 0.0) && (Bx - Bx == 0.0) && (By - By == 0.0);
+            push = !apart || !finite;         // (slack = +inf or NaN: never apart)
+          }
+          const unsigned long long sv = __ballot(push);
+          if (push)
+            w.pq[nqd + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sv, 0u))] =
+                (unsigned)owner | ((unsigned)slot << 6) | ((unsigned)sg << 11);
+          nqd += __popcll(sv);
+          if (nqd > kPolyQueue - 64) stage_b();
+        }
       }
+      stage_b();
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
