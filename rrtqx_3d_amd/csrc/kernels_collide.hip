@@ -413,6 +413,7 @@ __device__ bool edge_hits_polygon(double ax, double ay, double bx, double by, do
 
 // (index_before_time, transform_obs_to_time, edge_hits_moving: collide_device.hpp, shared with kernels_dubins.hip)
 
+constexpr int kPolyPairs = 256;        // (edge, obstacle) pairs a wave queues for the bounding-circle test
 constexpr int kPolyQueue = 512;        // (edge, polygon segment) tests a wave queues
 constexpr int kPolyWaveCand = 256;     // candidate obstacles a wave lists (more: the whole list is walked)
 constexpr int kPolyWaveSamples = 16;   // ... for at most this many samples per wave
@@ -425,6 +426,7 @@ struct PolyWave {
   unsigned cand[64];
   int first[64];
   int jidx[32];        // current group: list position of each of its obstacles
+  unsigned short pairq[kPolyPairs];   // (edge lane | obstacle slot << 6) of the pairs the box test leaves
   unsigned pq[kPolyQueue];         // (edge lane | obstacle slot << 6 | segment << 11) of the segment tests to run
   short wc[kPolyWaveCand];   // CSR mode: the obstacles any edge of the wave can reach (list positions, ascending)
 };
@@ -582,19 +584,7 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
         cand |= (c ? 1u : 0u) << b;
       }
     }
-    int incl = __popc(cand);
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o);
-      if (lane >= o) incl += v;
-    }
-    const int total = __shfl(incl, 63);
-    if (total > 0) {
-      w.cand[lane] = cand;
-      w.pre[lane + 1] = incl;
-      if (lane == 0) w.pre[0] = 0;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (__ballot(cand != 0u) != 0ull) {
       // The pairs are decided in two stages so that the lanes stay together.  Stage A, lane = pair: the reference's
       // first test (bounding circle, explicitEdgeCheck2D :1536-1539), which settles balls and the obstacles that
       // move in time and drops about half of the polygons; for the others every polygon segment whose box comes
@@ -627,16 +617,20 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
         }
         nqd = 0;
       };
-      for (int p0 = 0; p0 < total; p0 += 64) {
+      // stage A over the first `np` entries of the pair queue
+      int npair = 0;                                        // wave-uniform: pairs queued
+      auto stage_a = [&]() {
+       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+       __builtin_amdgcn_wave_barrier();
+       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+       for (int p0 = 0; p0 < npair; p0 += 64) {
         const int p = p0 + lane;
         int owner = 0, slot = 0, vb0 = 0, P = 0;           // P > 0: a polygon past the bounding circle
         double elx = 0.0, ehx = 0.0, ely = 0.0, ehy = 0.0, slack = 0.0;
-        if (p < total) {
-          for (int step = 32; step > 0; step >>= 1)            // largest L with pre[L] <= p
-            if (w.pre[owner + step] <= p) owner += step;
-          unsigned bits = w.cand[owner];
-          for (int r = p - w.pre[owner]; r > 0; --r) bits &= bits - 1;
-          slot = __ffs((int)bits) - 1;
+        if (p < npair) {
+          const unsigned pe = w.pairq[p];
+          owner = (int)(pe & 63u);
+          slot = (int)(pe >> 6);
           const int j = w.jidx[slot];
           const double eax = w.e[0][owner], eay = w.e[1][owner], ebx = w.e[3][owner], eby = w.e[4][owner];
           const int kind = (int)meta[4 * j + 3];
@@ -683,7 +677,22 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
           nqd += __popcll(sv);
           if (nqd > kPolyQueue - 64) stage_b();
         }
+       }
+       npair = 0;
+      };
+      // the wave's (edge, obstacle) pairs: every edge hands out one set bit of its mask per round
+      for (unsigned rem = cand; __ballot(rem != 0u) != 0ull;) {
+        const bool has = rem != 0u;
+        const int slot = has ? __ffs((int)rem) - 1 : 0;
+        rem &= rem - 1u;
+        const unsigned long long pv = __ballot(has);
+        if (has)
+          w.pairq[npair + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pv, 0u))] =
+              (unsigned short)(lane | (slot << 6));
+        npair += __popcll(pv);
+        if (npair > kPolyPairs - 64) stage_a();
       }
+      stage_a();
       stage_b();
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
