@@ -824,52 +824,44 @@ __global__ __launch_bounds__(256) void points_polygons_kernel(const double *__re
   if (i >= np) return;
   const double px = p[i * stride + 0], py = p[i * stride + 1];
   const double pt = has_moving ? p[i * stride + 2] : 0.0;      // point[3] = time (kinds 6 / 7)
-  // ---- quickCheck ----
-  for (int j0 = 0; j0 < m; j0 += 64) {
-    const int j = j0 + lane;
-    bool in = false;
-    if (j < m) {
-      double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
-      const double rad = meta[4 * j + 2];
-      const int kind = (int)meta[4 * j + 3];
-      const bool mov = (kind == 6 || kind == 7);
-      double dx = 0.0, dy = 0.0;
-      if (mov) {                                               // R/DRRT.jl:1289-1305
-        transform_obs_to_time(path + 3 * (size_t)path_off[j], path_off[j + 1] - path_off[j], pt, dx, dy);
-        cx = cx + dx; cy = cy + dy;
-      }
-      if (!(sqrt_rn(sq2(cx, cy, px, py)) > rad))
-        in = kind == 1 || (kind == 3 && point_in_polygon(px, py, vxy, off[j], off[j + 1])) ||
-             (mov && point_in_polygon<true>(px, py, vxy, off[j], off[j + 1], dx, dy));
-    }
-    if (__ballot(in) != 0ull) {
-      if (lane == 0) { unsafe[i] = 1; if (clearance) clearance[i] = 0.0; }
-      return;
-    }
-  }
-  // ---- explicitPointCheck2D over the list ----
+  // One pass over the list, 64 obstacles at a time: the quickCheck of the group (an OR: "inside any obstacle"),
+  // then the group's share of the explicitPointCheck2D loop.  The reference runs the whole quick pass first; both
+  // end the call with unsafe = 1 and certificate 0 when they find something and neither influences the other
+  // (the certificate comes from the explicit loop alone), so doing them group by group gives the same outputs
+  // with every obstacle record read and every centre distance taken once.
   double ret_cert = __builtin_inf();
   for (int j0 = 0; j0 < m; j0 += 64) {
     const int j = j0 + lane;
     const bool valid = j < m;
     double rad = 0.0, dx = 0.0, dy = 0.0, tdc = 0.0;
     int kind = 0;
-    bool near = true;
+    bool near = true, in = false;
     if (valid) {
       double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
       rad = meta[4 * j + 2];
       kind = (int)meta[4 * j + 3];
-      if (kind == 6 || kind == 7) {                            // R/DRRT.jl:1395-1408
+      const bool mov = (kind == 6 || kind == 7);
+      if (mov) {                                               // R/DRRT.jl:1289-1305, 1395-1408
         transform_obs_to_time(path + 3 * (size_t)path_off[j], path_off[j + 1] - path_off[j], pt, dx, dy);
         cx = cx + dx; cy = cy + dy;
       }
-      tdc = sqrt_rn(sq2(cx, cy, px, py)) - robot_radius;       // distance from the robot boundary to the centre
+      const double dc = sqrt_rn(sq2(cx, cy, px, py));
+      // ---- quickCheck (:1258-1331) ----
+      if (!(dc > rad))
+        in = kind == 1 || (kind == 3 && point_in_polygon(px, py, vxy, off[j], off[j + 1])) ||
+             (mov && point_in_polygon<true>(px, py, vxy, off[j], off[j + 1], dx, dy));
+      tdc = dc - robot_radius;                                 // distance from the robot boundary to the centre
       // Only the flag is wanted (no certificate): an obstacle whose bounding circle the robot clears by a margin
       // far above any rounding can neither be "bad" nor, through the certificate, make the loop skip one that
       // is (its own distance exceeds the margin, and an obstacle within the margin is skipped only by a
       // certificate below it) -- so the loop runs over the near obstacles alone, same order, same arithmetic.
       if (!clearance && (tdc - rad > 1e-6 * (1.0 + fabs(cx) + fabs(cy) + fabs(px) + fabs(py) + fabs(rad)))) near = false;
     }
+    if (__ballot(in) != 0ull) {
+      if (lane == 0) { unsafe[i] = 1; if (clearance) clearance[i] = 0.0; }
+      return;
+    }
+    // ---- explicitPointCheck2D over the group (:1343-1427) ----
     unsigned long long todo = __ballot(valid && near);
     for (;;) {
       const unsigned long long c = __ballot(valid && !(tdc - rad > ret_cert)) & todo;
