@@ -386,30 +386,8 @@ __device__ double segment_dist_sqrd(double pax, double pay, double pbx, double p
   return r;
 }
 
-// explicitEdgeCheck2D for kinds 1 and 3, R/DRRT.jl:1523-1578
-__device__ bool edge_hits_polygon(double ax, double ay, double bx, double by, double robot_radius,
-                                  const double *__restrict__ meta, const int32_t *__restrict__ off,
-                                  const double *__restrict__ vxy, int j) {
-  const double cx = meta[4 * j + 0], cy = meta[4 * j + 1], rad = meta[4 * j + 2];
-  const int kind = (int)meta[4 * j + 3];
-  double dsq = dist_sqrd_point_to_segment(cx, cy, ax, ay, bx, by);
-  double rr = robot_radius + rad;
-  if (dsq > rr * rr) return false;
-  if (kind == 1) return true;
-  if (kind == 3) {
-    const int b = off[j], e = off[j + 1];
-    const int P = e - b;
-    if (P < 2) return false;
-    double Ax = vxy[2 * (e - 1)], Ay = vxy[2 * (e - 1) + 1];
-    const double rr2 = robot_radius * robot_radius;
-    for (int v = b; v < e; ++v) {
-      double Bx = vxy[2 * v], By = vxy[2 * v + 1];
-      if (segment_dist_sqrd(ax, ay, bx, by, Ax, Ay, Bx, By) < rr2) return true;
-      Ax = Bx; Ay = By;
-    }
-  }
-  return false;
-}
+// (explicitEdgeCheck2D for kinds 1 and 3, R/DRRT.jl:1523-1578: its bounding-circle test and its segment tests are
+// stages A and B of edges_polygons_kernel below)
 
 // (index_before_time, transform_obs_to_time, edge_hits_moving: collide_device.hpp, shared with kernels_dubins.hip)
 
@@ -417,13 +395,11 @@ constexpr int kPolyPairs = 256;        // (edge, obstacle) pairs a wave queues f
 constexpr int kPolyQueue = 512;        // (edge, polygon segment) tests a wave queues
 constexpr int kPolyWaveCand = 256;     // candidate obstacles a wave lists (more: the whole list is walked)
 constexpr int kPolyWaveSamples = 16;   // ... for at most this many samples per wave
-// per-wave scratch of edges_polygons_kernel: the wave's 64 edges, the survivor masks of the current
-// group of 32 obstacles with their prefix sum, and each edge's first hit (list position)
+// per-wave scratch of edges_polygons_kernel: the wave's 64 edges, the boxes of the current group of 32 obstacles,
+// each edge's first hit (list position), the queues of the two test stages, the wave's candidate obstacles
 struct PolyWave {
   double e[6][64];     // ax, ay, at, bx, by, bt per lane
   float4 box[32];      // current group: bounding boxes (xlo, xhi, ylo, yhi) rounded outward to fp32
-  int pre[65];
-  unsigned cand[64];
   int first[64];
   int jidx[32];        // current group: list position of each of its obstacles
   unsigned short pairq[kPolyPairs];   // (edge lane | obstacle slot << 6) of the pairs the box test leaves
@@ -486,9 +462,9 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
   // The list is walked 32 obstacles at a time.  First every lane (= edge) drops, with a box test, the
   // obstacles whose bounding circle it cannot reach (explicitEdgeCheck2D's first test, :1536-1539,
   // fails for them for certain) and keeps the rest as a bit mask.  The
-  // surviving (edge, obstacle) pairs of the wave -- typically fewer than one per edge -- are then numbered
-  // through by a prefix sum and dealt out one per lane for the full test, whichever edge they belong to,
-  // so the wave does not wait on the one or two edges that lie near several obstacles.  An edge's first
+  // surviving (edge, obstacle) pairs of the wave are then queued and dealt out one per lane for the tests
+  // (stages A and B below), whichever edge they belong to, so the wave does not wait on the one or two edges
+  // that lie near several obstacles.  An edge's first
   // hit is the smallest list position among its hits; an edge that has hit takes no part in later
   // groups.  The set of tests that can decide a result and the arithmetic of each are unchanged.
   __shared__ PolyWave s_w[4];
