@@ -481,8 +481,7 @@ struct TileLds {
   int sok[kTileB];             // the sample's coordinates are finite and moderate (screens apply)
   float4 srp[kTileB];          // the sample's probe of the fp32 reach table (centre, inflated ball radius)
   double sbase[kTileB];        // ball radius + slack of the exact list test
-  int sqn[2];                  // (sample, sphere) pairs the screen left over, one queue per sample-pass wave
-  int sq[2][64];
+  int sq[2][64];               // (sample, sphere) pairs the screen left over, one queue per sample-pass wave
   int ssl[kTileB][kSphListCap];
   SphRec ssr[kTileB][kSphListCap];   // ... and their records, fetched by the sample pass (the hand-out's edge tests
                                      //     then wait for the neighbour's coordinates only)
@@ -614,6 +613,14 @@ __device__ __forceinline__ int wave_scan_incl(int v, const int identity) {
 #undef RRTX_SCAN_STEP
   return v;
 }
+// a double from the lane N places up in the same row of 16 lanes (row_shl:N; lanes without such a lane keep their own)
+template <int N>
+__device__ __forceinline__ double row_up_d(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp((int)(b & 0xffffffffll), (int)(b & 0xffffffffll), 0x100 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), 0x100 + N, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
 // the value of the lane before (lane 0: `first`); wave_shr:1
 __device__ __forceinline__ int wave_prev(int v, const int first) {
   return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
@@ -643,12 +650,13 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
     const ChunkExt *__restrict__ chunk_ext, const typename QRecT<D>::type *__restrict__ copies_s, const typename QRecFT<D>::type *__restrict__ copies_f,
     const Scalars *__restrict__ sc, int n_parts, int2 *__restrict__ ev, int slice_cap,
     const ConfirmArgs a, const ConfirmArgs *__restrict__ ca, const TileGrid tg, const ExtendDev x,
-    int *__restrict__ visits) {
+    int *__restrict__ visits, const int n_copies_known) {
   __shared__ TileLds<D> sm;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int part = blockIdx.x % n_parts;
-  const int n_copies = sc->n_copies;
+  // (without ghosts the host knows the number of copies: no device word to wait for before the first tile)
+  const int n_copies = n_copies_known >= 0 ? n_copies_known : sc->n_copies;
   const int n_tiles = (n_copies + kTileB - 1) / kTileB;
   const int slice = (int)blockIdx.x * (kScanThreads / 64) + wave;
   int2 *__restrict__ mine = ev + (size_t)slice * (size_t)slice_cap;
@@ -702,22 +710,18 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
         }
       }
       {
-        // the copies sit in lanes 0 .. kTileB - 1: four butterfly steps bring their extremes to lane 0
+        // the copies sit in lanes 0 .. kTileB - 1 = one DPP row: four row shifts bring their extremes to lane 0
         static_assert(kTileB == 16, "reach reduction covers lanes 0..15");
-        const int l = lane_here();
-#pragma unroll
-        for (int off = kTileB / 2; off > 0; off >>= 1) {
-          lo = fmin(lo, wshfl_d(lo, l ^ off));
-          hi = fmax(hi, wshfl_d(hi, l ^ off));
-          ylo = fmin(ylo, wshfl_d(ylo, l ^ off));
-          yhi = fmax(yhi, wshfl_d(yhi, l ^ off));
-          zlo = fmin(zlo, wshfl_d(zlo, l ^ off));
-          zhi = fmax(zhi, wshfl_d(zhi, l ^ off));
-        }
+#define RRTX_REACH_STEP(N)                                                                   \
+        lo = fmin(lo, row_up_d<N>(lo)); hi = fmax(hi, row_up_d<N>(hi));                     \
+        ylo = fmin(ylo, row_up_d<N>(ylo)); yhi = fmax(yhi, row_up_d<N>(yhi));               \
+        zlo = fmin(zlo, row_up_d<N>(zlo)); zhi = fmax(zhi, row_up_d<N>(zhi));
+        RRTX_REACH_STEP(8) RRTX_REACH_STEP(4) RRTX_REACH_STEP(2) RRTX_REACH_STEP(1)
+#undef RRTX_REACH_STEP
       }
       if (lane == 0) {
         sm.lo = lo; sm.hi = hi; sm.ylo = ylo; sm.yhi = yhi; sm.zlo = zlo; sm.zhi = zhi;
-        sm.n_list = 0; sm.sqn[0] = 0; sm.sqn[1] = 0; sm.n_groups = 0; sm.gmode = 0;
+        sm.n_list = 0; sm.n_groups = 0; sm.gmode = 0;
       }
     }
     __syncthreads();
@@ -836,6 +840,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
             const int ipx = __float_as_int(mypf.x), ipy = __float_as_int(mypf.y), ipz = __float_as_int(mypf.z),
                       ipw = __float_as_int(mypf.w);
             const int nsamp = q1 - q0;
+            int nqueued = 0;                            // wave-uniform: near pairs this wave has queued
             for (int pr0 = 0; pr0 < n_pairs; pr0 += 128) {
               const int pr = pr0 + (t - 128);
               float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -857,20 +862,26 @@ __global__ __launch_bounds__(kScanThreads, 4) void nn_tile_kernel(
                 const f32x2 b2 = bnd * bnd;
                 // the left-over pairs are queued (no load in this loop) and evaluated one per lane below
                 const bool na = va && !(d.x > b2.x), nb = vb && !(d.y > b2.y);
-                if (__ballot(na || nb) == 0ull) continue;
-                for (int h2 = 0; h2 < 2; ++h2) {
-                  const int j = 2 * pr + h2;
-                  if (h2 == 0 ? na : nb) {
-                    const int at = atomicAdd(&sm.sqn[qw], 1);
-                    if (at < 64) sm.sq[qw][at] = cl | (j << 4);
-                    else exact(cl, j);               // queue full (dense obstacle field): right away
-                  }
+                const unsigned long long ma = __ballot(na), mb = __ballot(nb);
+                if ((ma | mb) == 0ull) continue;
+                // queue places from the wave's masks (a samples' worth of near pairs used to line up on one LDS counter)
+                const int at_a = nqueued + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0u));
+                const int at_b = nqueued + __popcll(ma) +
+                                 (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+                nqueued += __popcll(ma) + __popcll(mb);
+                if (na) {
+                  if (at_a < 64) sm.sq[qw][at_a] = cl | ((2 * pr) << 4);
+                  else exact(cl, 2 * pr);            // queue full (dense obstacle field): right away
+                }
+                if (nb) {
+                  if (at_b < 64) sm.sq[qw][at_b] = cl | ((2 * pr + 1) << 4);
+                  else exact(cl, 2 * pr + 1);
                 }
               }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            const int nq_ev = min(sm.sqn[qw], 64);
+            const int nq_ev = min(nqueued, 64);
             if (lane < nq_ev) {
               const int ev = sm.sq[qw][lane];
               exact(ev & 15, ev >> 4);
@@ -1332,17 +1343,17 @@ int launch_nn_radius(rrtx_ctx *ctx, const double *q_dev, const double *r_dev_thr
         hipLaunchKernelGGL((nn_tile_kernel<3, true>), dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
                            ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, reinterpret_cast<const ChunkExt *>(ctx->chunk_ext),
                            ctx->ws_copies_s.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(), sc, n_parts,
-                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, xd, ctx->ws_ev_cnt.as<int>());
+                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, xd, ctx->ws_ev_cnt.as<int>(), n_slots == 1 ? nq : -1);
       else if (D == 4)
         hipLaunchKernelGGL((nn_tile_kernel<4, false>), dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
                            ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, reinterpret_cast<const ChunkExt *>(ctx->chunk_ext),
                            ctx->ws_copies_s.as<QRec4>(), ctx->ws_copies_f.as<QRecF4>(), sc, n_parts,
-                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, xd, ctx->ws_ev_cnt.as<int>());
+                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, xd, ctx->ws_ev_cnt.as<int>(), n_slots == 1 ? nq : -1);
       else
         hipLaunchKernelGGL((nn_tile_kernel<3, false>), dim3((unsigned)nb), block, 0, st, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2],
                            ctx->sl_f[wi], ctx->sl_pp, n_nodes, n_chunks, reinterpret_cast<const ChunkExt *>(ctx->chunk_ext),
                            ctx->ws_copies_s.as<QRec3>(), ctx->ws_copies_f.as<QRecF3>(), sc, n_parts,
-                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, xd, ctx->ws_ev_cnt.as<int>());
+                           ctx->ws_ev_a.as<int2>(), slice_cap, ca, ca_dev, tg, xd, ctx->ws_ev_cnt.as<int>(), n_slots == 1 ? nq : -1);
     } else if (use_filter) {
       // persistent grid: opt_scan_blocks workgroups (multiple of 8) striding over the work
       unsigned pg = (unsigned)ctx->opt_scan_blocks / 8u * 8u;
