@@ -414,7 +414,9 @@ int launch_nn_finish(rrtx_ctx *ctx, const FinishLaunch &f) {
   const dim3 grid((unsigned)((f.nq + kFinQ - 1) / kFinQ)), block(kFinThreads);
   // lists of hundreds of entries and more (the caller made room for them): the build that sorts up to
   // kHugeSort entries in LDS (one workgroup per CU) instead of counting ranks over global memory
-  const bool huge = f.out_cap / (f.nq > 0 ? f.nq : 1) > 2048;
+  // (measured at C3, lists of ~1400: 1.0 ms in that build against 1.7 ms in the 8-waves-per-SIMD build, whose
+  //  64 registers the sort network spills -- so any call whose capacity allows for lists in the hundreds takes it)
+  const bool huge = f.out_cap / (f.nq > 0 ? f.nq : 1) > 512;
   if (D == 4) {
     if (huge) hipLaunchKernelGGL((nn_finish_kernel<4, kHugeSort>), grid, block, 0, ctx->stream, a);
     else hipLaunchKernelGGL((nn_finish_kernel<4, kBigSort>), grid, block, 0, ctx->stream, a);
