@@ -31,6 +31,30 @@ __device__ __forceinline__ double left_turn_dist(double ax, double ay, double bx
   if (theta < 0) theta = theta + 2 * kPi;
   return theta * r;
 }
+// The same two functions with one of the two angles given: the angle of the start pose seen from its right / left
+// circle and of the goal pose seen from its circles enter three words each (and the stored trajectory), always
+// through the same expression atan2(y - cy, x - cx) of the same operands, so they are computed once per edge
+// (16 atan2 per edge instead of 24 + 2 of the trajectory's 6; the values are the identical doubles).
+__device__ __forceinline__ double right_turn_from(double angle_a, double bx, double by, double cx, double cy, double r) {
+  double theta = angle_a - atan2(by - cy, bx - cx);
+  if (theta < 0) theta = theta + 2 * kPi;
+  return theta * r;
+}
+__device__ __forceinline__ double right_turn_to(double ax, double ay, double angle_b, double cx, double cy, double r) {
+  double theta = atan2(ay - cy, ax - cx) - angle_b;
+  if (theta < 0) theta = theta + 2 * kPi;
+  return theta * r;
+}
+__device__ __forceinline__ double left_turn_from(double angle_a, double bx, double by, double cx, double cy, double r) {
+  double theta = atan2(by - cy, bx - cx) - angle_a;
+  if (theta < 0) theta = theta + 2 * kPi;
+  return theta * r;
+}
+__device__ __forceinline__ double left_turn_to(double ax, double ay, double angle_b, double cx, double cy, double r) {
+  double theta = angle_b - atan2(ay - cy, ax - cx);
+  if (theta < 0) theta = theta + 2 * kPi;
+  return theta * r;
+}
 __device__ __forceinline__ double seg_len2(double ax, double ay, double bx, double by) {
   return sqrt_rn(sq2(ax, ay, bx, by));
 }
@@ -92,6 +116,10 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
   const double grcx = glx + r_min * cos(gt - kPi / 2.0), grcy = gly + r_min * sin(gt - kPi / 2.0);
   const double glcx = glx + r_min * cos(gt + kPi / 2.0), glcy = gly + r_min * sin(gt + kPi / 2.0);
 
+  // the poses' angles on their circles (see right_turn_from)
+  const double a_ir = atan2(ily - ircy, ilx - ircx), a_il = atan2(ily - ilcy, ilx - ilcx);
+  const double a_gr = atan2(gly - grcy, glx - grcx), a_gl = atan2(gly - glcy, glx - glcx);
+
   double best = __builtin_inf();
   int word = 6;
   double D, vx, vy, R, sq, a, b, first, second, third, len;
@@ -109,9 +137,9 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
       b = r_min * (R * vy - vx * sq);
       rsl1x = ircx - a; rsl2x = glcx + a;
       rsl1y = ircy - b; rsl2y = glcy + b;
-      first = right_turn_dist(ilx, ily, rsl1x, rsl1y, ircx, ircy, r_min);
+      first = right_turn_from(a_ir, rsl1x, rsl1y, ircx, ircy, r_min);
       second = seg_len2(rsl2x, rsl2y, rsl1x, rsl1y);
-      third = left_turn_dist(rsl2x, rsl2y, glx, gly, glcx, glcy, r_min);
+      third = left_turn_to(rsl2x, rsl2y, a_gl, glcx, glcy, r_min);
       len = first + second + third;
       if (best > len) { best = len; word = 0; }
     }
@@ -124,9 +152,9 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
     vx = dx / D; vy = dy / D;
     rsr1x = -r_min * vy + ircx; rsr2x = -r_min * vy + grcx;
     rsr1y = r_min * vx + ircy;  rsr2y = r_min * vx + grcy;
-    first = right_turn_dist(ilx, ily, rsr1x, rsr1y, ircx, ircy, r_min);
+    first = right_turn_from(a_ir, rsr1x, rsr1y, ircx, ircy, r_min);
     second = seg_len2(rsr2x, rsr2y, rsr1x, rsr1y);
-    third = right_turn_dist(rsr2x, rsr2y, glx, gly, grcx, grcy, r_min);
+    third = right_turn_to(rsr2x, rsr2y, a_gr, grcx, grcy, r_min);
     len = first + second + third;
     if (best > len) { best = len; word = 1; }
   }
@@ -138,9 +166,9 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
     rlr_cy = ircy + 2 * r_min * sin(theta);
     rlr_rlx = (rlr_cx + ircx) / 2.0; rlr_rly = (rlr_cy + ircy) / 2.0;
     rlr_lrx = (rlr_cx + grcx) / 2.0; rlr_lry = (rlr_cy + grcy) / 2.0;
-    first = right_turn_dist(ilx, ily, rlr_rlx, rlr_rly, ircx, ircy, r_min);
+    first = right_turn_from(a_ir, rlr_rlx, rlr_rly, ircx, ircy, r_min);
     second = left_turn_dist(rlr_rlx, rlr_rly, rlr_lrx, rlr_lry, rlr_cx, rlr_cy, r_min);
-    third = right_turn_dist(rlr_lrx, rlr_lry, glx, gly, grcx, grcy, r_min);
+    third = right_turn_to(rlr_lrx, rlr_lry, a_gr, grcx, grcy, r_min);
     len = first + second + third;
     if (best > len) { best = len; word = 2; }
   }
@@ -157,9 +185,9 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
       b = R * vy - vx * sq;
       lsr1x = ilcx + a * r_min; lsr2x = grcx - a * r_min;
       lsr1y = ilcy + b * r_min; lsr2y = grcy - b * r_min;
-      first = left_turn_dist(ilx, ily, lsr1x, lsr1y, ilcx, ilcy, r_min);
+      first = left_turn_from(a_il, lsr1x, lsr1y, ilcx, ilcy, r_min);
       second = seg_len2(lsr2x, lsr2y, lsr1x, lsr1y);
-      third = right_turn_dist(lsr2x, lsr2y, glx, gly, grcx, grcy, r_min);
+      third = right_turn_to(lsr2x, lsr2y, a_gr, grcx, grcy, r_min);
       len = first + second + third;
       if (best > len) { best = len; word = 3; }
     }
@@ -172,9 +200,9 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
     vx = dx / D; vy = dy / D;
     lsl1x = r_min * vy + ilcx;  lsl2x = r_min * vy + glcx;
     lsl1y = -r_min * vx + ilcy; lsl2y = -r_min * vx + glcy;
-    first = left_turn_dist(ilx, ily, lsl1x, lsl1y, ilcx, ilcy, r_min);
+    first = left_turn_from(a_il, lsl1x, lsl1y, ilcx, ilcy, r_min);
     second = seg_len2(lsl2x, lsl2y, lsl1x, lsl1y);
-    third = left_turn_dist(lsl2x, lsl2y, glx, gly, glcx, glcy, r_min);
+    third = left_turn_to(lsl2x, lsl2y, a_gl, glcx, glcy, r_min);
     len = first + second + third;
     if (best > len) { best = len; word = 4; }
   }
@@ -186,9 +214,9 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
     lrl_cy = ilcy + 2.0 * r_min * sin(theta);
     lrl_lrx = (lrl_cx + ilcx) / 2.0; lrl_lry = (lrl_cy + ilcy) / 2.0;
     lrl_rlx = (lrl_cx + glcx) / 2.0; lrl_rly = (lrl_cy + glcy) / 2.0;
-    first = left_turn_dist(ilx, ily, lrl_lrx, lrl_lry, ilcx, ilcy, r_min);
+    first = left_turn_from(a_il, lrl_lrx, lrl_lry, ilcx, ilcy, r_min);
     second = right_turn_dist(lrl_lrx, lrl_lry, lrl_rlx, lrl_rly, lrl_cx, lrl_cy, r_min);
-    third = left_turn_dist(lrl_rlx, lrl_rly, glx, gly, glcx, glcy, r_min);
+    third = left_turn_to(lrl_rlx, lrl_rly, a_gl, glcx, glcy, r_min);
     len = first + second + third;
     if (best > len) { best = len; word = 5; }
   }
@@ -205,13 +233,13 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
   // first piece (:511-555)
   if (fr) {
     if (word == 0) { px = rsl1x; py = rsl1y; } else if (word == 1) { px = rsr1x; py = rsr1y; } else { px = rlr_rlx; py = rlr_rly; }
-    phi_start = atan2(ily - ircy, ilx - ircx);
+    phi_start = a_ir;
     phi_end = atan2(py - ircy, px - ircx);
     if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi;
     out.pc[0] = make_arc(ircx, ircy, phi_start, phi_end, -dphi);
   } else {
     if (word == 4) { px = lsl1x; py = lsl1y; } else if (word == 3) { px = lsr1x; py = lsr1y; } else { px = lrl_lrx; py = lrl_lry; }
-    phi_start = atan2(ily - ilcy, ilx - ilcx);
+    phi_start = a_il;
     phi_end = atan2(py - ilcy, px - ilcx);
     if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi;
     out.pc[0] = make_arc(ilcx, ilcy, phi_start, phi_end, dphi);
@@ -237,13 +265,13 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
   if (tr) {
     if (word == 1) { px = rsr2x; py = rsr2y; } else if (word == 3) { px = lsr2x; py = lsr2y; } else { px = rlr_lrx; py = rlr_lry; }
     phi_start = atan2(py - grcy, px - grcx);
-    phi_end = atan2(gly - grcy, glx - grcx);
+    phi_end = a_gr;
     if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi;
     out.pc[2] = make_arc(grcx, grcy, phi_start, phi_end, -dphi);
   } else {
     if (word == 4) { px = lsl2x; py = lsl2y; } else if (word == 0) { px = rsl2x; py = rsl2y; } else { px = lrl_rlx; py = lrl_rly; }
     phi_start = atan2(py - glcy, px - glcx);
-    phi_end = atan2(gly - glcy, glx - glcx);
+    phi_end = a_gl;
     if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi;
     out.pc[2] = make_arc(glcx, glcy, phi_start, phi_end, dphi);
   }
