@@ -6,18 +6,18 @@
 // fp32 screen, exact fp64 confirmation.
 //
 // Radius search pipeline (all on ctx->stream, no host sync):
-//   pack    : queries -> slot table (query + ghosts), copy records, (x, y) bucket and rank of
+//   pack    : queries -> slot table (query + ghosts), copy records, grid bucket and rank of
 //             every copy, the root rule (<= instead of <, R/kdTree_general.jl:896 vs :830),
 //             per-call state
 //   place   : copies in bucket order + their fp32 screen records      (culled search)
-//   tile    : per tile of 16 copies: chunks within reach -> fp32 screen -> exact confirmation
-//             -> hits into the queries' buckets                          (culled search)
+//   tile    : per tile of 16 copies: groups of eight nodes within reach (cells of the slab index cut
+//             by bins of the third coordinate) -> fp32 screen -> exact confirmation -> hits into the
+//             queries' buckets; on the fused extend() path also the sample check and both edge flags
+//             of every neighbour                                          (culled search)
 //   [ prep, scan, confirm : the same three steps for the brute-force search, every tile of 64
 //             copies streams every node ]
-//   offsets : exclusive scan of the per-query counts
-//   scatter : overflow list -> behind the buckets (normally nothing to do)
-//   order   : per query: sort by node index, dist = sqrt(d2), owner, nearest
-//   order_big: the same for lists longer than 64
+//   finish  : offsets, order by node index, dist = sqrt(d2), owner, nearest, empty balls
+//             (kernels_finish.hip; offsets + scatter below only after a call that overflowed by much)
 #include "collide_device.hpp"
 #include "nn_device.hpp"
 
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kScanThreads) void nn_scan_kernel(
   (void)lane;
 }
 
-// Culled scan: the same records, written in x-bucket order (bucket start + the rank the pack
+// Culled scan: the same records, written in bucket order (query_grid; bucket start + the rank the pack
 // kernel drew), together with the fp64 copy and its (query, slot) tag.  Every workgroup first
 // scans the whole bucket histogram (<= 4096 counters) into LDS; that is cheaper than a launch.
 constexpr int kMaxQBuckets = 4096;
@@ -440,25 +440,26 @@ __global__ __launch_bounds__(kScanThreads, 5) void nn_scan_f32_kernel(
 
 // ---------------------------------------------------------- tile kernel ------
 // Culled range search, one workgroup per (tile of kTileB bucket-ordered copies, part):
-//   1. the tile's reach in x and in y: every copy's coordinate -+ its search radius, rounded outwards;
-//   2. the node chunks that can hold a neighbour.  The sorted part of the slab index is ordered by
-//      (x, y) grid cell, rows of cells running alternately left and right, so the cells within reach
-//      are ONE contiguous run of positions per row of cells: wave 0 reads two entries of the cell-start
-//      table per row and lists the chunks those runs touch (no pass over all chunk extents, no
-//      compaction; a row that continues in the chunk the previous one ended in does not list it
-//      twice).  Chunks of the appended tail are few and are tested by extent.  A listed chunk is
-//      still skipped when its own exact x / y extent misses the reach (a chunk outside it holds no
-//      node within range of any copy of the tile: |x_q - x_n| > R, or the same in y, implies that
-//      square alone is >= thr after rounding, and the other squares only add, exact_math.hpp sq3);
-//      part p of a tile takes chunks c = p mod n_parts;
-//   3. the screen of those chunks, one chunk per wave at a time (scan_chunk_f32), entries into the
-//      waves' slices;
+//   1. the tile's reach in x, y and the third coordinate: every copy's coordinate -+ its search radius,
+//      rounded outwards;
+//   2. the nodes that can hold a neighbour.  The sorted part of the slab index is ordered by (x, y) grid cell
+//      (rows of cells running alternately left and right) and inside a cell by bin of the third coordinate,
+//      so the positions of a cell within reach that can matter are ONE run: wave 0 (lane = cell) reads two
+//      entries of the cell-start table and lists the GROUPS of eight positions (one scan lane's nodes) the
+//      runs touch, each group once (step 2a below).  A tile whose groups do not fit its list falls back to
+//      whole chunks: one contiguous run of positions per row of cells.  Chunks of the appended tail are few and
+//      are tested by extent.  A listed chunk is still skipped when its own exact x / y extent misses the reach
+//      (a node outside the reach in one coordinate is out of range of every copy of the tile: |x_q - x_n| > R
+//      implies that square alone is >= thr after rounding, and the other squares only add, exact_math.hpp sq3);
+//      part p of a tile takes units u = p mod n_parts;
+//   3. the screen of the list, 64 groups (or one chunk) per wave at a time (scan_chunk_f32), entries into
+//      the waves' slices;
 //   4. exact confirmation of the workgroup's entries, hits collected per copy in LDS;
 //   5. one counter update per copy, then the copy's hits go to its query's bucket in one piece
 //      (16-byte records, consecutive slots).
 constexpr int kTileB = 16;            // copies per tile
 constexpr int kTbLcap = 96;           // hits per copy collected in LDS (more: straight to the bucket)
-constexpr int kTbList = 1024;         // chunk ids per pass of step 2
+constexpr int kTbList = 1024;         // chunk ids per pass of step 2 (tail chunks; whole-chunk fallback)
 constexpr int kTbSlack = 512;
 
 constexpr int kTbGroups = 1024;       // 8-position groups a tile can list (more: whole chunks, step 2)

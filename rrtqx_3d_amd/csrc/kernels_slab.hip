@@ -1,6 +1,7 @@
 // kernels_slab.hip -- the slab index of the culled range search: a copy of the
-// screen arrays ordered by (x, y) grid cell with per-chunk extents, rebuilt on the stream when
-// enough nodes have been appended.  gfx950 only.
+// screen arrays ordered by (x, y) grid cell and bin of the third coordinate, with the first position of
+// every (cell, bin) and per-chunk extents, rebuilt on the stream when enough nodes have been appended.
+// gfx950 only.
 #include "nn_device.hpp"
 
 namespace rrtx {
@@ -9,11 +10,11 @@ namespace {
 
 // ------------------------------------------------------------ slab index ------
 // Rebuild of the slab-ordered shadow (rare: when enough nodes were appended since the last
-// one).  A counting sort of the nodes by equal-width x slab; the order inside a slab is the
-// order in which the atomics happened to land, which no result depends on.
+// one).  A counting sort of the nodes by (cell, bin); the order inside a bin is the order in
+// which the atomics happened to land, which no result depends on.
 static_assert(kSlabChunk == kChunkF, "the culled scan visits one slab-index chunk per work unit");
 
-// (SlabParams: nn_device.hpp)
+// (SlabParams: rrtx_internal.hpp)
 
 __global__ void slab_params_kernel(const unsigned long long *__restrict__ xrange, int Kx, int Ky, int Kz,
                                    SlabParams *__restrict__ sp, int *__restrict__ hist) {

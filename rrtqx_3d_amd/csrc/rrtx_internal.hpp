@@ -98,8 +98,9 @@ struct rrtx_ctx {
 
   // Slab-ordered copy of the fp32 shadow for the culled range scan (kernels_nn.hip, "slab
   // index").  Positions [0, sl_n_sorted) hold nodes 0..sl_n_sorted-1 ordered by equal-width
-  // (x, y) grid cell; positions >= sl_n_sorted hold node p at position p (appended since the
-  // last rebuild).  chunk_ext: exact fp64 x and y extent of every 512-position chunk (enc_ord).
+  // (x, y) grid cell and, inside a cell, by bin of the third coordinate (sl_kz bins); positions
+  // >= sl_n_sorted hold node p at position p (appended since the last rebuild; a batch appended
+  // as a sorted run is in cell order inside its own range of positions).  chunk_ext: exact fp64 x and y extent of every 512-position chunk (enc_ord).
   // Inside a chunk the positions are lane-major: scan lane L owns positions 8 L .. 8 L + 7, so
   // its eight nodes are two 16-byte loads per array and the exact re-test of a flagged lane
   // reads eight consecutive doubles (sl_d: the same order in fp64).
@@ -175,7 +176,7 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_copies;   // QRec copies
   rrtx::DevBuf ws_copies_f; // fp32 prefilter copies
   rrtx::DevBuf ws_copy_meta;// int32 owner, slot per copy
-  rrtx::DevBuf ws_copies_s, ws_meta_s;  // copies / meta in x-bucket order (culled scan)
+  rrtx::DevBuf ws_copies_s, ws_meta_s;  // copies / meta in bucket order (culled scan)
   rrtx::DevBuf ws_cb, ws_qhist;         // (bucket, rank) per copy; bucket histogram
   rrtx::DevBuf ws_bkt;      // per-query hit buckets (16-byte records)
   int bkt_mult = 2;         // bucket capacity in units of the average list length the caller made room for
