@@ -448,9 +448,11 @@ def main():
             for s in range(2):
                 parallel.exchange_hit_bitmasks_grouped(d_bits[s], rank)
         fence()
-        sample_every = 4 if steps >= 8 else 1
+        # (every 10th step of a default run: an instrumented step costs ~10 us more, every 4th step was 2.5 us of a
+        #  54 us step -- tools/graph_probe.py times the same calls without events at 0.0516 ms)
+        sample_every = 10 if steps >= 20 else (4 if steps >= 8 else 1)
         if profile:
-            # HIP events around the dominant kernel only, and only on every 4th step: two event records
+            # HIP events around the dominant kernel only, and only on every n-th step: two event records
             # drain the pipeline for ~10 us
             ctx.set_option(_capi.RRTX_OPT_PROFILE_EVERY, sample_every)
             ctx.profile(1)
@@ -492,7 +494,8 @@ def main():
         fence()
         st_all = ctx.stats()
         ctx.profile(0)
-        extras["kernel_ms_all"] = {"nn_pack_place_finish": st_all.ms_nn_finish / 5}
+        extras["kernel_ms_all"] = {"nn_pack_place_finish": st_all.ms_nn_finish / 5,
+                                   "nn_scan_separate_pass": st_all.ms_nn_scan / max(st_all.launches_nn_scan, 1)}
         # the brute-force form of the search (every tile of 64 copies streams every node, north_star's
         # kernel) measured beside the default culled form: a short pass with culling switched off
         if args.nn_filter and args.nn_cull and st.last_scan_units > 0:
