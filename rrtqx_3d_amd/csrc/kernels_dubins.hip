@@ -486,6 +486,21 @@ __device__ bool seg_hits_polygon_past_circle(double ax, double ay, double bx, do
 //     whatever the lengths of the individual polylines are, and an edge that has collided drops
 //     out of the numbering.
 // Same set of tests, same arithmetic in each.  Every lane of the wave calls this together.
+// Measuring build (python -m rrtqx_3d_amd.build --clocks, tools/dubins_clocks.py): wall-clock ticks (100 MHz) every
+// wave spends in the stages of the fused Dubins preamble, summed over the launch:
+//   0 steering  1 stage 1a (boxes)  2 stage 1b (chord tests)  3 arc screen  4 stage 2a (pieces, bounding circles)
+//   5 stage 2b (polygon tests of the queued pairs)  6 waves
+#ifdef RRTX_TILE_CLOCKS
+__device__ unsigned long long g_dub_clk[8];
+#define RRTX_DUB_T(var) const unsigned long long var = wall_clock64()
+#define RRTX_DUB_ADD(k, a, b) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dub_clk[k], (b) - (a)); } while (0)
+#define RRTX_DUB_ACC(acc, a, b) acc += (b) - (a)
+#else
+#define RRTX_DUB_T(var) do { } while (0)
+#define RRTX_DUB_ADD(k, a, b) do { } while (0)
+#define RRTX_DUB_ACC(acc, a, b) do { } while (0)
+#endif
+
 template <bool TIME>
 struct WaveDubinsT {
   Piece pc[64][3];
@@ -527,6 +542,7 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
   const int rows = st.pc[0].len + st.pc[1].len + st.pc[2].len;
   for (int j0 = 0; j0 < m; j0 += 64) {
     const int j1 = (j0 + 64 < m) ? j0 + 64 : m;
+    RRTX_DUB_T(t_1a);
     // ---- stage 1a (lane = edge): obstacles whose bounding circle, inflated like the chord test, the
     // chord's box cannot reach fail that test for certain (box widened by 1e-9 against ~1e-15 of
     // rounding; NaN / overflow keep the obstacle)
@@ -558,6 +574,8 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
     if (lane == 0) w.pstart[0] = 0;
     __builtin_amdgcn_wave_barrier();
     const int pairs = __shfl(incl, 63);
+    RRTX_DUB_T(t_1b);
+    RRTX_DUB_ADD(1, t_1a, t_1b);
     // ---- stage 1b (lane = one surviving (edge, obstacle) pair): the inflated chord test (:757-760) ----
     for (int p = lane; p < pairs; p += 64) {
       int e = 0;
@@ -578,6 +596,8 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
       if (h1) atomicOr(&w.mask[e], 1ull << b);
     }
     __builtin_amdgcn_wave_barrier();
+    RRTX_DUB_T(t_arc);
+    RRTX_DUB_ADD(2, t_1b, t_arc);
     const unsigned long long mask = w.mask[lane];
     // ---- arc screen (lane = edge): every stored row of an arc lies on its circle (centre c, radius r_min),
     // so a piece of the arc -- and the short piece that joins it to the next one, whose far end is the
@@ -656,6 +676,11 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
     constexpr int kPqCap = (TIME ? 6 : 4) * 128;
     if (lane == 0) w.pqn = 0;
     __builtin_amdgcn_wave_barrier();
+    RRTX_DUB_T(t_2);
+    RRTX_DUB_ADD(3, t_arc, t_2);
+#ifdef RRTX_TILE_CLOCKS
+    unsigned long long acc_b = 0ull;
+#endif
     // b) lane = one queued (piece, obstacle) pair that got past the bounding circle: the full test
     auto test_pair = [&](unsigned int ent) {
       const int ee = (int)(ent & 63u), row = (int)((ent >> 6) & 255u), j = j0 + (int)(ent >> 14);
@@ -774,8 +799,11 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
             const int n = w.pqn;                       // wave-uniform
             if (n < at_least || n == 0) break;
             const int take = n < 64 ? n : 64;
+            RRTX_DUB_T(t_b0);
             if (lane < take) test_pair(w.pq[n - take + lane]);
             __builtin_amdgcn_wave_barrier();
+            RRTX_DUB_T(t_b1);
+            RRTX_DUB_ACC(acc_b, t_b0, t_b1);
             if (lane == 0) w.pqn = n - take;
             __builtin_amdgcn_wave_barrier();
           }
@@ -786,6 +814,15 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
       base += win;
     }
     __builtin_amdgcn_wave_barrier();
+#ifdef RRTX_TILE_CLOCKS
+    {
+      const unsigned long long t_end = wall_clock64();
+      if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_dub_clk[5], acc_b);
+        atomicAdd(&g_dub_clk[4], (t_end - t_2) - acc_b);
+      }
+    }
+#endif
   }
   return valid && w.done[lane] != 0;
 }
@@ -821,7 +858,11 @@ __global__ __launch_bounds__(256, TIME ? 2 : 3) void candidate_dubins_kernel(
     g[0] = nx[n]; g[1] = ny[n]; g[2] = nz[n]; g[3] = nw[n];
   }
   Steer st;
+  RRTX_DUB_T(t_s0);
   dubins_steer<true>(s, g, r_min, st);
+  RRTX_DUB_T(t_s1);
+  RRTX_DUB_ADD(0, t_s0, t_s1);
+  RRTX_DUB_ADD(6, 0ull, 1ull);
   int bad_move = 0;
   if (valid) {
     cost_out[e] = TIME ? dist_with_time(st.cost, s[2], g[2]) : st.cost;
@@ -830,7 +871,10 @@ __global__ __launch_bounds__(256, TIME ? 2 : 3) void candidate_dubins_kernel(
   }
   const bool ho = wave_dubins_collides<TIME>(w, valid, st, s, g, r_min, robot_radius, tab);
   if (valid) hit_out[e] = (ho ? 1 : 0) | bad_move;
+  RRTX_DUB_T(t_s2);
   dubins_steer<true>(g, s, r_min, st);
+  RRTX_DUB_T(t_s3);
+  RRTX_DUB_ADD(0, t_s2, t_s3);
   bad_move = 0;
   if (valid) {
     cost_in[e] = TIME ? dist_with_time(st.cost, g[2], s[2]) : st.cost;
@@ -925,6 +969,17 @@ int check_space(rrtx_ctx *ctx) {
 }
 
 }  // namespace
+
+#ifdef RRTX_TILE_CLOCKS
+extern "C" int rrtx_debug_dubins_clocks(unsigned long long *out, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dub_clk), sizeof(unsigned long long) * 8);
+  if (reset) {
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dub_clk), z, sizeof(z));
+  }
+  return rc;
+}
+#endif
 
 int launch_candidate_dubins(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
                             const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap, double r_min,
