@@ -576,24 +576,92 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
     const int pairs = __shfl(incl, 63);
     RRTX_DUB_T(t_1b);
     RRTX_DUB_ADD(1, t_1a, t_1b);
-    // ---- stage 1b (lane = one surviving (edge, obstacle) pair): the inflated chord test (:757-760) ----
-    for (int p = lane; p < pairs; p += 64) {
-      int e = 0;
-      for (int step = 32; step > 0; step >>= 1)
-        if (w.pstart[e + step] <= p) e += step;
-      unsigned long long bits = w.cand[e];
-      for (int r = p - w.pstart[e]; r > 0; --r) bits &= bits - 1ull;
-      const int b = __ffsll((long long)bits) - 1;
-      const int j = j0 + b;
-      bool h1;
-      if (TIME && meta[4 * j + 3] >= 6.0)
-        h1 = edge_hits_moving(w.chord[0][e], w.chord[1][e], w.chord[TIME ? 4 : 0][e], w.chord[2][e], w.chord[3][e],
-                              w.chord[TIME ? 5 : 0][e], robot_radius + 2 * r_min, meta[4 * j + 0], meta[4 * j + 1],
-                              meta[4 * j + 2], tab.path + 3 * (size_t)tab.poff[j], tab.poff[j + 1] - tab.poff[j]);
-      else
-        h1 = seg_hits_polygon(w.chord[0][e], w.chord[1][e], w.chord[2][e], w.chord[3][e], robot_radius + 2 * r_min, meta,
-                              off, vxy, j);
-      if (h1) atomicOr(&w.mask[e], 1ull << b);
+    // ---- stage 1b: the inflated chord test (:757-760) of the surviving (edge, obstacle) pairs, in two steps that
+    // keep the lanes together (as edges_polygons_kernel does, kernels_collide.hip).  A, lane = pair: the polygon
+    // test's bounding-circle step, which settles balls and moving obstacles; for a polygon that passes, every
+    // segment whose box comes within the test radius of the chord's box is queued (a segment farther away than
+    // that in x or in y cannot come out of the segment test below radius^2).  B, lane = queued (pair, segment): the
+    // segment test; any segment within the radius marks the obstacle (an OR over the segments).  The queue
+    // borrows w.pm, which the arc screen writes afterwards. ----
+    {
+      const double rad1 = robot_radius + 2 * r_min;
+      const double rr2 = rad1 * rad1;
+      const double gap_min = fabs(rad1) * (1.0 + 1e-9);
+      unsigned int *sq = reinterpret_cast<unsigned int *>(&w.pm[0][0]);
+      constexpr int kSqCap = 3 * 64 * 2;                         // 32-bit entries in w.pm
+      int nsq = 0;                                               // wave-uniform
+      auto seg_round = [&]() {                                   // B: up to 64 queued tests from the end of the queue
+        __builtin_amdgcn_wave_barrier();
+        const int take = nsq < 64 ? nsq : 64;
+        if (lane < take) {
+          const unsigned int ent = sq[nsq - take + lane];
+          const int e = (int)(ent & 63u), b = (int)((ent >> 6) & 63u), sg = (int)(ent >> 12);
+          const int j = j0 + b;
+          const int vb0 = off[j], P = off[j + 1] - vb0;
+          const int va = vb0 + (sg == 0 ? P - 1 : sg - 1), vb = vb0 + sg;
+          if (seg_dist_sqrd(w.chord[0][e], w.chord[1][e], w.chord[2][e], w.chord[3][e], vxy[2 * va], vxy[2 * va + 1],
+                            vxy[2 * vb], vxy[2 * vb + 1]) < rr2)
+            atomicOr(&w.mask[e], 1ull << b);
+        }
+        __builtin_amdgcn_wave_barrier();
+        nsq -= take;
+      };
+      for (int p0 = 0; p0 < pairs; p0 += 64) {
+        const int p = p0 + lane;
+        int e = 0, b = 0, vb0 = 0, P = 0;                        // P > 0: a polygon past the bounding circle
+        double elx = 0.0, ehx = 0.0, ely = 0.0, ehy = 0.0, slack = 0.0;
+        if (p < pairs) {
+          for (int step = 32; step > 0; step >>= 1)
+            if (w.pstart[e + step] <= p) e += step;
+          unsigned long long bits = w.cand[e];
+          for (int r = p - w.pstart[e]; r > 0; --r) bits &= bits - 1ull;
+          b = __ffsll((long long)bits) - 1;
+          const int j = j0 + b;
+          const double ax = w.chord[0][e], ay = w.chord[1][e], bx = w.chord[2][e], by = w.chord[3][e];
+          if (TIME && meta[4 * j + 3] >= 6.0) {
+            if (edge_hits_moving(ax, ay, w.chord[TIME ? 4 : 0][e], bx, by, w.chord[TIME ? 5 : 0][e], rad1, meta[4 * j + 0],
+                                 meta[4 * j + 1], meta[4 * j + 2], tab.path + 3 * (size_t)tab.poff[j],
+                                 tab.poff[j + 1] - tab.poff[j]))
+              atomicOr(&w.mask[e], 1ull << b);
+          } else if (!seg_outside_circle(ax, ay, bx, by, rad1, meta, j)) {
+            const int kind = (int)meta[4 * j + 3];
+            if (kind == 1) atomicOr(&w.mask[e], 1ull << b);
+            else if (kind == 3) {
+              vb0 = off[j];
+              P = off[j + 1] - vb0;
+              if (P < 2) P = 0;
+              elx = fmin(ax, bx); ehx = fmax(ax, bx); ely = fmin(ay, by); ehy = fmax(ay, by);
+              slack = gap_min + 1e-9 * (fabs(elx) + fabs(ehx) + fabs(ely) + fabs(ehy));
+              // (fmin / fmax drop a NaN operand: a chord with a non-finite coordinate keeps every segment)
+              if (!(ax - ax == 0.0 && ay - ay == 0.0 && bx - bx == 0.0 && by - by == 0.0)) slack = __builtin_inf();
+            }
+          }
+        }
+        int pmax = P;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pmax = max(pmax, __shfl_xor(pmax, o));
+        // (at least one round per group of pairs, so that the last group always reaches the final drain below)
+        const int n_sg = pmax > 0 ? pmax : 1;
+        for (int sg = 0; sg < n_sg; ++sg) {
+          bool push = false;
+          if (sg < P) {
+            const int va = vb0 + (sg == 0 ? P - 1 : sg - 1), vb = vb0 + sg;
+            const double Ax = vxy[2 * va], Ay = vxy[2 * va + 1], Bx = vxy[2 * vb], By = vxy[2 * vb + 1];
+            const bool apart = (fmin(Ax, Bx) - ehx > slack) || (elx - fmax(Ax, Bx) > slack) ||
+                               (fmin(Ay, By) - ehy > slack) || (ely - fmax(Ay, By) > slack);
+            const bool finite = (Ax - Ax == 0.0) && (Ay - Ay == 0.0) && (Bx - Bx == 0.0) && (By - By == 0.0);
+            push = !apart || !finite;                            // (slack = +inf or NaN: never apart)
+          }
+          const unsigned long long sv = __ballot(push);
+          if (push)
+            sq[nsq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sv, 0u))] =
+                (unsigned)e | ((unsigned)b << 6) | ((unsigned)sg << 12);
+          nsq += __popcll(sv);
+          // one site for the segment test: rounds of 64 while the queue could overflow, the rest after the last pair
+          const bool last = (p0 + 64 >= pairs) && (sg + 1 == n_sg);
+          while (nsq > kSqCap - 64 || (last && nsq > 0)) seg_round();
+        }
+      }
     }
     __builtin_amdgcn_wave_barrier();
     RRTX_DUB_T(t_arc);
