@@ -548,20 +548,37 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
     // rounding; NaN / overflow keep the obstacle)
     w.chord[0][lane] = sx; w.chord[1][lane] = sy; w.chord[2][lane] = gx; w.chord[3][lane] = gy;   // (stage 2 reuses it)
     if constexpr (TIME) { w.chord[4][lane] = sp[2]; w.chord[5][lane] = gp[2]; }
+    // The obstacles' boxes (bounding circle inflated like the chord test, widened by 1e-9, rounded outward to fp32)
+    // are worked out once per wave -- lane b = obstacle j0 + b, kept in w.pm, which is free until the arc screen --
+    // and every edge then compares its chord's box (widened and rounded outward the same way) with them: four fp32
+    // compares per (edge, obstacle) instead of a dozen fp64 operations.  Disjoint boxes fail the chord test for certain.
+    float4 *obox = reinterpret_cast<float4 *>(&w.pm[0][0]);
+    if (j0 + lane < j1) {
+      const int j = j0 + lane;
+      const float inf = __builtin_inff();
+      float4 o = {-inf, inf, -inf, inf};
+      if (!(TIME && meta[4 * j + 3] >= 6.0)) {                 // (a moving obstacle is not where its record says)
+        const double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
+        const double R = fabs((robot_radius + 2 * r_min) + meta[4 * j + 2]) * (1.0 + 1e-9) + 1e-9 * (1.0 + fabs(cx) + fabs(cy));
+        o.x = __double2float_rd(cx - R); o.y = __double2float_ru(cx + R);
+        o.z = __double2float_rd(cy - R); o.w = __double2float_ru(cy + R);
+      }
+      obox[lane] = o;
+    }
+    __builtin_amdgcn_wave_barrier();
     unsigned long long cand = 0ull;
     if (valid && !w.done[lane]) {
-      // (NaN-propagating min / max: a chord with a NaN coordinate keeps every obstacle)
-      const double cxmin = jl_min(sx, gx), cxmax = jl_max(sx, gx), cymin = jl_min(sy, gy), cymax = jl_max(sy, gy);
+      // (NaN-propagating min / max: a chord with a NaN coordinate keeps every obstacle -- every compare below is false)
       const double cslack = 1e-9 * jl_max(jl_max(fabs(sx), fabs(gx)), jl_max(fabs(sy), fabs(gy)));
-      for (int j = j0; j < j1; ++j) {
-        const double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
-        const double R = fabs((robot_radius + 2 * r_min) + meta[4 * j + 2]) * (1.0 + 1e-9) +
-                         1e-9 * (1.0 + fabs(cx) + fabs(cy)) + cslack;
-        bool c = !(cxmax < cx - R || cxmin > cx + R || cymax < cy - R || cymin > cy + R);
-        if constexpr (TIME) c = c || meta[4 * j + 3] >= 6.0;     // a moving obstacle is not where its record says
-        cand |= (c ? 1ull : 0ull) << (j - j0);
+      const float exlo = __double2float_rd(jl_min(sx, gx) - cslack), exhi = __double2float_ru(jl_max(sx, gx) + cslack);
+      const float eylo = __double2float_rd(jl_min(sy, gy) - cslack), eyhi = __double2float_ru(jl_max(sy, gy) + cslack);
+      for (int b = 0; b < j1 - j0; ++b) {
+        const float4 o = obox[b];
+        const bool c = !(exhi < o.x || exlo > o.y || eyhi < o.z || eylo > o.w);
+        cand |= (c ? 1ull : 0ull) << b;
       }
     }
+    __builtin_amdgcn_wave_barrier();      // (the boxes are read before stage 1b's queue takes w.pm)
     w.cand[lane] = cand;
     w.mask[lane] = 0ull;
     int incl = __popcll(cand);
