@@ -270,10 +270,18 @@ int slab_refresh(rrtx_ctx *ctx, long long n_tiles) {
   const int K = side * side;
   const int Kz = ((ctx->opt_tune >> 8) & 0xff) ? ((ctx->opt_tune >> 8) & 0xff) : kSlabKz;
   const int KK = K * Kz;                  // sort keys: (cell, bin of the third coordinate)
+  // Workspaces sized for the node CAPACITY, not the current count: a tree that grows towards its capacity then
+  // rebuilds without a hipFree / hipMalloc pair (each a device synchronisation, occasionally milliseconds) in
+  // the middle of the caller's stream of searches and appends.
+  const int64_t n_cap = ctx->cap_nodes > n ? ctx->cap_nodes : n;
+  int side_cap = (int)std::sqrt((double)n_cap / (double)cell_nodes);
+  if (side_cap < side) side_cap = side;
+  if (side_cap > 256) side_cap = 256;
+  const size_t kk_cap = (size_t)side_cap * side_cap * Kz + 1;
   RRTX_HIP(ctx, ctx->ws_slab_params.ensure(sizeof(SlabParams)));
-  RRTX_HIP(ctx, ctx->ws_slab_hist.ensure(sizeof(int) * (size_t)(KK + 1)));
-  RRTX_HIP(ctx, ctx->ws_slab_start.ensure(sizeof(int) * (size_t)(KK + 1)));
-  RRTX_HIP(ctx, ctx->ws_slab_sr.ensure(sizeof(int2) * (size_t)n));
+  RRTX_HIP(ctx, ctx->ws_slab_hist.ensure(sizeof(int) * kk_cap));
+  RRTX_HIP(ctx, ctx->ws_slab_start.ensure(sizeof(int) * kk_cap));
+  RRTX_HIP(ctx, ctx->ws_slab_sr.ensure(sizeof(int2) * (size_t)n_cap));
   SlabParams *sp = ctx->ws_slab_params.as<SlabParams>();
   int *hist = ctx->ws_slab_hist.as<int>();
   int *start = ctx->ws_slab_start.as<int>();
