@@ -74,6 +74,29 @@ def test_radius_c2_bit_exact(small3, oracle):
     assert len(idx) > 1024  # non-trivial lists
 
 
+def test_radius_long_lists_every_length(oracle):
+    """The long-list build of the finishing kernel places a list's entries by counting inside index bins
+    (no sort network): lists of 65 ... 8192 entries and the rank-counting path beyond, with indices that are
+    spread evenly (uniform background), packed into a few bins (a cluster appended as one block next to a lone
+    far index), and every entry in ONE bin (a cluster whose indices are consecutive)."""
+    rng = np.random.default_rng(77)
+    bg = rng.uniform(-400, 400, (150_000, 3))
+    cl = rng.normal(0, 1.0, (12_000, 3)) + [900.0, 900.0, 900.0]       # indices 150000..161999, far from the rest
+    lone = np.array([[900.0, 900.0, 905.0]])
+    pts = np.r_[lone, bg, cl]                                            # index 0 sits inside the cluster's ball
+    tree = oracle.KDTree(3)
+    tree.insert_many(pts)
+    c = np.array([900.0, 900.0, 900.0])
+    Q = np.r_[np.tile(c, (10, 1)) + rng.normal(0, 0.2, (10, 3)), rng.uniform(-400, 400, (6, 3))]
+    r = np.array([0.35, 0.5, 0.7, 1.0, 1.4, 2.0, 2.6, 3.2, 4.9, 30.0, 40.0, 60.0, 90.0, 120.0, 150.0, 5.0])
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        offsets, idx, dist = ctx.nn_radius(Q, r)
+        lens = np.diff(offsets)
+        assert lens.max() > 8192 and np.any((lens > 64) & (lens <= 2048)) and np.any((lens > 2048) & (lens <= 8192))
+        _check_csr(offsets, idx, dist, _oracle_lists(tree, Q, r))
+
+
 def test_radius_capacity_two_call(small3):
     pts, tree, ctx = small3
     Q = synth.queries(64, 3)
