@@ -563,11 +563,15 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
     if (__ballot(cand != 0u) != 0ull) {
       // The pairs are decided in two stages so that the lanes stay together.  Stage A, lane = pair: the reference's
       // first test (bounding circle, explicitEdgeCheck2D :1536-1539), which settles balls and the obstacles that
-      // move in time and drops about half of the polygons; for the others every polygon segment whose box comes
-      // within the robot radius of the edge's box is queued.  (A segment farther away than that in x or in y cannot
-      // come out of segmentDistSqrd below robotRadius^2: two segments that far apart do not straddle each other's
-      // lines, not even within rounding -- the crossing point of the lines would have to sit on both -- and their
-      // four point-segment distances are at least the gap.)  Stage B, lane = queued (edge, segment): the
+      // move in time and drops about half of the polygons; for the others a polygon segment is queued unless its
+      // box stays farther than the robot radius from the edge's box in x or in y AND segmentDistSqrd's first
+      // side test (R/DRRT.jl:1150-1167, evaluated here with the reference's own operations: the edge's slope, the
+      // two differences, the strict comparisons) finds both of its ends on one side of the edge's line.  For such
+      // a segment the reference returns the smallest of four point-to-segment distances, each at least the gap,
+      // never below robotRadius^2.  The side test is part of the condition because the reference answers 0.0 --
+      // a hit -- whenever neither side test separates the two, however far apart they are: segments on one common
+      // line (an edge running along the extension of a polygon side), NaN differences.
+      // Stage B, lane = queued (edge, segment): the
       // reference's segment test; any segment within the robot radius is a hit (an OR over the segments, their
       // order does not matter).  Same tests on the pairs that can decide anything, same arithmetic; a hit enters
       // the edge's first-hit minimum as before.
@@ -603,6 +607,8 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
         const int p = p0 + lane;
         int owner = 0, slot = 0, vb0 = 0, P = 0;           // P > 0: a polygon past the bounding circle
         double elx = 0.0, ehx = 0.0, ely = 0.0, ehy = 0.0, slack = 0.0;
+        double pax = 0.0, pay = 0.0, em = 0.0;             // the edge's first end and slope (R/DRRT.jl:1158)
+        bool evert = false;                                // the edge is "close to vertical" (:1151)
         if (p < npair) {
           const unsigned pe = w.pairq[p];
           owner = (int)(pe & 63u);
@@ -628,6 +634,9 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
                 slack = gap_min + 1e-9 * (fabs(elx) + fabs(ehx) + fabs(ely) + fabs(ehy));
                 // (fmin / fmax drop a NaN operand: an edge with a non-finite coordinate keeps every segment)
                 if (!(eax - eax == 0.0 && eay - eay == 0.0 && ebx - ebx == 0.0 && eby - eby == 0.0)) slack = __builtin_inf();
+                pax = eax; pay = eay;
+                evert = fabs(ebx - eax) < .000001;
+                if (!evert) em = (eby - eay) / (ebx - eax);
               }
             }
           }
@@ -644,7 +653,14 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
             const bool apart = (fmin(Ax, Bx) - ehx > slack) || (elx - fmax(Ax, Bx) > slack) ||
                                (fmin(Ay, By) - ehy > slack) || (ely - fmax(Ay, By) > slack);
             const bool finite = (Ax - Ax == 0.0) && (Ay - Ay == 0.0) && (Bx - Bx == 0.0) && (By - By == 0.0);
-            push = !apart || !finite;         // (slack = +inf or NaN: never apart)
+            bool one_side;                                 // segmentDistSqrd's first test, as the reference computes it
+            if (evert) one_side = (Ax >= pax && Bx >= pax) || (Ax <= pax && Bx <= pax);
+            else {
+              const double diff_a = (em * (Ax - pax) + pay) - Ay;
+              const double diff_b = (em * (Bx - pax) + pay) - By;
+              one_side = (diff_a > 0.0 && diff_b > 0.0) || (diff_a < 0.0 && diff_b < 0.0);
+            }
+            push = !(apart && one_side) || !finite;        // (slack = +inf or NaN: never apart)
           }
           const unsigned long long sv = __ballot(push);
           if (push)

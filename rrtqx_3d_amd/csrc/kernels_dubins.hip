@@ -627,6 +627,8 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
         const int p = p0 + lane;
         int e = 0, b = 0, vb0 = 0, P = 0;                        // P > 0: a polygon past the bounding circle
         double elx = 0.0, ehx = 0.0, ely = 0.0, ehy = 0.0, slack = 0.0;
+        double pax = 0.0, pay = 0.0, em = 0.0;                   // the chord's first end and slope (R/DRRT.jl:1158)
+        bool evert = false;                                      // the chord is "close to vertical" (:1151)
         if (p < pairs) {
           for (int step = 32; step > 0; step >>= 1)
             if (w.pstart[e + step] <= p) e += step;
@@ -651,6 +653,9 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
               slack = gap_min + 1e-9 * (fabs(elx) + fabs(ehx) + fabs(ely) + fabs(ehy));
               // (fmin / fmax drop a NaN operand: a chord with a non-finite coordinate keeps every segment)
               if (!(ax - ax == 0.0 && ay - ay == 0.0 && bx - bx == 0.0 && by - by == 0.0)) slack = __builtin_inf();
+              pax = ax; pay = ay;
+              evert = fabs(bx - ax) < .000001;
+              if (!evert) em = (by - ay) / (bx - ax);
             }
           }
         }
@@ -667,7 +672,17 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
             const bool apart = (fmin(Ax, Bx) - ehx > slack) || (elx - fmax(Ax, Bx) > slack) ||
                                (fmin(Ay, By) - ehy > slack) || (ely - fmax(Ay, By) > slack);
             const bool finite = (Ax - Ax == 0.0) && (Ay - Ay == 0.0) && (Bx - Bx == 0.0) && (By - By == 0.0);
-            push = !apart || !finite;                            // (slack = +inf or NaN: never apart)
+            // a segment is dropped only if segmentDistSqrd's first side test, computed as the reference computes it
+            // (R/DRRT.jl:1150-1167), also separates it from the chord: without a separating side test the reference
+            // answers 0.0 however far apart the two are (segments on one common line), see kernels_collide.hip
+            bool one_side;
+            if (evert) one_side = (Ax >= pax && Bx >= pax) || (Ax <= pax && Bx <= pax);
+            else {
+              const double diff_a = (em * (Ax - pax) + pay) - Ay;
+              const double diff_b = (em * (Bx - pax) + pay) - By;
+              one_side = (diff_a > 0.0 && diff_b > 0.0) || (diff_a < 0.0 && diff_b < 0.0);
+            }
+            push = !(apart && one_side) || !finite;              // (slack = +inf or NaN: never apart)
           }
           const unsigned long long sv = __ballot(push);
           if (push)

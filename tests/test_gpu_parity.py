@@ -540,6 +540,28 @@ def test_polygons_edges_degenerate_and_boundary_inputs(oracle):
         p0[k, :2] = [x0 + 4.75, y0]; p1[k, :2] = [x0 + 5.5, y0]; k += 1               # collinear with the bottom side
         p0[k, :2] = [x0 - 1.5, y0 + 2]; p1[k, :2] = [x0 - 0.75, y0 + 2]; k += 1       # collinear with the top side
         p0[k, :2] = [x0, y0 - 1.5]; p1[k, :2] = [x0, y0 - 0.75]; k += 1               # collinear with the left side
+        # the same inside the bounding circle (robot radius 0.5) but more than the robot radius away from the side:
+        # nothing but the side tests themselves tells the reference's answer (0.0, a hit, for the horizontal ones;
+        # the "close to vertical" branch is not strict and separates the vertical one)
+        p0[k, :2] = [x0 + 4.51, y0]; p1[k, :2] = [x0 + 4.515, y0]; k += 1
+        p0[k, :2] = [x0 - 0.515, y0 + 2]; p1[k, :2] = [x0 - 0.51, y0 + 2]; k += 1
+        p0[k, :2] = [x0, y0 - 0.515]; p1[k, :2] = [x0, y0 - 0.51]; k += 1
+    # ... and on the extension of a slanted side, where the slope and the differences round: every variant one ulp
+    # off in one coordinate must still come out as the reference's own operations say
+    tri = np.array([[50.0, 50.0], [53.0, 54.0], [49.0, 57.0]])
+    polys.append(tri); kinds.append(3)
+    ps = oracle.PolygonSet(polys, kinds=kinds)
+    for i in range(240):
+        a = np.array([53.75, 55.0]); b = np.array([54.125, 55.5])
+        if i >= 120:                                                 # beyond the other end of the side
+            a = np.array([49.578125, 49.4375]); b = np.array([49.53125, 49.375])
+        v = i % 120
+        if v > 0:
+            tgt = (a, b)[(v >> 1) & 1]
+            c = (v >> 2) & 1
+            for _ in range(1 + (v >> 3)):
+                tgt[c] = np.nextafter(tgt[c], np.inf if v & 1 else -np.inf)
+        p0[k, :2] = a; p1[k, :2] = b; k += 1
     p1[1500:1540] = p0[1500:1540]                                   # zero-length edges
     p0[1540:1550, 0] = np.nan; p1[1550:1560, 1] = np.nan            # NaN endpoints
     p0[1560:1570, 0] = np.inf; p1[1570:1580, 1] = -np.inf
@@ -551,6 +573,9 @@ def test_polygons_edges_degenerate_and_boundary_inputs(oracle):
             hit, first = ctx.edges_check(p0, p1, rr, kind=1)
             rh, rf = oracle.edges_check_polygons(ps, p0, p1, rr)
             assert np.array_equal(hit, rh) and np.array_equal(first, rf)
+            if rr == 0.5:
+                # the far collinear edges do "cross" in the reference, the vertical one does not
+                assert rh[k - 240] == 1 and rh[k - 120] == 1 and list(rh[k - 243:k - 240]) == [1, 1, 0]
         assert 0 < hit.sum() < len(hit)
 
 
