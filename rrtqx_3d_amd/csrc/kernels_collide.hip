@@ -399,6 +399,7 @@ constexpr int kPolyWaveSamples = 16;   // ... for at most this many samples per 
 // each edge's first hit (list position), the queues of the two test stages, the wave's candidate obstacles
 struct PolyWave {
   double e[6][64];     // ax, ay, at, bx, by, bt per lane
+  double em[64];       // the edge's slope (by - ay) / (bx - ax) as segmentDistSqrd divides it (R/DRRT.jl:1158)
   float4 box[32];      // current group: bounding boxes (xlo, xhi, ylo, yhi) rounded outward to fp32
   int first[64];
   int jidx[32];        // current group: list position of each of its obstacles
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
                                                              const double *__restrict__ meta,
                                                              const int32_t *__restrict__ off,
                                                              const double *__restrict__ vxy,
+                                                             const double *__restrict__ vslope,
                                                              const int32_t *__restrict__ path_off,
                                                              const double *__restrict__ path, int has_moving,
                                                              const int32_t *__restrict__ orig, int m_begin,
@@ -518,6 +520,7 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
   }
   w.e[0][lane] = ax; w.e[1][lane] = ay; w.e[2][lane] = at;
   w.e[3][lane] = bx; w.e[4][lane] = by; w.e[5][lane] = bt;
+  w.em[lane] = (by - ay) / (bx - ax);          // (read only where the edge is not "close to vertical")
   w.first[lane] = 0x7fffffff;
   // The edge's own box, widened by far more than any rounding of the exact test (1e-9 relative against
   // ~1e-15) and rounded outward to fp32.  NaN-propagating min / max: an edge with a NaN coordinate keeps
@@ -564,9 +567,10 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
       // The pairs are decided in two stages so that the lanes stay together.  Stage A, lane = pair: the reference's
       // first test (bounding circle, explicitEdgeCheck2D :1536-1539), which settles balls and the obstacles that
       // move in time and drops about half of the polygons; for the others a polygon segment is queued unless its
-      // box stays farther than the robot radius from the edge's box in x or in y AND segmentDistSqrd's first
-      // side test (R/DRRT.jl:1150-1167, evaluated here with the reference's own operations: the edge's slope, the
-      // two differences, the strict comparisons) finds both of its ends on one side of the edge's line.  For such
+      // box stays farther than the robot radius from the edge's box in x or in y AND one of segmentDistSqrd's two
+      // side tests (R/DRRT.jl:1150-1188, evaluated here with the reference's own operations: the slopes -- the
+      // polygon sides' are divided once when the list is set --, the two differences, the strict comparisons)
+      // finds both ends of one segment on one side of the other's line.  For such
       // a segment the reference returns the smallest of four point-to-segment distances, each at least the gap,
       // never below robotRadius^2.  The side test is part of the condition because the reference answers 0.0 --
       // a hit -- whenever neither side test separates the two, however far apart they are: segments on one common
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
         const int p = p0 + lane;
         int owner = 0, slot = 0, vb0 = 0, P = 0;           // P > 0: a polygon past the bounding circle
         double elx = 0.0, ehx = 0.0, ely = 0.0, ehy = 0.0, slack = 0.0;
-        double pax = 0.0, pay = 0.0, em = 0.0;             // the edge's first end and slope (R/DRRT.jl:1158)
+        double pax = 0.0, pay = 0.0, pbx = 0.0, pby = 0.0, em = 0.0;   // the edge's ends and slope (R/DRRT.jl:1158)
         bool evert = false;                                // the edge is "close to vertical" (:1151)
         if (p < npair) {
           const unsigned pe = w.pairq[p];
@@ -634,9 +638,9 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
                 slack = gap_min + 1e-9 * (fabs(elx) + fabs(ehx) + fabs(ely) + fabs(ehy));
                 // (fmin / fmax drop a NaN operand: an edge with a non-finite coordinate keeps every segment)
                 if (!(eax - eax == 0.0 && eay - eay == 0.0 && ebx - ebx == 0.0 && eby - eby == 0.0)) slack = __builtin_inf();
-                pax = eax; pay = eay;
+                pax = eax; pay = eay; pbx = ebx; pby = eby;
                 evert = fabs(ebx - eax) < .000001;
-                if (!evert) em = (eby - eay) / (ebx - eax);
+                if (!evert) em = w.em[owner];
               }
             }
           }
@@ -645,22 +649,39 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
         int pmax = P;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) pmax = max(pmax, __shfl_xor(pmax, o));
+        // (a side starts where the one before it ends: that vertex, whether it is finite and its difference in the
+        // first side test are carried from round to round)
+        double Ax = 0.0, Ay = 0.0, diff_a1 = 0.0;
+        bool fin_a = false;
+        if (P > 0) {
+          Ax = vxy[2 * (vb0 + P - 1)]; Ay = vxy[2 * (vb0 + P - 1) + 1];
+          fin_a = (Ax - Ax == 0.0) && (Ay - Ay == 0.0);
+          diff_a1 = (em * (Ax - pax) + pay) - Ay;
+        }
         for (int sg = 0; sg < pmax; ++sg) {
           bool push = false;
           if (sg < P) {
-            const int va = vb0 + (sg == 0 ? P - 1 : sg - 1), vb = vb0 + sg;
-            const double Ax = vxy[2 * va], Ay = vxy[2 * va + 1], Bx = vxy[2 * vb], By = vxy[2 * vb + 1];
+            const int vb = vb0 + sg;
+            const double Bx = vxy[2 * vb], By = vxy[2 * vb + 1];
             const bool apart = (fmin(Ax, Bx) - ehx > slack) || (elx - fmax(Ax, Bx) > slack) ||
                                (fmin(Ay, By) - ehy > slack) || (ely - fmax(Ay, By) > slack);
-            const bool finite = (Ax - Ax == 0.0) && (Ay - Ay == 0.0) && (Bx - Bx == 0.0) && (By - By == 0.0);
-            bool one_side;                                 // segmentDistSqrd's first test, as the reference computes it
+            const bool fin_b = (Bx - Bx == 0.0) && (By - By == 0.0);
+            const bool finite = fin_a && fin_b;
+            const double diff_b1 = (em * (Bx - pax) + pay) - By;
+            bool one_side;                                 // segmentDistSqrd's side tests, as the reference computes them
             if (evert) one_side = (Ax >= pax && Bx >= pax) || (Ax <= pax && Bx <= pax);
+            // (both differences strictly positive or both strictly negative <=> their product is positive, except that
+            // the product of two tiny ones can round to zero: the side then just goes to the exact test)
+            else one_side = diff_a1 * diff_b1 > 0.0;
+            if (fabs(Bx - Ax) < .000001) one_side = one_side || (pax >= Ax && pbx >= Ax) || (pax <= Ax && pbx <= Ax);
             else {
-              const double diff_a = (em * (Ax - pax) + pay) - Ay;
-              const double diff_b = (em * (Bx - pax) + pay) - By;
-              one_side = (diff_a > 0.0 && diff_b > 0.0) || (diff_a < 0.0 && diff_b < 0.0);
+              const double qm = vslope[vb];                // (By - Ay) / (Bx - Ax), divided once when the list was set
+              const double diff_a = (qm * (pax - Ax) + Ay) - pay;
+              const double diff_b = (qm * (pbx - Ax) + Ay) - pby;
+              one_side = one_side || diff_a * diff_b > 0.0;
             }
             push = !(apart && one_side) || !finite;        // (slack = +inf or NaN: never apart)
+            Ax = Bx; Ay = By; fin_a = fin_b; diff_a1 = diff_b1;
           }
           const unsigned long long sv = __ballot(push);
           if (push)
@@ -1041,7 +1062,7 @@ int sync_polygons(rrtx_ctx *ctx) {
   const int m = (int)ctx->poly_active.size();
   std::vector<double> meta;
   std::vector<int32_t> off(1, 0), orig;
-  std::vector<double> vxy, path;
+  std::vector<double> vxy, path, slope;
   std::vector<int32_t> path_off(1, 0);
   bool moving = false;
   for (int i = 0; i < m; ++i) {
@@ -1061,6 +1082,12 @@ int sync_polygons(rrtx_ctx *ctx) {
     for (int v = ctx->poly_off[i]; v < ctx->poly_off[i + 1]; ++v) {
       vxy.push_back(ctx->poly_vxy[2 * (size_t)v]);
       vxy.push_back(ctx->poly_vxy[2 * (size_t)v + 1]);
+      // slope of the side (previous vertex -> v) as segmentDistSqrd's second side test computes it (R/DRRT.jl:1178;
+      // one correctly rounded division, the same on the host and on the device); read only where the side is not
+      // "close to vertical", so a division by zero here is never looked at
+      const int u = v > ctx->poly_off[i] ? v - 1 : ctx->poly_off[i + 1] - 1;
+      slope.push_back((ctx->poly_vxy[2 * (size_t)v + 1] - ctx->poly_vxy[2 * (size_t)u + 1]) /
+                      (ctx->poly_vxy[2 * (size_t)v] - ctx->poly_vxy[2 * (size_t)u]));
     }
     off.push_back((int32_t)(vxy.size() / 2));
     orig.push_back(i);
@@ -1073,6 +1100,9 @@ int sync_polygons(rrtx_ctx *ctx) {
     RRTX_HIP(ctx, ctx->d_poly_off.ensure(sizeof(int32_t) * off.size()));
     RRTX_HIP(ctx, ctx->d_poly_vxy.ensure(sizeof(double) * (vxy.size() + 2)));
     RRTX_HIP(ctx, ctx->d_poly_orig.ensure(sizeof(int32_t) * na));
+    RRTX_HIP(ctx, ctx->d_poly_slope.ensure(sizeof(double) * (slope.size() + 1)));
+    if (!slope.empty())
+      RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_slope.p, slope.data(), sizeof(double) * slope.size(), hipMemcpyHostToDevice));
     RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_meta.p, meta.data(), sizeof(double) * meta.size(), hipMemcpyHostToDevice));
     RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_off.p, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
     if (!vxy.empty())
@@ -1199,7 +1229,8 @@ int launch_candidate_edges_polygons(rrtx_ctx *ctx, const double *q_dev, int nq, 
   span_begin(ctx, KF_EDGES);
   hipLaunchKernelGGL(edges_polygons_kernel, dim3((unsigned)((2 * cap + 255) / 256)), dim3(256), 0, ctx->stream,
                      (const double *)nullptr, (const double *)nullptr, ctx->dim, 0ll, csr, ctx->d_poly_meta.as<double>(),
-                     ctx->d_poly_off.as<int32_t>(), ctx->d_poly_vxy.as<double>(), ctx->d_poly_path_off.as<int32_t>(),
+                     ctx->d_poly_off.as<int32_t>(), ctx->d_poly_vxy.as<double>(), ctx->d_poly_slope.as<double>(),
+                     ctx->d_poly_path_off.as<int32_t>(),
                      ctx->d_poly_path.as<double>(), ctx->poly_has_moving ? 1 : 0, ctx->d_poly_orig.as<int32_t>(), 0,
                      ctx->poly_n_active, robot_radius, hit_out_dev, (int32_t *)nullptr);
   span_end(ctx);
@@ -1224,7 +1255,8 @@ int launch_edges_polygons(rrtx_ctx *ctx, const double *p0_dev, const double *p1_
   span_begin(ctx, KF_EDGES);
   hipLaunchKernelGGL(edges_polygons_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
                      p1_dev, ctx->dim, (long long)ne, PolyCsr{}, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
-                     ctx->d_poly_vxy.as<double>(), ctx->d_poly_path_off.as<int32_t>(), ctx->d_poly_path.as<double>(),
+                     ctx->d_poly_vxy.as<double>(), ctx->d_poly_slope.as<double>(), ctx->d_poly_path_off.as<int32_t>(),
+                     ctx->d_poly_path.as<double>(),
                      ctx->poly_has_moving ? 1 : 0, ctx->d_poly_orig.as<int32_t>(), pb, pe, robot_radius, hit_dev,
                      first_hit_dev);
   span_end(ctx);

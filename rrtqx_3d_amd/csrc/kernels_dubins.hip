@@ -365,6 +365,7 @@ struct PolyTab {
   const double *meta;        // per active obstacle {cx, cy, radius, kind}
   const int32_t *off;        // vertex CSR
   const double *vxy;
+  const double *vslope;      // per vertex: slope of the side that ends there (sync_polygons)
   const int32_t *poff;       // path CSR (kinds 6 / 7)
   const double *path;        // rows (dx, dy, t)
   int m;
@@ -627,7 +628,7 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
         const int p = p0 + lane;
         int e = 0, b = 0, vb0 = 0, P = 0;                        // P > 0: a polygon past the bounding circle
         double elx = 0.0, ehx = 0.0, ely = 0.0, ehy = 0.0, slack = 0.0;
-        double pax = 0.0, pay = 0.0, em = 0.0;                   // the chord's first end and slope (R/DRRT.jl:1158)
+        double pax = 0.0, pay = 0.0, pbx = 0.0, pby = 0.0, em = 0.0;   // the chord's ends and slope (R/DRRT.jl:1158)
         bool evert = false;                                      // the chord is "close to vertical" (:1151)
         if (p < pairs) {
           for (int step = 32; step > 0; step >>= 1)
@@ -653,7 +654,7 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
               slack = gap_min + 1e-9 * (fabs(elx) + fabs(ehx) + fabs(ely) + fabs(ehy));
               // (fmin / fmax drop a NaN operand: a chord with a non-finite coordinate keeps every segment)
               if (!(ax - ax == 0.0 && ay - ay == 0.0 && bx - bx == 0.0 && by - by == 0.0)) slack = __builtin_inf();
-              pax = ax; pay = ay;
+              pax = ax; pay = ay; pbx = bx; pby = by;
               evert = fabs(bx - ax) < .000001;
               if (!evert) em = (by - ay) / (bx - ax);
             }
@@ -664,25 +665,40 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
         for (int o = 32; o > 0; o >>= 1) pmax = max(pmax, __shfl_xor(pmax, o));
         // (at least one round per group of pairs, so that the last group always reaches the final drain below)
         const int n_sg = pmax > 0 ? pmax : 1;
+        // (a side starts where the one before it ends: that vertex, whether it is finite and its difference in the
+        // first side test are carried from round to round)
+        double Ax = 0.0, Ay = 0.0, diff_a1 = 0.0;
+        bool fin_a = false;
+        if (P > 0) {
+          Ax = vxy[2 * (vb0 + P - 1)]; Ay = vxy[2 * (vb0 + P - 1) + 1];
+          fin_a = (Ax - Ax == 0.0) && (Ay - Ay == 0.0);
+          diff_a1 = (em * (Ax - pax) + pay) - Ay;
+        }
         for (int sg = 0; sg < n_sg; ++sg) {
           bool push = false;
           if (sg < P) {
-            const int va = vb0 + (sg == 0 ? P - 1 : sg - 1), vb = vb0 + sg;
-            const double Ax = vxy[2 * va], Ay = vxy[2 * va + 1], Bx = vxy[2 * vb], By = vxy[2 * vb + 1];
+            const int vb = vb0 + sg;
+            const double Bx = vxy[2 * vb], By = vxy[2 * vb + 1];
             const bool apart = (fmin(Ax, Bx) - ehx > slack) || (elx - fmax(Ax, Bx) > slack) ||
                                (fmin(Ay, By) - ehy > slack) || (ely - fmax(Ay, By) > slack);
-            const bool finite = (Ax - Ax == 0.0) && (Ay - Ay == 0.0) && (Bx - Bx == 0.0) && (By - By == 0.0);
-            // a segment is dropped only if segmentDistSqrd's first side test, computed as the reference computes it
-            // (R/DRRT.jl:1150-1167), also separates it from the chord: without a separating side test the reference
+            const bool fin_b = (Bx - Bx == 0.0) && (By - By == 0.0);
+            const bool finite = fin_a && fin_b;
+            const double diff_b1 = (em * (Bx - pax) + pay) - By;
+            // a segment is dropped only if one of segmentDistSqrd's side tests, computed as the reference computes them
+            // (R/DRRT.jl:1150-1188), also separates it from the chord: without a separating side test the reference
             // answers 0.0 however far apart the two are (segments on one common line), see kernels_collide.hip
             bool one_side;
             if (evert) one_side = (Ax >= pax && Bx >= pax) || (Ax <= pax && Bx <= pax);
+            else one_side = diff_a1 * diff_b1 > 0.0;           // (a product that rounds to zero: the side is kept)
+            if (fabs(Bx - Ax) < .000001) one_side = one_side || (pax >= Ax && pbx >= Ax) || (pax <= Ax && pbx <= Ax);
             else {
-              const double diff_a = (em * (Ax - pax) + pay) - Ay;
-              const double diff_b = (em * (Bx - pax) + pay) - By;
-              one_side = (diff_a > 0.0 && diff_b > 0.0) || (diff_a < 0.0 && diff_b < 0.0);
+              const double qm = tab.vslope[vb];
+              const double diff_a = (qm * (pax - Ax) + Ay) - pay;
+              const double diff_b = (qm * (pbx - Ax) + Ay) - pby;
+              one_side = one_side || diff_a * diff_b > 0.0;
             }
             push = !(apart && one_side) || !finite;              // (slack = +inf or NaN: never apart)
+            Ax = Bx; Ay = By; fin_a = fin_b; diff_a1 = diff_b1;
           }
           const unsigned long long sv = __ballot(push);
           if (push)
@@ -1054,6 +1070,7 @@ PolyTab poly_tab(rrtx_ctx *ctx) {
   t.meta = ctx->d_poly_meta.as<double>();
   t.off = ctx->d_poly_off.as<int32_t>();
   t.vxy = ctx->d_poly_vxy.as<double>();
+  t.vslope = ctx->d_poly_slope.as<double>();
   t.poff = ctx->d_poly_path_off.as<int32_t>();
   t.path = ctx->d_poly_path.as<double>();
   t.m = ctx->poly_n_active;

@@ -158,6 +158,7 @@ struct rrtx_ctx {
   std::vector<uint8_t> poly_kind, poly_active;
   bool poly_dirty = true;
   int poly_n_active = 0;
+  rrtx::DevBuf d_poly_slope;   // per vertex v: slope of the side that ends at v, (y_v - y_prev) / (x_v - x_prev) (R/DRRT.jl:1178)
   rrtx::DevBuf d_poly_off, d_poly_vxy, d_poly_meta; // meta: per active obstacle {cx, cy, radius, kind} doubles
   rrtx::DevBuf d_poly_orig;
   rrtx::DevBuf ws_knn_off, ws_knn_idx, ws_knn_dist, ws_knn_misc;   // k-nearest via range-search lists
