@@ -18,7 +18,7 @@ def test_bench_help_runs_without_gpu():
 
 def test_committed_bench_line_has_the_contract_fields():
     baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_v4_bench.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_v5_bench.json")))
     assert line["metric"] == baseline["metric"]
     for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -43,7 +43,7 @@ def test_committed_bench_line_has_the_contract_fields():
 
 
 def test_committed_c3_line_and_traffic_file():
-    c3 = json.load(open(os.path.join(ROOT, "profiles", "r02_v4_bench_c3.json")))
+    c3 = json.load(open(os.path.join(ROOT, "profiles", "r02_v5_bench_c3.json")))
     assert c3["config"]["edge"] == "DubinsEdge" and c3["cpu_baseline"]["kind"] == "port" and c3["value"] > 0
     assert c3["roofline"]["bound"] == "valu_fp64"
     tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))

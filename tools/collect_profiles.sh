@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy the outputs of scripts_gpu_profile.sh / scripts_gpu_pmc.sh / scripts_gpu_static.sh (gpurun_out/<tag>*) into
-# profiles/ under the names profiles/README.md lists.   usage: tools/collect_profiles.sh r02_v4
+# profiles/ under the names profiles/README.md lists.   usage: tools/collect_profiles.sh r02_v5
 set -e
 tag=$1
 g=gpurun_out
