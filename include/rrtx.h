@@ -266,8 +266,7 @@ int rrtx_graph_cost_update(rrtx_ctx *ctx, int root_idx, double *lmc /* n_nodes *
 /* explicitPointCheck (R/DRRT_Q.jl:1520-1556; quick=0: explicitPointCheck3D,
  * :1558-1590).  unsafe[i] in {0,1}; clearance[i] = the returned certificate
  * (0.0 when unsafe); clearance may be NULL when only the flag is wanted (the
- * polygon check then evaluates the obstacles near each point only -- the same
- * flag). kind as above. */
+ * same obstacles are looked at either way). kind as above. */
 int rrtx_points_check(rrtx_ctx *ctx, int kind, const double *p, int64_t np, double robot_radius,
                       int quick, uint8_t *unsafe, double *clearance);
 

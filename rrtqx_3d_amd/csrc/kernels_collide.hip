@@ -772,23 +772,33 @@ __device__ double dist_to_polygon_sqrd(double px, double py, const double *__res
   return best;
 }
 
-// One polygon against one point with the wave's lanes dealt over the polygon's edges (all lanes hold the
-// same point): pointInPolygon's crossing count (:1009-1056) and distToPolygonSqrd's minimum (:1087-1106).
-// Each edge's contribution is computed as the sequential loops do; a crossing count is an integer sum and
-// the minimum (NaN never taken, as `dd < best` never takes it) does not depend on the order.
-template <bool MOV>
-__device__ void wave_point_vs_polygon(double px, double py, const double *__restrict__ vxy, int b, int e, double ox,
-                                      double oy, bool &inside, double &dsq) {
+// the value lane l (a constant) holds, as a wave-uniform value
+__device__ __forceinline__ double lane_f64(double v, int l) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// One polygon against one point with the eight lanes of a lane group dealt over the polygon's edges (the eight
+// hold the same point and the same polygon; other groups of the wave work on other polygons at the same time, and
+// the whole wave must call this -- it uses ballots): pointInPolygon's crossing count (:1009-1056) and
+// distToPolygonSqrd's minimum (:1087-1106).  Each edge's contribution is computed as the sequential loops do; a
+// crossing count is an integer sum and the minimum (NaN never taken, as `dd < best` never takes it) does not depend
+// on the order.  n_rounds: wave-uniform, ceil(longest polygon of the wave / 8).
+__device__ void group8_point_vs_polygon(double px, double py, const double *__restrict__ vxy, int b, int e, bool mov,
+                                        double ox, double oy, int n_rounds, bool &inside, double &dsq) {
   const int lane = threadIdx.x & 63;
+  const int sub = lane & 7, shift = lane & 56;
   int crossings = 0;
   double best = __builtin_inf();
-  for (int v0 = b; v0 < e; v0 += 64) {
-    const int v = v0 + lane;
+  for (int k = 0; k < n_rounds; ++k) {
+    const int v = b + 8 * k + sub;
     bool c = false;
     if (v < e) {
       const int sv = (v == b) ? e - 1 : v - 1;
       double sx = vxy[2 * sv], sy = vxy[2 * sv + 1], ex = vxy[2 * v], ey = vxy[2 * v + 1];
-      if (MOV) { sx = sx + ox; sy = sy + oy; ex = ex + ox; ey = ey + oy; }
+      if (mov) { sx = sx + ox; sy = sy + oy; ex = ex + ox; ey = ey + oy; }
       if ((sy > py && ey < py) || (sy < py && ey > py)) {
         if (sx > px && ex > px) {
           c = true;
@@ -803,10 +813,10 @@ __device__ void wave_point_vs_polygon(double px, double py, const double *__rest
       const double dd = dist_sqrd_point_to_segment(px, py, sx, sy, ex, ey);
       if (dd < best) best = dd;
     }
-    crossings += __popcll(__ballot(c));
+    crossings += __popc((unsigned)((__ballot(c) >> shift) & 0xffull));
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int o = 4; o > 0; o >>= 1) {
     const double other = __shfl_xor(best, o);
     if (other < best) best = other;
   }
@@ -818,11 +828,16 @@ __device__ void wave_point_vs_polygon(double px, double py, const double *__rest
 // explicitPointCheck2D loop (:1343-1427); Wdist over the first two coordinates.  One wave per point.
 //   quick pass: lane = obstacle, 64 at a time; "inside any obstacle" is an OR, so order is free.
 //   explicit pass: the reference skips obstacle j when (centre distance - robotRadius) - radius exceeds
-//   the running certificate, which only changes when an obstacle is evaluated; so between two
-//   evaluations the next obstacle to evaluate is the first one in list order that the current
-//   certificate does not skip -- found with a ballot over the 64 obstacles of the chunk -- and the
-//   evaluation itself (polygon containment + distance) is dealt over the polygon's edges.  Same
-//   obstacles evaluated in the same order with the same arithmetic as the sequential loop.
+//   the running certificate, which only changes when an obstacle is evaluated.  The next eight obstacles of the
+//   list that the current certificate does not skip -- found with a ballot over the 64 obstacles of the chunk --
+//   are evaluated at once, eight lanes each (polygon containment + distance dealt over the polygon's edges), and
+//   their results are then gone through in list order with the reference's skip test against the certificate as
+//   it stands by then: an obstacle an earlier one of the eight makes the reference skip is dropped unlooked-at
+//   (its evaluation was wasted work, not a result).  Same obstacles taken into account in the same order with
+//   the same arithmetic as the sequential loop -- whether or not the caller wants the certificate: a far obstacle
+//   cannot be left out of a flag-only call, since pointInPolygon answers "inside" for points far outside a polygon
+//   when the ray meets a vertex whose two sides lie on opposite sides of it (the crossing tests are strict), and
+//   whether the reference looks at such an obstacle is decided by the certificates of everything before it.
 __global__ __launch_bounds__(256) void points_polygons_kernel(const double *__restrict__ p, int stride,
                                                               long long np, const double *__restrict__ meta,
                                                               const int32_t *__restrict__ off,
@@ -847,9 +862,10 @@ __global__ __launch_bounds__(256) void points_polygons_kernel(const double *__re
     const int j = j0 + lane;
     const bool valid = j < m;
     double rad = 0.0, dx = 0.0, dy = 0.0, tdc = 0.0;
-    int kind = 0;
-    bool near = true, in = false;
+    int kind = 0, vb_j = 0, ve_j = 0;
+    bool in = false;
     if (valid) {
+      vb_j = off[j]; ve_j = off[j + 1];                        // (asked for here: one round trip less per round below)
       double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
       rad = meta[4 * j + 2];
       kind = (int)meta[4 * j + 3];
@@ -861,51 +877,66 @@ __global__ __launch_bounds__(256) void points_polygons_kernel(const double *__re
       const double dc = sqrt_rn(sq2(cx, cy, px, py));
       // ---- quickCheck (:1258-1331) ----
       if (!(dc > rad))
-        in = kind == 1 || (kind == 3 && point_in_polygon(px, py, vxy, off[j], off[j + 1])) ||
-             (mov && point_in_polygon<true>(px, py, vxy, off[j], off[j + 1], dx, dy));
+        in = kind == 1 || (kind == 3 && point_in_polygon(px, py, vxy, vb_j, ve_j)) ||
+             (mov && point_in_polygon<true>(px, py, vxy, vb_j, ve_j, dx, dy));
       tdc = dc - robot_radius;                                 // distance from the robot boundary to the centre
-      // Only the flag is wanted (no certificate): an obstacle whose bounding circle the robot clears by a margin
-      // far above any rounding can neither be "bad" nor, through the certificate, make the loop skip one that
-      // is (its own distance exceeds the margin, and an obstacle within the margin is skipped only by a
-      // certificate below it) -- so the loop runs over the near obstacles alone, same order, same arithmetic.
-      if (!clearance && (tdc - rad > 1e-6 * (1.0 + fabs(cx) + fabs(cy) + fabs(px) + fabs(py) + fabs(rad)))) near = false;
     }
     if (__ballot(in) != 0ull) {
       if (lane == 0) { unsafe[i] = 1; if (clearance) clearance[i] = 0.0; }
       return;
     }
     // ---- explicitPointCheck2D over the group (:1343-1427) ----
-    unsigned long long todo = __ballot(valid && near);
+    unsigned long long todo = __ballot(valid);
     for (;;) {
-      const unsigned long long c = __ballot(valid && !(tdc - rad > ret_cert)) & todo;
+      unsigned long long c = __ballot(valid && !(tdc - rad > ret_cert)) & todo;
       if (c == 0ull) break;
-      const int l = __ffsll((long long)c) - 1;                 // next obstacle of the list that is not skipped
-      todo &= ~((2ull << l) - 1ull);
-      const int jl = j0 + l;
-      const int kind_l = __shfl(kind, l);
-      double this_dist = __shfl(tdc, l);
+      // the next (up to) eight obstacles of the list that are not skipped: lane group g takes the g-th of them
+      int my_l = -1, n_c = 0, last_l = 0;
+      for (; n_c < 8 && c != 0ull; ++n_c) {
+        last_l = __ffsll((long long)c) - 1;
+        c &= c - 1ull;
+        if ((lane >> 3) == n_c) my_l = last_l;
+      }
+      todo &= ~((2ull << last_l) - 1ull);
+      const int src = my_l >= 0 ? my_l : 0;
+      const int kind_l = __shfl(kind, src);
+      const double tdc_l = __shfl(tdc, src), rad_l = __shfl(rad, src);
+      const double dx_l = __shfl(dx, src), dy_l = __shfl(dy, src);
+      const bool poly = my_l >= 0 && kind_l != 1;
+      int vb = __shfl(vb_j, src), ve = __shfl(ve_j, src);
+      if (!poly) { vb = 0; ve = 0; }
+      int n_rounds = (ve - vb + 7) >> 3;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) n_rounds = max(n_rounds, __shfl_xor(n_rounds, o));
+      bool inside;
+      double dsq;
+      group8_point_vs_polygon(px, py, vxy, vb, ve, kind_l != 3, dx_l, dy_l, n_rounds, inside, dsq);
+      double this_dist;
       bool bad;
       if (kind_l == 1) {
-        this_dist = this_dist - __shfl(rad, l);
+        this_dist = tdc_l - rad_l;
         bad = this_dist < 0.0;
+      } else if (inside) {
+        this_dist = tdc_l;                                     // (not looked at: the call ends here)
+        bad = true;
       } else {
-        bool inside;
-        double dsq;
-        if (kind_l == 3) wave_point_vs_polygon<false>(px, py, vxy, off[jl], off[jl + 1], 0.0, 0.0, inside, dsq);
-        else wave_point_vs_polygon<true>(px, py, vxy, off[jl], off[jl + 1], __shfl(dx, l), __shfl(dy, l), inside, dsq);
-        if (inside) {
-          bad = true;
-        } else {
-          this_dist = sqrt_rn(dsq) - robot_radius;
-          bad = this_dist < 0.0;
+        this_dist = sqrt_rn(dsq) - robot_radius;
+        bad = this_dist < 0.0;
+      }
+      // the eight in list order, each behind the reference's skip test against the certificate as it stands now
+      // (v_readlane from the first lane of each group: the values are wave-uniform from here on)
+      const double gap_l = tdc_l - rad_l;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if (g >= n_c) break;
+        if (lane_f64(gap_l, 8 * g) > ret_cert) continue;
+        if (__builtin_amdgcn_readlane((int)bad, 8 * g) != 0) {
+          if (lane == 0) { unsafe[i] = 1; if (clearance) clearance[i] = 0.0; }
+          return;
         }
+        const double this_cert = jl_min(ret_cert, lane_f64(this_dist, 8 * g));
+        if (this_cert < ret_cert) ret_cert = this_cert;
       }
-      if (bad) {
-        if (lane == 0) { unsafe[i] = 1; if (clearance) clearance[i] = 0.0; }
-        return;
-      }
-      const double this_cert = jl_min(ret_cert, this_dist);
-      if (this_cert < ret_cert) ret_cert = this_cert;
     }
   }
   if (lane == 0) { unsafe[i] = 0; if (clearance) clearance[i] = ret_cert; }

@@ -1,0 +1,136 @@
+"""Soak on a lattice: scenes whose every coordinate is a multiple of 1/4 -- axis-aligned boxes, right triangles
+and diamonds, balls with lattice centres, edges between lattice points, nodes and samples on the lattice, search
+radii that are distances between lattice points.  Random real scenes never put a point exactly on a line, a
+distance exactly on a threshold or two segments on one line; here almost every test sits on such a boundary:
+strict / non-strict comparisons, the "close to vertical" branches, segmentDistSqrd's coincident lines, the
+inclusive root rule of the range search, ties of the nearest neighbour.  Everything through the C-ABI against
+the oracle, bit for bit."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle import oracle as O  # noqa: E402
+from rrtqx_3d_amd.context import Context  # noqa: E402
+
+
+def lattice(rng, span, shape):
+    return rng.integers(-4 * span, 4 * span + 1, shape).astype(np.float64) / 4.0
+
+
+def lattice_polygons(rng, m, span):
+    polys, kinds = [], []
+    for _ in range(m):
+        c = lattice(rng, span, 2)
+        w, h = rng.integers(1, 13, 2) / 4.0
+        shape = int(rng.integers(0, 4))
+        if shape == 0:
+            v = [[0, 0], [w, 0], [w, h], [0, h]]                       # box, counter-clockwise
+        elif shape == 1:
+            v = [[0, 0], [0, h], [w, h], [w, 0]]                       # box, clockwise
+        elif shape == 2:
+            v = [[0, 0], [w, 0], [0, h]]                               # right triangle
+        else:
+            v = [[w, 0], [2 * w, h], [w, 2 * h], [0, h]]               # diamond (slopes +-h/w)
+        polys.append(c + np.array(v, dtype=np.float64))
+        kinds.append(1 if rng.uniform() < 0.15 else 3)
+    return polys, kinds
+
+
+def scene(sc):
+    rng = np.random.default_rng(310_000 + sc)
+    span = int(rng.choice([3, 6, 12]))
+    out = {"edges": 0, "hits": 0, "nbrs": 0}
+    # ---- polygons: edges, points ----
+    m = int(rng.choice([1, 7, 33, 90]))
+    polys, kinds = lattice_polygons(rng, m, span)
+    ps = O.PolygonSet(polys, kinds=kinds)
+    ne = 1200
+    p0 = np.zeros((ne, 3)); p1 = np.zeros((ne, 3))
+    p0[:, :2] = lattice(rng, span, (ne, 2))
+    step = rng.integers(-12, 13, (ne, 2)).astype(np.float64) / 4.0
+    step[: ne // 3, rng.integers(0, 2)] = 0.0                           # a third axis-aligned
+    p1[:, :2] = p0[:, :2] + step
+    rr = float(rng.choice([0.0, 0.25, 0.5, 1.0]))
+    with Context(3) as ctx:
+        ctx.nodes_append([[0, 0, 0]])
+        ctx.polygons_set(polys, kinds=kinds)
+        hit, first = ctx.edges_check(p0, p1, rr, kind=1)
+        oh, of = O.edges_check_polygons(ps, p0, p1, rr)
+        assert np.array_equal(hit, oh) and np.array_equal(first, of), f"scene {sc}: polygon edges differ"
+        pts = p0[:300]
+        unsafe, clr = ctx.points_check(pts, rr, kind=1)
+        exp = [O.point_check_polygons(ps, p, rr) for p in pts]
+        assert np.array_equal(unsafe.astype(bool), np.array([e[0] for e in exp])), f"scene {sc}: polygon points differ"
+        assert np.array_equal(clr, np.array([e[1] for e in exp])), f"scene {sc}: polygon clearances differ"
+        flag_only, _ = ctx.points_check(pts, rr, kind=1, want_clearance=False)
+        assert np.array_equal(flag_only, unsafe), f"scene {sc}: flag-only polygon point check differs"
+        out["edges"] += ne; out["hits"] += int(hit.sum())
+    # ---- balls in 3-D: edges, points ----
+    ms = int(rng.choice([1, 30, 200]))
+    sph = np.c_[lattice(rng, span, (ms, 3)), rng.integers(1, 9, ms) / 4.0]
+    act = (rng.uniform(size=ms) > 0.1).astype(np.uint8)
+    osph, mo = O.make_spheres(sph, act)
+    q0 = lattice(rng, span, (ne, 3))
+    q1 = q0 + rng.integers(-8, 9, (ne, 3)) / 4.0
+    q1[:15] = q0[:15]                                                   # zero-length edges
+    with Context(3) as ctx:
+        ctx.nodes_append([[0, 0, 0]])
+        ctx.spheres_set(sph, act)
+        hit, first = ctx.edges_check(q0, q1, rr)
+        oh, of = O.edges_check_spheres(osph, mo, q0, q1, rr)
+        assert np.array_equal(hit, oh) and np.array_equal(first, of), f"scene {sc}: sphere edges differ"
+        for quick in (True, False):
+            unsafe, clr = ctx.points_check(q0[:400], rr, quick=quick)
+            ou, oc = O.points_check_spheres(osph, mo, q0[:400], rr, quick=quick)
+            assert np.array_equal(unsafe, ou) and np.array_equal(clr, oc), f"scene {sc}: sphere points differ"
+        out["edges"] += ne; out["hits"] += int(hit.sum())
+    # ---- search on the lattice: distances exactly on the radius, ties of the nearest neighbour ----
+    n = int(rng.choice([300, 3000, 20000]))
+    nodes = np.unique(lattice(rng, span, (n, 3)), axis=0)
+    nodes = nodes[rng.permutation(len(nodes))]
+    tree = O.KDTree(3)
+    tree.insert_many(nodes)
+    Q = lattice(rng, span, (64, 3))
+    r = float(rng.choice([0.75, 1.25, 2.5, 3.25]))                      # 3-4-5 and 5-12-13 triples in quarters
+    with Context(3) as ctx:
+        ctx.spheres_set(sph, act)
+        ctx.nodes_append(nodes)
+        offsets, idx, dist = ctx.nn_radius(Q, r)
+        for i, q in enumerate(Q):
+            oi, ok = tree.within_range(r, q)
+            o = np.argsort(oi, kind="stable")
+            a, b = offsets[i], offsets[i + 1]
+            assert np.array_equal(idx[a:b], oi[o]) and np.array_equal(dist[a:b], ok[o]), f"scene {sc}: range search differs"
+        out["nbrs"] += len(idx)
+        ex = ctx.extend_candidates(Q, r, rr)
+        assert np.array_equal(ex["offsets"], offsets) and np.array_equal(ex["idx"], idx), f"scene {sc}: fused lists differ"
+        # both directed edges of every neighbour, as the reference checks them one by one
+        nbr = nodes[idx]
+        own = np.repeat(np.arange(len(Q)), np.diff(offsets))
+        ho, _ = O.edges_check_spheres(osph, mo, Q[own], nbr, rr)
+        hi, _ = O.edges_check_spheres(osph, mo, nbr, Q[own], rr)
+        assert np.array_equal(ex["hit_out"], ho) and np.array_equal(ex["hit_in"], hi), f"scene {sc}: fused edge flags differ"
+        nidx, ndist = ctx.nn_nearest(Q)
+        for i, q in enumerate(Q):
+            ri, rd = tree.nearest(q)
+            assert ndist[i] == rd, f"scene {sc}: nearest distance differs"
+            # ties: the reference keeps the first it meets in its tree walk, the device the lowest index (documented)
+            d_all = np.sqrt(((nodes - q) ** 2).sum(axis=1))
+            assert d_all[nidx[i]] == d_all.min()
+    return out
+
+
+if __name__ == "__main__":
+    n_scen = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    t0 = time.time()
+    tot = {"edges": 0, "hits": 0, "nbrs": 0}
+    for sc in range(n_scen):
+        o = scene(sc)
+        for k in tot:
+            tot[k] += o[k]
+        if (sc + 1) % 10 == 0:
+            print(f"{sc + 1} scenes ok, {tot}, {time.time() - t0:.0f} s", flush=True)
+    print("SOAK OK", n_scen, tot)
