@@ -42,7 +42,7 @@ def lattice_polygons(rng, m, span):
 def scene(sc):
     rng = np.random.default_rng(310_000 + sc)
     span = int(rng.choice([3, 6, 12]))
-    out = {"edges": 0, "hits": 0, "nbrs": 0}
+    out = {"edges": 0, "hits": 0, "nbrs": 0, "dubins_edges": 0, "dubins_flips": 0}
     # ---- polygons: edges, points ----
     m = int(rng.choice([1, 7, 33, 90]))
     polys, kinds = lattice_polygons(rng, m, span)
@@ -68,6 +68,55 @@ def scene(sc):
         flag_only, _ = ctx.points_check(pts, rr, kind=1, want_clearance=False)
         assert np.array_equal(flag_only, unsafe), f"scene {sc}: flag-only polygon point check differs"
         out["edges"] += ne; out["hits"] += int(hit.sum())
+    # ---- the same list with obstacles that move in time (kinds 6 / 7): path rows and times on the lattice, edges
+    # and points whose third coordinate (time) falls exactly on path times ----
+    mk = list(kinds)
+    paths = [None] * m
+    for jj in range(m):
+        if rng.uniform() < 0.3:
+            mk[jj] = int(rng.choice([6, 7]))
+            rows = int(rng.integers(1, 6))
+            paths[jj] = np.c_[lattice(rng, 2, (rows, 2)), np.sort(rng.integers(0, 9, rows)).astype(np.float64)]
+    act_m = [int(rng.uniform() > 0.1) for _ in range(m)]
+    psm = O.PolygonSet(polys, kinds=mk, active=act_m, paths=paths)
+    p0[:, 2] = rng.integers(-1, 10, ne); p1[:, 2] = p0[:, 2] + rng.integers(-3, 4, ne)
+    with Context(3) as ctx:
+        ctx.nodes_append([[0, 0, 0]])
+        ctx.polygons_set(polys, kinds=mk, active=act_m, paths=paths)
+        hit, first = ctx.edges_check(p0, p1, rr, kind=1)
+        oh, of = O.edges_check_polygons(psm, p0, p1, rr)
+        assert np.array_equal(hit, oh) and np.array_equal(first, of), f"scene {sc}: edges against moving obstacles differ"
+        pts = p0[:300]
+        unsafe, clr = ctx.points_check(pts, rr, kind=1)
+        exp = [O.point_check_polygons(psm, p, rr) for p in pts]
+        assert np.array_equal(unsafe.astype(bool), np.array([e[0] for e in exp])), f"scene {sc}: points against moving obstacles differ"
+        assert np.array_equal(clr, np.array([e[1] for e in exp])), f"scene {sc}: clearances against moving obstacles differ"
+        out["edges"] += ne; out["hits"] += int(hit.sum())
+    # ---- Dubins edges between lattice poses (headings multiples of pi / 4).  Counted, not asserted: the arcs come
+    # out of sin / cos / atan2, which differ in the last bit between the host's libm, the device's and Julia's, and
+    # on a lattice that bit decides things -- a piece that grazes a side (boolean), or an arc of length exactly 0
+    # that comes out of the mod 2 pi as a full turn when the difference rounds to -1e-16 (a goal exactly ahead on
+    # the start's heading line: the cost then differs by 2 pi r_min).  Neither side is "right" without the
+    # reference's own libm; the counts are bounded in the test so that a real defect would show ----
+    nd = 300
+    ds = np.zeros((nd, 4)); dg = np.zeros((nd, 4))
+    ds[:, :2] = lattice(rng, span, (nd, 2)); ds[:, 3] = rng.integers(0, 8, nd) * (np.pi / 4)
+    dg[:, :2] = ds[:, :2] + rng.integers(-16, 17, (nd, 2)) / 4.0; dg[:, 3] = rng.integers(0, 8, nd) * (np.pi / 4)
+    r_min = float(rng.choice([0.5, 1.0, 2.0]))
+    with Context(4) as ctx:
+        ctx.nodes_append(ds[:2])
+        ctx.polygons_set(polys, kinds=kinds)
+        cost, word, dhit, tl = ctx.dubins_edges_check(ds, dg, r_min, rr)
+    flips = 0
+    for i2 in range(nd):
+        c_o, w_o, traj = O.dubins_steer(ds[i2], dg[i2], r_min)
+        h_o, _ = O.dubins_edge_check_polygons(ps, ds[i2], dg[i2], traj, rr, r_min)
+        if not (cost[i2] == c_o or abs(cost[i2] - c_o) <= 1e-6 * max(1.0, abs(c_o))):
+            print(f"scene {sc}: Dubins cost differs: s={ds[i2].tolist()} g={dg[i2].tolist()} r_min={r_min} "
+                  f"device {cost[i2]!r} {bytes(word[i2]).decode() if hasattr(word[i2], '__len__') else word[i2]} oracle {c_o!r} {w_o}", flush=True)
+            out["dubins_cost_diffs"] = out.get("dubins_cost_diffs", 0) + 1
+        flips += int(bool(dhit[i2]) != bool(h_o))
+    out["dubins_edges"] = nd; out["dubins_flips"] = flips
     # ---- balls in 3-D: edges, points ----
     ms = int(rng.choice([1, 30, 200]))
     sph = np.c_[lattice(rng, span, (ms, 3)), rng.integers(1, 9, ms) / 4.0]
@@ -126,11 +175,11 @@ def scene(sc):
 if __name__ == "__main__":
     n_scen = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     t0 = time.time()
-    tot = {"edges": 0, "hits": 0, "nbrs": 0}
+    tot = {"edges": 0, "hits": 0, "nbrs": 0, "dubins_edges": 0, "dubins_flips": 0}
     for sc in range(n_scen):
         o = scene(sc)
-        for k in tot:
-            tot[k] += o[k]
+        for k in o:
+            tot[k] = tot.get(k, 0) + o[k]
         if (sc + 1) % 10 == 0:
             print(f"{sc + 1} scenes ok, {tot}, {time.time() - t0:.0f} s", flush=True)
     print("SOAK OK", n_scen, tot)
