@@ -13,6 +13,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from oracle import oracle as O  # noqa: E402
+from rrtqx_3d_amd import _capi  # noqa: E402
 from rrtqx_3d_amd.context import Context  # noqa: E402
 
 
@@ -169,6 +170,49 @@ def scene(sc):
             # ties: the reference keeps the first it meets in its tree walk, the device the lowest index (documented)
             d_all = np.sqrt(((nodes - q) ** 2).sum(axis=1))
             assert d_all[nidx[i]] == d_all.min()
+    # ---- the fused preamble against the polygon list (RRTX_OPT_EXTEND_OBSTACLES = 1): its edges come straight
+    # from the lists and walk only the obstacles near their samples; held to the oracle edge by edge ----
+    with Context(3) as ctx:
+        ctx.nodes_append(nodes)
+        ctx.polygons_set(polys, kinds=mk, active=act_m, paths=paths)
+        ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 1)
+        Qt = Q.copy(); Qt[:, 2] = rng.integers(0, 9, len(Q))
+        ex = ctx.extend_candidates(Qt, r, rr)
+        own = np.repeat(np.arange(len(Qt)), np.diff(ex["offsets"]))
+        nbr = nodes[ex["idx"]]
+        ho, _ = O.edges_check_polygons(psm, Qt[own], nbr, rr)
+        hi, _ = O.edges_check_polygons(psm, nbr, Qt[own], rr)
+        assert np.array_equal(ex["hit_out"], ho) and np.array_equal(ex["hit_in"], hi), f"scene {sc}: fused polygon edge flags differ"
+        exp = np.array([O.point_check_polygons(psm, q, rr)[0] for q in Qt])
+        assert np.array_equal(ex["sample_unsafe"].astype(bool), exp), f"scene {sc}: fused polygon sample flags differ"
+    # ---- the same in the Dubins space [x y 0 theta], theta wrapped at 2 pi (R/DRRT.jl:3312): headings multiples
+    # of pi / 4 (0 and 2 pi - the wrap point itself - included), ghost copies, distances exactly on the radius ----
+    n4 = int(rng.choice([200, 2500]))
+    nodes4 = np.zeros((n4, 4))
+    nodes4[:, :2] = lattice(rng, span, (n4, 2))
+    nodes4[:, 3] = rng.integers(0, 9, n4) * (np.pi / 4)
+    nodes4 = np.unique(nodes4, axis=0)
+    nodes4 = nodes4[rng.permutation(len(nodes4))]
+    tree4 = O.KDTree(4, wraps=[3], wrap_points=[2.0 * np.pi])
+    tree4.insert_many(nodes4)
+    Q4 = np.zeros((48, 4))
+    Q4[:, :2] = lattice(rng, span, (48, 2))
+    Q4[:, 3] = rng.integers(0, 9, 48) * (np.pi / 4)
+    r4 = float(rng.choice([0.75, 1.25, np.pi / 4, np.pi / 2, 3.25]))
+    with Context(4) as ctx:
+        ctx.set_wrap(3, 2.0 * np.pi)
+        ctx.nodes_append(nodes4)
+        offsets, idx, dist = ctx.nn_radius(Q4, r4)
+        for i, q in enumerate(Q4):
+            oi, ok = tree4.within_range(r4, q)
+            o = np.argsort(oi, kind="stable")
+            a, b = offsets[i], offsets[i + 1]
+            assert np.array_equal(idx[a:b], oi[o]) and np.array_equal(dist[a:b], ok[o]), f"scene {sc}: wrapped range search differs"
+        out["nbrs"] += len(idx)
+        nidx, ndist = ctx.nn_nearest(Q4)
+        for i, q in enumerate(Q4):
+            ri, rd = tree4.nearest(q)
+            assert ndist[i] == rd, f"scene {sc}: wrapped nearest distance differs"
     return out
 
 
