@@ -163,6 +163,8 @@ def scene(sc):
         ho, _ = O.edges_check_spheres(osph, mo, Q[own], nbr, rr)
         hi, _ = O.edges_check_spheres(osph, mo, nbr, Q[own], rr)
         assert np.array_equal(ex["hit_out"], ho) and np.array_equal(ex["hit_in"], hi), f"scene {sc}: fused edge flags differ"
+        su, _ = O.points_check_spheres(osph, mo, Q, rr, quick=True)
+        assert np.array_equal(ex["sample_unsafe"], su), f"scene {sc}: fused sample flags differ"
         nidx, ndist = ctx.nn_nearest(Q)
         for i, q in enumerate(Q):
             ri, rd = tree.nearest(q)
