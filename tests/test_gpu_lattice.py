@@ -20,11 +20,13 @@ _spec.loader.exec_module(soak_lattice)
 
 @pytest.mark.parametrize("first", [0, 120])
 def test_lattice_scenes_match_the_oracle(oracle, first):
-    edges = flips = dubins = diffs = 0
+    edges = flips = dubins = diffs = own = 0
     for sc in range(first, first + 8):
         o = soak_lattice.scene(sc)
         edges += o["edges"]; flips += o["dubins_flips"]; dubins += o["dubins_edges"]; diffs += o.get("dubins_cost_diffs", 0)
+        own += o.get("dubins_own_flips", 0)
     assert edges == 8 * 3600
+    assert own == 0                        # the two-stage check itself: the oracle's answer on the device's own polyline
     # Dubins between lattice poses: the last bit of sin / cos / atan2 (host libm vs device) decides grazing pieces
     # and zero-length arcs that wrap to a full turn; 100 scenes: 25 booleans and 1 cost of 30 000 edges
     assert flips <= dubins // 100 and diffs <= 2

@@ -108,6 +108,15 @@ def scene(sc):
         ctx.nodes_append(ds[:2])
         ctx.polygons_set(polys, kinds=kinds)
         cost, word, dhit, tl = ctx.dubins_edges_check(ds, dg, r_min, rr)
+        toff, txy = ctx.dubins_trajectory(ds, dg, r_min)
+    # the check itself is exact: fed the DEVICE's polyline, the oracle's two-stage check gives the device's boolean
+    for i2 in range(nd):
+        if np.isfinite(cost[i2]) and toff[i2 + 1] > toff[i2]:
+            h_own, _ = O.dubins_edge_check_polygons(ps, ds[i2], dg[i2], txy[toff[i2]:toff[i2 + 1]], rr, r_min)
+            if bool(dhit[i2]) != bool(h_own):
+                print(f"scene {sc}: Dubins check differs on the device's own polyline: s={ds[i2].tolist()} g={dg[i2].tolist()} "
+                      f"r_min={r_min} rr={rr} device {dhit[i2]} oracle {h_own}", flush=True)
+                out["dubins_own_flips"] = out.get("dubins_own_flips", 0) + 1
     flips = 0
     for i2 in range(nd):
         c_o, w_o, traj = O.dubins_steer(ds[i2], dg[i2], r_min)
