@@ -26,6 +26,7 @@ constexpr int kFinQ = kFinThreads / 32;   // queries per workgroup
 constexpr int kBigSort = 2048;      // LDS sort of the normal build of the kernel
 constexpr int kHugeSort = 8192;     // ... of the build for calls with long lists (dense balls: Dubins spaces, sweeps)
 constexpr int kFinBins = 2048;      // index bins of the long-list build's placement
+constexpr int kFinCrowd = 128;      // ... and the most entries a bin may hold before the list goes to the sort network
 
 struct FinishArgs {
   const int *count;
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(kFinThreads, KSORT > kBigSort ? 2 : 8) void nn_fini
     }
     double best = __builtin_inf();
     int best_i = 0x7fffffff;
+    bool placed = false;                                   // workgroup-uniform: the list was written by counting
     if (KSORT > kBigSort && gk <= KSORT) {
       // Long-list build: no sort network.  The node indices of a list are distinct and spread over the tree, so
       // every entry finds its place by counting: the entries are dealt into kFinBins equal-width bins of
@@ -291,6 +293,9 @@ __global__ __launch_bounds__(kFinThreads, KSORT > kBigSort ? 2 : 8) void nn_fini
       // the number of bin mates with a smaller index (ties, which a list does not have, by arrival).  Every thread
       // keeps its entries in registers and writes them straight to their places of the caller's arrays: 8
       // barriers per list instead of the 66 of a 2048-entry bitonic network (C3, lists of ~1400: 60 -> ~10 us).
+      // A list whose indices crowd into few bins (a block of consecutive indices next to a lone far one in a
+      // large tree) would make the in-bin count long: more than kFinCrowd entries in one bin send the list to the
+      // sort network below instead (nothing has been written by then).
       constexpr int kEpt = KSORT / kFinThreads;
       int my_idx[kEpt], my_fl[kEpt], my_bin[kEpt], my_in[kEpt];
       double my_d2[kEpt];
@@ -334,14 +339,22 @@ __global__ __launch_bounds__(kFinThreads, KSORT > kBigSort ? 2 : 8) void nn_fini
           const int o = __shfl_up(v, off);
           if (lane >= off) v += o;
         }
-        if (lane == 63) sm.mm[wave] = v;
+        int cmax = max(max(c0, c1), max(c2, c3));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+        if (lane == 63) { sm.mm[wave] = v; sm.mm[kFinThreads / 64 + wave] = cmax; }
         __syncthreads();
         int pre = v - mine;
         for (int w = 0; w < wave; ++w) pre += sm.mm[w];
         sm.bins[4 * t] = pre; sm.bins[4 * t + 1] = pre + c0; sm.bins[4 * t + 2] = pre + c0 + c1; sm.bins[4 * t + 3] = pre + c0 + c1 + c2;
         if (t == kFinThreads - 1) sm.bins[kFinBins] = pre + mine;
       }
+      int crowd = 0;
+#pragma unroll
+      for (int w = 0; w < kFinThreads / 64; ++w) crowd = max(crowd, sm.mm[kFinThreads / 64 + w]);
+      placed = crowd <= kFinCrowd;
       __syncthreads();
+     if (placed) {
       int *t_idx = sm.s_idx;                                          // the indices in bin order ...
       int *t_pos = reinterpret_cast<int *>(sm.s_d2);                  // ... and where each came from
 #pragma unroll
@@ -372,6 +385,9 @@ __global__ __launch_bounds__(kFinThreads, KSORT > kBigSort ? 2 : 8) void nn_fini
           if (a.hit_out) { a.hit_out[gb + rank] = my_fl[e] & 1; a.hit_in[gb + rank] = (my_fl[e] >> 1) & 1; }
         }
       }
+     }
+    }
+    if (placed) {
     } else if (gk <= KSORT) {
       int n2 = 64;
       while (n2 < gk) n2 <<= 1;

@@ -97,6 +97,28 @@ def test_radius_long_lists_every_length(oracle):
         _check_csr(offsets, idx, dist, _oracle_lists(tree, Q, r))
 
 
+def test_radius_long_lists_crowded_index_bins(oracle):
+    """A block of consecutive indices next to a lone far index in a large tree crowds the 2048 index bins of the
+    counting placement (hundreds of entries in one bin): such a list goes to the sort network instead; lists of the
+    same call that do spread out are still placed by counting.  Against the oracle."""
+    rng = np.random.default_rng(78)
+    bg = rng.uniform(-400, 400, (594_000, 3))
+    cl = rng.normal(0, 1.0, (6_000, 3)) + [900.0, 900.0, 900.0]        # indices 594001..600000
+    lone = np.array([[900.0, 900.0, 903.0]])
+    pts = np.r_[lone, bg, cl]
+    tree = oracle.KDTree(3)
+    tree.insert_many(pts)
+    c = np.array([900.0, 900.0, 900.0])
+    Q = np.r_[np.tile(c, (4, 1)) + rng.normal(0, 0.2, (4, 3)), rng.uniform(-400, 400, (2, 3))]
+    r = np.array([1.0, 2.0, 3.2, 30.0, 60.0, 80.0])
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        offsets, idx, dist = ctx.nn_radius(Q, r)
+        lens = np.diff(offsets)
+        assert np.sum((lens > 512) & (lens <= 8192)) >= 4
+        _check_csr(offsets, idx, dist, _oracle_lists(tree, Q, r))
+
+
 def test_radius_capacity_two_call(small3):
     pts, tree, ctx = small3
     Q = synth.queries(64, 3)
