@@ -695,6 +695,36 @@ def test_polygon_kat_k7(oracle):
         assert list(hit) == [1, 0]
 
 
+def test_polygon_kats_k11_k12(oracle):
+    """The two reference quirks of tests/test_oracle_kat.py K11 / K12 through the C-ABI: an edge on the extension of
+    a polygon side, inside the bounding circle and farther than the robot radius from the side, is a hit
+    (segmentDistSqrd answers 0.0 for segments on one line); a point far left of a triangle at the height of its
+    left vertex is "inside" (strict crossing tests) -- with and without the certificate, and also when an obstacle
+    earlier in the list gives the loop a certificate first (the triangle is then skipped by the reference, and the
+    point is safe)."""
+    box = [[0.0, 0.0], [4.0, 0.0], [4.0, 2.0], [0.0, 2.0]]
+    tri = [[0.0, 0.0], [2.0, -1.0], [2.0, 1.0]]
+    near_box = [[-5.5, 2.0], [-4.5, 2.0], [-4.5, 3.0], [-5.5, 3.0]]   # 1.9 from the first point: certificate 1.9 < 4.49
+    with Context(3) as ctx:
+        ctx.nodes_append([[0, 0, 0]])
+        ctx.polygons_set([box])
+        p0 = [[4.51, 0.0, 0], [4.51, 0.001, 0], [0.0, -0.515, 0]]
+        p1 = [[4.515, 0.0, 0], [4.515, 0.001, 0], [0.0, -0.51, 0]]
+        hit, _ = ctx.edges_check(p0, p1, 0.5, kind=1)
+        rh, _ = oracle.edges_check_polygons(oracle.PolygonSet([box]), np.array(p0), np.array(p1), 0.5)
+        assert list(hit) == [1, 0, 0] and list(rh) == [1, 0, 0]
+        pts = np.array([[-5.0, 0.0, 0], [-5.0, 0.5, 0], [5.0, 0.0, 0]])
+        for polys, expect in (([tri], [1, 0, 0]), ([near_box, tri], [0, 0, 0]), ([tri, near_box], [1, 0, 0])):
+            ctx.polygons_set(polys)
+            ps = oracle.PolygonSet(polys)
+            exp = [oracle.point_check_polygons(ps, p, 0.1) for p in pts]
+            assert [int(e[0]) for e in exp] == expect
+            unsafe, clr = ctx.points_check(pts, 0.1, kind=1)
+            assert list(unsafe) == expect and np.array_equal(clr, np.array([e[1] for e in exp]))
+            flag, _ = ctx.points_check(pts, 0.1, kind=1, want_clearance=False)
+            assert list(flag) == expect
+
+
 def test_radius_wrapped_theta_c3(oracle):
     """Dubins space [x y 0 theta], theta wraps at 2*pi (R/DRRT.jl:3312): ghost rule + dedupe."""
     n = 20_000

@@ -79,6 +79,35 @@ def test_segment_dist_branches(oracle):
     assert oracle.segment_dist_sqrd([0, 0], [2, 0], [1, 0], [1, 3]) == 0.0
 
 
+def test_k11_segments_on_one_line_far_apart(oracle):
+    """Hand-derived from R/DRRT.jl:1144-1202: with P = (5,0)-(6,0) and Q = (0,0)-(1,0) the slope of P is 0, both
+    differences (m*(Q.x - PA.x) + PA.y) - Q.y are exactly 0, so "Q on one side of P" (strict > / <) fails; the same
+    for P against Q; possibleIntersect stays true and the function returns 0.0 although the segments are 4 apart.
+    On a vertical common line the first branch compares with >= / <= and does separate them: the distance is
+    real.  A slanted common line behaves like the horizontal one whenever the differences round to 0 (here all
+    four products are exact).  The device's segment rejection has to reproduce this (kernels_collide.hip, stage A)."""
+    assert oracle.segment_dist_sqrd([5, 0], [6, 0], [0, 0], [1, 0]) == 0.0
+    assert oracle.segment_dist_sqrd([0, 5], [0, 6], [0, 0], [0, 1]) == 16.0
+    assert oracle.segment_dist_sqrd([8, 4], [12, 6], [0, 0], [2, 1]) == 0.0           # slope 1/2, exact
+    # one unit off the common line: the side tests separate, the result is the end-point distance
+    assert oracle.segment_dist_sqrd([5, 1], [6, 1], [0, 0], [1, 0]) == 17.0
+
+
+def test_k12_point_in_polygon_ray_through_a_vertex(oracle):
+    """Hand-derived from R/DRRT.jl:1009-1056: an edge is counted only if its ends lie STRICTLY on opposite sides of
+    the ray's height.  Triangle (0,0), (2,-1), (2,1), point (-5, 0): the two edges at the vertex (0,0) are not
+    counted (one end at the ray's height), the edge (2,-1)-(2,1) is, with both x right of the point: one crossing,
+    odd, "inside" -- for a point 5 to the left of the polygon.  One ulp off that height the count is 2.  The
+    explicit point check meets this whenever it evaluates such an obstacle, however far away it is, which is why a
+    flag-only call cannot leave far obstacles out (kernels_collide.hip, points_polygons_kernel)."""
+    tri = [[0, 0], [2, -1], [2, 1]]
+    assert oracle.point_in_polygon([-5, 0], tri)
+    assert not oracle.point_in_polygon([-5, np.nextafter(0.0, 1.0)], tri)
+    assert not oracle.point_in_polygon([-5, 0.5], tri) and oracle.point_in_polygon([1.5, 0.5], tri)
+    # a point on the far side of the same ray: no edge has both ends to its right
+    assert not oracle.point_in_polygon([5, 0], tri)
+
+
 def test_point_in_polygon(oracle):
     sq = [[0, 0], [1, 0], [1, 1], [0, 1]]
     assert oracle.point_in_polygon([.5, .5], sq)
