@@ -224,6 +224,16 @@ def scene(sc):
         for i, q in enumerate(Q4):
             ri, rd = tree4.nearest(q)
             assert ndist[i] == rd, f"scene {sc}: wrapped nearest distance differs"
+        # the fused Dubins preamble against the stand-alone entry points (same device arithmetic: bit for bit)
+        ctx.polygons_set(polys, kinds=kinds)
+        exd = ctx.extend_candidates_dubins(Q4, r4, rr, r_min)
+        assert np.array_equal(exd["offsets"], offsets) and np.array_equal(exd["idx"], idx), f"scene {sc}: fused Dubins lists differ"
+        own = np.repeat(np.arange(len(Q4)), np.diff(offsets))
+        if len(idx):
+            c_o, w_o, h_o, _ = ctx.dubins_edges_check(Q4[own], nodes4[idx], r_min, rr)
+            c_i, w_i, h_i, _ = ctx.dubins_edges_check(nodes4[idx], Q4[own], r_min, rr)
+            assert np.array_equal(exd["cost_out"], c_o) and np.array_equal(exd["cost_in"], c_i), f"scene {sc}: fused Dubins costs differ"
+            assert np.array_equal(exd["hit_out"], h_o) and np.array_equal(exd["hit_in"], h_i), f"scene {sc}: fused Dubins flags differ"
     return out
 
 
