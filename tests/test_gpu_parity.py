@@ -471,9 +471,10 @@ def test_polygons_edges_and_points(oracle):
 
 
 def test_polygon_point_flag_without_certificate_matches_full_check(oracle):
-    """explicitPointCheck with no certificate wanted walks only the obstacles near each point: the flag must be
-    the one the full sequential emulation returns -- random points, points at the robot radius from a polygon
-    edge or a ball to within ulps, points on bounding circles, moving obstacles, non-finite points."""
+    """explicitPointCheck with no certificate wanted (clearance == NULL) must return the flag of the call that
+    wants it -- random points, points at the robot radius from a polygon edge or a ball to within ulps, points on
+    bounding circles, moving obstacles, non-finite points.  (Until the end of round 2 the flag-only call walked the
+    near obstacles only; the lattice scenes showed that wrong, tests/test_gpu_lattice.py, K12.)"""
     rng = np.random.default_rng(78)
     polys, kinds, paths = [], [], []
     for i in range(200):
@@ -649,7 +650,7 @@ def test_extend_candidates_against_polygon_list(oracle, with_moving):
 @pytest.mark.parametrize("seed", range(4))
 def test_extend_polygon_path_equals_explicit_edge_and_point_checks(seed):
     """The fused preamble's polygon checks take shortcuts the stand-alone entry points do not (a wave of candidate
-    edges walks only the obstacles near its samples; the sample check evaluates near obstacles only): on random
+    edges walks only the obstacles near its samples; the sample check is a flag-only call): on random
     scenes -- many obstacles, balls, moving and inactive ones, short and long radii, samples on top of nodes
     (zero-length edges), a NaN sample -- both must give what rrtx_edges_check / rrtx_points_check give for the
     same edges and points (those walk the whole list and are held to the oracle elsewhere)."""
