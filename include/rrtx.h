@@ -132,6 +132,9 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out);
  *   several GPUs (rrtqx_3d_amd/parallel.py): its node 0 is an ordinary node. */
 #define RRTX_OPT_ROOT_RULE 13
 int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value);
+/* The value an option currently has (as rrtx_set_option normalised it): callers that size buffers by an
+ * option -- the row width of rrtx_dubins_trajectory -- read it here instead of keeping a shadow copy. */
+int rrtx_get_option(rrtx_ctx *ctx, int option, int64_t *value);
 
 /* Host-only helper (no GPU needed): the exact thresholds on SQUARED distances the kernels
  * compare against, so that no device sqrt sits on a decision path:
@@ -298,10 +301,18 @@ int rrtx_dubins_edges_check(rrtx_ctx *ctx, const double *s, const double *g, int
 /* edge.trajectory of calculateTrajectory(S, ::DubinsEdge) (:506-701): the discretised polyline
  * (0.1 rad arc steps, Julia float-range length rule), P_i rows of (x, y) per edge -- rows of (x, y, t) with
  * RRTX_OPT_SPACE_HAS_TIME, the last row being the end node's (x, y, t) (:684-696) -- CSR layout:
- * traj_off[ne+1] (rows), traj_xy[(2 or 3) * total rows].  Two-call pattern: if the total exceeds
- * cap_rows the call returns RRTX_E_CAPACITY with *needed_rows set (traj_off is still valid). */
+ * traj_off[ne+1] (rows), traj_xy[cols * total rows].  `cols` is the row width the caller's buffer was sized
+ * for and must be the context's (2, or 3 with RRTX_OPT_SPACE_HAS_TIME; rrtx_get_option tells): anything else is
+ * RRTX_E_INVALID and nothing is written -- a caller whose idea of the space drifted from the context's gets an
+ * error, not a buffer overrun.  Two-call pattern: if the total exceeds cap_rows the call returns
+ * RRTX_E_CAPACITY with *needed_rows set (traj_off is still valid). */
 int rrtx_dubins_trajectory(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min,
-                           int64_t *traj_off, double *traj_xy, int64_t cap_rows, int64_t *needed_rows);
+                           int64_t *traj_off, double *traj_xy, int cols, int64_t cap_rows, int64_t *needed_rows);
+
+/* Diagnostics: the deterministic transcendentals of include/rrtx_detmath.h evaluated ON THE DEVICE, element-wise
+ * over host arrays (op 0 sin(x), 1 cos(x), 2 atan2(y, x), 3 acos(x); y may be NULL for the one-argument ops).
+ * The parity suite holds the device build of that header against the host build bit for bit with it. */
+int rrtx_detmath_eval(rrtx_ctx *ctx, int op, const double *x, const double *y, int64_t n, double *out);
 
 /* ---- fused per-sample preamble of extend() (A13) ----------------------------- */
 /* For each of nq samples: kdFindWithinRange + for every neighbour both directed

@@ -503,15 +503,19 @@ function calculateTrajectory(S::TS, edge::DubinsEdge) where {TS}
   if edge.Wdist == Inf                           # no trajectory is built (:661-662)
     return
   end
-  cols = S.spaceHasTime ? 3 : 2
+  # the row width is the CONTEXT's, not S's (the two can drift apart until syncDubinsSpace runs again); the call
+  # refuses a width that is not the context's instead of overrunning `rows`
+  hasTime = Ref{Int64}(0)
+  rrtx_check(tree, ccall((:rrtx_get_option, LIBRRTX), Cint, (Ptr{Cvoid}, Cint, Ref{Int64}), tree.ctx, 12, hasTime))
+  cols = hasTime[] != 0 ? 3 : 2
   off = Vector{Int64}(undef, 2)
   cap = 256
   while true
     rows = Array{Float64}(undef, cols, cap)      # column-major cols x cap == row-major cap x cols on the C side
     needed = Ref{Int64}(0)
     rc = GC.@preserve s g off rows ccall((:rrtx_dubins_trajectory, LIBRRTX), Cint,
-        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Ptr{Int64}, Ptr{Cdouble}, Int64, Ref{Int64}),
-        tree.ctx, s, g, 1, S.minTurningRadius, off, rows, cap, needed)
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Ptr{Int64}, Ptr{Cdouble}, Cint, Int64, Ref{Int64}),
+        tree.ctx, s, g, 1, S.minTurningRadius, off, rows, cols, cap, needed)
     if rc == RRTX_E_CAPACITY
       cap = Int(needed[])
       continue

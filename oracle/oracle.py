@@ -13,6 +13,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "librrtx_oracle.so")
+# the same source with glibc's sin / cos / atan2 / acos on the Dubins paths (-DORC_LIBM_TRIG): CPU cross-check only
+_LIBM_PATH = os.path.join(_HERE, "_build", "librrtx_oracle_libm.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -36,8 +38,9 @@ def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "rrtx_oracle.c")
     src2 = os.path.join(_HERE, "rrtx_oracle_graph.c")
     hdr = os.path.join(_HERE, "rrtx_oracle.h")
-    stale = (not os.path.exists(_LIB_PATH)
-             or any(os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, src2, hdr)))
+    dm = os.path.join(_HERE, "..", "include", "rrtx_detmath.h")
+    stale = (not os.path.exists(_LIB_PATH) or not os.path.exists(_LIBM_PATH)
+             or any(os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, src2, hdr, dm)))
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _LIB_PATH
@@ -111,8 +114,11 @@ def lib() -> C.CDLL:
     L.orc_dubins_edge_check_polygons.restype = C.c_int
     L.orc_dubins_edge_check_polygons.argtypes = [C.POINTER(Polygon), C.c_int, c_double_p, c_double_p,
                                                  c_double_p, C.c_int, C.c_double, C.c_double, c_int32_p]
-    L.orc_dubins_steer_time.argtypes = [c_double_p, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p,
-                                        C.c_char_p, c_double_p, C.c_int, C.POINTER(C.c_int)]
+    for f in (L.orc_dubins_steer_time, L.orc_dubins_steer_time_pw):
+        f.argtypes = [c_double_p, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p,
+                      C.c_char_p, c_double_p, C.c_int, C.POINTER(C.c_int)]
+    L.orc_dm_eval.restype = C.c_int
+    L.orc_dm_eval.argtypes = [C.c_int, c_double_p, c_double_p, C.c_int64, c_double_p]
     L.orc_dubins_valid_move_time.restype = C.c_int
     L.orc_dubins_valid_move_time.argtypes = [c_double_p, c_double_p, C.c_double, C.c_double, C.c_double]
     L.orc_dubins_edge_check_polygons_time.restype = C.c_int
@@ -424,17 +430,44 @@ def dubins_edge_check_polygons(ps: PolygonSet, s, g, traj, robot_radius, r_min):
     return bool(hit), fh.value
 
 
-def dubins_steer_time(s, g, r_min: float):
-    """calculateTrajectory(S, ::DubinsEdge) with S.spaceHasTime: (dist, Wdist, velocity, word, traj[P,3])."""
+def dubins_steer_time(s, g, r_min: float, piecewise: bool = False):
+    """calculateTrajectory(S, ::DubinsEdge) with S.spaceHasTime: (dist, Wdist, velocity, word, traj[P,3]).
+    piecewise: the time column as the HIP kernels form it (orc_dubins_steer_time_pw) instead of the reference's
+    running sum; the two differ by rounding only."""
     s, g = _vec(s), _vec(g)
     dist, wdist, vel = C.c_double(), C.c_double(), C.c_double()
     word = C.create_string_buffer(4)
     cap = 1024
     traj = np.zeros((cap, 3), dtype=np.float64)
     n = C.c_int()
-    lib().orc_dubins_steer_time(_dp(s), _dp(g), r_min, C.byref(dist), C.byref(wdist), C.byref(vel), word, _dp(traj),
-                                cap, C.byref(n))
+    fn = lib().orc_dubins_steer_time_pw if piecewise else lib().orc_dubins_steer_time
+    fn(_dp(s), _dp(g), r_min, C.byref(dist), C.byref(wdist), C.byref(vel), word, _dp(traj), cap, C.byref(n))
     return dist.value, wdist.value, vel.value, word.value.decode(), traj[: n.value].copy()
+
+
+DM_SIN, DM_COS, DM_ATAN2, DM_ACOS = 0, 1, 2, 3
+
+
+def dm_eval(op: int, x, y=None) -> np.ndarray:
+    """include/rrtx_detmath.h element-wise on the host: sin(x), cos(x), atan2(y, x), acos(x)."""
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    y = x if y is None else np.ascontiguousarray(y, dtype=np.float64).ravel()
+    assert x.shape == y.shape
+    out = np.empty_like(x)
+    rc = lib().orc_dm_eval(op, _dp(x), _dp(y), x.size, _dp(out))
+    assert rc == 0, "the default oracle build must not be the libm cross-check build"
+    return out
+
+
+def libm_variant() -> C.CDLL:
+    """librrtx_oracle_libm.so: the Dubins functions with glibc's transcendentals (orc_dubins_steer only is bound)."""
+    build()
+    L = C.CDLL(_LIBM_PATH)
+    L.orc_dubins_steer.argtypes = [c_double_p, c_double_p, C.c_double, c_double_p, C.c_char_p,
+                                   c_double_p, C.c_int, C.POINTER(C.c_int)]
+    L.orc_dm_eval.restype = C.c_int
+    L.orc_dm_eval.argtypes = [C.c_int, c_double_p, c_double_p, C.c_int64, c_double_p]
+    return L
 
 
 def dubins_valid_move_time(s, g, velocity: float, v_min: float, v_max: float) -> bool:

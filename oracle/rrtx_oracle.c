@@ -5,18 +5,42 @@
  * Every function cites the reference lines it follows (R/ = code_RRTQx_3D/).
  * Julia semantics reproduced on purpose:
  *   - sum() of < 16 elements is a sequential left fold (Base reduce.jl);
- *   - x.^2 and x^2 are x*x; x^2.0 is libm pow(x, 2.0);
+ *   - x.^2 and x^2 are x*x; x^2.0 (one site, R/DRRT_DubinsEdge_functions.jl:367) is pow(x, 2.0), whose
+ *     correctly rounded value is fl(x*x): written x*x here and on the device;
  *   - min/max propagate NaN and order signed zeros;
  *   - no implicit FMA (build with -ffp-contract=off);
  *   - a:s:b float ranges: literal-fallback length rule of Base (twiceprecision.jl).
+ *
+ * Transcendentals on the Dubins paths (sin, cos, atan, acos) are NOT libm calls: they come from
+ * include/rrtx_detmath.h, one deterministic IEEE implementation compiled into this file and into
+ * the HIP kernels alike, so that device and checker agree to the last bit where the reference's
+ * branches (`theta < 0`, strict `bestDist > len`) decide on it.  What stays un-pinnable is the
+ * distance of that implementation from Julia's libm (< 2 ulp against glibc, tests/test_detmath.py).
+ * Build with -DORC_LIBM_TRIG (librrtx_oracle_libm.so) for the literal form -- glibc sin / cos / atan2 /
+ * acos, one cos and one sin per arc row -- which the CPU tests hold against the default build within
+ * rounding on poses in general position.
  */
 #include "rrtx_oracle.h"
+
+#include "../include/rrtx_detmath.h"
 
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
 #define ORC_PI 3.141592653589793 /* Float64(pi) */
+
+#ifdef ORC_LIBM_TRIG
+#define t_sin sin
+#define t_cos cos
+#define t_atan2 atan2
+#define t_acos acos
+#else
+#define t_sin rrtx_dm_sin
+#define t_cos rrtx_dm_cos
+#define t_atan2 rrtx_dm_atan2
+#define t_acos rrtx_dm_acos
+#endif
 
 /* Julia 1.0 Base.min/max for Float64 (base/math.jl) */
 static double jl_min(double x, double y) {
@@ -924,18 +948,34 @@ int orc_point_check_polygons(const orc_polygon *obs, int m, const double *p, dou
 
 /* rightTurnDist / leftTurnDist, R/DRRT_distance_functions.jl:62-80 */
 static double right_turn_dist(const double *a, const double *b, const double *c, double r) {
-  double theta = atan2(a[1] - c[1], a[0] - c[0]) - atan2(b[1] - c[1], b[0] - c[0]);
+  double theta = t_atan2(a[1] - c[1], a[0] - c[0]) - t_atan2(b[1] - c[1], b[0] - c[0]);
   if (theta < 0) theta = theta + 2 * ORC_PI;
   return theta * r;
 }
 static double left_turn_dist(const double *a, const double *b, const double *c, double r) {
-  double theta = atan2(b[1] - c[1], b[0] - c[0]) - atan2(a[1] - c[1], a[0] - c[0]);
+  double theta = t_atan2(b[1] - c[1], b[0] - c[0]) - t_atan2(a[1] - c[1], a[0] - c[0]);
   if (theta < 0) theta = theta + 2 * ORC_PI;
   return theta * r;
 }
 static double seg_len2(const double *a, const double *b) {
   double dx = a[0] - b[0], dy = a[1] - b[1];
   return sqrt(dx * dx + dy * dy);
+}
+
+int orc_dm_eval(int op, const double *x, const double *y, int64_t n, double *out) {
+  for (int64_t i = 0; i < n; ++i) {
+    switch (op) {
+      case 0: out[i] = rrtx_dm_sin(x[i]); break;
+      case 1: out[i] = rrtx_dm_cos(x[i]); break;
+      case 2: out[i] = rrtx_dm_atan2(y[i], x[i]); break;
+      default: out[i] = rrtx_dm_acos(x[i]); break;
+    }
+  }
+#ifdef ORC_LIBM_TRIG
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 /* Length of start:step:stop for Float64 in Julia's literal fallback branch
@@ -962,33 +1002,46 @@ static void sink_push(traj_sink *s, double x, double y) {
   s->n++;
 }
 /* one arc: phis = (phi_end == phi_start) ? phi_start : collect(phi_start:step:phi_end);
- * x = cx .+ r*cos.(phis)  (R/DRRT_DubinsEdge_functions.jl:529-532 and siblings) */
+ * x = cx .+ r*cos.(phis)  (R/DRRT_DubinsEdge_functions.jl:529-532 and siblings).  Row k is at
+ * phi_start + k * step; its cos / sin are the shared definition of include/rrtx_detmath.h (one angle
+ * addition on cos / sin of phi_start), the literal cos(phi), sin(phi) in the ORC_LIBM_TRIG build. */
 static void sink_arc(traj_sink *s, const double *c, double r, double phi_start, double phi_end, double step) {
-  if (phi_end == phi_start) {
-    sink_push(s, c[0] + r * cos(phi_start), c[1] + r * sin(phi_start));
-    return;
-  }
-  int64_t len = orc_julia_range_len(phi_start, step, phi_end);
+  const int64_t len = (phi_end == phi_start) ? 1 : orc_julia_range_len(phi_start, step, phi_end);
+#ifdef ORC_LIBM_TRIG
   for (int64_t i = 0; i < len; ++i) {
     double phi = phi_start + (double)i * step;
     sink_push(s, c[0] + r * cos(phi), c[1] + r * sin(phi));
   }
+#else
+  static const double arc_cos[RRTX_DM_ARC_TAB] = RRTX_DM_ARC_COS_INIT;
+  static const double arc_sin[RRTX_DM_ARC_TAB] = RRTX_DM_ARC_SIN_INIT;
+  double a, b;
+  rrtx_dm_sincos(phi_start, &b, &a);
+  for (int64_t i = 0; i < len; ++i) {
+    double ck, sk, x, y;
+    if (i < RRTX_DM_ARC_TAB) { ck = arc_cos[i]; sk = arc_sin[i]; }
+    else rrtx_dm_sincos((double)i * .1, &sk, &ck);
+    rrtx_dm_arc_row(c[0], c[1], r, a, b, ck, sk, step < 0.0, &x, &y);
+    sink_push(s, x, y);
+  }
+#endif
 }
 
 /* calculateTrajectory(S, edge::DubinsEdge), R/DRRT_DubinsEdge_functions.jl:329-709,
  * space without time (S.spaceHasTime == false). */
-void orc_dubins_steer(const double *s, const double *g, double r_min, double *cost,
-                      char *word, double *traj, int traj_cap, int *traj_len) {
+static void dubins_steer_pieces(const double *s, const double *g, double r_min, double *cost,
+                                char *word, double *traj, int traj_cap, int *traj_len, int *piece_len) {
+  if (piece_len) piece_len[0] = piece_len[1] = piece_len[2] = 0;
   const double il[2] = {s[0], s[1]};
   const double it = s[3];
   const double gl[2] = {g[0], g[1]};
   const double gt = g[3];
 
   /* circle centres, :348-357 */
-  double irc[2] = {il[0] + r_min * cos(it - ORC_PI / 2.0), il[1] + r_min * sin(it - ORC_PI / 2.0)};
-  double ilc[2] = {il[0] + r_min * cos(it + ORC_PI / 2.0), il[1] + r_min * sin(it + ORC_PI / 2.0)};
-  double grc[2] = {gl[0] + r_min * cos(gt - ORC_PI / 2.0), gl[1] + r_min * sin(gt - ORC_PI / 2.0)};
-  double glc[2] = {gl[0] + r_min * cos(gt + ORC_PI / 2.0), gl[1] + r_min * sin(gt + ORC_PI / 2.0)};
+  double irc[2] = {il[0] + r_min * t_cos(it - ORC_PI / 2.0), il[1] + r_min * t_sin(it - ORC_PI / 2.0)};
+  double ilc[2] = {il[0] + r_min * t_cos(it + ORC_PI / 2.0), il[1] + r_min * t_sin(it + ORC_PI / 2.0)};
+  double grc[2] = {gl[0] + r_min * t_cos(gt - ORC_PI / 2.0), gl[1] + r_min * t_sin(gt - ORC_PI / 2.0)};
+  double glc[2] = {gl[0] + r_min * t_cos(gt + ORC_PI / 2.0), gl[1] + r_min * t_sin(gt + ORC_PI / 2.0)};
 
   double best = INFINITY;
   const char *best_type = "xxx";
@@ -996,7 +1049,7 @@ void orc_dubins_steer(const double *s, const double *g, double r_min, double *co
 
   /* rsl, :367-388 */
   double rsl_t1[2] = {NAN, NAN}, rsl_t2[2] = {NAN, NAN};
-  D = sqrt(pow(glc[0] - irc[0], 2.0) + pow(glc[1] - irc[1], 2.0));
+  D = sqrt((glc[0] - irc[0]) * (glc[0] - irc[0]) + (glc[1] - irc[1]) * (glc[1] - irc[1])); /* ^2.0, see header */
   v[0] = (glc[0] - irc[0]) / D; v[1] = (glc[1] - irc[1]) / D;
   R = -2.0 * r_min / D;
   if (!(fabs(R) > 1.0)) {
@@ -1029,9 +1082,9 @@ void orc_dubins_steer(const double *s, const double *g, double r_min, double *co
   /* rlr, :411-431 (D, v from rsr) */
   double rlr_rl[2] = {NAN, NAN}, rlr_lr[2] = {NAN, NAN}, rlr_c[2] = {NAN, NAN};
   if (D < 4.0 * r_min) {
-    double theta = -acos(D / (4 * r_min)) + atan2(v[1], v[0]);
-    rlr_c[0] = irc[0] + 2 * r_min * cos(theta);
-    rlr_c[1] = irc[1] + 2 * r_min * sin(theta);
+    double theta = -t_acos(D / (4 * r_min)) + t_atan2(v[1], v[0]);
+    rlr_c[0] = irc[0] + 2 * r_min * t_cos(theta);
+    rlr_c[1] = irc[1] + 2 * r_min * t_sin(theta);
     rlr_rl[0] = (rlr_c[0] + irc[0]) / 2.0; rlr_rl[1] = (rlr_c[1] + irc[1]) / 2.0;
     rlr_lr[0] = (rlr_c[0] + grc[0]) / 2.0; rlr_lr[1] = (rlr_c[1] + grc[1]) / 2.0;
     first = right_turn_dist(il, rlr_rl, irc, r_min);
@@ -1076,9 +1129,9 @@ void orc_dubins_steer(const double *s, const double *g, double r_min, double *co
   /* lrl, :481-501 (D, v from lsl) */
   double lrl_rl[2] = {NAN, NAN}, lrl_lr[2] = {NAN, NAN}, lrl_c[2] = {NAN, NAN};
   if (D < 4.0 * r_min) {
-    double theta = acos(D / (4 * r_min)) + atan2(v[1], v[0]);
-    lrl_c[0] = ilc[0] + 2.0 * r_min * cos(theta);
-    lrl_c[1] = ilc[1] + 2.0 * r_min * sin(theta);
+    double theta = t_acos(D / (4 * r_min)) + t_atan2(v[1], v[0]);
+    lrl_c[0] = ilc[0] + 2.0 * r_min * t_cos(theta);
+    lrl_c[1] = ilc[1] + 2.0 * r_min * t_sin(theta);
     lrl_lr[0] = (lrl_c[0] + ilc[0]) / 2.0; lrl_lr[1] = (lrl_c[1] + ilc[1]) / 2.0;
     lrl_rl[0] = (lrl_c[0] + glc[0]) / 2.0; lrl_rl[1] = (lrl_c[1] + glc[1]) / 2.0;
     first = left_turn_dist(il, lrl_lr, ilc, r_min);
@@ -1106,17 +1159,18 @@ void orc_dubins_steer(const double *s, const double *g, double r_min, double *co
   /* first piece, :511-555 */
   if (best_type[0] == 'r') {
     p = is_rsl ? rsl_t1 : (is_rsr ? rsr_t1 : rlr_rl);
-    phi_start = atan2(il[1] - irc[1], il[0] - irc[0]);
-    phi_end = atan2(p[1] - irc[1], p[0] - irc[0]);
+    phi_start = t_atan2(il[1] - irc[1], il[0] - irc[0]);
+    phi_end = t_atan2(p[1] - irc[1], p[0] - irc[0]);
     if (phi_end > phi_start) phi_end = phi_end - 2.0 * ORC_PI;
     sink_arc(&sink, irc, r_min, phi_start, phi_end, -delta_phi);
   } else {
     p = is_lsl ? lsl_t1 : (is_lsr ? lsr_t1 : lrl_lr);
-    phi_start = atan2(il[1] - ilc[1], il[0] - ilc[0]);
-    phi_end = atan2(p[1] - ilc[1], p[0] - ilc[0]);
+    phi_start = t_atan2(il[1] - ilc[1], il[0] - ilc[0]);
+    phi_end = t_atan2(p[1] - ilc[1], p[0] - ilc[0]);
     if (phi_end < phi_start) phi_end = phi_end + 2.0 * ORC_PI;
     sink_arc(&sink, ilc, r_min, phi_start, phi_end, delta_phi);
   }
+  if (piece_len) piece_len[0] = sink.n;
 
   /* second piece, :559-608 */
   if (best_type[1] == 's') {
@@ -1125,32 +1179,38 @@ void orc_dubins_steer(const double *s, const double *g, double r_min, double *co
     sink_push(&sink, p1[0], p1[1]);
     sink_push(&sink, p2[0], p2[1]);
   } else if (best_type[1] == 'r') {   /* lrl */
-    phi_start = atan2(lrl_lr[1] - lrl_c[1], lrl_lr[0] - lrl_c[0]);
-    phi_end = atan2(lrl_rl[1] - lrl_c[1], lrl_rl[0] - lrl_c[0]);
+    phi_start = t_atan2(lrl_lr[1] - lrl_c[1], lrl_lr[0] - lrl_c[0]);
+    phi_end = t_atan2(lrl_rl[1] - lrl_c[1], lrl_rl[0] - lrl_c[0]);
     if (phi_end > phi_start) phi_end = phi_end - 2.0 * ORC_PI;
     sink_arc(&sink, lrl_c, r_min, phi_start, phi_end, -delta_phi);
   } else {                            /* rlr */
-    phi_start = atan2(rlr_rl[1] - rlr_c[1], rlr_rl[0] - rlr_c[0]);
-    phi_end = atan2(rlr_lr[1] - rlr_c[1], rlr_lr[0] - rlr_c[0]);
+    phi_start = t_atan2(rlr_rl[1] - rlr_c[1], rlr_rl[0] - rlr_c[0]);
+    phi_end = t_atan2(rlr_lr[1] - rlr_c[1], rlr_lr[0] - rlr_c[0]);
     if (phi_end < phi_start) phi_end = phi_end + 2.0 * ORC_PI;
     sink_arc(&sink, rlr_c, r_min, phi_start, phi_end, delta_phi);
   }
+  if (piece_len) piece_len[1] = sink.n - piece_len[0];
 
   /* third piece, :611-655 */
   if (best_type[2] == 'r') {
     p = is_rsr ? rsr_t2 : (is_lsr ? lsr_t2 : rlr_lr);
-    phi_start = atan2(p[1] - grc[1], p[0] - grc[0]);
-    phi_end = atan2(gl[1] - grc[1], gl[0] - grc[0]);
+    phi_start = t_atan2(p[1] - grc[1], p[0] - grc[0]);
+    phi_end = t_atan2(gl[1] - grc[1], gl[0] - grc[0]);
     if (phi_end > phi_start) phi_end = phi_end - 2.0 * ORC_PI;
     sink_arc(&sink, grc, r_min, phi_start, phi_end, -delta_phi);
   } else {
     p = is_lsl ? lsl_t2 : (is_rsl ? rsl_t2 : lrl_rl);
-    phi_start = atan2(p[1] - glc[1], p[0] - glc[0]);
-    phi_end = atan2(gl[1] - glc[1], gl[0] - glc[0]);
+    phi_start = t_atan2(p[1] - glc[1], p[0] - glc[0]);
+    phi_end = t_atan2(gl[1] - glc[1], gl[0] - glc[0]);
     if (phi_end < phi_start) phi_end = phi_end + 2.0 * ORC_PI;
     sink_arc(&sink, glc, r_min, phi_start, phi_end, delta_phi);
   }
+  if (piece_len) piece_len[2] = sink.n - piece_len[0] - piece_len[1];
   if (traj_len) *traj_len = sink.n;
+}
+void orc_dubins_steer(const double *s, const double *g, double r_min, double *cost,
+                      char *word, double *traj, int traj_cap, int *traj_len) {
+  dubins_steer_pieces(s, g, r_min, cost, word, traj, traj_cap, traj_len, NULL);
 }
 
 /* explicitEdgeCheck(S, edge::DubinsEdge, obstacle) over the obstacle list,
@@ -1182,12 +1242,13 @@ int orc_dubins_edge_check_polygons(const orc_polygon *obs, int m, const double *
  * so far (sum of the straight pieces between stored rows, accumulated left to right, :691-695) over the
  * velocity, and the last row is overwritten with the end node's (x, y, t) (:696).  traj3 (may be NULL)
  * receives up to traj_cap rows of (x, y, t). */
-void orc_dubins_steer_time(const double *s, const double *g, double r_min, double *dist, double *wdist,
-                           double *velocity, char *word, double *traj3, int traj_cap, int *traj_len) {
+static void dubins_steer_time_impl(const double *s, const double *g, double r_min, double *dist, double *wdist,
+                                   double *velocity, char *word, double *traj3, int traj_cap, int *traj_len,
+                                   int piecewise) {
   double best;
-  int n = 0;
+  int n = 0, plen[3];
   double *xy = (double *)malloc(sizeof(double) * 2 * (size_t)(traj_cap > 0 ? traj_cap : 1));
-  orc_dubins_steer(s, g, r_min, &best, word, xy, traj_cap, &n);
+  dubins_steer_pieces(s, g, r_min, &best, word, xy, traj_cap, &n, plen);
   *wdist = best;
   if (best == INFINITY) {                 /* :661-662: no trajectory, no velocity */
     *dist = INFINITY;
@@ -1205,14 +1266,51 @@ void orc_dubins_steer_time(const double *s, const double *g, double r_min, doubl
     const int rows = n < traj_cap ? n : traj_cap;
     for (int i = 0; i < rows; ++i) { traj3[3 * i] = xy[2 * i]; traj3[3 * i + 1] = xy[2 * i + 1]; traj3[3 * i + 2] = 0.0; }
     traj3[2] = s[2];
-    double cumulative = 0.0;
-    for (int i = 1; i < rows - 1; ++i) {
-      cumulative += orc_euclid(xy + 2 * (i - 1), xy + 2 * i, 2);
-      traj3[3 * i + 2] = s[2] - cumulative / vel;
+    if (!piecewise) {
+      double cumulative = 0.0;
+      for (int i = 1; i < rows - 1; ++i) {
+        cumulative += orc_euclid(xy + 2 * (i - 1), xy + 2 * i, 2);
+        traj3[3 * i + 2] = s[2] - cumulative / vel;
+      }
+    } else if (n <= traj_cap) {
+      /* distance walked at row k of a piece = (distance at the piece's first row) + k x (the piece's first
+       * chord); the junctions between pieces are measured once */
+      double run = 0.0;
+      int first = 0, have_last = 0, last = 0;
+      for (int pi = 0; pi < 3; ++pi) {
+        if (plen[pi] <= 0) continue;
+        if (have_last) run = run + orc_euclid(xy + 2 * last, xy + 2 * first, 2);
+        const double cum0 = run;
+        double chord = 0.0;
+        if (plen[pi] > 1) {
+          chord = orc_euclid(xy + 2 * first, xy + 2 * (first + 1), 2);
+          run = run + (double)(plen[pi] - 1) * chord;
+        }
+        for (int k = 0; k < plen[pi]; ++k) {
+          const int row = first + k;
+          if (row > 0 && row < n - 1) traj3[3 * row + 2] = s[2] - (cum0 + (double)k * chord) / vel;
+        }
+        last = first + plen[pi] - 1;
+        first += plen[pi];
+        have_last = 1;
+      }
     }
     if (n <= traj_cap) { traj3[3 * (n - 1)] = g[0]; traj3[3 * (n - 1) + 1] = g[1]; traj3[3 * (n - 1) + 2] = g[2]; }
   }
   free(xy);
+}
+void orc_dubins_steer_time(const double *s, const double *g, double r_min, double *dist, double *wdist,
+                           double *velocity, char *word, double *traj3, int traj_cap, int *traj_len) {
+  dubins_steer_time_impl(s, g, r_min, dist, wdist, velocity, word, traj3, traj_cap, traj_len, 0);
+}
+/* The same edge with the time column as the HIP kernels form it (they cannot afford a running sum over up to
+ * 190 rows per directed edge): inside a piece every step is the piece's first chord, so the distance walked at
+ * row k of a piece is (distance at its first row) + k * chord.  Differs from the reference's left-to-right sum
+ * (above) by rounding only -- tests/test_oracle_kat.py bounds the difference at 1e-12 relative and requires the
+ * same collision booleans on the suite's scenes; the device is compared with THIS form bit for bit. */
+void orc_dubins_steer_time_pw(const double *s, const double *g, double r_min, double *dist, double *wdist,
+                              double *velocity, char *word, double *traj3, int traj_cap, int *traj_len) {
+  dubins_steer_time_impl(s, g, r_min, dist, wdist, velocity, word, traj3, traj_cap, traj_len, 1);
 }
 
 /* validMove(S, edge::DubinsEdge) with S.spaceHasTime, R/DRRT_DubinsEdge_functions.jl:115-121 */

@@ -137,10 +137,17 @@ int orc_dubins_edge_check_polygons(const orc_polygon *obs, int m, const double *
  * two-stage edge check whose pieces carry time (kinds 6 / 7 are tested at their time stamps). */
 void orc_dubins_steer_time(const double *s, const double *g, double r_min, double *dist, double *wdist,
                            double *velocity, char *word, double *traj3, int traj_cap, int *traj_len);
+/* the same with the time column formed piece by piece as the HIP kernels do (see rrtx_oracle.c) */
+void orc_dubins_steer_time_pw(const double *s, const double *g, double r_min, double *dist, double *wdist,
+                              double *velocity, char *word, double *traj3, int traj_cap, int *traj_len);
 int orc_dubins_valid_move_time(const double *s, const double *g, double velocity, double v_min, double v_max);
 int orc_dubins_edge_check_polygons_time(const orc_polygon *obs, int m, const double *s, const double *g,
                                         const double *traj3, int traj_len, double robot_radius, double r_min,
                                         int32_t *first_hit);
+/* the shared deterministic transcendentals of include/rrtx_detmath.h, element-wise (tests compare them with
+ * libm here and with the device's build of the same header bit for bit).
+ * op: 0 sin(x)  1 cos(x)  2 atan2(y, x)  3 acos(x);  returns 1 in the ORC_LIBM_TRIG build, else 0 */
+int orc_dm_eval(int op, const double *x, const double *y, int64_t n, double *out);
 /* Julia float range length for start:step:stop in the literal fallback branch */
 int64_t orc_julia_range_len(double start, double step, double stop);
 

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("rrtx_profile", C.c_int, [_VP, C.c_int]),
     ("rrtx_stats", C.c_int, [_VP, C.POINTER(Stats)]),
     ("rrtx_set_option", C.c_int, [_VP, C.c_int, C.c_int64]),
+    ("rrtx_get_option", C.c_int, [_VP, C.c_int, c_int64_p]),
     ("rrtx_nodes_append", C.c_int, [_VP, _VP, C.c_int64, c_int64_p]),
     ("rrtx_nodes_count", C.c_int64, [_VP]),
     ("rrtx_nodes_append_dev", C.c_int, [_VP, _VP, C.c_int64]),
@@ -104,7 +105,8 @@ SYMBOLS = [
     ("rrtx_set_dubins_velocity", C.c_int, [_VP, C.c_double, C.c_double]),
     ("rrtx_dubins_steer_full", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP, _VP, _VP, _VP]),
     ("rrtx_dubins_edges_check", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_double, _VP, _VP, _VP, _VP]),
-    ("rrtx_dubins_trajectory", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP, C.c_int64, c_int64_p]),
+    ("rrtx_dubins_trajectory", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP, C.c_int, C.c_int64, c_int64_p]),
+    ("rrtx_detmath_eval", C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, _VP]),
     ("rrtx_extend_candidates", C.c_int, [_VP, _VP, C.c_int, C.c_double, C.c_double, _VP, _VP, _VP, _VP, _VP,
                                          C.c_int64, c_int64_p, _VP, _VP, _VP]),
     ("rrtx_extend_candidates_dubins", C.c_int, [_VP, _VP, C.c_int, C.c_double, C.c_double, C.c_double, _VP, _VP, _VP, _VP,

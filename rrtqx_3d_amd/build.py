@@ -21,7 +21,8 @@ LIB_CLK = os.path.join(HERE, "librrtx_hip_clk.so")
 
 SOURCES = ["rrtx_capi.hip", "kernels_nn.hip", "kernels_finish.hip", "kernels_nearest.hip", "kernels_slab.hip", "kernels_sweep.hip", "kernels_graph.hip", "kernels_collide.hip",
            "kernels_dubins.hip"]
-HEADERS = ["rrtx_internal.hpp", "exact_math.hpp", "nn_device.hpp", "collide_device.hpp", os.path.join("..", "..", "include", "rrtx.h")]
+HEADERS = ["rrtx_internal.hpp", "exact_math.hpp", "nn_device.hpp", "collide_device.hpp", os.path.join("..", "..", "include", "rrtx.h"),
+           os.path.join("..", "..", "include", "rrtx_detmath.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -70,6 +70,16 @@ class Context:
     def set_option(self, option: int, value: int):
         self._check(self._lib.rrtx_set_option(self._h, option, value))
 
+    def get_option(self, option: int) -> int:
+        v = C.c_int64()
+        self._check(self._lib.rrtx_get_option(self._h, option, C.byref(v)))
+        return int(v.value)
+
+    @property
+    def space_has_time(self) -> bool:
+        """CSpace.spaceHasTime as the CONTEXT holds it (no shadow copy: buffers are sized from this)."""
+        return self.get_option(_capi.RRTX_OPT_SPACE_HAS_TIME) != 0
+
     def stats(self) -> Stats:
         s = Stats()
         self._check(self._lib.rrtx_stats(self._h, C.byref(s)))
@@ -220,7 +230,6 @@ class Context:
 
     def set_space_has_time(self, has_time: bool):
         """CSpace.spaceHasTime for the Dubins entry points (dim = 4: [x y t theta])."""
-        self.space_has_time = bool(has_time)
         self.set_option(_capi.RRTX_OPT_SPACE_HAS_TIME, 1 if has_time else 0)
 
     def set_dubins_velocity(self, v_min: float, v_max: float):
@@ -263,17 +272,25 @@ class Context:
         ne = s.shape[0]
         off = np.empty(ne + 1, dtype=np.int64)
         cap = max(64 * ne, 64)
-        cols = 3 if getattr(self, "space_has_time", False) else 2
+        cols = 3 if self.space_has_time else 2
         while True:
             xy = np.empty((cap, cols), dtype=np.float64)
             needed = C.c_int64()
             rc = self._lib.rrtx_dubins_trajectory(self._h, _capi._ptr(s), _capi._ptr(g), ne, r_min, _capi._ptr(off),
-                                                  _capi._ptr(xy), cap, C.byref(needed))
+                                                  _capi._ptr(xy), cols, cap, C.byref(needed))
             if rc == _capi.RRTX_E_CAPACITY:
                 cap = int(needed.value)
                 continue
             self._check(rc)
             return off, xy[: int(needed.value)]
+
+    def detmath_eval(self, op: int, x, y=None):
+        """include/rrtx_detmath.h on the device, element-wise: 0 sin(x), 1 cos(x), 2 atan2(y, x), 3 acos(x)."""
+        x = f64(x, (-1,))
+        y = x if y is None else f64(y, (-1,))
+        out = np.empty_like(x)
+        self._check(self._lib.rrtx_detmath_eval(self._h, op, _capi._ptr(x), _capi._ptr(y), x.size, _capi._ptr(out)))
+        return out
 
     # ---- fused extend() preamble --------------------------------------------------------------
     def extend_candidates(self, q, r: float, robot_radius: float, cap: Optional[int] = None):

@@ -6,9 +6,13 @@
 // CSpace.spaceHasTime -- in [x y t theta] with the time-stamped trajectory of :660-697, validMove of
 // :115-121 and obstacles that move in time (kinds 6 / 7, R/DRRT.jl:1579-1651).  gfx950 only.
 //
-// Transcendentals come from the ROCm device library, not Julia's libm, so edge
-// costs carry the 1e-6 relative tolerance north_star allows; everything else
-// keeps the reference's operation order (no FMA contraction).
+// Transcendentals (sin, cos, atan2, acos, the rows of a sampled arc) are NOT the ROCm device library's: they are
+// include/rrtx_detmath.h, one deterministic sequence of IEEE operations compiled into this file and into the CPU
+// checker alike, so the two agree to the last bit where the reference's branches decide on it (`theta < 0 ->
+// + 2 pi`, strict `bestDist > len`, a piece grazing a polygon side).  Against Julia's own libm the costs keep the
+// 1e-6 relative tolerance north_star allows; everything else keeps the reference's operation order (no FMA
+// contraction).
+#include "../../include/rrtx_detmath.h"
 #include "collide_device.hpp"
 #include "exact_math.hpp"
 #include "rrtx_internal.hpp"
@@ -21,37 +25,37 @@ constexpr double kPi = 3.141592653589793;
 
 __device__ __forceinline__ double right_turn_dist(double ax, double ay, double bx, double by, double cx,
                                                   double cy, double r) {
-  double theta = atan2(ay - cy, ax - cx) - atan2(by - cy, bx - cx);
+  double theta = rrtx_dm_atan2(ay - cy, ax - cx) - rrtx_dm_atan2(by - cy, bx - cx);
   if (theta < 0) theta = theta + 2 * kPi;
   return theta * r;
 }
 __device__ __forceinline__ double left_turn_dist(double ax, double ay, double bx, double by, double cx,
                                                  double cy, double r) {
-  double theta = atan2(by - cy, bx - cx) - atan2(ay - cy, ax - cx);
+  double theta = rrtx_dm_atan2(by - cy, bx - cx) - rrtx_dm_atan2(ay - cy, ax - cx);
   if (theta < 0) theta = theta + 2 * kPi;
   return theta * r;
 }
 // The same two functions with one of the two angles given: the angle of the start pose seen from its right / left
 // circle and of the goal pose seen from its circles enter three words each (and the stored trajectory), always
-// through the same expression atan2(y - cy, x - cx) of the same operands, so they are computed once per edge
+// through the same expression rrtx_dm_atan2(y - cy, x - cx) of the same operands, so they are computed once per edge
 // (16 atan2 per edge instead of 24 + 2 of the trajectory's 6; the values are the identical doubles).
 __device__ __forceinline__ double right_turn_from(double angle_a, double bx, double by, double cx, double cy, double r) {
-  double theta = angle_a - atan2(by - cy, bx - cx);
+  double theta = angle_a - rrtx_dm_atan2(by - cy, bx - cx);
   if (theta < 0) theta = theta + 2 * kPi;
   return theta * r;
 }
 __device__ __forceinline__ double right_turn_to(double ax, double ay, double angle_b, double cx, double cy, double r) {
-  double theta = atan2(ay - cy, ax - cx) - angle_b;
+  double theta = rrtx_dm_atan2(ay - cy, ax - cx) - angle_b;
   if (theta < 0) theta = theta + 2 * kPi;
   return theta * r;
 }
 __device__ __forceinline__ double left_turn_from(double angle_a, double bx, double by, double cx, double cy, double r) {
-  double theta = atan2(by - cy, bx - cx) - angle_a;
+  double theta = rrtx_dm_atan2(by - cy, bx - cx) - angle_a;
   if (theta < 0) theta = theta + 2 * kPi;
   return theta * r;
 }
 __device__ __forceinline__ double left_turn_to(double ax, double ay, double angle_b, double cx, double cy, double r) {
-  double theta = angle_b - atan2(ay - cy, ax - cx);
+  double theta = angle_b - rrtx_dm_atan2(ay - cy, ax - cx);
   if (theta < 0) theta = theta + 2 * kPi;
   return theta * r;
 }
@@ -72,9 +76,9 @@ struct Piece {
 // collect(phi_start:-+0.1:phi_end)), so its point is one angle addition on the arc's own cos / sin of
 // phi_start instead of a cos and a sin per row (the polyline walk is most of the Dubins edge check).
 // The two forms differ by an ulp or two in the coordinates -- as device and Julia libm do anyway.
-constexpr int kArcTab = 72;           // an arc spans less than 2 pi: at most 63 rows
-__device__ const double kArcCos[kArcTab] = {1.0, 0.9950041652780258, 0.9800665778412416, 0.955336489125606, 0.9210609940028851, 0.8775825618903728, 0.8253356149096782, 0.7648421872844884, 0.6967067093471654, 0.6216099682706644, 0.5403023058681398, 0.4535961214255773, 0.3623577544766734, 0.26749882862458735, 0.16996714290024081, 0.0707372016677029, -0.029199522301288815, -0.12884449429552486, -0.2272020946930871, -0.3232895668635036, -0.4161468365471424, -0.5048461045998576, -0.5885011172553458, -0.6662760212798244, -0.7373937155412458, -0.8011436155469337, -0.8568887533689473, -0.9040721420170612, -0.9422223406686583, -0.9709581651495907, -0.9899924966004454, -0.9991351502732795, -0.9982947757947531, -0.9874797699088649, -0.9667981925794609, -0.9364566872907963, -0.896758416334147, -0.848100031710408, -0.7909677119144165, -0.7259323042001399, -0.6536436208636119, -0.5748239465332685, -0.4902608213406994, -0.40079917207997545, -0.30733286997841935, -0.2107957994307797, -0.11215252693505398, -0.01238866346289056, 0.08749898343944727, 0.18651236942257576, 0.28366218546322625, 0.37797774271298107, 0.4685166713003771, 0.5543743361791615, 0.6346928759426347, 0.70866977429126, 0.7755658785102502, 0.8347127848391598, 0.8855195169413194, 0.9274784307440359, 0.960170286650366, 0.9832684384425847, 0.9965420970232175, 0.9998586363834151, 0.9931849187581926, 0.9765876257280235, 0.9502325919585293, 0.9143831482353194, 0.8693974903498248, 0.8157251001253568, 0.7539022543433046, 0.6845466664428059};
-__device__ const double kArcSin[kArcTab] = {0.0, 0.09983341664682815, 0.19866933079506122, 0.2955202066613396, 0.3894183423086505, 0.479425538604203, 0.5646424733950355, 0.6442176872376911, 0.7173560908995228, 0.7833269096274834, 0.8414709848078965, 0.8912073600614354, 0.9320390859672264, 0.963558185417193, 0.9854497299884603, 0.9974949866040544, 0.9995736030415051, 0.9916648104524686, 0.9738476308781951, 0.9463000876874145, 0.9092974268256817, 0.8632093666488737, 0.8084964038195901, 0.74570521217672, 0.6754631805511506, 0.5984721441039565, 0.5155013718214642, 0.4273798802338298, 0.33498815015590466, 0.23924932921398198, 0.1411200080598672, 0.04158066243329049, -0.058374143427580086, -0.15774569414324865, -0.25554110202683167, -0.35078322768961984, -0.44252044329485246, -0.5298361409084934, -0.6118578909427193, -0.6877661591839741, -0.7568024953079282, -0.8182771110644108, -0.8715757724135882, -0.9161659367494549, -0.951602073889516, -0.977530117665097, -0.9936910036334645, -0.9999232575641008, -0.9961646088358406, -0.9824526126243325, -0.9589242746631385, -0.9258146823277321, -0.8834546557201531, -0.8322674422239008, -0.7727644875559871, -0.7055403255703919, -0.6312666378723208, -0.5506855425976376, -0.4646021794137566, -0.373876664830236, -0.27941549819892586, -0.18216250427209502, -0.0830894028174964, 0.0168139004843506, 0.11654920485049364, 0.21511998808781552, 0.3115413635133787, 0.4048499206165983, 0.49411335113860894, 0.5784397643882001, 0.6569865987187891, 0.7289690401258765};
+constexpr int kArcTab = RRTX_DM_ARC_TAB;           // an arc spans less than 2 pi: at most 63 rows
+__device__ const double kArcCos[kArcTab] = RRTX_DM_ARC_COS_INIT;
+__device__ const double kArcSin[kArcTab] = RRTX_DM_ARC_SIN_INIT;
 
 struct Steer {
   double cost;
@@ -95,7 +99,8 @@ __device__ __forceinline__ int julia_range_len(double start, double step, double
 
 __device__ __forceinline__ Piece make_arc(double cx, double cy, double phi_start, double phi_end, double step) {
   Piece p;
-  p.cx = cx; p.cy = cy; p.a = cos(phi_start); p.b = sin(phi_start); p.kind = step < 0.0 ? 2 : 0;
+  p.cx = cx; p.cy = cy; p.kind = step < 0.0 ? 2 : 0;
+  rrtx_dm_sincos(phi_start, &p.b, &p.a);
   p.len = (phi_end == phi_start) ? 1 : julia_range_len(phi_start, step, phi_end);
   return p;
 }
@@ -111,14 +116,19 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
   const double ilx = s[0], ily = s[1], it = s[3];
   const double glx = g[0], gly = g[1], gt = g[3];
   // circle centres (:348-357)
-  const double ircx = ilx + r_min * cos(it - kPi / 2.0), ircy = ily + r_min * sin(it - kPi / 2.0);
-  const double ilcx = ilx + r_min * cos(it + kPi / 2.0), ilcy = ily + r_min * sin(it + kPi / 2.0);
-  const double grcx = glx + r_min * cos(gt - kPi / 2.0), grcy = gly + r_min * sin(gt - kPi / 2.0);
-  const double glcx = glx + r_min * cos(gt + kPi / 2.0), glcy = gly + r_min * sin(gt + kPi / 2.0);
+  double sn, cs;
+  rrtx_dm_sincos(it - kPi / 2.0, &sn, &cs);
+  const double ircx = ilx + r_min * cs, ircy = ily + r_min * sn;
+  rrtx_dm_sincos(it + kPi / 2.0, &sn, &cs);
+  const double ilcx = ilx + r_min * cs, ilcy = ily + r_min * sn;
+  rrtx_dm_sincos(gt - kPi / 2.0, &sn, &cs);
+  const double grcx = glx + r_min * cs, grcy = gly + r_min * sn;
+  rrtx_dm_sincos(gt + kPi / 2.0, &sn, &cs);
+  const double glcx = glx + r_min * cs, glcy = gly + r_min * sn;
 
   // the poses' angles on their circles (see right_turn_from)
-  const double a_ir = atan2(ily - ircy, ilx - ircx), a_il = atan2(ily - ilcy, ilx - ilcx);
-  const double a_gr = atan2(gly - grcy, glx - grcx), a_gl = atan2(gly - glcy, glx - glcx);
+  const double a_ir = rrtx_dm_atan2(ily - ircy, ilx - ircx), a_il = rrtx_dm_atan2(ily - ilcy, ilx - ilcx);
+  const double a_gr = rrtx_dm_atan2(gly - grcy, glx - grcx), a_gl = rrtx_dm_atan2(gly - glcy, glx - glcx);
 
   double best = __builtin_inf();
   int word = 6;
@@ -161,9 +171,10 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
   // rlr (:411-431; D, v from rsr)
   double rlr_cx = 0, rlr_cy = 0, rlr_rlx = 0, rlr_rly = 0, rlr_lrx = 0, rlr_lry = 0;
   if (D < 4.0 * r_min) {
-    double theta = -acos(D / (4 * r_min)) + atan2(vy, vx);
-    rlr_cx = ircx + 2 * r_min * cos(theta);
-    rlr_cy = ircy + 2 * r_min * sin(theta);
+    double theta = -rrtx_dm_acos(D / (4 * r_min)) + rrtx_dm_atan2(vy, vx);
+    rrtx_dm_sincos(theta, &sn, &cs);
+    rlr_cx = ircx + 2 * r_min * cs;
+    rlr_cy = ircy + 2 * r_min * sn;
     rlr_rlx = (rlr_cx + ircx) / 2.0; rlr_rly = (rlr_cy + ircy) / 2.0;
     rlr_lrx = (rlr_cx + grcx) / 2.0; rlr_lry = (rlr_cy + grcy) / 2.0;
     first = right_turn_from(a_ir, rlr_rlx, rlr_rly, ircx, ircy, r_min);
@@ -209,9 +220,10 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
   // lrl (:481-501; D, v from lsl)
   double lrl_cx = 0, lrl_cy = 0, lrl_lrx = 0, lrl_lry = 0, lrl_rlx = 0, lrl_rly = 0;
   if (D < 4.0 * r_min) {
-    double theta = acos(D / (4 * r_min)) + atan2(vy, vx);
-    lrl_cx = ilcx + 2.0 * r_min * cos(theta);
-    lrl_cy = ilcy + 2.0 * r_min * sin(theta);
+    double theta = rrtx_dm_acos(D / (4 * r_min)) + rrtx_dm_atan2(vy, vx);
+    rrtx_dm_sincos(theta, &sn, &cs);
+    lrl_cx = ilcx + 2.0 * r_min * cs;
+    lrl_cy = ilcy + 2.0 * r_min * sn;
     lrl_lrx = (lrl_cx + ilcx) / 2.0; lrl_lry = (lrl_cy + ilcy) / 2.0;
     lrl_rlx = (lrl_cx + glcx) / 2.0; lrl_rly = (lrl_cy + glcy) / 2.0;
     first = left_turn_from(a_il, lrl_lrx, lrl_lry, ilcx, ilcy, r_min);
@@ -234,13 +246,13 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
   if (fr) {
     if (word == 0) { px = rsl1x; py = rsl1y; } else if (word == 1) { px = rsr1x; py = rsr1y; } else { px = rlr_rlx; py = rlr_rly; }
     phi_start = a_ir;
-    phi_end = atan2(py - ircy, px - ircx);
+    phi_end = rrtx_dm_atan2(py - ircy, px - ircx);
     if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi;
     out.pc[0] = make_arc(ircx, ircy, phi_start, phi_end, -dphi);
   } else {
     if (word == 4) { px = lsl1x; py = lsl1y; } else if (word == 3) { px = lsr1x; py = lsr1y; } else { px = lrl_lrx; py = lrl_lry; }
     phi_start = a_il;
-    phi_end = atan2(py - ilcy, px - ilcx);
+    phi_end = rrtx_dm_atan2(py - ilcy, px - ilcx);
     if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi;
     out.pc[0] = make_arc(ilcx, ilcy, phi_start, phi_end, dphi);
   }
@@ -250,13 +262,13 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
   else if (word == 3) out.pc[1] = make_line(lsr1x, lsr1y, lsr2x, lsr2y);
   else if (word == 4) out.pc[1] = make_line(lsl1x, lsl1y, lsl2x, lsl2y);
   else if (word == 5) {   // lrl: middle is a right turn
-    phi_start = atan2(lrl_lry - lrl_cy, lrl_lrx - lrl_cx);
-    phi_end = atan2(lrl_rly - lrl_cy, lrl_rlx - lrl_cx);
+    phi_start = rrtx_dm_atan2(lrl_lry - lrl_cy, lrl_lrx - lrl_cx);
+    phi_end = rrtx_dm_atan2(lrl_rly - lrl_cy, lrl_rlx - lrl_cx);
     if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi;
     out.pc[1] = make_arc(lrl_cx, lrl_cy, phi_start, phi_end, -dphi);
   } else {                // rlr: middle is a left turn
-    phi_start = atan2(rlr_rly - rlr_cy, rlr_rlx - rlr_cx);
-    phi_end = atan2(rlr_lry - rlr_cy, rlr_lrx - rlr_cx);
+    phi_start = rrtx_dm_atan2(rlr_rly - rlr_cy, rlr_rlx - rlr_cx);
+    phi_end = rrtx_dm_atan2(rlr_lry - rlr_cy, rlr_lrx - rlr_cx);
     if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi;
     out.pc[1] = make_arc(rlr_cx, rlr_cy, phi_start, phi_end, dphi);
   }
@@ -264,13 +276,13 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
   const bool tr = (word == 1 || word == 3 || word == 2);   // last letter 'r'
   if (tr) {
     if (word == 1) { px = rsr2x; py = rsr2y; } else if (word == 3) { px = lsr2x; py = lsr2y; } else { px = rlr_lrx; py = rlr_lry; }
-    phi_start = atan2(py - grcy, px - grcx);
+    phi_start = rrtx_dm_atan2(py - grcy, px - grcx);
     phi_end = a_gr;
     if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi;
     out.pc[2] = make_arc(grcx, grcy, phi_start, phi_end, -dphi);
   } else {
     if (word == 4) { px = lsl2x; py = lsl2y; } else if (word == 0) { px = rsl2x; py = rsl2y; } else { px = lrl_rlx; py = lrl_rly; }
-    phi_start = atan2(py - glcy, px - glcx);
+    phi_start = rrtx_dm_atan2(py - glcy, px - glcx);
     phi_end = a_gl;
     if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi;
     out.pc[2] = make_arc(glcx, glcy, phi_start, phi_end, dphi);
@@ -285,10 +297,8 @@ __device__ __forceinline__ void piece_point(const Piece &p, int k, double r_min,
     // phi = phi_start -+ k * 0.1
     const int kc = k < kArcTab ? k : kArcTab - 1;
     double ck = kArcCos[kc], sk = kArcSin[kc];
-    if (k >= kArcTab) { ck = cos((double)k * .1); sk = sin((double)k * .1); }     // (cannot happen: an arc is < 2 pi)
-    if (p.kind == 2) sk = -sk;
-    x = p.cx + r_min * (p.a * ck - p.b * sk);
-    y = p.cy + r_min * (p.b * ck + p.a * sk);
+    if (k >= kArcTab) rrtx_dm_sincos((double)k * .1, &sk, &ck);     // (cannot happen: an arc is < 2 pi)
+    rrtx_dm_arc_row(p.cx, p.cy, r_min, p.a, p.b, ck, sk, p.kind == 2, &x, &y);
   }
 }
 
@@ -397,6 +407,19 @@ __global__ __launch_bounds__(256) void dubins_steer_kernel(const double *__restr
   if (velocity) velocity[i] = has_time ? vel : 0.0;
   if (valid) valid[i] = (!has_time || valid_move_time(t0, t1, vel, vmin, vmax)) ? 1 : 0;
   if (word) write_word(word, i, st.word);
+}
+
+// include/rrtx_detmath.h element-wise (rrtx_detmath_eval: the suite compares this build of the header with the host's)
+__global__ __launch_bounds__(256) void detmath_eval_kernel(int op, const double *__restrict__ x, const double *__restrict__ y,
+                                                           long long n, double *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r;
+  if (op == 0) r = rrtx_dm_sin(x[i]);
+  else if (op == 1) r = rrtx_dm_cos(x[i]);
+  else if (op == 2) r = rrtx_dm_atan2(y[i], x[i]);
+  else r = rrtx_dm_acos(x[i]);
+  out[i] = r;
 }
 
 // polygon helpers live in kernels_collide.hip; the Dubins check needs the same
@@ -943,92 +966,152 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
   return valid && w.done[lane] != 0;
 }
 
-// Candidate Dubins edges of extend(): CSR entry e = (sample qi, node idx[e]); both directed edges
-// sample->near and near->sample are steered and checked (R/DRRT_Q.jl:1951-1963, 2600-2602 with
-// Edge = DubinsEdge).  TIME: costs are edge.dist in [x y t theta], the pieces carry time, and bit 1 of
-// a hit byte says !validMove (findBestParent blocks an edge on explicitEdgeCheck || !validMove, :1960).
-template <bool TIME>
-__global__ __launch_bounds__(256, TIME ? 2 : 3) void candidate_dubins_kernel(
-    const double *__restrict__ q, const int64_t *__restrict__ offsets, int nq, const int32_t *__restrict__ idx,
-    const int32_t *__restrict__ owner, const double *__restrict__ nx, const double *__restrict__ ny,
-    const double *__restrict__ nz, const double *__restrict__ nw, int n_nodes, long long cap, double r_min,
-    double robot_radius, double vmin, double vmax, const PolyTab tab, double *__restrict__ cost_out,
-    double *__restrict__ cost_in, uint8_t *__restrict__ word_out, uint8_t *__restrict__ word_in,
-    uint8_t *__restrict__ hit_out, uint8_t *__restrict__ hit_in) {
-  __shared__ WaveDubinsT<TIME> wd[4];
-  WaveDubinsT<TIME> &w = wd[threadIdx.x >> 6];
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = offsets[nq];
-  if (total > cap) return;      // capacity overflow: the CSR arrays are only partly written
-  bool valid = e < total;
-  int qi = 0, n = 0;
-  if (valid) {
-    qi = owner[e];
-    n = idx[e];
-    valid = (unsigned)qi < (unsigned)nq && (unsigned)n < (unsigned)n_nodes;   // defensive
+// ---- steering and checking are two launches -------------------------------------------------------------------
+// Round 3: calculateTrajectory's six words (16 atan2, 6 sincos, 2 acos -- ~4 000 instructions once the shared
+// deterministic transcendentals are inlined) and the two-stage check no longer share a kernel: the steering kernel
+// leaves a 128-byte record per directed edge (the three pieces, the cost, lengths / kinds / word) and the check
+// kernel starts at stage 1a with the record in hand.  The check kernel's registers are then the check's alone, and
+// the steering kernel runs at full occupancy with every lane busy.  Edges go through in chunks of kDubChunk, so the
+// records of a chunk (256 MB) are written and read back while they are still in the Infinity Cache.
+constexpr long long kDubChunk = 2ll << 20;
+
+// where the edges of a launch come from
+struct EdgeSrc {
+  int mode;                        // 0: rows s[i], g[i];  1: candidate edges of extend() (CSR entry e = (sample, node));
+                                   // 2: mirrored edges (start node, end node) through a list of edge ids
+  int dir;                         // mode 1: 0 = sample -> node, 1 = node -> sample
+  const double *s, *g;             // mode 0 (rows of 4)
+  const double *q;                 // mode 1: samples (rows of 4)
+  const int64_t *offsets;          //         offsets[nq] = number of CSR entries
+  const int32_t *idx, *owner;      //         node and sample of every entry
+  int nq;
+  const int32_t *ids;              // mode 2: edge ids (null: ids are first, first + 1, ...)
+  const int32_t *es, *ee;          //         start / end node of every mirrored edge
+  long long first;
+  const double *nx, *ny, *nz, *nw; // node table (modes 1, 2)
+  int n_nodes;
+  long long cap;                   // mode 1: the caller's capacity (an overflowing CSR is left alone)
+};
+
+// start and goal pose of edge i; false: no such edge (past the end, or indices that point nowhere)
+__device__ __forceinline__ bool load_edge(const EdgeSrc &src, long long i, long long n, double *s, double *g) {
+  if (src.mode == 0) {
+    if (i >= n) return false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s[k] = src.s[4 * i + k]; g[k] = src.g[4 * i + k]; }
+    return true;
   }
-  if (__ballot(valid) == 0ull) return;   // the grid covers the caller's capacity
-  double s[4] = {0, 0, 0, 0}, g[4] = {1, 0, 0, 0};
-  if (valid) {
-    for (int k = 0; k < 4; ++k) s[k] = q[4 * (size_t)qi + k];
-    g[0] = nx[n]; g[1] = ny[n]; g[2] = nz[n]; g[3] = nw[n];
+  if (src.mode == 1) {
+    const long long total = src.offsets[src.nq];
+    if (total > src.cap || i >= total) return false;   // capacity overflow: the CSR arrays are only partly written
+    const int qi = src.owner[i], nd = src.idx[i];
+    if ((unsigned)qi >= (unsigned)src.nq || (unsigned)nd >= (unsigned)src.n_nodes) return false;   // defensive
+    const double n0 = src.nx[nd], n1 = src.ny[nd], n2 = src.nz[nd], n3 = src.nw[nd];
+    const double q0 = src.q[4 * (size_t)qi], q1 = src.q[4 * (size_t)qi + 1], q2 = src.q[4 * (size_t)qi + 2],
+                 q3 = src.q[4 * (size_t)qi + 3];
+    const bool rev = src.dir != 0;
+    s[0] = rev ? n0 : q0; s[1] = rev ? n1 : q1; s[2] = rev ? n2 : q2; s[3] = rev ? n3 : q3;
+    g[0] = rev ? q0 : n0; g[1] = rev ? q1 : n1; g[2] = rev ? q2 : n2; g[3] = rev ? q3 : n3;
+    return true;
   }
-  Steer st;
-  RRTX_DUB_T(t_s0);
-  dubins_steer<true>(s, g, r_min, st);
-  RRTX_DUB_T(t_s1);
-  RRTX_DUB_ADD(0, t_s0, t_s1);
-  RRTX_DUB_ADD(6, 0ull, 1ull);
-  int bad_move = 0;
-  if (valid) {
-    cost_out[e] = TIME ? dist_with_time(st.cost, s[2], g[2]) : st.cost;
-    if (word_out) write_word(word_out, e, st.word);
-    if (TIME && !valid_move_time(s[2], g[2], st.cost / (s[2] - g[2]), vmin, vmax)) bad_move = 2;
-  }
-  const bool ho = wave_dubins_collides<TIME>(w, valid, st, s, g, r_min, robot_radius, tab);
-  if (valid) hit_out[e] = (ho ? 1 : 0) | bad_move;
-  RRTX_DUB_T(t_s2);
-  dubins_steer<true>(g, s, r_min, st);
-  RRTX_DUB_T(t_s3);
-  RRTX_DUB_ADD(0, t_s2, t_s3);
-  bad_move = 0;
-  if (valid) {
-    cost_in[e] = TIME ? dist_with_time(st.cost, g[2], s[2]) : st.cost;
-    if (word_in) write_word(word_in, e, st.word);
-    if (TIME && !valid_move_time(g[2], s[2], st.cost / (g[2] - s[2]), vmin, vmax)) bad_move = 2;
-  }
-  const bool hi = wave_dubins_collides<TIME>(w, valid, st, g, s, r_min, robot_radius, tab);
-  if (valid) hit_in[e] = (hi ? 1 : 0) | bad_move;
+  if (i >= n) return false;
+  const long long id = src.ids ? (long long)src.ids[i] : src.first + i;
+  const int a = src.es[id], b = src.ee[id];
+  if ((unsigned)a >= (unsigned)src.n_nodes || (unsigned)b >= (unsigned)src.n_nodes) return false;
+  s[0] = src.nx[a]; s[1] = src.ny[a]; s[2] = src.nz[a]; s[3] = src.nw[a];
+  g[0] = src.nx[b]; g[1] = src.ny[b]; g[2] = src.nz[b]; g[3] = src.nw[b];
+  return true;
 }
 
-// explicitEdgeCheck(S, ::DubinsEdge, ob) over the polygon list (:750-774):
-// stage 1 = straight chord with radius robotRadius + 2*minTurningRadius,
-// stage 2 = every stored polyline piece with robotRadius.
+// the record: doubles 0-11 the three pieces (cx, cy, a, b), 12 the cost (bestDist), 13 the packed integers
+// (len0 | len1 << 16 | len2 << 32 | kinds << 48 (2 bits each) | word << 56); 14, 15 unused (128-byte records)
+constexpr int kRecDoubles = 16;
+__device__ __forceinline__ void store_rec(double *__restrict__ rec, const Steer &st) {
+  double2 *r2 = reinterpret_cast<double2 *>(rec);
+#pragma unroll
+  for (int pi = 0; pi < 3; ++pi) {
+    r2[2 * pi] = make_double2(st.pc[pi].cx, st.pc[pi].cy);
+    r2[2 * pi + 1] = make_double2(st.pc[pi].a, st.pc[pi].b);
+  }
+  unsigned long long m = 0ull;
+#pragma unroll
+  for (int pi = 0; pi < 3; ++pi) {
+    const int len = st.pc[pi].len < 0 ? 0 : (st.pc[pi].len > 65535 ? 65535 : st.pc[pi].len);
+    m |= (unsigned long long)len << (16 * pi);
+    m |= (unsigned long long)(st.pc[pi].kind & 3) << (48 + 2 * pi);
+  }
+  m |= (unsigned long long)(st.word & 7) << 56;
+  r2[6] = make_double2(st.cost, __longlong_as_double((long long)m));
+}
+__device__ __forceinline__ void load_rec(const double *__restrict__ rec, Steer &st) {
+  const double2 *r2 = reinterpret_cast<const double2 *>(rec);
+#pragma unroll
+  for (int pi = 0; pi < 3; ++pi) {
+    const double2 c = r2[2 * pi], ab = r2[2 * pi + 1];
+    st.pc[pi].cx = c.x; st.pc[pi].cy = c.y; st.pc[pi].a = ab.x; st.pc[pi].b = ab.y;
+  }
+  const double2 cm = r2[6];
+  st.cost = cm.x;
+  const unsigned long long m = (unsigned long long)__double_as_longlong(cm.y);
+#pragma unroll
+  for (int pi = 0; pi < 3; ++pi) {
+    st.pc[pi].len = (int)((m >> (16 * pi)) & 0xffffull);
+    st.pc[pi].kind = (int)((m >> (48 + 2 * pi)) & 3ull);
+  }
+  st.word = (int)((m >> 56) & 7ull);
+}
+
+// calculateTrajectory of the edges [base, base + count) of the source: the record of edge base + k at rec[k],
+// cost = edge.dist (sqrt(Wdist^2 + dt^2) in a space with time), the word, the number of polyline rows.
+__global__ __launch_bounds__(256) void dubins_steer_rec_kernel(const EdgeSrc src, long long base, long long count, long long n,
+                                                               double r_min, int has_time, double *__restrict__ rec,
+                                                               double *__restrict__ cost, uint8_t *__restrict__ word,
+                                                               int32_t *__restrict__ traj_len) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const long long i = base + k;
+  double s[4] = {0, 0, 0, 0}, g[4] = {1, 0, 0, 0};
+  const bool valid = load_edge(src, i, n, s, g);
+  if (__ballot(valid) == 0ull) return;          // (mode 1: the grid covers the caller's capacity)
+  Steer st;
+  dubins_steer<true>(s, g, r_min, st);
+  store_rec(rec + kRecDoubles * k, st);
+  if (!valid) return;
+  if (cost) cost[i] = has_time ? dist_with_time(st.cost, s[2], g[2]) : st.cost;
+  if (word) write_word(word, i, st.word);
+  if (traj_len) traj_len[i] = st.pc[0].len + st.pc[1].len + st.pc[2].len;
+}
+
+// explicitEdgeCheck(S, ::DubinsEdge, ob) over the polygon list (:750-774) for the steered edges of a chunk:
+// stage 1 = straight chord with radius robotRadius + 2*minTurningRadius, stage 2 = every stored polyline piece
+// with robotRadius.  TIME: the pieces carry time; for the candidate edges of extend() (mode 1) bit 1 of the hit
+// byte says !validMove (findBestParent blocks an edge on explicitEdgeCheck || !validMove, R/DRRT_Q.jl:1960).
+// spread: a wave takes every n_waves-th edge of the chunk instead of 64 neighbours -- edges that arrive grouped
+// by their sample cost what the sample's surroundings make them cost, and all waves should get the same mix.
 template <bool TIME>
-__global__ __launch_bounds__(256) void dubins_edges_check_kernel(
-    const double *__restrict__ s, const double *__restrict__ g, long long ne, double r_min,
-    double robot_radius, const PolyTab tab, double *__restrict__ cost, uint8_t *__restrict__ word,
-    uint8_t *__restrict__ hit, int32_t *__restrict__ traj_len) {
+__global__ __launch_bounds__(256, TIME ? 2 : 3) void dubins_check_rec_kernel(
+    const EdgeSrc src, long long base, long long count, long long n, int spread, double r_min, double robot_radius,
+    double vmin, double vmax, const PolyTab tab, const double *__restrict__ rec, uint8_t *__restrict__ hit) {
   __shared__ WaveDubinsT<TIME> wd[4];
   WaveDubinsT<TIME> &w = wd[threadIdx.x >> 6];
-  // Edges arrive grouped by their sample, and the cost of an edge is decided by where its sample
-  // lies (near a polygon every polyline has to be walked, elsewhere none): a wave therefore takes
-  // every n_waves-th edge instead of 64 neighbours, so that all waves get the same mix.
-  const long long n_waves = (ne + 63) / 64;
-  const long long gw = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long i = (long long)(threadIdx.x & 63) * n_waves + gw;
-  const bool valid = gw < n_waves && i < ne;
-  const long long ic = valid ? i : ne - 1;        // inactive lanes repeat the last edge (ne > 0)
-  Steer st;
-  dubins_steer<true>(s + 4 * ic, g + 4 * ic, r_min, st);
-  const int P = st.pc[0].len + st.pc[1].len + st.pc[2].len;
-  if (valid) {
-    if (cost) cost[i] = TIME ? dist_with_time(st.cost, s[4 * ic + 2], g[4 * ic + 2]) : st.cost;
-    if (word) write_word(word, i, st.word);
-    if (traj_len) traj_len[i] = P;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long k = t;
+  if (spread) {
+    const long long n_waves = (count + 63) / 64;
+    const long long gw = t >> 6;
+    k = (gw < n_waves) ? (long long)(threadIdx.x & 63) * n_waves + gw : count;
   }
-  const bool h = wave_dubins_collides<TIME>(w, valid, st, s + 4 * ic, g + 4 * ic, r_min, robot_radius, tab);
-  if (valid) hit[i] = h ? 1 : 0;
+  double s[4] = {0, 0, 0, 0}, g[4] = {1, 0, 0, 0};
+  const bool valid = k < count && load_edge(src, base + k, n, s, g);
+  if (__ballot(valid) == 0ull) return;
+  Steer st;
+  load_rec(rec + kRecDoubles * (valid ? k : 0), st);
+  if (!valid) { st.cost = __builtin_inf(); st.word = 6; st.pc[0].len = st.pc[1].len = st.pc[2].len = 0; }
+  RRTX_DUB_ADD(6, 0ull, 1ull);
+  int bad_move = 0;
+  if (TIME && src.mode == 1 && valid && !valid_move_time(s[2], g[2], st.cost / (s[2] - g[2]), vmin, vmax)) bad_move = 2;
+  const bool h = wave_dubins_collides<TIME>(w, valid, st, s, g, r_min, robot_radius, tab);
+  if (valid) hit[base + k] = (uint8_t)((h ? 1 : 0) | bad_move);
 }
 
 // edge.trajectory (R/DRRT_DubinsEdge_functions.jl:684-701): the polyline of every edge, written at
@@ -1098,6 +1181,33 @@ extern "C" int rrtx_debug_dubins_clocks(unsigned long long *out, int reset) {
 }
 #endif
 
+// steer + check of the edges [0, n) of a source, chunk by chunk
+static int run_dubins_edges(rrtx_ctx *ctx, const EdgeSrc &src, long long n, int spread, double r_min, double robot_radius,
+                            const PolyTab &tab, bool check, double *cost, uint8_t *word, uint8_t *hit, int32_t *traj_len) {
+  const long long chunk = n < kDubChunk ? n : kDubChunk;
+  RRTX_HIP(ctx, ctx->ws_dub_rec.ensure(sizeof(double) * kRecDoubles * (size_t)chunk));
+  double *rec = ctx->ws_dub_rec.as<double>();
+  const int has_time = ctx->opt_space_has_time ? 1 : 0;
+  for (long long base = 0; base < n; base += chunk) {
+    const long long count = (n - base < chunk) ? n - base : chunk;
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    hipLaunchKernelGGL(dubins_steer_rec_kernel, grid, block, 0, ctx->stream, src, base, count, n, r_min, has_time, rec, cost,
+                       word, traj_len);
+    if (!check) continue;
+    if (has_time)
+      hipLaunchKernelGGL(dubins_check_rec_kernel<true>, grid, block, 0, ctx->stream, src, base, count, n, spread, r_min,
+                         robot_radius, ctx->dubins_vmin, ctx->dubins_vmax, tab, rec, hit);
+    else
+      hipLaunchKernelGGL(dubins_check_rec_kernel<false>, grid, block, 0, ctx->stream, src, base, count, n, spread, r_min,
+                         robot_radius, ctx->dubins_vmin, ctx->dubins_vmax, tab, rec, hit);
+  }
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+// Candidate Dubins edges of extend(): CSR entry e = (sample qi, node idx[e]); both directed edges
+// sample->near and near->sample are steered and checked (R/DRRT_Q.jl:1951-1963, 2600-2602 with
+// Edge = DubinsEdge).
 int launch_candidate_dubins(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
                             const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap, double r_min,
                             double robot_radius, double *cost_out, double *cost_in, uint8_t *word_out,
@@ -1108,19 +1218,27 @@ int launch_candidate_dubins(rrtx_ctx *ctx, const double *q_dev, int nq, const in
   if (rc) return rc;
   if ((rc = check_space(ctx))) return rc;
   const PolyTab tab = poly_tab(ctx);
+  EdgeSrc src = {};
+  src.mode = 1;
+  src.q = q_dev; src.offsets = offsets_dev; src.idx = idx_dev; src.owner = owner_dev; src.nq = nq;
+  src.nx = ctx->nodes[0]; src.ny = ctx->nodes[1]; src.nz = ctx->nodes[2]; src.nw = ctx->nodes[3];
+  src.n_nodes = (int)ctx->n_nodes;
+  src.cap = (long long)cap;
   span_begin(ctx, KF_DUBINS);
-  const dim3 grid((unsigned)((cap + 255) / 256)), block(256);
-  if (ctx->opt_space_has_time)
-    hipLaunchKernelGGL(candidate_dubins_kernel<true>, grid, block, 0, ctx->stream, q_dev, offsets_dev, nq, idx_dev,
-                       owner_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[3], (int)ctx->n_nodes,
-                       (long long)cap, r_min, robot_radius, ctx->dubins_vmin, ctx->dubins_vmax, tab, cost_out, cost_in,
-                       word_out, word_in, hit_out, hit_in);
-  else
-    hipLaunchKernelGGL(candidate_dubins_kernel<false>, grid, block, 0, ctx->stream, q_dev, offsets_dev, nq, idx_dev,
-                       owner_dev, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[3], (int)ctx->n_nodes,
-                       (long long)cap, r_min, robot_radius, ctx->dubins_vmin, ctx->dubins_vmax, tab, cost_out, cost_in,
-                       word_out, word_in, hit_out, hit_in);
+  src.dir = 0;
+  rc = run_dubins_edges(ctx, src, (long long)cap, 0, r_min, robot_radius, tab, true, cost_out, word_out, hit_out, nullptr);
+  if (!rc) {
+    src.dir = 1;
+    rc = run_dubins_edges(ctx, src, (long long)cap, 0, r_min, robot_radius, tab, true, cost_in, word_in, hit_in, nullptr);
+  }
   span_end(ctx);
+  return rc;
+}
+
+int launch_detmath_eval(rrtx_ctx *ctx, int op, const double *x_dev, const double *y_dev, int64_t n, double *out_dev) {
+  if (n <= 0) return RRTX_OK;
+  hipLaunchKernelGGL(detmath_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, x_dev, y_dev,
+                     (long long)n, out_dev);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
 }
@@ -1162,17 +1280,13 @@ int launch_dubins_edges_check(rrtx_ctx *ctx, const double *s_dev, const double *
   if (rc) return rc;
   if ((rc = check_space(ctx))) return rc;
   const PolyTab tab = poly_tab(ctx);
+  EdgeSrc src = {};
+  src.mode = 0;
+  src.s = s_dev; src.g = g_dev;
   span_begin(ctx, KF_DUBINS);
-  const dim3 grid((unsigned)((ne + 255) / 256)), block(256);
-  if (ctx->opt_space_has_time)
-    hipLaunchKernelGGL(dubins_edges_check_kernel<true>, grid, block, 0, ctx->stream, s_dev, g_dev, (long long)ne, r_min,
-                       robot_radius, tab, cost_dev, word_dev, hit_dev, traj_len_dev);
-  else
-    hipLaunchKernelGGL(dubins_edges_check_kernel<false>, grid, block, 0, ctx->stream, s_dev, g_dev, (long long)ne, r_min,
-                       robot_radius, tab, cost_dev, word_dev, hit_dev, traj_len_dev);
+  rc = run_dubins_edges(ctx, src, (long long)ne, 1, r_min, robot_radius, tab, true, cost_dev, word_dev, hit_dev, traj_len_dev);
   span_end(ctx);
-  RRTX_HIP(ctx, hipGetLastError());
-  return RRTX_OK;
+  return rc;
 }
 
 }  // namespace rrtx

@@ -423,7 +423,7 @@ int rrtx_destroy(rrtx_ctx *ctx) {
                     &ctx->d_poly_orig, &ctx->d_poly_path_off, &ctx->d_poly_path, &ctx->ws_knn_off, &ctx->ws_knn_idx,
                     &ctx->ws_knn_dist, &ctx->ws_knn_misc, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
                     &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_bsum, &ctx->ws_scalars, &ctx->ws_scalars_nn, &ctx->ws_tmp,
-                    &ctx->ws_owner, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
+                    &ctx->ws_owner, &ctx->ws_dub_rec, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
                     &ctx->ws_out_u8b, &ctx->ws_out_i32, &ctx->ws_out_f64, &ctx->ws_partial, &ctx->ws_thr, &ctx->ws_mask, &ctx->ws_i32a, &ctx->ws_i32b,
                     &ctx->ws_slab_hist, &ctx->ws_slab_start, &ctx->ws_slab_sr, &ctx->ws_slab_params, &ctx->ws_run_hist, &ctx->ws_run_sr,
                     &ctx->ws_copies_s,
@@ -495,6 +495,27 @@ int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value) {
       return RRTX_OK;
     }
     default: return fail(ctx, RRTX_E_INVALID, "set_option: unknown option %d", option);
+  }
+}
+
+int rrtx_get_option(rrtx_ctx *ctx, int option, int64_t *value) {
+  CHECK_CTX(ctx);
+  if (!value) return fail(ctx, RRTX_E_INVALID, "get_option: null output");
+  switch (option) {
+    case RRTX_OPT_NN_FILTER: *value = ctx->opt_nn_filter ? 1 : 0; return RRTX_OK;
+    case RRTX_OPT_SCAN_BLOCKS: *value = ctx->opt_scan_blocks; return RRTX_OK;
+    case RRTX_OPT_SCAN_ITEMS: *value = ctx->opt_scan_items; return RRTX_OK;
+    case RRTX_OPT_SCAN_TILE_Q: *value = ctx->opt_tile_q; return RRTX_OK;
+    case RRTX_OPT_NN_CULL: *value = ctx->opt_nn_cull; return RRTX_OK;
+    case RRTX_OPT_PROFILE_EVERY: *value = ctx->opt_profile_every; return RRTX_OK;
+    case RRTX_OPT_KNN_LISTS: *value = ctx->opt_knn_lists ? 1 : 0; return RRTX_OK;
+    case RRTX_OPT_EXTEND_OBSTACLES: *value = ctx->opt_extend_polygons ? 1 : 0; return RRTX_OK;
+    case RRTX_OPT_TUNE: *value = ctx->opt_tune; return RRTX_OK;
+    case RRTX_OPT_ROOT_RULE: *value = ctx->opt_root_rule ? 1 : 0; return RRTX_OK;
+    case RRTX_OPT_SPACE_HAS_TIME: *value = ctx->opt_space_has_time ? 1 : 0; return RRTX_OK;
+    case RRTX_OPT_NEAREST_REC_CAP: *value = (int64_t)ctx->opt_nearest_rec_cap; return RRTX_OK;
+    case RRTX_OPT_BUCKET_MULT: *value = ctx->bkt_mult; return RRTX_OK;
+    default: return fail(ctx, RRTX_E_INVALID, "get_option: unknown option %d", option);
   }
 }
 
@@ -1118,10 +1139,13 @@ int rrtx_dubins_edges_check(rrtx_ctx *ctx, const double *s, const double *g, int
 }
 
 int rrtx_dubins_trajectory(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min,
-                           int64_t *traj_off, double *traj_xy, int64_t cap_rows, int64_t *needed_rows) {
+                           int64_t *traj_off, double *traj_xy, int cols_in, int64_t cap_rows, int64_t *needed_rows) {
   CHECK_CTX(ctx);
   if (ne < 0 || cap_rows < 0 || (ne > 0 && (!s || !g || !traj_off)) || (cap_rows > 0 && !traj_xy))
     return fail(ctx, RRTX_E_INVALID, "dubins_trajectory: bad arguments");
+  if (cols_in != (ctx->opt_space_has_time ? 3 : 2))
+    return fail(ctx, RRTX_E_INVALID, "dubins_trajectory: rows are %d doubles wide in this context (RRTX_OPT_SPACE_HAS_TIME = %d), "
+                "the caller's buffer was sized for %d", ctx->opt_space_has_time ? 3 : 2, ctx->opt_space_has_time ? 1 : 0, cols_in);
   if (ne == 0) { if (needed_rows) *needed_rows = 0; if (traj_off) traj_off[0] = 0; return RRTX_OK; }
   if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
   const size_t pb = sizeof(double) * (size_t)ne * 4;
@@ -1152,6 +1176,24 @@ int rrtx_dubins_trajectory(rrtx_ctx *ctx, const double *s, const double *g, int6
                                 ctx->ws_out_off.as<int64_t>(), ctx->ws_out_f64.as<double>(), total, nullptr);
   if (rc) return rc;
   RRTX_HIP(ctx, hipMemcpyAsync(traj_xy, ctx->ws_out_f64.p, sizeof(double) * cols * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
+int rrtx_detmath_eval(rrtx_ctx *ctx, int op, const double *x, const double *y, int64_t n, double *out) {
+  CHECK_CTX(ctx);
+  if (n < 0 || op < 0 || op > 3 || (n > 0 && (!x || !out)) || (op == 2 && n > 0 && !y))
+    return fail(ctx, RRTX_E_INVALID, "detmath_eval: bad arguments");
+  if (n == 0) return RRTX_OK;
+  const size_t pb = sizeof(double) * (size_t)n;
+  int rc = stage_in(ctx, ctx->ws_q, x, pb);
+  if (rc) return rc;
+  rc = stage_in(ctx, ctx->ws_q2, y ? y : x, pb);
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_dist.ensure(pb));
+  rc = launch_detmath_eval(ctx, op, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>(), n, ctx->ws_out_dist.as<double>());
+  if (rc) return rc;
+  RRTX_HIP(ctx, hipMemcpyAsync(out, ctx->ws_out_dist.p, pb, hipMemcpyDeviceToHost, ctx->stream));
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RRTX_OK;
 }

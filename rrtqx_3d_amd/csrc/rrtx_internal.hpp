@@ -191,6 +191,7 @@ struct rrtx_ctx {
   int scalars_flip = 0;
   rrtx::DevBuf ws_tmp;      // list entries that did not fit their bucket, in CSR position
   rrtx::DevBuf ws_owner;    // int32 owner query of every CSR entry (extend_candidates)
+  rrtx::DevBuf ws_dub_rec;  // 128-byte records of the steered Dubins edges of one chunk (kernels_dubins.hip)
   rrtx::DevBuf ws_out_off, ws_out_idx, ws_out_dist, ws_out_u8a, ws_out_u8b, ws_out_i32, ws_out_f64;
   rrtx::DevBuf ws_partial;  // nearest partials
   rrtx::DevBuf ws_thr;      // per-query thresholds
@@ -311,6 +312,7 @@ int launch_candidate_dubins(rrtx_ctx *ctx, const double *q_dev, int nq, const in
                             const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap, double r_min,
                             double robot_radius, double *cost_out, double *cost_in, uint8_t *word_out,
                             uint8_t *word_in, uint8_t *hit_out, uint8_t *hit_in);
+int launch_detmath_eval(rrtx_ctx *ctx, int op, const double *x_dev, const double *y_dev, int64_t n, double *out_dev);
 int launch_dubins_trajectory(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
                              const int64_t *traj_off_dev, double *traj_xy_dev, int64_t cap_rows,
                              int32_t *traj_len_dev);

@@ -9,7 +9,7 @@ What it writes
                     (environments/building2.txt: 31 spheres; rand_Static.txt: 35
                     polygons; rand_StaticTime_7.txt: 13 moving polygons with their
                     paths).  These are inputs the reference ships, not code.
-  hotpath_v1.npz    seeded inputs + expected outputs of the hot path computed by
+  hotpath_v2.npz    seeded inputs + expected outputs of the hot path computed by
                     the CPU oracle (oracle/rrtx_oracle.c).  The reference itself
                     is Julia and cannot run here, and it ships no expected
                     outputs for this path, so these vectors pin the ORACLE's
@@ -116,8 +116,16 @@ def main():
     out.update(w_nodes=wp, w_queries=wq, w_radius=np.float64(6.0), w_offsets=np.array(woff, dtype=np.int64),
                w_idx=np.concatenate(widx).astype(np.int32), w_key=np.concatenate(wkey))
 
-    np.savez_compressed(os.path.join(HERE, "hotpath_v1.npz"), **out)
-    print("wrote", os.path.join(HERE, "hotpath_v1.npz"), os.path.getsize(os.path.join(HERE, "hotpath_v1.npz")), "bytes")
+    # ---- the shared deterministic transcendentals (include/rrtx_detmath.h) as THIS build of the oracle evaluates
+    #      them: pins the header's results against compiler / flag drift on either target -------------------------
+    ang = np.concatenate([rng.uniform(-20, 20, 1500), np.arange(-32, 33) * (math.pi / 4), rng.normal(0, 1, 483) * 1e-3])
+    ay, ax = rng.normal(0, 5, 2048), rng.normal(0, 5, 2048)
+    ac = np.concatenate([rng.uniform(-1, 1, 1900), 1.0 - 10.0 ** rng.uniform(-16, -1, 148)])
+    out.update(dm_ang=ang, dm_sin=O.dm_eval(O.DM_SIN, ang), dm_cos=O.dm_eval(O.DM_COS, ang), dm_y=ay, dm_x=ax,
+               dm_atan2=O.dm_eval(O.DM_ATAN2, ax, ay), dm_acos_in=ac, dm_acos=O.dm_eval(O.DM_ACOS, ac))
+
+    np.savez_compressed(os.path.join(HERE, "hotpath_v2.npz"), **out)
+    print("wrote", os.path.join(HERE, "hotpath_v2.npz"), os.path.getsize(os.path.join(HERE, "hotpath_v2.npz")), "bytes")
 
 
 if __name__ == "__main__":

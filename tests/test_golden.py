@@ -1,4 +1,4 @@
-"""Committed fixtures (tests/golden/hotpath_v1.npz, made by tests/golden/make_golden.py).
+"""Committed fixtures (tests/golden/hotpath_v2.npz, made by tests/golden/make_golden.py).
 
 CPU leg: the oracle still reproduces them (guards the oracle against drift).
 GPU leg: the HIP path reproduces them through the C-ABI without the oracle."""
@@ -14,7 +14,7 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 
 @pytest.fixture(scope="module")
 def gold():
-    return np.load(os.path.join(G, "hotpath_v1.npz"), allow_pickle=False)
+    return np.load(os.path.join(G, "hotpath_v2.npz"), allow_pickle=False)
 
 
 @pytest.fixture(scope="module")
@@ -97,10 +97,12 @@ def test_gpu_reproduces_polygon_dubins_wrapped_slices(gold, env):
         unsafe, clr = ctx.points_check(gold["p_edges0"], 0.5, kind=1)
         assert np.array_equal(unsafe, gold["p_unsafe"]) and np.array_equal(clr, gold["p_clearance"])
         cost, word, dh, tl = ctx.dubins_edges_check(gold["d_start"], gold["d_goal"], 1.0, 0.5)
-        # Dubins: 1e-6 relative (north_star tolerance; device libm != host libm)
-        assert np.all(np.abs(cost - gold["d_cost"]) <= 1e-6 * np.maximum(1.0, np.abs(gold["d_cost"])))
-        assert (word != gold["d_word"]).sum() <= 2
-        assert (dh != gold["d_hit"]).sum() <= 1
+        # Dubins: exact (device and oracle share include/rrtx_detmath.h)
+        assert np.array_equal(cost, gold["d_cost"]) and np.array_equal(word, gold["d_word"])
+        assert np.array_equal(dh, gold["d_hit"]) and np.array_equal(tl, gold["d_traj_len"])
+        for op, x, y, ref in ((0, gold["dm_ang"], None, gold["dm_sin"]), (1, gold["dm_ang"], None, gold["dm_cos"]),
+                              (2, gold["dm_x"], gold["dm_y"], gold["dm_atan2"]), (3, gold["dm_acos_in"], None, gold["dm_acos"])):
+            assert np.array_equal(ctx.detmath_eval(op, x, y).view(np.uint64), ref.view(np.uint64)), op
         off, idx, key = ctx.nn_radius(gold["w_queries"], float(gold["w_radius"]))
         assert np.array_equal(off, gold["w_offsets"]) and np.array_equal(idx, gold["w_idx"])
         assert np.array_equal(key, gold["w_key"])

@@ -2,7 +2,7 @@
 validMove, the time-stamped trajectory (R/DRRT_DubinsEdge_functions.jl:115-121, 660-697) and the
 two-stage edge check against static polygons and polygons that move in time (kinds 6 / 7,
 :750-774 + R/DRRT.jl:1579-1651), through the C-ABI against the oracle.  Costs and times within the
-1e-6 relative tolerance north_star gives Dubins edges; words / booleans may differ only on numerical
+exact since round 3 (shared deterministic transcendentals, include/rrtx_detmath.h); was: words / booleans may differ only on numerical
 ties (the tests bound the count).  Moving obstacles: the reference's own
 environments/rand_StaticTime_7.txt (tests/golden/env_inputs.json)."""
 import json
@@ -51,21 +51,18 @@ def test_steer_full_and_trajectory_with_time(oracle):
         assert np.array_equal(cost, out["dist"])                     # rrtx_dubins_steer returns edge.dist
         off, traj = ctx.dubins_trajectory(s[:400], g[:400], RMIN)
         assert traj.shape[1] == 3
-        word_ties = valid_ties = 0
         for k in range(len(s)):
-            d, w, v, word, tr = oracle.dubins_steer_time(s[k], g[k], RMIN)
-            assert abs(out["wdist"][k] - w) <= 1e-6 * max(1.0, abs(w))
-            assert abs(out["dist"][k] - d) <= 1e-6 * max(1.0, abs(d))
-            assert abs(out["velocity"][k] - v) <= 1e-6 * max(1.0, abs(v))
-            word_ties += out["word"][k].decode() != word
-            ok = oracle.dubins_valid_move_time(s[k], g[k], v, VMIN, VMAX)
-            valid_ties += bool(out["valid_move"][k]) != ok
-            if k < 400 and out["word"][k].decode() == word:
+            d, w, v, word, tr = oracle.dubins_steer_time(s[k], g[k], RMIN, piecewise=True)
+            assert out["wdist"][k] == w and out["dist"][k] == d and out["velocity"][k] == v, k
+            assert out["word"][k].decode() == word, k
+            assert bool(out["valid_move"][k]) == oracle.dubins_valid_move_time(s[k], g[k], v, VMIN, VMAX), k
+            if k < 400:
                 mine = traj[off[k]:off[k + 1]]
-                assert mine.shape == tr.shape
-                assert np.allclose(mine[:, :2], tr[:, :2], atol=1e-9) and np.allclose(mine[:, 2], tr[:, 2], atol=1e-9)
+                assert np.array_equal(mine, tr), k          # (x, y, t) rows bit for bit
                 assert mine[0, 2] == s[k, 2] and np.array_equal(mine[-1], g[k, :3])
-        assert word_ties <= 2 and valid_ties <= 2
+                # the reference's own running sum (oracle default) differs from the piecewise time column by rounding only
+                tr_ref = oracle.dubins_steer_time(s[k], g[k], RMIN)[4]
+                assert np.array_equal(tr_ref[:, :2], tr[:, :2]) and np.allclose(tr_ref[:, 2], tr[:, 2], rtol=1e-12, atol=1e-12)
         assert 0.2 < out["valid_move"].mean() < 0.95
         # without the option the same calls are the space-without-time ones
         ctx.set_space_has_time(False)
@@ -95,16 +92,16 @@ def test_dubins_edges_check_with_time_static_and_moving(oracle):
             ctx.dubins_edges_check(s[:8], g[:8], RMIN, RR)
         ctx.set_space_has_time(True)
         cost, word, hit, tl = ctx.dubins_edges_check(s, g, RMIN, RR)
-        mism = 0
+        ref_flips = 0
         for k in range(len(s)):
-            d, w, v, wd, tr = oracle.dubins_steer_time(s[k], g[k], RMIN)
-            assert abs(cost[k] - d) <= 1e-6 * max(1.0, abs(d))
-            if word[k].decode() != wd:
-                continue
-            assert tl[k] == len(tr)
+            d, w, v, wd, tr = oracle.dubins_steer_time(s[k], g[k], RMIN, piecewise=True)
+            assert cost[k] == d and word[k].decode() == wd and tl[k] == len(tr), k
             h, _ = oracle.dubins_edge_check_polygons_time(ps, s[k], g[k], tr, RR, RMIN)
-            mism += bool(hit[k]) != h
-        assert mism <= 2
+            assert bool(hit[k]) == h, k
+            if k % 5 == 0:      # the reference's running-sum time column gives the same booleans on these scenes
+                tr_ref = oracle.dubins_steer_time(s[k], g[k], RMIN)[4]
+                ref_flips += oracle.dubins_edge_check_polygons_time(ps, s[k], g[k], tr_ref, RR, RMIN)[0] != h
+        assert ref_flips == 0
         assert 0.05 < hit.mean() < 0.9
         # the moving ones matter: with them switched off fewer edges collide
         act2 = active.copy(); act2[:m] = 0
@@ -135,18 +132,42 @@ def test_fused_dubins_preamble_with_time(oracle):
         out = ctx.extend_candidates_dubins(Q, r, RR, RMIN)
         off, idx = out["offsets"], out["idx"]
         assert len(idx) > 200
-        mism = 0
         for i in range(nq):
             ri, rk = tree.within_range(r, Q[i])
             o = np.argsort(ri)
             assert np.array_equal(idx[off[i]:off[i + 1]], ri[o]) and np.array_equal(out["key"][off[i]:off[i + 1]], rk[o])
             for e in range(off[i], off[i + 1]):
                 for (a, b, ck, hk) in ((Q[i], pts[idx[e]], "cost_out", "hit_out"), (pts[idx[e]], Q[i], "cost_in", "hit_in")):
-                    d, w, v, wd, tr = oracle.dubins_steer_time(a, b, RMIN)
-                    assert abs(out[ck][e] - d) <= 1e-6 * max(1.0, abs(d))
+                    d, w, v, wd, tr = oracle.dubins_steer_time(a, b, RMIN, piecewise=True)
+                    assert out[ck][e] == d, (e, ck)
                     h, _ = oracle.dubins_edge_check_polygons_time(ps, a, b, tr, RR, RMIN)
                     bad = not oracle.dubins_valid_move_time(a, b, v, VMIN, VMAX)
-                    mism += int(out[hk][e]) != (int(h) | (2 if bad else 0))
-        assert mism <= 3
+                    assert int(out[hk][e]) == (int(h) | (2 if bad else 0)), (e, hk)
         both = out["hit_out"].astype(int) | out["hit_in"].astype(int)
         assert (both & 2).any() and (out["hit_out"] & 1).any()   # invalid moves and collisions both occur
+
+
+def test_trajectory_row_width_is_the_contexts():
+    """rrtx_dubins_trajectory writes 2 or 3 doubles per row by the CONTEXT's RRTX_OPT_SPACE_HAS_TIME; the
+    caller states the width its buffer was sized for and a mismatch is an error, not an overrun.  The Python wrapper
+    reads the width from the context (rrtx_get_option), so setting the option directly cannot desynchronise it."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    s, g = _edges(rng, 64)
+    with Context(4) as ctx:
+        ctx.set_option(_capi.RRTX_OPT_SPACE_HAS_TIME, 1)            # not through set_space_has_time
+        assert ctx.space_has_time and ctx.get_option(_capi.RRTX_OPT_SPACE_HAS_TIME) == 1
+        off, traj = ctx.dubins_trajectory(s, g, RMIN)
+        assert traj.shape[1] == 3 and off[-1] == len(traj) and np.array_equal(traj[0, :3], s[0, :3])
+        # a caller that still believes in two columns is refused and its buffer left alone
+        offs = np.zeros(len(s) + 1, dtype=np.int64)
+        buf = np.full((int(off[-1]), 2), -7.0)
+        needed = C.c_int64()
+        rc = ctx._lib.rrtx_dubins_trajectory(ctx._h, _capi._ptr(s), _capi._ptr(g), len(s), RMIN, _capi._ptr(offs),
+                                             _capi._ptr(buf), 2, len(buf), C.byref(needed))
+        assert rc == _capi.RRTX_E_INVALID and (buf == -7.0).all()
+        ctx.set_option(_capi.RRTX_OPT_SPACE_HAS_TIME, 0)
+        off2, traj2 = ctx.dubins_trajectory(s, g, RMIN)
+        assert traj2.shape[1] == 2 and np.array_equal(off2, off)
+        with pytest.raises(RrtxError):
+            ctx.get_option(999)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# cost propagation (N4): parity tests, timings, rocprofv3 kernel stats.   usage: scripts_gpu_graph.sh <tag>
+# cost propagation (N4): parity tests, timings, rocprofv3 kernel stats.   usage: tools/gpu/scripts_gpu_graph.sh <tag>
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=${1:-r02_graph}
 out=gpurun_out/$tag

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes for the bench (separate passes; --kernel-trace only, as the pool requires).
-# usage: scripts_gpu_pmc.sh <tag>   -> gpurun_out/<tag>/pN_per_kernel_avg.csv + traffic.json
+# usage: tools/gpu/scripts_gpu_pmc.sh <tag>   -> gpurun_out/<tag>/pN_per_kernel_avg.csv + traffic.json
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=${1:-r02_pmc}
 out=gpurun_out/$tag

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes for the C3 line (fused Dubins preamble): instruction mix and lane utilisation of candidate_dubins_kernel.
-# usage: scripts_gpu_pmc_c3.sh <tag>   -> gpurun_out/<tag>/pN_per_kernel_avg.csv + lanes.json
+# usage: tools/gpu/scripts_gpu_pmc_c3.sh <tag>   -> gpurun_out/<tag>/pN_per_kernel_avg.csv + lanes.json
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=${1:-r02_pmc_dubins_fused}
 out=gpurun_out/$tag

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Two PMC passes (instruction mix, lane utilisation) for an arbitrary python script of this repo.
-# usage: scripts_gpu_pmc_cmd.sh <tag> <script.py> [args]   -> gpurun_out/<tag>/pN_per_kernel_avg.csv
+# usage: tools/gpu/scripts_gpu_pmc_cmd.sh <tag> <script.py> [args]   -> gpurun_out/<tag>/pN_per_kernel_avg.csv
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export PYTHONPATH="$GRAFT_REPO_ROOT"
 tag=$1; shift

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round profile: parity tests, default bench (with CPU baseline) + rocprofv3 kernel stats of the same command,
-# the C3 line.   usage: scripts_gpu_profile.sh <tag>
+# the C3 line.   usage: tools/gpu/scripts_gpu_profile.sh <tag>
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=${1:-r02_v1}
 out=gpurun_out/$tag

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-2 GPU check: parity tests, bench line, rocprofv3 kernel stats of the same bench command
-# usage: scripts_gpu_r2.sh <tag> [pytest-args...]
+# usage: tools/gpu/scripts_gpu_r2.sh <tag> [pytest-args...]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=${1:-r02_a}; shift
 out=gpurun_out/$tag

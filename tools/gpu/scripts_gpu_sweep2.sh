@@ -1,6 +1,6 @@
 #!/bin/bash
 # phase clocks of the tile kernel (measuring build), then the bench for each RRTX_OPT_TUNE value (no pytest)
-# usage: scripts_gpu_sweep2.sh <tune> [<tune> ...]
+# usage: tools/gpu/scripts_gpu_sweep2.sh <tune> [<tune> ...]
 mkdir -p gpurun_out
 timeout -k 10 200 python tools/tile_clocks.py > gpurun_out/tile_clocks.txt 2>&1 || { tail -5 gpurun_out/tile_clocks.txt; exit 1; }
 cat gpurun_out/tile_clocks.txt

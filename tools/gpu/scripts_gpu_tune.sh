@@ -1,6 +1,6 @@
 #!/bin/bash
 # parity tests once, then the bench under rocprofv3 --kernel-trace --stats for each RRTX_OPT_TUNE value
-# usage: scripts_gpu_tune.sh <tag> <tune> [<tune> ...]
+# usage: tools/gpu/scripts_gpu_tune.sh <tag> <tune> [<tune> ...]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=$1; shift
 out=gpurun_out/$tag

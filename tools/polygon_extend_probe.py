@@ -1,6 +1,6 @@
 """The fused extend() preamble against the polygon list at C4 scale (edges from the CSR lists: edges_polygons_kernel
 in CSR mode, points_polygons_kernel without a certificate), a few calls: meant to be run under rocprofv3
-(kernel trace or --pmc, scripts_gpu_pmc_cmd.sh)."""
+(kernel trace or --pmc, tools/gpu/scripts_gpu_pmc_cmd.sh)."""
 import os
 import sys
 

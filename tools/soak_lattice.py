@@ -121,7 +121,7 @@ def scene(sc):
     for i2 in range(nd):
         c_o, w_o, traj = O.dubins_steer(ds[i2], dg[i2], r_min)
         h_o, _ = O.dubins_edge_check_polygons(ps, ds[i2], dg[i2], traj, rr, r_min)
-        if not (cost[i2] == c_o or abs(cost[i2] - c_o) <= 1e-6 * max(1.0, abs(c_o))):
+        if not (cost[i2] == c_o or (np.isnan(cost[i2]) and np.isnan(c_o))) or bytes(word[i2]).decode() != w_o or tl[i2] != len(traj):
             print(f"scene {sc}: Dubins cost differs: s={ds[i2].tolist()} g={dg[i2].tolist()} r_min={r_min} "
                   f"device {cost[i2]!r} {bytes(word[i2]).decode() if hasattr(word[i2], '__len__') else word[i2]} oracle {c_o!r} {w_o}", flush=True)
             out["dubins_cost_diffs"] = out.get("dubins_cost_diffs", 0) + 1
