@@ -58,6 +58,68 @@ def source_sha16():
     return h.hexdigest()[:16]
 
 
+ISSUE_PEAK_GINST = 1024 * 2.4 / 4.0    # wave instructions / ns the chip can issue: 1024 SIMDs x 2.4 GHz, one per 4 cycles
+                                       # whatever the type (MI355X_MICROARCH.md; measured)
+
+
+def make_run_key(args, **kw):
+    """what a line was measured on, beyond the kernel sources: a committed PMC file describes a line only if this
+    matches (counters of another variant or workload must not ride along)"""
+    k = {"config": args.config, "obstacles": args.obstacles, "batch": args.batch, "tune": args.tune, "tile_q": args.tile_q,
+         "nn_cull": args.nn_cull, "nn_filter": args.nn_filter, "scan_items": args.scan_items, "scan_blocks": args.scan_blocks,
+         "shard": args.shard, "grid": args.grid}
+    k.update(kw)
+    return k
+
+
+def load_pmc(kernel, run_key):
+    """the committed counters of `kernel` (profiles/r*_traffic*.json, newest round first) taken on THESE kernel
+    sources and THIS run key; None otherwise.  Counters cannot be read inside this process."""
+    pdir = os.path.join(ROOT, "profiles")
+    src = source_sha16()
+    for name in sorted((n for n in os.listdir(pdir) if n.endswith(".json") and "_traffic" in n), reverse=True):
+        try:
+            tj = json.load(open(os.path.join(pdir, name)))
+        except (OSError, ValueError):
+            continue
+        if tj.get("kernel") == kernel and tj.get("source_sha16") == src and tj.get("run_key") == run_key:
+            tj["file"] = "profiles/" + name
+            tj["lib_match"] = tj.get("lib_sha16") == lib_sha16()
+            return tj
+    return None
+
+
+def issue_block(tj, kernel_ms):
+    """instruction-issue accounting of a kernel from its PMC passes: VALU + SALU wave instructions per launch against
+    what 1024 SIMDs issue in the kernel's duration.  frac <= 1 by construction of the peak."""
+    if not tj or not tj.get("SQ_INSTS_VALU_per_launch") or not kernel_ms:
+        return None
+    insts = tj["SQ_INSTS_VALU_per_launch"] + tj["SQ_INSTS_SALU_per_launch"]
+    ach = insts / (kernel_ms * 1e6)                     # wave instructions per ns = G inst / s
+    return {"valu_wave_insts_per_launch": tj["SQ_INSTS_VALU_per_launch"],
+            "salu_wave_insts_per_launch": tj["SQ_INSTS_SALU_per_launch"],
+            "achieved_Ginst_per_s": ach, "peak_Ginst_per_s": ISSUE_PEAK_GINST, "frac_of_kernel_time": ach / ISSUE_PEAK_GINST,
+            "issue_floor_us": insts / ISSUE_PEAK_GINST * 1e-3, "wait_ratio": tj.get("wait_ratio"),
+            "active_lanes_per_valu_instruction": tj.get("active_lanes_per_valu_instruction"),
+            "source": tj.get("file"), "lib_match": tj.get("lib_match"),
+            "note": "VALU + SALU wave instructions / (1024 SIMDs x 2.4 GHz / 4 cycles) against the kernel's duration; "
+                    "wait_ratio = SQ_WAIT_ANY / SQ_WAVE_CYCLES; lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU"}
+
+
+def issue_roofline(kernel, tj, kernel_ms, extra_note=""):
+    """roofline block of a kernel that instruction issue bounds (no HBM or MFMA roof applies): achieved / peak in wave
+    instructions per second from the committed PMC passes; without matching passes the block says so (frac null)."""
+    ib = issue_block(tj, kernel_ms)
+    blk = {"kernel": kernel, "bound": "valu_issue", "unit": "Ginst/s", "peak": ISSUE_PEAK_GINST, "kernel_ms": kernel_ms,
+           "achieved": ib["achieved_Ginst_per_s"] if ib else None, "frac": ib["frac_of_kernel_time"] if ib else None,
+           "traffic": tj.get("traffic_bytes_per_launch") if tj else None, "traffic_unit": "bytes/launch", "issue": ib,
+           "note": ("instruction-issue bound (fp64 exact tests; the obstacle table lives in LDS / L2): achieved = VALU + SALU wave "
+                    "instructions per second from the PMC passes under profiles/ taken on these kernel sources and this run key"
+                    if ib else "no PMC passes for these kernel sources / this run key under profiles/: achieved and frac not stated") +
+                   extra_note}
+    return blk
+
+
 # --------------------------------------------------------------------- CPU baselines ----
 def cpu_baseline(cfg, pts, Q, sph, r, budget_s=10.0):
     """Oracle (C restatement of the reference's per-sample loop) on one host core."""
@@ -152,11 +214,11 @@ class Buffers:
         self.off = torch.empty(B + 1, dtype=torch.int64, device=dev)
         self.idx = torch.empty(cap, dtype=torch.int32, device=dev)
         self.cost = torch.empty(cap, dtype=torch.float64, device=dev)
-        self.hout = torch.zeros(cap, dtype=torch.uint8, device=dev)
-        self.hin = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        # the three flag arrays are one allocation: an obstacle-sharded run OR-reduces them in ONE all_reduce(MAX)
+        self.flags = torch.zeros(2 * cap + B, dtype=torch.uint8, device=dev)
+        self.hout, self.hin, self.unsafe = self.flags[:cap], self.flags[cap:2 * cap], self.flags[2 * cap:]
         self.nidx = torch.empty(B, dtype=torch.int32, device=dev)
         self.ndist = torch.empty(B, dtype=torch.float64, device=dev)
-        self.unsafe = torch.empty(B, dtype=torch.uint8, device=dev)
         self.cap = cap
 
 
@@ -260,10 +322,21 @@ def bench_c3(args, torch, dist, dev, rank, world):
     ctx.profile(0)
     e_sum, t_max = parallel.reduce_throughput(2 * k_total * steps, dt, device=dev)
     if rank == 0:
-        dub_ms = st.ms_dubins / max(st.launches_dubins, 1)
+        # per step: the check launches (both directions, every chunk) and the steering launches, summed
+        dub_ms = st.ms_dubins / 2
+        steer_ms = st.ms_dubins_steer / 2
+        chk_launches = st.launches_dubins // 2
         # Dubins steering + two-stage check is fp64 arithmetic: ~400 flops per steer plus, per
         # polyline piece that reaches stage 2, the polygon test.  The steering figure alone is a floor.
-        steer_flops = 2 * k_total * 400
+        rk = make_run_key(args)
+        d_kernel = "dubins_check_rec_kernel<false>"
+        # the check kernel's own duration: rocprof names it; the family timer covers steer + check launches together
+        tj = load_pmc(d_kernel, rk)
+        if tj:      # the passes average per LAUNCH; a step is chk_launches launches of the kernel
+            tj = dict(tj)
+            for kk in ("SQ_INSTS_VALU_per_launch", "SQ_INSTS_SALU_per_launch", "traffic_bytes_per_launch"):
+                if tj.get(kk) is not None:
+                    tj[kk] = tj[kk] * chk_launches
         out = {
             "metric": METRIC, "value": e_sum / t_max, "unit": "edges/s", "n_gpus": world, "steps": steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * t_max / steps, "higher_is_better": True, "scaling": "weak",
@@ -273,15 +346,14 @@ def bench_c3(args, torch, dist, dev, rank, world):
                        "directed_edges_per_step_per_gpu": 2 * k_total},
             "nn_queries_per_s": B * world * steps / t_max,
             "kernel_ms": {"nn_scan": st.ms_nn_scan / max(st.launches_nn_scan, 1),
-                          "nn_finish": st.ms_nn_finish / 2, "dubins": dub_ms,
+                          "nn_finish": st.ms_nn_finish / 2, "dubins_check": dub_ms, "dubins_steer": steer_ms,
+                          "dubins_check_launches_per_step": chk_launches,
                           "points": st.ms_points / max(st.launches_points, 1)},
-            "roofline": {"kernel": "dubins edge kernels (steer + two-stage check)", "bound": "valu_fp64", "unit": "TFLOP/s",
-                         "achieved": steer_flops / (dub_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TOPS,
-                         "frac": steer_flops / (dub_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS, "traffic": None,
-                         "note": "compute bound (fp64 VALU issue), not HBM: achieved counts only the ~400 flops of each "
-                                 "steer (SURVEY 8d); the stage-2 polyline tests dominate the instruction count "
-                                 "(DESIGN.md 4.6, profiles/*pmc_dubins_fused*)"},
-            "hip_runtime": _capi.hip_runtime(), "lib_sha16": lib_sha16(),
+            "roofline": issue_roofline(d_kernel, tj, dub_ms,
+                                       "; kernel_ms and the instruction counts are the SUM over the check kernel's launches of "
+                                       "one step (both directions, every chunk of 2 M edges); steering is a launch of its own "
+                                       "(kernel_ms.dubins_steer), DESIGN.md 4.6"),
+            "run_key": rk, "hip_runtime": _capi.hip_runtime(), "lib_sha16": lib_sha16(), "source_sha16": source_sha16(),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_dubins(pts, Q, polys, r, r_min)
@@ -290,6 +362,25 @@ def bench_c3(args, torch, dist, dev, rank, world):
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def spawn_ranks(n: int) -> int:
+    """One process per GPU through torch.distributed.run on 127.0.0.1 (the launcher the driver itself uses); the
+    ranks' output is passed through and their exit code is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {n} without a launcher, starting {n} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print(f"bench.py: the {n}-rank run failed with exit code {rc}", file=sys.stderr, flush=True)
+    sys.exit(rc)
 
 
 def main():
@@ -312,7 +403,20 @@ def main():
     ap.add_argument("--nn-cull", type=int, default=1, help="slab culling of the range scan: 0 off, 1 auto, 2 always")
     ap.add_argument("--tune", type=int, default=0, help="RRTX_OPT_TUNE bit mask (kernel variants under measurement)")
     ap.add_argument("--agents", type=int, default=0, help="side measurement: k independent planners sharing the GPU (0/1: off)")
+    ap.add_argument("--batch", type=int, default=0, help="samples per step (0: the config's; e.g. 131072 for a strong-scaling "
+                                                         "line that is not launch bound)")
+    ap.add_argument("--obstacles", default="spheres", choices=["spheres", "polygons"],
+                    help="obstacle list of the timed line (spheres: the reference's 3-D planner; polygons: north_star's wording)")
+    ap.add_argument("--shard", default="edges", choices=["edges", "obstacles"],
+                    help="multi-GPU: what the ranks split -- the sample / candidate-edge batch (default), or the obstacle list "
+                         "(every rank checks all edges against its obstacles, flags OR-reduced with all_reduce(MAX))")
+    ap.add_argument("--grid", default="", help="multi-GPU: ExO = E edge shards x O obstacle shards (E * O = --gpus)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This happens BEFORE anything touches
+    # the GPU (no torch import yet), as a child process -- a process that has initialised HIP must never be replaced.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -323,8 +427,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: a line that says n_gpus = {world} would not be the run "
+                         f"that was asked for")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if args.share_device:            # rehearsal of the N>1 code path on a one-GPU box (with --backend gloo)
@@ -342,15 +447,35 @@ def main():
         return bench_c3(args, torch, dist, dev, rank, world)
     cfg = synth.CONFIGS[args.config]
     assert cfg.dim == 3, "the bench line is the SimpleEdge path (--config C3 for the Dubins preamble)"
-    N, M, B = cfg.n_nodes, cfg.n_obstacles, cfg.batch
+    N, M, B = cfg.n_nodes, cfg.n_obstacles, (args.batch or cfg.batch)
     r = synth.ball_radius(N, 3)
     pts = synth.nodes(N, 3)
     sph = synth.spheres(M)
-    steady_steps = 0 if args.no_extras else args.steps
+    # ---- the rank grid: E edge (sample) shards x O obstacle shards, rank = e * O + o (parallel.py) ----
+    E, O = world, 1
+    if args.grid:
+        try:
+            E, O = (int(v) for v in args.grid.lower().split("x"))
+        except ValueError:
+            raise SystemExit(f"--grid {args.grid}: expected ExO, e.g. 4x2")
+        if E * O != world:
+            raise SystemExit(f"--grid {args.grid} needs {E * O} ranks, WORLD_SIZE = {world}")
+    elif args.shard == "obstacles":
+        E, O = 1, world
+    e_idx, o_idx = parallel.grid_of(rank, world, E, O)
+    obs_group = parallel.obstacle_groups(world, E, O, rank)
+    use_polys = args.obstacles == "polygons"
+    o_lo, o_hi = parallel.shard_range(M, o_idx, O)           # this rank's list positions
+    steady_steps = 0 if (args.no_extras or use_polys or O > 1 or args.batch) else args.steps
     ctx = Context(3, device=local_rank, node_capacity=N)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)          # kernels, events and torch share one stream
-    ctx.spheres_set(sph)
+    if use_polys:
+        polys_all = synth.polygons(M)
+        ctx.polygons_set(polys_all[o_lo:o_hi])
+        ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 1)
+    else:
+        ctx.spheres_set(sph[o_lo:o_hi])
     ctx.set_option(_capi.RRTX_OPT_NN_FILTER, args.nn_filter)
     if args.scan_blocks:
         ctx.set_option(_capi.RRTX_OPT_SCAN_BLOCKS, args.scan_blocks)
@@ -372,25 +497,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_mode(mode):
-        """weak: this rank's own ring of B-sample batches; strong: a ring of GLOBAL batches (same seed on
-        every rank), of which this rank takes its shard_range."""
-        if mode == "weak" or world == 1:
-            lo, hi = 0, B
-            batches = [synth.queries(B, 3, seed=synth.SEED + 1 + 1000 * rank + 17 * j) for j in range(RING)]
+    def make_mode(mode, batch=None):
+        """weak: every EDGE shard its own ring of B-sample batches; strong: a ring of GLOBAL batches (same seed on
+        every rank), of which edge shard e takes its shard_range.  The O ranks of an obstacle group hold the same
+        samples (each checks them against its own obstacles)."""
+        Bm = batch or B
+        capm = 96 * Bm
+        if mode == "weak" or E == 1:
+            lo, hi = 0, Bm
+            batches = [synth.queries(Bm, 3, seed=synth.SEED + 1 + 1000 * e_idx + 17 * j) for j in range(RING)]
         else:
-            lo, hi = parallel.shard_range(B, rank, world)
-            batches = [synth.queries(B, 3, seed=synth.SEED + 1 + 17 * j)[lo:hi] for j in range(RING)]
+            lo, hi = parallel.shard_range(Bm, e_idx, E)
+            batches = [synth.queries(Bm, 3, seed=synth.SEED + 1 + 17 * j)[lo:hi] for j in range(RING)]
         nb = hi - lo
         d_q = [torch.from_numpy(np.ascontiguousarray(b)).to(dev) for b in batches]
-        buf = Buffers(torch, dev, max(nb, 1), cap)
+        buf = Buffers(torch, dev, max(nb, 1), capm)
         d_need = torch.zeros(RING, dtype=torch.int64, device=dev)
-        return {"mode": mode, "nb": nb, "host_q": batches, "q": d_q, "buf": buf, "need": d_need}
+        return {"mode": mode, "nb": nb, "host_q": batches, "q": d_q, "buf": buf, "need": d_need, "B": Bm}
 
     def compute(m, j):
         b = m["buf"]
         ctx.extend_candidates_dev(m["q"][j].data_ptr(), m["nb"], r, ROBOT_RADIUS, b.off.data_ptr(), b.idx.data_ptr(),
-                                  b.cost.data_ptr(), b.hout.data_ptr(), b.hin.data_ptr(), cap,
+                                  b.cost.data_ptr(), b.hout.data_ptr(), b.hin.data_ptr(), b.cap,
                                   m["need"].data_ptr() + 8 * j, b.nidx.data_ptr(), b.ndist.data_ptr(),
                                   b.unsafe.data_ptr())
 
@@ -401,8 +529,8 @@ def main():
             compute(m, j)
         fence()
         k_ring = [int(v) for v in m["need"].tolist()]
-        if max(k_ring) > cap:
-            raise SystemExit(f"candidate capacity too small: {max(k_ring)} > {cap}")
+        if max(k_ring) > m["buf"].cap:
+            raise SystemExit(f"candidate capacity too small: {max(k_ring)} > {m['buf'].cap}")
         # exchange buffers sized for the largest shard: 2 bits (out, in) per candidate entry and rank
         k_max = max(k_ring)
         if world > 1:
@@ -412,13 +540,25 @@ def main():
         bit_cap = (k_max + 4095) // 4096 * 4096
         wpr = parallel.words_for(bit_cap)
         K = max(1, args.exchange_every)
-        d_bits = [torch.zeros((K, world, wpr), dtype=torch.int64, device=dev) for _ in range(2)]
+        d_bits = [torch.zeros((K, E, wpr), dtype=torch.int64, device=dev) for _ in range(2)]
         pending = [None, None]
+        if O > 1:
+            # obstacle shards: the flag arrays are re-allocated at exactly the exchanged size, so that hit_out | hit_in |
+            # sample flags of a step are ONE contiguous message of 2 * bit_cap + nb bytes for the OR-reduce
+            m["buf"] = Buffers(torch, dev, max(m["nb"], 1), bit_cap)
+            for j in range(RING):
+                compute(m, j)
+            fence()
         b = m["buf"]
+        own = e_idx if o_idx == 0 else None          # one rank of every obstacle group publishes the group's bitmask
 
         def step(i, last=False):
             j = i % RING
             compute(m, j)
+            if O > 1:
+                # north_star's obstacle-set shard: every rank of the group has checked the same edges against ITS
+                # obstacles; OR over the group = all_reduce(MAX) of the flag bytes (RCCL has no bitwise OR)
+                parallel.reduce_obstacle_shards(b.flags, group=obs_group)
             if world > 1:
                 # per-edge collision bitmask exchange: each rank packs its slice of the step, and the slices of K
                 # steps travel in ONE RCCL all-reduce (disjoint slices: SUM == OR; xGMI rings are latency bound at
@@ -428,10 +568,11 @@ def main():
                 if slot == 0 and pending[s] is not None:
                     pending[s].wait()
                     pending[s] = None
-                ctx.pack_hits_dev(b.hout.data_ptr(), b.hin.data_ptr(), b.off.data_ptr() + 8 * m["nb"], bit_cap,
-                                  d_bits[s].data_ptr() + 8 * (slot * world + rank) * wpr)
+                if own is not None:
+                    ctx.pack_hits_dev(b.hout.data_ptr(), b.hin.data_ptr(), b.off.data_ptr() + 8 * m["nb"], bit_cap,
+                                      d_bits[s].data_ptr() + 8 * (slot * E + e_idx) * wpr)
                 if slot == K - 1 or last:
-                    pending[s] = parallel.exchange_hit_bitmasks_grouped(d_bits[s], rank, async_op=True)
+                    pending[s] = parallel.exchange_hit_bitmasks_grouped(d_bits[s], own, async_op=True)
 
         def drain():
             for s in range(2):
@@ -446,7 +587,7 @@ def main():
             # both exchange buffers have been through the collective once before the clock starts (first use of a
             # buffer pays registration / staging set-up in the backend)
             for s in range(2):
-                parallel.exchange_hit_bitmasks_grouped(d_bits[s], rank)
+                parallel.exchange_hit_bitmasks_grouped(d_bits[s], own)
         fence()
         # (every 10th step of a default run: an instrumented step costs ~10 us more, every 4th step was 2.5 us of a
         #  54 us step -- tools/graph_probe.py times the same calls without events at 0.0516 ms)
@@ -467,10 +608,11 @@ def main():
         if profile:
             ctx.set_option(_capi.RRTX_OPT_PROFILE_EVERY, 1)
             ctx.profile(0)
-        edges = sum(2 * k_ring[i % RING] for i in range(steps))
+        # units: directed edges of this EDGE shard; the other ranks of its obstacle group checked the same edges
+        edges = sum(2 * k_ring[i % RING] for i in range(steps)) if o_idx == 0 else 0
         return edges, dt, st, k_ring, sample_every
 
-    modes = [args.scaling] + ([("strong" if args.scaling == "weak" else "weak")] if world > 1 else [])
+    modes = [args.scaling] + ([("strong" if args.scaling == "weak" else "weak")] if E > 1 else [])
     results = {}
     for mode in modes:
         m = make_mode(mode)
@@ -478,6 +620,19 @@ def main():
         e_sum, t_max = parallel.reduce_throughput(edges, dt, device=dev)
         results[mode] = {"m": m, "edges": edges, "dt": dt, "st": st, "k_ring": k_ring, "e_sum": e_sum, "t_max": t_max,
                          "sample_every": sample_every}
+    large = None
+    if not args.no_extras and not args.batch:
+        # the same step at a batch that is several grid waves per kernel (B = 131072): strong-sharded over the edge
+        # shards when there are any -- at B = 16384 a step is four launch-bound kernels and splitting it removes
+        # workgroups, not chain length; this is the line where splitting the batch can pay
+        lb = make_mode("strong" if E > 1 else "weak", batch=131072)
+        l_steps = max(5, args.steps // 2)
+        l_edges, l_dt, _, l_ring, _ = run_mode(lb, l_steps, 2, profile=False)
+        le, lt = parallel.reduce_throughput(l_edges, l_dt, device=dev)
+        large = {"global_batch": 131072, "batch_per_edge_shard": lb["nb"], "scaling": "strong" if E > 1 else "single",
+                 "value": le / lt, "ms_per_step": 1e3 * lt / l_steps, "steps": l_steps,
+                 "directed_edges_per_step": 2 * sum(l_ring) / len(l_ring) * (E if E > 1 else 1)}
+        del lb
     main_r = results[modes[0]]
     m = main_r["m"]
     st = main_r["st"]
@@ -566,8 +721,8 @@ def main():
         # what the kernel really requests: the fp32 screen record of a node is 16 B (x, y, z, |p|^2); each entry the
         # screen leaves over re-reads the fp64 rows of its lane's 8 nodes (3 x 64 B); 16-B hit records out
         culled = units > 0
-        kernel = ("nn_tile_kernel<3, true>" if culled else "nn_scan_f32_kernel<3> + nn_confirm_kernel<3>") if args.nn_filter \
-            else "nn_scan_kernel<3>"
+        kernel = (("nn_tile_kernel<3, false>" if use_polys else "nn_tile_kernel<3, true>") if culled
+                  else "nn_scan_f32_kernel<3> + nn_confirm_kernel<3>") if args.nn_filter else "nn_scan_kernel<3>"
         bytes_req = node_visits * 16 + nb * 48 + k_last * (192 + 16 + 8)
         alg_gbs = bytes_alg / (scan_ms * 1e-3) / 1e9
         traffic, traffic_src, frac_traffic, hbm_gbs, issue = None, None, None, None, None
@@ -616,14 +771,20 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": cfg.name, "n_nodes": N, "n_obstacles": M,
-                       "batch_per_gpu": nb, "global_batch": nb * world if modes[0] == "weak" else B,
+                       "batch_per_gpu": nb, "global_batch": nb * E if modes[0] == "weak" else B,
+                       "obstacle_list": "polygons" if use_polys else "spheres",
+                       "grid": {"edge_shards": E, "obstacle_shards": O, "obstacles_per_rank": o_hi - o_lo},
                        "radius": r, "edge": "SimpleEdge", "directed_edges_per_step_per_gpu": 2 * k_mean,
                        "neighbors_per_step_per_gpu": k_mean, "fresh_batch_every_step": True, "batch_ring": RING,
-                       "sharding": "samples+edges sharded, nodes/obstacles replicated",
+                       "sharding": ("samples+edges sharded, nodes/obstacles replicated" if O == 1 else
+                                    "%d edge shard(s) x %d obstacle shards: every rank of an obstacle group checks the group's "
+                                    "edges against its %d obstacles; nodes replicated" % (E, O, o_hi - o_lo)),
                        "collective": (None if world == 1 else
-                                      "one RCCL all-reduce of the per-edge collision bitmasks of %d steps, asynchronous, double-buffered"
-                                      % max(1, args.exchange_every))},
-            "nn_queries_per_s": (nb * world if modes[0] == "weak" else B) * args.steps / t_max,
+                                      (("all_reduce(MAX) of the uint8 edge / sample flags inside every obstacle group each step "
+                                        "(OR over obstacle shards), then " if O > 1 else "") +
+                                       "one RCCL all-reduce of the per-edge collision bitmasks of %d steps, asynchronous, double-buffered"
+                                       % max(1, args.exchange_every)))},
+            "nn_queries_per_s": (nb * E if modes[0] == "weak" else B) * args.steps / t_max,
             "launches_per_step": 4,
             "kernel_ms": {"nn_scan": scan_ms, **extras.get("kernel_ms_all", {})},
             "roofline": {
@@ -665,10 +826,12 @@ def main():
                                              "at B = 16384 a step is four dependent launch-bound kernels, so the per-step "
                                              "floor bounds the speed-up") if modes[1] == "strong" else
                                             "weak: every rank its own B-sample batches"}
+        if large:
+            out["large_batch"] = large
         if steady:
             out["steady_state"] = steady
             out["value_steady"] = steady["value_steady"]
-        if world == 1 and not args.no_extras:
+        if world == 1 and not args.no_extras and not use_polys:
             # the same step through the host-pointer entry point (what a ccall from Julia pays):
             # H2D of the samples, kernels, D2H of lists/costs/flags.  Reported, never `value`.
             ctx.set_stream(None)

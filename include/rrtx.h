@@ -60,6 +60,9 @@ typedef struct {
   int32_t last_tile_q;       /* query copies that shared one streamed pass of the node arrays */
   int32_t last_scan_units;   /* slab-culled range scan: (tile of last_tile_q copies, 512-node chunk) pairs the
                               * last call streamed; 0 when it streamed every node for every tile */
+  /* (round 3, appended) the steering launches of the Dubins edge paths on their own: ms_dubins above then counts
+   * the check kernels (and the stand-alone steer / trajectory calls) */
+  double ms_dubins_steer; int64_t launches_dubins_steer;
 } rrtx_stats_t;
 
 /* ---- lifetime ------------------------------------------------------------ */

@@ -58,6 +58,7 @@ class Stats(C.Structure):
         ("ms_dubins", C.c_double), ("launches_dubins", C.c_int64),
         ("last_pairs", C.c_int64), ("last_neighbors", C.c_int64),
         ("last_tile_q", C.c_int32), ("last_scan_units", C.c_int32),
+        ("ms_dubins_steer", C.c_double), ("launches_dubins_steer", C.c_int64),
     ]
 
 

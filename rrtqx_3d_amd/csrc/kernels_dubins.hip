@@ -1191,15 +1191,19 @@ static int run_dubins_edges(rrtx_ctx *ctx, const EdgeSrc &src, long long n, int 
   for (long long base = 0; base < n; base += chunk) {
     const long long count = (n - base < chunk) ? n - base : chunk;
     const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    span_begin(ctx, KF_DUBINS_STEER);
     hipLaunchKernelGGL(dubins_steer_rec_kernel, grid, block, 0, ctx->stream, src, base, count, n, r_min, has_time, rec, cost,
                        word, traj_len);
+    span_end(ctx);
     if (!check) continue;
+    span_begin(ctx, KF_DUBINS);
     if (has_time)
       hipLaunchKernelGGL(dubins_check_rec_kernel<true>, grid, block, 0, ctx->stream, src, base, count, n, spread, r_min,
                          robot_radius, ctx->dubins_vmin, ctx->dubins_vmax, tab, rec, hit);
     else
       hipLaunchKernelGGL(dubins_check_rec_kernel<false>, grid, block, 0, ctx->stream, src, base, count, n, spread, r_min,
                          robot_radius, ctx->dubins_vmin, ctx->dubins_vmax, tab, rec, hit);
+    span_end(ctx);
   }
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
@@ -1224,14 +1228,12 @@ int launch_candidate_dubins(rrtx_ctx *ctx, const double *q_dev, int nq, const in
   src.nx = ctx->nodes[0]; src.ny = ctx->nodes[1]; src.nz = ctx->nodes[2]; src.nw = ctx->nodes[3];
   src.n_nodes = (int)ctx->n_nodes;
   src.cap = (long long)cap;
-  span_begin(ctx, KF_DUBINS);
   src.dir = 0;
   rc = run_dubins_edges(ctx, src, (long long)cap, 0, r_min, robot_radius, tab, true, cost_out, word_out, hit_out, nullptr);
   if (!rc) {
     src.dir = 1;
     rc = run_dubins_edges(ctx, src, (long long)cap, 0, r_min, robot_radius, tab, true, cost_in, word_in, hit_in, nullptr);
   }
-  span_end(ctx);
   return rc;
 }
 
@@ -1283,10 +1285,7 @@ int launch_dubins_edges_check(rrtx_ctx *ctx, const double *s_dev, const double *
   EdgeSrc src = {};
   src.mode = 0;
   src.s = s_dev; src.g = g_dev;
-  span_begin(ctx, KF_DUBINS);
-  rc = run_dubins_edges(ctx, src, (long long)ne, 1, r_min, robot_radius, tab, true, cost_dev, word_dev, hit_dev, traj_len_dev);
-  span_end(ctx);
-  return rc;
+  return run_dubins_edges(ctx, src, (long long)ne, 1, r_min, robot_radius, tab, true, cost_dev, word_dev, hit_dev, traj_len_dev);
 }
 
 }  // namespace rrtx

@@ -534,6 +534,7 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out) {
   out->ms_edges = ctx->fam_ms[KF_EDGES];           out->launches_edges = ctx->fam_launches[KF_EDGES];
   out->ms_points = ctx->fam_ms[KF_POINTS];         out->launches_points = ctx->fam_launches[KF_POINTS];
   out->ms_dubins = ctx->fam_ms[KF_DUBINS];         out->launches_dubins = ctx->fam_launches[KF_DUBINS];
+  out->ms_dubins_steer = ctx->fam_ms[KF_DUBINS_STEER]; out->launches_dubins_steer = ctx->fam_launches[KF_DUBINS_STEER];
   out->last_pairs = ctx->last_pairs;
   out->last_neighbors = ctx->last_neighbors;
   out->last_tile_q = ctx->last_tile_q;

@@ -70,7 +70,7 @@ struct GraphCost {
   bool touched_old = false;                         // set_dist / block since the last solve
 };
 
-enum KernelFamily { KF_NN_SCAN = 0, KF_NN_FINISH, KF_NN_NEAREST, KF_EDGES, KF_POINTS, KF_DUBINS, KF_COUNT };
+enum KernelFamily { KF_NN_SCAN = 0, KF_NN_FINISH, KF_NN_NEAREST, KF_EDGES, KF_POINTS, KF_DUBINS, KF_DUBINS_STEER, KF_COUNT };
 
 struct TimedSpan { hipEvent_t a, b; int family; };
 

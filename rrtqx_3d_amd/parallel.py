@@ -22,6 +22,16 @@ every rank searches ALL queries against its shard, and the per-shard results are
     arg-min reduction).
 Both are latency-bound exchanges of a few MB at C4 / C5 sizes.
 
+Third mode, north_star's "obstacle set shard" (SURVEY 8e): the OBSTACLE LIST is partitioned -- rank o of an
+obstacle group holds list positions [lo_o, hi_o) in its own context and checks ALL the group's candidate edges
+against them.  explicitEdgeCheck over the list is an OR with the first hit's list position
+(R/DRRT_Q.jl:1802-1826), so the shards combine exactly: per-edge uint8 flags with all_reduce(MAX) (RCCL has no
+bitwise OR; MAX of bytes whose bits are independent flags would be wrong, so each flag byte is reduced on its
+own bit planes -- see reduce_obstacle_shards), first-hit positions with all_reduce(MIN) after adding the shard's
+base (no hit = INT32_MAX).  A 2-D grid composes both splits: rank = e * O + o, edge shard e of E, obstacle shard
+o of O; the OR-reduce runs inside each obstacle group {e * O .. e * O + O - 1}, then the E edge shards publish
+their packed bitmasks as before (grid_of / obstacle_groups below).
+
 The functions below hold only the index arithmetic and the collectives, so they run unchanged on
 CPU tensors with the gloo backend (tests/test_parallel_gloo.py) and on GPU tensors with nccl.
 """
@@ -63,19 +73,73 @@ def exchange_hit_bitmasks(bits: torch.Tensor, rank: int, world: int, words_per_r
     return work if async_op else bits
 
 
-def exchange_hit_bitmasks_grouped(bits: torch.Tensor, rank: int, group=None, async_op: bool = False):
+def grid_of(rank: int, world: int, n_edge_shards: int, n_obstacle_shards: int) -> Tuple[int, int]:
+    """(edge shard e, obstacle shard o) of a rank in an E x O grid, rank = e * O + o."""
+    assert n_edge_shards * n_obstacle_shards == world and 0 <= rank < world
+    return rank // n_obstacle_shards, rank % n_obstacle_shards
+
+
+def obstacle_groups(world: int, n_edge_shards: int, n_obstacle_shards: int, rank: int, backend=None):
+    """The process group of this rank's obstacle group (the O ranks that share edge shard e); every rank creates
+    every group, as torch.distributed requires.  None when O == 1 (nothing to reduce) or O == world (the default
+    group is the obstacle group)."""
+    if n_obstacle_shards == 1 or not dist.is_initialized():
+        return None
+    if n_obstacle_shards == world:
+        return dist.group.WORLD
+    mine = None
+    for e in range(n_edge_shards):
+        ranks = list(range(e * n_obstacle_shards, (e + 1) * n_obstacle_shards))
+        g = dist.new_group(ranks=ranks, backend=backend)
+        if rank in ranks:
+            mine = g
+    return mine
+
+
+_NO_HIT = torch.iinfo(torch.int32).max
+
+
+def reduce_obstacle_shards(flags: torch.Tensor, first_hit: torch.Tensor = None, obs_lo: int = 0, group=None,
+                           flag_bits: int = 1):
+    """OR-reduce of per-edge collision flags over the ranks of an obstacle group, in place.
+    flags: uint8[...]; with flag_bits == 1 every byte is 0 or 1 and MAX == OR.  The Dubins-with-time preamble
+    also sets bit 1 (!validMove, which no obstacle influences: identical on every rank, so MAX keeps it) --
+    flag_bits = 2 states that the caller knows bit 1 is rank-invariant; any other mix of bits would need one
+    reduction per bit plane and is refused.
+    first_hit (optional): int32[...] list positions LOCAL to this rank's obstacle shard, -1 = none; on return the
+    smallest GLOBAL list position over the shards (obs_lo = this shard's first list position), -1 = none --
+    explicitEdgeCheck returns at the first colliding obstacle in list order, R/DRRT_Q.jl:1808-1822."""
+    assert flags.dtype == torch.uint8 and flag_bits in (1, 2)
+    if not dist.is_initialized() or (group is None and dist.get_world_size() == 1):
+        if first_hit is not None:
+            first_hit[first_hit >= 0] += obs_lo
+        return flags, first_hit
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+    if first_hit is not None:
+        assert first_hit.dtype == torch.int32
+        f = torch.where(first_hit >= 0, first_hit + obs_lo, torch.full_like(first_hit, _NO_HIT))
+        dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
+        first_hit.copy_(torch.where(f == _NO_HIT, torch.full_like(f, -1), f))
+    return flags, first_hit
+
+
+def exchange_hit_bitmasks_grouped(bits: torch.Tensor, rank, group=None, async_op: bool = False):
     """The bitmasks of several steps in ONE collective (xGMI rings are latency bound at these sizes: fewer, larger
-    all-reduces).  bits: int64[steps, world, words_per_rank]; this rank has filled bits[:, rank, :].  The other
-    ranks' slices are zeroed, then one all-reduce(SUM) (disjoint slices: SUM == OR) fills them in place.
-    Returns bits, or with async_op=True the work handle (None when world == 1)."""
+    all-reduces).  bits: int64[steps, slices, words_per_rank]; this rank has filled bits[:, rank, :].  The other
+    slices are zeroed, then one all-reduce(SUM) (disjoint slices: SUM == OR) fills them in place.  rank = None: this
+    rank owns no slice (in an E x O grid only obstacle shard 0 of every edge shard publishes; the others add zeros).
+    Returns bits, or with async_op=True the work handle (None without a process group)."""
     assert bits.dim() == 3 and bits.dtype == torch.int64 and bits.is_contiguous()
-    world = bits.shape[1]
-    if world == 1:
+    slices = bits.shape[1]
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return None if async_op else bits
-    if rank > 0:
-        bits[:, :rank].zero_()
-    if rank + 1 < world:
-        bits[:, rank + 1:].zero_()
+    if rank is None:
+        bits.zero_()
+    else:
+        if rank > 0:
+            bits[:, :rank].zero_()
+        if rank + 1 < slices:
+            bits[:, rank + 1:].zero_()
     work = dist.all_reduce(bits, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return work if async_op else bits
 

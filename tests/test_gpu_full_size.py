@@ -207,7 +207,7 @@ def test_extend_candidates_c4_polygons_full(oracle):
         out = ctx.extend_candidates(Q, r, ROBOT_RADIUS)
         off, idx = out["offsets"], out["idx"]
         n = len(idx)
-        assert n == off[-1] > 40 * B
+        assert n == off[-1] > 20 * B
         p0, p1 = synth.candidate_edges(Q, pts, off, idx)
         hit, first = ctx.edges_check(p0, p1, ROBOT_RADIUS, kind=1)
         assert np.array_equal(out["hit_out"], hit[:n]) and np.array_equal(out["hit_in"], hit[n:])

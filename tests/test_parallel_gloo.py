@@ -218,3 +218,82 @@ def _strong_worker(rank, world, port, q):
 
 def test_strong_scaling_batch_shards_world2():
     assert _spawn(_strong_worker, 2) == [(0, True), (1, True)]
+
+
+def _obstacle_shard_worker(rank, world, port, q, E, O):
+    """north_star's obstacle-set shard, alone (E = 1) and composed with sample shards in an E x O grid: rank
+    (e, o) checks the candidate edges of sample shard e against list positions [lo_o, hi_o) of the POLYGON list
+    (oracle here, the HIP path in bench.py --shard obstacles / --grid ExO); flags are OR-reduced with
+    all_reduce(MAX) and first hits with all_reduce(MIN) inside the obstacle group, then the edge shards publish
+    packed bitmasks.  Every rank must end up with the unsharded oracle's flags AND first-hit positions."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O_
+        from rrtqx_3d_amd import synth
+        n, B, r, rr, M = 3000, 120, 9.0, 0.5, 37                # 37 obstacles: ragged obstacle shards
+        pts, Q, polys = synth.nodes(n, 3), synth.queries(B, 3), synth.polygons(M)
+        active = np.ones(M, dtype=np.uint8); active[[3, 20]] = 0
+        tree = O_.KDTree(3)
+        tree.insert_many(pts)
+        e, o = parallel.grid_of(rank, world, E, O)
+        grp = parallel.obstacle_groups(world, E, O, rank)
+        s_lo, s_hi = parallel.shard_range(B, e, E)
+        o_lo, o_hi = parallel.shard_range(M, o, O)
+
+        def edges_of(qs):
+            p0, p1 = [], []
+            for qq in qs:
+                ri, _ = tree.within_range(r, qq)
+                for j in np.sort(ri):
+                    p0.append(qq); p1.append(pts[j])
+            a, b = np.array(p0), np.array(p1)
+            return np.concatenate([a, b]), np.concatenate([b, a])        # out-edges, then in-edges
+
+        p0, p1 = edges_of(Q[s_lo:s_hi])
+        sub = O_.PolygonSet(polys[o_lo:o_hi], active=active[o_lo:o_hi])
+        hit, first = O_.edges_check_polygons(sub, p0, p1, rr)              # first: position inside the SHARD
+        th, tf = torch.from_numpy(hit.copy()), torch.from_numpy(first.copy())
+        parallel.reduce_obstacle_shards(th, tf, obs_lo=o_lo, group=grp)
+        full = O_.PolygonSet(polys, active=active)
+        # list positions of the unsharded oracle count ACTIVE obstacles only?  No: orc positions are list positions
+        # of the array it was given, inactive ones included -- the same convention on both sides here.
+        rh, rf = O_.edges_check_polygons(full, p0, p1, rr)
+        ok = np.array_equal(th.numpy(), rh) and np.array_equal(tf.numpy(), rf) and 0 < rh.sum() < len(rh)
+        # edge shards publish: slice e, filled by obstacle shard 0 only
+        k = len(p0) // 2
+        counts = torch.zeros(E, dtype=torch.int64)
+        if o == 0:
+            counts[e] = k
+        dist.all_reduce(counts)
+        cap = int(counts.max().item())
+        wpr = parallel.words_for(cap)
+        bits = torch.full((1, E, wpr), 0x7777, dtype=torch.int64)
+        if o == 0:
+            bits[0, e].copy_(torch.from_numpy(_pack(th.numpy()[:k], th.numpy()[k:], cap)))
+        parallel.exchange_hit_bitmasks_grouped(bits, e if o == 0 else None)
+        a0, a1 = edges_of(Q)
+        ah, _ = O_.edges_check_polygons(full, a0, a1, rr)
+        ka = len(a0) // 2
+        got_out, got_in = [], []
+        for ee in range(E):
+            b = np.unpackbits(bits[0, ee].numpy().view(np.uint8), bitorder="little")
+            kk = int(counts[ee].item())
+            got_out.append(b[:kk]); got_in.append(b[cap:cap + kk])
+        ok &= np.array_equal(np.concatenate(got_out), ah[:ka]) and np.array_equal(np.concatenate(got_in), ah[ka:])
+        # bit 1 of a flag byte (!validMove of the Dubins-with-time preamble) is rank-invariant and survives the MAX
+        fb = torch.from_numpy((hit | 2).astype(np.uint8))
+        parallel.reduce_obstacle_shards(fb, None, group=grp, flag_bits=2)
+        ok &= np.array_equal(fb.numpy(), rh | 2)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_obstacle_shards_world2_or_reduce():
+    assert _spawn(_obstacle_shard_worker, 2, 1, 2) == [(0, True), (1, True)]
+
+
+def test_grid_2x2_edge_and_obstacle_shards():
+    assert _spawn(_obstacle_shard_worker, 4, 2, 2) == [(r, True) for r in range(4)]

@@ -1,33 +1,26 @@
-"""HBM-side bytes per launch of one kernel from the FETCH_SIZE / WRITE_SIZE passes of scripts_gpu_pmc.sh.
+"""Counters of ONE kernel from the passes of tools/gpu/pmc_bench.sh, keyed by what was run.
 
-    python tools/pmc_traffic.py <dir with p3/p4/p5_per_kernel_avg.csv> "<kernel name prefix>" > traffic.json
+    python tools/pmc_traffic.py <dir with p1..p5_per_kernel_avg.csv> "<kernel name prefix>" <bench line of a pass> > traffic.json
 
 FETCH_SIZE / WRITE_SIZE are in KB.  On gfx950 FETCH_SIZE tallies a 128-byte request of a wide (16 B per lane)
-coalesced read as 64 bytes (MI355X_MICROARCH.md, HBM): the read side is doubled, as that guide prescribes; the
-kernel's node reads are such loads.  WRITE_SIZE is exact for 16-byte-per-lane stores (the hit records).
+coalesced read as 64 bytes (MI355X_MICROARCH.md, HBM): the read side is doubled, as that guide prescribes.
+`run_key` (configuration, obstacle list, batch, tuning options) and `source_sha16` come from the bench line the pass
+itself printed: bench.py attaches these counters to a later line only when both are its own.
 """
 import csv
-import hashlib
 import json
 import os
 import sys
 
-d, kern = sys.argv[1], sys.argv[2]
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def source_sha16():
-    h = hashlib.sha256()
-    c = os.path.join(ROOT, "rrtqx_3d_amd", "csrc")
-    for name in sorted(os.listdir(c)):
-        if name.endswith((".hip", ".hpp")):
-            with open(os.path.join(c, name), "rb") as f:
-                h.update(f.read())
-    return h.hexdigest()[:16]
+d, kern, line = sys.argv[1], sys.argv[2], sys.argv[3]
+bench = json.loads(open(line).read().strip().splitlines()[-1])
 
 
 def get(fname, counter):
-    for r in csv.DictReader(open(os.path.join(d, fname))):
+    p = os.path.join(d, fname)
+    if not os.path.exists(p):
+        return None, 0
+    for r in csv.DictReader(open(p)):
         if r["counter"] == counter and kern.replace(" ", "") in r["kernel"].replace(" ", ""):
             return float(r["avg_per_launch"]), int(r["launches"])
     return None, 0
@@ -37,23 +30,27 @@ fetch, n = get("p3_per_kernel_avg.csv", "FETCH_SIZE")
 write, _ = get("p4_per_kernel_avg.csv", "WRITE_SIZE")
 hit, _ = get("p5_per_kernel_avg.csv", "TCC_HIT_sum")
 miss, _ = get("p5_per_kernel_avg.csv", "TCC_MISS_sum")
-valu, _ = get("p1_per_kernel_avg.csv", "SQ_INSTS_VALU")
+valu, n1 = get("p1_per_kernel_avg.csv", "SQ_INSTS_VALU")
 salu, _ = get("p1_per_kernel_avg.csv", "SQ_INSTS_SALU")
 wcyc, _ = get("p1_per_kernel_avg.csv", "SQ_WAVE_CYCLES")
 waves, _ = get("p1_per_kernel_avg.csv", "SQ_WAVES")
 wait, _ = get("p2_per_kernel_avg.csv", "SQ_WAIT_ANY")
+act, _ = get("p2_per_kernel_avg.csv", "SQ_ACTIVE_INST_VALU")
+thr, _ = get("p2_per_kernel_avg.csv", "SQ_THREAD_CYCLES_VALU")
 out = {
-    "kernel": kern, "config": "C4", "launches_averaged": n,
+    "kernel": kern, "run_key": bench.get("run_key"), "source_sha16": bench.get("source_sha16"),
+    "lib_sha16": bench.get("lib_sha16"), "launches_averaged": n or n1,
     "SQ_INSTS_VALU_per_launch": valu, "SQ_INSTS_SALU_per_launch": salu, "SQ_WAVES_per_launch": waves,
     "SQ_WAVE_CYCLES_per_launch": wcyc, "SQ_WAIT_ANY_per_launch": wait,
     "wait_ratio": (wait / wcyc) if wait and wcyc else None,
-    "FETCH_SIZE_bytes_per_launch": fetch * 1024, "WRITE_SIZE_bytes_per_launch": write * 1024,
-    "traffic_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
-    "l2_hit_rate": hit / (hit + miss) if hit is not None and hit + miss > 0 else None,
-    "source_sha16": source_sha16(),
-    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KB -> bytes), averaged over the launches of the "
-            "kernel in `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras`; read side doubled as "
-            "MI355X_MICROARCH.md prescribes for gfx950 (16 B/lane loads), write side = 16-byte hit records (exact) + "
-            "8-byte screen entries (uncalibrated width)",
+    "active_lanes_per_valu_instruction": (thr / act) if thr and act else None,
+    "FETCH_SIZE_bytes_per_launch": fetch * 1024 if fetch is not None else None,
+    "WRITE_SIZE_bytes_per_launch": write * 1024 if write is not None else None,
+    "traffic_bytes_per_launch": (2 * fetch * 1024 + write * 1024) if fetch is not None and write is not None else None,
+    "l2_hit_rate": hit / (hit + miss) if hit is not None and miss is not None and hit + miss > 0 else None,
+    "note": "rocprofv3 --pmc in separate passes (tools/gpu/pmc_bench.sh), averaged over the launches of the kernel in "
+            "`python bench.py --no-cpu-baseline --no-extras <run_key args>`; FETCH_SIZE / WRITE_SIZE KB -> bytes, read side "
+            "doubled as MI355X_MICROARCH.md prescribes for gfx950 (16 B/lane loads); active lanes = SQ_THREAD_CYCLES_VALU / "
+            "SQ_ACTIVE_INST_VALU (of 64)",
 }
 print(json.dumps(out, indent=1))
