@@ -247,6 +247,27 @@ int64_t rrtx_graph_edges_count(rrtx_ctx *ctx);
 int rrtx_graph_edges_clear(rrtx_ctx *ctx);
 int rrtx_obstacle_sweep(rrtx_ctx *ctx, int obstacle, double search_range, double robot_radius, int32_t *edge_ids,
                         int64_t cap, int64_t *needed);
+/* The obstacle sweeps of the POLYGON list -- the 2-D Euclidean and the Dubins space, with or without time
+ * (legacy planner, R/DRRT.jl:3048-3290; BASELINE config 5's "dynamic discoverable obstacles" run these).  The edge
+ * type is the context's: dim = 3 SimpleEdge, dim = 4 DubinsEdge (r_min = S.minTurningRadius; with
+ * RRTX_OPT_SPACE_HAS_TIME the pieces carry time).  `obstacle` is a list position of rrtx_polygons_set.
+ *   nodes: findPointsInConflictWithObstacle (:3048-3125) -- static kinds: range robotRadius + delta + ob.radius
+ *     around ob.position (Dubins space: around [x y 0.0 pi] with range + pi; a dim = 3 tree is the 2-D space at
+ *     z = 0); kinds 6 / 7: one query per path segment at [ob.position 0.0] + (path[i] + path[i+1]) / 2 with range +
+ *     half the segment's length, accumulated (kdFindMoreWithinRange); the root with <=, ghosts of wrapped dimensions
+ *     as the range search takes them.  A static obstacle in a space with time is the reference's
+ *     error("this type of obstacle not coded for this type of space") -> RRTX_E_STATE;
+ *   mode 0, addNewObstacle's loop (:3127-3200): the mirrored edges that START at such a node (its out-neighbour
+ *     edges and parent edge) for which explicitEdgeCheck(S, edge, ob) is true -- the caller sets their dist = Inf
+ *     (rrtx_graph_edges_block);
+ *   mode 1, removeObstacle's loop (:3202-3290): of those edges the ones that are blocked in the mirror
+ *     (dist == Inf), collide with ob, and with no OTHER obstacle that is in use -- the caller resets them to
+ *     distOriginal (the reference also asks startTime <= timeElapsed <= startTime + lifeSpan of the others: fold
+ *     it into their `active` flags).  ob itself must still be in use, as it is in the reference until the loop
+ *     is over (:3287); an obstacle not in use collides with nothing and the sweep returns no edge.
+ * edge_ids: ascending, two-call capacity pattern (RRTX_E_CAPACITY with *needed set). */
+int rrtx_obstacle_sweep_polygon(rrtx_ctx *ctx, int obstacle, double robot_radius, double delta, double r_min, int mode,
+                                int32_t *edge_ids, int64_t cap, int64_t *needed);
 /* Cost propagation over the edge mirror: the fixed point that rewire / reduceInconsistency /
  * propogateDescendants (R/DRRT_Q.jl:2490-2541, 2647-2817) drive rrtLMC to when changeThresh = 0 and the queue
  * runs dry -- lmc(root) = 0, lmc(v) = min over mirrored edges v -> u with finite dist of lmc(u) + dist (one
@@ -300,6 +321,11 @@ int rrtx_dubins_steer_full(rrtx_ctx *ctx, const double *s, const double *g, int6
 int rrtx_dubins_edges_check(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne,
                             double r_min, double robot_radius, double *cost, uint8_t *word,
                             uint8_t *hit, int32_t *traj_len);
+
+/* explicitEdgeCheck(S, edge::DubinsEdge, ob) (:750-774) against ONE obstacle of the polygon list (list position;
+ * an obstacle not in use collides with nothing, R/DRRT.jl:1525): what addNewObstacle asks per edge (R/DRRT.jl:3157). */
+int rrtx_dubins_edges_check_obstacle(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min,
+                                     double robot_radius, int obstacle, uint8_t *hit);
 
 /* edge.trajectory of calculateTrajectory(S, ::DubinsEdge) (:506-701): the discretised polyline
  * (0.1 rad arc steps, Julia float-range length rule), P_i rows of (x, y) per edge -- rows of (x, y, t) with

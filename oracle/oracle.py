@@ -117,6 +117,8 @@ def lib() -> C.CDLL:
     for f in (L.orc_dubins_steer_time, L.orc_dubins_steer_time_pw):
         f.argtypes = [c_double_p, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p,
                       C.c_char_p, c_double_p, C.c_int, C.POINTER(C.c_int)]
+    L.orc_find_points_in_conflict_polygon.restype = C.c_void_p
+    L.orc_find_points_in_conflict_polygon.argtypes = [C.c_void_p, C.POINTER(Polygon), C.c_double, C.c_double, C.c_int, C.c_int]
     L.orc_dm_eval.restype = C.c_int
     L.orc_dm_eval.argtypes = [C.c_int, c_double_p, c_double_p, C.c_int64, c_double_p]
     L.orc_dubins_valid_move_time.restype = C.c_int
@@ -406,6 +408,85 @@ def point_check_polygons(ps: PolygonSet, p, robot_radius):
     cl = C.c_double()
     r = lib().orc_point_check_polygons(ps.arr, ps.m, _dp(p), robot_radius, C.byref(cl))
     return bool(r), cl.value
+
+
+def points_in_conflict_polygon(tree: "KDTree", ps: "PolygonSet", j: int, robot_radius: float, delta: float,
+                               has_time: bool, has_theta: bool) -> np.ndarray:
+    """findPointsInConflictWithObstacle(S, KD, ob::Obstacle, root) (R/DRRT.jl:3048-3125) for obstacle j of the
+    list: the node indices of the range list in list order; raises where the reference does."""
+    L = lib()
+    lst = L.orc_find_points_in_conflict_polygon(tree._h, C.byref(ps.arr[j]), robot_radius, delta, int(has_time), int(has_theta))
+    if not lst:
+        raise RuntimeError("this type of obstacle not coded for this type of space")
+    n = L.orc_list_length(lst)
+    idx = np.empty(n, dtype=np.int32)
+    key = np.empty(n, dtype=np.float64)
+    L.orc_list_read(lst, n, idx.ctypes.data_as(c_int32_p), _dp(key))
+    L.orc_kd_empty_range_list(tree._h, lst)
+    return idx
+
+
+def explicit_edge_check_obstacle(ps: "PolygonSet", j: int, a, b, robot_radius: float, dubins: bool, r_min: float = 0.0,
+                                 has_time: bool = False, piecewise_time: bool = True) -> bool:
+    """explicitEdgeCheck(S, edge, ob) against ONE obstacle of the list: SimpleEdge -> explicitEdgeCheck2D
+    (R/DRRT_SimpleEdge_functions.jl:210-212 with the polygon ob), DubinsEdge -> the two-stage check
+    (R/DRRT_DubinsEdge_functions.jl:750-774) on the edge's own trajectory."""
+    a, b = _vec(a), _vec(b)
+    one = C.byref(ps.arr[j])
+    if not dubins:
+        return bool(lib().orc_edge_check_polygon(one, _dp(a), _dp(b), robot_radius))
+    fh = C.c_int32()
+    if has_time:
+        d, w, v, wd, tr = dubins_steer_time(a, b, r_min, piecewise=piecewise_time)
+        if not np.isfinite(w) or len(tr) == 0:
+            tr = np.zeros((0, 3))
+        return bool(lib().orc_dubins_edge_check_polygons_time(one, 1, _dp(a), _dp(b), _dp(np.ascontiguousarray(tr)), len(tr),
+                                                              robot_radius, r_min, C.byref(fh)))
+    c, w, traj = dubins_steer(a, b, r_min)
+    r = lib().orc_dubins_edge_check_polygons(one, 1, _dp(a), _dp(b), _dp(np.ascontiguousarray(traj)), len(traj), robot_radius,
+                                             r_min, C.byref(fh))
+    if r < 0:
+        raise RuntimeError("Dubins edges against moving obstacles need the time-parameterised trajectory")
+    return bool(r)
+
+
+def add_new_obstacle_edges(tree: "KDTree", pts: np.ndarray, e_start, e_end, ps: "PolygonSet", j: int, robot_radius: float,
+                           delta: float, dubins: bool, r_min: float = 0.0, has_time: bool = False) -> np.ndarray:
+    """The edge loop of addNewObstacle (R/DRRT.jl:3127-3200) over a mirror of the planner's directed edges: every
+    edge that STARTS at a node of findPointsInConflictWithObstacle's list (its out-neighbour edges and its parent
+    edge) and for which explicitEdgeCheck(S, edge, ob) is true -- the edges the reference sets to dist = Inf.
+    Ascending edge ids."""
+    nodes = set(points_in_conflict_polygon(tree, ps, j, robot_radius, delta, has_time, dubins).tolist())
+    out = []
+    for e in range(len(e_start)):
+        if int(e_start[e]) in nodes and explicit_edge_check_obstacle(ps, j, pts[e_start[e]], pts[e_end[e]], robot_radius, dubins,
+                                                                     r_min, has_time):
+            out.append(e)
+    return np.array(out, dtype=np.int32)
+
+
+def remove_obstacle_edges(tree: "KDTree", pts: np.ndarray, e_start, e_end, e_dist, ps: "PolygonSet", j: int,
+                          robot_radius: float, delta: float, dubins: bool, r_min: float = 0.0, has_time: bool = False) -> np.ndarray:
+    """The edge loop of removeObstacle (R/DRRT.jl:3202-3290): edges that start at a node in conflict, are blocked
+    (dist == Inf), collide with ob, and with no OTHER obstacle that is in use (the caller's `unused` flags say which
+    are; the reference also asks startTime <= timeElapsed <= startTime + lifeSpan, which the caller folds into those
+    flags) -- the edges the reference resets to distOriginal.  Ascending edge ids."""
+    nodes = set(points_in_conflict_polygon(tree, ps, j, robot_radius, delta, has_time, dubins).tolist())
+    out = []
+    for e in range(len(e_start)):
+        if int(e_start[e]) not in nodes or e_dist[e] != np.inf:
+            continue
+        a, b = pts[e_start[e]], pts[e_end[e]]
+        if not explicit_edge_check_obstacle(ps, j, a, b, robot_radius, dubins, r_min, has_time):
+            continue
+        other = False
+        for k in range(ps.m):
+            if k != j and not ps.arr[k].unused and explicit_edge_check_obstacle(ps, k, a, b, robot_radius, dubins, r_min, has_time):
+                other = True
+                break
+        if not other:
+            out.append(e)
+    return np.array(out, dtype=np.int32)
 
 
 def dubins_steer(s, g, r_min: float, want_traj: bool = True):

@@ -77,6 +77,7 @@ double orc_ball_radius(double delta, double ball_constant, int64_t n, int d) {
 /* A2-A5  kd-tree                                                            */
 /* ------------------------------------------------------------------------ */
 #define ORC_MAX_WRAPS 8
+#define ORC_MAX_DIM 8
 
 struct orc_kd {
   int d;
@@ -940,6 +941,63 @@ int orc_point_check_polygons(const orc_polygon *obs, int m, const double *p, dou
   }
   if (clearance) *clearance = ret_cert;
   return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* A14b  findPointsInConflictWithObstacle(S, KD, ob::Obstacle, root), R/DRRT.jl:3048-3125: the nodes whose   */
+/* edges addNewObstacle / removeObstacle (:3127-3290) re-check against a polygon obstacle.                   */
+/*   kinds 1-5, Euclidean space without time: range = robotRadius + delta + ob.radius around ob.position     */
+/*     (the legacy planner is 2-D; a d = 3 tree is that space embedded at z = 0: the query gets a 0.0 third   */
+/*     coordinate -- the reference's own 1x2 query would not broadcast against 1x3 node rows);                */
+/*   kinds 1-5, Dubins space without time: query [x y 0.0 pi], range + pi (:3061-3065);                       */
+/*   kinds 1-5 in a space with time: the reference raises (:3067) -> NULL;                                    */
+/*   kinds 6-7: one query per path segment i -> j = i + 1 (a single row: i = j = 1) at                        */
+/*     [ob.position 0.0] + (path[i, :] + path[j, :]) / 2.0 (x, y AND time), range = base +                    */
+/*     euclidianDist(path[i, :], path[j, :]) / 2.0, both + pi / [.. pi] for the Dubins car; the first query   */
+/*     makes the list, the others add to it (kdFindMoreWithinRange; inHeap keeps a node from entering twice).  */
+/* Returns the range list (the caller empties it), NULL where the reference raises.                           */
+/* ------------------------------------------------------------------------ */
+orc_list *orc_find_points_in_conflict_polygon(orc_kd *t, const orc_polygon *ob, double robot_radius, double delta,
+                                              int has_time, int has_theta) {
+  const int d = t->d;
+  double q[ORC_MAX_DIM];
+  for (int k = 0; k < ORC_MAX_DIM; ++k) q[k] = 0.0;
+  if (ob->kind >= 1 && ob->kind <= 5) {
+    if (!has_time && !has_theta) {
+      if (d != 2 && d != 3) return NULL;
+      const double search_range = robot_radius + delta + ob->radius;
+      q[0] = ob->cx; q[1] = ob->cy;
+      return orc_kd_find_within_range(t, search_range, q);
+    }
+    if (!has_time && has_theta) {
+      if (d != 4) return NULL;
+      const double search_range = robot_radius + delta + ob->radius + ORC_PI;
+      q[0] = ob->cx; q[1] = ob->cy; q[2] = 0.0; q[3] = ORC_PI;
+      return orc_kd_find_within_range(t, search_range, q);
+    }
+    return NULL;                          /* error("this type of obstacle not coded for this type of space") */
+  }
+  if (ob->kind >= 6 && ob->kind <= 7) {
+    if (ob->npath < 1 || d != (has_theta ? 4 : 3)) return NULL;
+    const double base = robot_radius + delta + ob->radius;
+    orc_list *L = NULL;
+    for (int i = 0; i < ob->npath; ++i) {
+      const int j = (ob->npath == 1) ? 0 : i + 1;
+      const double *pi_ = ob->path + 3 * i, *pj = ob->path + 3 * j;
+      /* queryPose = [ob.position 0.0] + val/2.0, val = path[i, :] + path[j, :] */
+      q[0] = ob->cx + (pi_[0] + pj[0]) / 2.0;
+      q[1] = ob->cy + (pi_[1] + pj[1]) / 2.0;
+      q[2] = 0.0 + (pi_[2] + pj[2]) / 2.0;
+      if (has_theta) q[3] = ORC_PI;
+      double search_range = base + orc_euclid(pi_, pj, 3) / 2.0;
+      if (has_theta) search_range += ORC_PI;
+      if (i == 0) L = orc_kd_find_within_range(t, search_range, q);
+      else orc_kd_find_more_within_range(t, search_range, q, L);
+      if (j == ob->npath - 1) break;
+    }
+    return L;
+  }
+  return NULL;                            /* error("this case not coded yet") */
 }
 
 /* ------------------------------------------------------------------------ */

@@ -119,6 +119,12 @@ int orc_edge_check_polygons(const orc_polygon *obs, int m, const double *p0, con
 int orc_point_check_polygons(const orc_polygon *obs, int m, const double *p, double robot_radius,
                              double *clearance);
 
+/* findPointsInConflictWithObstacle(S, KD, ob::Obstacle, root) for the polygon list (R/DRRT.jl:3048-3125): the
+ * range list of the nodes whose edges addNewObstacle / removeObstacle (:3127-3290) re-check; NULL where the
+ * reference raises.  The caller empties the list (orc_kd_empty_range_list). */
+orc_list *orc_find_points_in_conflict_polygon(orc_kd *t, const orc_polygon *ob, double robot_radius, double delta,
+                                              int has_time, int has_theta);
+
 /* ---- A6/A7/A11: steering ------------------------------------------------ */
 /* Dubins calculateTrajectory (R/DRRT_DubinsEdge_functions.jl:329-709), space
  * without time.  s, g are [x y t theta].  traj (may be NULL) receives up to

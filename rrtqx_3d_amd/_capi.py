@@ -108,6 +108,8 @@ SYMBOLS = [
     ("rrtx_dubins_edges_check", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_double, _VP, _VP, _VP, _VP]),
     ("rrtx_dubins_trajectory", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP, C.c_int, C.c_int64, c_int64_p]),
     ("rrtx_detmath_eval", C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, _VP]),
+    ("rrtx_obstacle_sweep_polygon", C.c_int, [_VP, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _VP, C.c_int64, c_int64_p]),
+    ("rrtx_dubins_edges_check_obstacle", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, C.c_double, C.c_int, _VP]),
     ("rrtx_extend_candidates", C.c_int, [_VP, _VP, C.c_int, C.c_double, C.c_double, _VP, _VP, _VP, _VP, _VP,
                                          C.c_int64, c_int64_p, _VP, _VP, _VP]),
     ("rrtx_extend_candidates_dubins", C.c_int, [_VP, _VP, C.c_int, C.c_double, C.c_double, C.c_double, _VP, _VP, _VP, _VP,

@@ -453,6 +453,34 @@ class Context:
             self._check(rc)
             return ids[:int(needed.value)]
 
+    def obstacle_sweep_polygon(self, obstacle: int, robot_radius: float, delta: float, r_min: float = 0.0,
+                               remove: bool = False, cap: Optional[int] = None):
+        """The edge loops of addNewObstacle / removeObstacle for the polygon list (R/DRRT.jl:3048-3290): ids
+        (ascending) of the mirrored edges that start at a node in conflict with polygon `obstacle` and collide with it
+        (remove: that are blocked, collide with it and with no other obstacle in use).  SimpleEdge in a dim = 3
+        context, DubinsEdge (r_min) in a dim = 4 one."""
+        if cap is None:
+            cap = 4096
+        while True:
+            ids = np.empty(max(cap, 1), dtype=np.int32)
+            needed = C.c_int64()
+            rc = self._lib.rrtx_obstacle_sweep_polygon(self._h, obstacle, robot_radius, delta, r_min, 1 if remove else 0,
+                                                       _capi._ptr(ids), cap, C.byref(needed))
+            if rc == _capi.RRTX_E_CAPACITY:
+                cap = int(needed.value)
+                continue
+            self._check(rc)
+            return ids[:int(needed.value)]
+
+    def dubins_edges_check_obstacle(self, s, g, r_min: float, robot_radius: float, obstacle: int):
+        """explicitEdgeCheck(S, edge::DubinsEdge, ob) against polygon `obstacle` alone."""
+        s = f64(s, (-1, 4))
+        g = f64(g, (-1, 4))
+        hit = np.empty(s.shape[0], dtype=np.uint8)
+        self._check(self._lib.rrtx_dubins_edges_check_obstacle(self._h, _capi._ptr(s), _capi._ptr(g), s.shape[0], r_min,
+                                                               robot_radius, obstacle, _capi._ptr(hit)))
+        return hit
+
     def edges_check_idx(self, start_idx, end_idx, robot_radius: float, obstacle: int = -1, obstacle_mask=None,
                         want_first: bool = True):
         """Edges as node-index pairs (obstacle sweeps, R/DRRT_Q.jl:3220-3362)."""

@@ -973,6 +973,8 @@ __global__ __launch_bounds__(256) void pack_hits_kernel(const uint8_t *__restric
   if (lane == 0) words[w] = m;
 }
 
+}  // namespace
+
 // map a list-position range [begin, end) onto the packed active table
 void packed_range(const std::vector<int32_t> &orig, int begin, int end, int &pb, int &pe) {
   pb = 0;
@@ -980,8 +982,6 @@ void packed_range(const std::vector<int32_t> &orig, int begin, int end, int &pb,
   pe = pb;
   while (pe < (int)orig.size() && orig[pe] < end) ++pe;
 }
-
-}  // namespace
 
 // ------------------------------------------------------------- host glue -----
 
@@ -1081,7 +1081,7 @@ static const int32_t *sph_orig_dev(rrtx_ctx *ctx) {
   return reinterpret_cast<const int32_t *>(ctx->d_sph_aux.as<double>() + 2 * (size_t)ctx->sph_n_active);
 }
 
-static std::vector<int32_t> active_positions(const std::vector<uint8_t> &active) {
+std::vector<int32_t> active_positions(const std::vector<uint8_t> &active) {
   std::vector<int32_t> o;
   for (int i = 0; i < (int)active.size(); ++i)
     if (active[i]) o.push_back(i);

@@ -1273,15 +1273,49 @@ int launch_dubins_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev,
   return RRTX_OK;
 }
 
+// the packed (active-only) obstacles [pb, pe) as a table of their own: obstacle-relative pointers shift, the vertex /
+// slope / path arrays keep their global offsets
+static PolyTab tab_range(const PolyTab &t, int pb, int pe) {
+  PolyTab r = t;
+  if (pb < 0) pb = 0;
+  if (pe > t.m) pe = t.m;
+  if (pe < pb) pe = pb;
+  r.meta = t.meta + 4 * (size_t)pb;
+  r.off = t.off + pb;
+  r.poff = t.poff + pb;
+  r.m = pe - pb;
+  return r;
+}
+
+// explicitEdgeCheck(S, edge::DubinsEdge, ob) for MIRRORED edges ids_dev[k] (start node -> end node) against the packed
+// obstacles [pb, pe): what the obstacle sweeps of the Dubins space run (R/DRRT.jl:3157, 3236-3249)
+int launch_dubins_edges_idx(rrtx_ctx *ctx, const int32_t *ids_dev, int64_t n, double r_min, double robot_radius, int pb,
+                            int pe, uint8_t *hit_dev) {
+  if (n <= 0) return RRTX_OK;
+  if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
+  int rc = sync_polygons(ctx);
+  if (rc) return rc;
+  if ((rc = check_space(ctx))) return rc;
+  const PolyTab tab = tab_range(poly_tab(ctx), pb, pe);
+  if (tab.m <= 0) { RRTX_HIP(ctx, hipMemsetAsync(hit_dev, 0, (size_t)n, ctx->stream)); return RRTX_OK; }
+  EdgeSrc src = {};
+  src.mode = 2;
+  src.ids = ids_dev; src.es = ctx->ge_start; src.ee = ctx->ge_end;
+  src.nx = ctx->nodes[0]; src.ny = ctx->nodes[1]; src.nz = ctx->nodes[2]; src.nw = ctx->nodes[3];
+  src.n_nodes = (int)ctx->n_nodes;
+  RRTX_HIP(ctx, hipMemsetAsync(hit_dev, 0, (size_t)n, ctx->stream));     // (an id that points nowhere is not written)
+  return run_dubins_edges(ctx, src, (long long)n, 1, r_min, robot_radius, tab, true, nullptr, nullptr, hit_dev, nullptr);
+}
+
 int launch_dubins_edges_check(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
                               double robot_radius, double *cost_dev, uint8_t *word_dev, uint8_t *hit_dev,
-                              int32_t *traj_len_dev) {
+                              int32_t *traj_len_dev, int pb, int pe) {
   if (ne <= 0) return RRTX_OK;
   if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
   int rc = sync_polygons(ctx);
   if (rc) return rc;
   if ((rc = check_space(ctx))) return rc;
-  const PolyTab tab = poly_tab(ctx);
+  const PolyTab tab = (pb >= 0) ? tab_range(poly_tab(ctx), pb, pe) : poly_tab(ctx);
   EdgeSrc src = {};
   src.mode = 0;
   src.s = s_dev; src.g = g_dev;

@@ -75,10 +75,90 @@ __global__ __launch_bounds__(1024) void sweep_scan_kernel(const int *__restrict_
   if (t == 1023) out[n] = prefix;
 }
 
-// flagged edge ids, ascending: block offset + rank inside the block
+// ---- polygon / Dubins space (R/DRRT.jl:3048-3290) ----
+// findPointsInConflictWithObstacle there is one range query (static obstacle) or one per path segment (kinds 6 / 7,
+// accumulated with kdFindMoreWithinRange), each with its ghosts in wrapped dimensions: a node is in the list when
+// ANY of them finds it -- dist < range, the root with <= for the un-wrapped query points (kdTree_general.jl:896,
+// 934) and < for the ghosts.  thr_root is the root's threshold (= thr_lt where the root gets no <=).
+struct SweepQuery { double x, y, z, w, thr_lt, thr_root; };
+
+__global__ void sweep_mark_multi_kernel(const double *__restrict__ nx, const double *__restrict__ ny,
+                                        const double *__restrict__ nz, const double *__restrict__ nw, int n, int dim,
+                                        const SweepQuery *__restrict__ qs, int nqs, uint8_t *__restrict__ mark) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = nx[i], y = ny[i], z = nz[i], w = (dim == 4) ? nw[i] : 0.0;
+  bool in = false;
+  for (int k = 0; k < nqs; ++k) {
+    const SweepQuery q = qs[k];
+    const double s = (dim == 4) ? sq4(q.x, q.y, q.z, q.w, x, y, z, w) : sq3(q.x, q.y, q.z, x, y, z);
+    in = in || (s < q.thr_lt) || (i == 0 && s < q.thr_root);
+  }
+  mark[i] = in ? 1 : 0;
+}
+
+// flag[e] = edge e of the mirror starts at a marked node (and, blocked_only: edge.dist == Inf); per-block counts
+__global__ __launch_bounds__(kSweepBlock) void sweep_select_kernel(const int32_t *__restrict__ e_start, long long ne,
+                                                                   int n_nodes, const uint8_t *__restrict__ mark,
+                                                                   const double *__restrict__ e_dist, int blocked_only,
+                                                                   uint8_t *__restrict__ flag, int *__restrict__ block_count) {
+  __shared__ int wcnt[kSweepBlock / 64];
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool sel = false;
+  if (e < ne) {
+    const int a = e_start[e];
+    sel = (unsigned)a < (unsigned)n_nodes && mark[a] != 0 && (!blocked_only || e_dist[e] == __builtin_inf());
+    flag[e] = sel ? 1 : 0;
+  }
+  const unsigned long long m = __ballot(sel);
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int w = 0; w < kSweepBlock / 64; ++w) c += wcnt[w];
+    block_count[blockIdx.x] = c;
+  }
+}
+
+// flag[k] = hit[k] and none of the "other obstacle" results (may be null); per-block counts
+__global__ __launch_bounds__(kSweepBlock) void sweep_combine_kernel(const uint8_t *__restrict__ hit, const uint8_t *__restrict__ o1,
+                                                                    const uint8_t *__restrict__ o2, long long n,
+                                                                    uint8_t *__restrict__ flag, int *__restrict__ block_count) {
+  __shared__ int wcnt[kSweepBlock / 64];
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool f = false;
+  if (k < n) {
+    f = hit[k] != 0 && !(o1 && o1[k] != 0) && !(o2 && o2[k] != 0);
+    flag[k] = f ? 1 : 0;
+  }
+  const unsigned long long m = __ballot(f);
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int w = 0; w < kSweepBlock / 64; ++w) c += wcnt[w];
+    block_count[blockIdx.x] = c;
+  }
+}
+
+// start / end rows (dim doubles each) of the mirrored edges ids[k]
+__global__ void sweep_gather_kernel(const int32_t *__restrict__ ids, long long n, const int32_t *__restrict__ es,
+                                    const int32_t *__restrict__ ee, const double *__restrict__ naos, int dim,
+                                    double *__restrict__ p0, double *__restrict__ p1) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int id = ids[k];
+  const double4 a = reinterpret_cast<const double4 *>(naos)[es[id]], b = reinterpret_cast<const double4 *>(naos)[ee[id]];
+  p0[dim * k] = a.x; p0[dim * k + 1] = a.y; p0[dim * k + 2] = a.z;
+  p1[dim * k] = b.x; p1[dim * k + 1] = b.y; p1[dim * k + 2] = b.z;
+  if (dim == 4) { p0[dim * k + 3] = a.w; p1[dim * k + 3] = b.w; }
+}
+
+// flagged positions, ascending: block offset + rank inside the block; ids (may be null) maps a position to what is written
 __global__ __launch_bounds__(kSweepBlock) void sweep_write_kernel(const uint8_t *__restrict__ flag, long long ne,
                                                                   const long long *__restrict__ block_start,
-                                                                  int32_t *__restrict__ out, long long cap) {
+                                                                  int32_t *__restrict__ out, long long cap,
+                                                                  const int32_t *__restrict__ ids = nullptr) {
   __shared__ int wcnt[kSweepBlock / 64];
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool hit = e < ne && flag[e] != 0;
@@ -89,7 +169,7 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_write_kernel(const uint8_t 
   if (!hit) return;
   long long pos = block_start[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
   for (int w = 0; w < wave; ++w) pos += wcnt[w];
-  if (pos < cap) out[pos] = (int32_t)e;
+  if (pos < cap) out[pos] = ids ? ids[e] : (int32_t)e;
 }
 
 }  // namespace
@@ -122,6 +202,67 @@ int launch_obstacle_sweep(rrtx_ctx *ctx, const double centre[3], double thr_lt, 
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   *total_dev = ctx->ws_sweep_start.as<long long>() + nb;
+  return RRTX_OK;
+}
+
+// ---- the polygon / Dubins sweep: compaction steps shared by rrtx_obstacle_sweep_polygon (rrtx_capi.hip) ----
+int launch_sweep_mark_multi(rrtx_ctx *ctx, const void *queries_host, int nqs) {
+  const int n = (int)ctx->n_nodes;
+  RRTX_HIP(ctx, ctx->ws_sweep_mark.ensure((size_t)n));
+  RRTX_HIP(ctx, ctx->ws_mask.ensure(sizeof(SweepQuery) * (size_t)nqs));
+  RRTX_HIP(ctx, hipMemcpyAsync(ctx->ws_mask.p, queries_host, sizeof(SweepQuery) * (size_t)nqs, hipMemcpyHostToDevice, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (the caller's table is a local)
+  hipLaunchKernelGGL(sweep_mark_multi_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->nodes[0], ctx->nodes[1],
+                     ctx->nodes[2], ctx->nodes[3], n, ctx->dim, ctx->ws_mask.as<SweepQuery>(), nqs, ctx->ws_sweep_mark.as<uint8_t>());
+  RRTX_HIP(ctx, hipGetLastError());
+  return RRTX_OK;
+}
+
+// positions with flag != 0 -> out (ids[position] when ids is given), ascending; *total_dev = their number
+static int compact_flags(rrtx_ctx *ctx, long long n, const int32_t *ids_dev, int32_t *out_dev, long long cap, long long **total_dev) {
+  const int nb = (int)((n + kSweepBlock - 1) / kSweepBlock);
+  hipLaunchKernelGGL(sweep_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->ws_sweep_cnt.as<int>(),
+                     ctx->ws_sweep_start.as<long long>(), nb);
+  if (nb > 0 && cap > 0)
+    hipLaunchKernelGGL(sweep_write_kernel, dim3(nb), dim3(kSweepBlock), 0, ctx->stream, ctx->ws_sweep_flag.as<uint8_t>(), n,
+                       ctx->ws_sweep_start.as<long long>(), out_dev, cap, ids_dev);
+  RRTX_HIP(ctx, hipGetLastError());
+  *total_dev = ctx->ws_sweep_start.as<long long>() + nb;
+  return RRTX_OK;
+}
+
+// mirrored edges that start at a marked node (blocked_only: and have dist == Inf) -> ascending ids in out_dev
+int launch_sweep_select(rrtx_ctx *ctx, int blocked_only, int32_t *out_dev, long long cap, long long **total_dev) {
+  const long long ne = ctx->ge_n;
+  const int nb = (int)((ne + kSweepBlock - 1) / kSweepBlock);
+  RRTX_HIP(ctx, ctx->ws_sweep_flag.ensure((size_t)(ne > 0 ? ne : 1)));
+  RRTX_HIP(ctx, ctx->ws_sweep_cnt.ensure(sizeof(int) * (size_t)(nb + 1)));
+  RRTX_HIP(ctx, ctx->ws_sweep_start.ensure(sizeof(long long) * (size_t)(nb + 2)));
+  if (nb > 0)
+    hipLaunchKernelGGL(sweep_select_kernel, dim3(nb), dim3(kSweepBlock), 0, ctx->stream, ctx->ge_start, ne, (int)ctx->n_nodes,
+                       ctx->ws_sweep_mark.as<uint8_t>(), ctx->ge_dist, blocked_only, ctx->ws_sweep_flag.as<uint8_t>(),
+                       ctx->ws_sweep_cnt.as<int>());
+  return compact_flags(ctx, ne, nullptr, out_dev, cap, total_dev);
+}
+
+// of the n candidates ids_dev[k]: those with hit[k] and neither o1[k] nor o2[k] -> their ids, ascending
+int launch_sweep_finish(rrtx_ctx *ctx, const int32_t *ids_dev, long long n, const uint8_t *hit, const uint8_t *o1,
+                        const uint8_t *o2, int32_t *out_dev, long long cap, long long **total_dev) {
+  const int nb = (int)((n + kSweepBlock - 1) / kSweepBlock);
+  RRTX_HIP(ctx, ctx->ws_sweep_flag.ensure((size_t)(n > 0 ? n : 1)));
+  RRTX_HIP(ctx, ctx->ws_sweep_cnt.ensure(sizeof(int) * (size_t)(nb + 1)));
+  RRTX_HIP(ctx, ctx->ws_sweep_start.ensure(sizeof(long long) * (size_t)(nb + 2)));
+  if (nb > 0)
+    hipLaunchKernelGGL(sweep_combine_kernel, dim3(nb), dim3(kSweepBlock), 0, ctx->stream, hit, o1, o2, n,
+                       ctx->ws_sweep_flag.as<uint8_t>(), ctx->ws_sweep_cnt.as<int>());
+  return compact_flags(ctx, n, ids_dev, out_dev, cap, total_dev);
+}
+
+int launch_sweep_gather(rrtx_ctx *ctx, const int32_t *ids_dev, long long n, double *p0_dev, double *p1_dev) {
+  if (n <= 0) return RRTX_OK;
+  hipLaunchKernelGGL(sweep_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ids_dev, n, ctx->ge_start,
+                     ctx->ge_end, ctx->nodes_aos, ctx->dim, p0_dev, p1_dev);
+  RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
 }
 

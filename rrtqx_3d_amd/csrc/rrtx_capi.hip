@@ -978,6 +978,166 @@ int rrtx_graph_cost_update_dev(rrtx_ctx *ctx, int root_idx, double *lmc_dev, int
   return graph_cost_dev(ctx, "graph_cost_update", root_idx, true, lmc_dev, parent_edge_dev);
 }
 
+// ---- obstacle sweeps of the polygon / Dubins space (R/DRRT.jl:3048-3290) ----------------------------------------
+namespace {
+struct SweepQ { double x, y, z, w, thr_lt, thr_root; };    // layout of kernels_sweep.hip's SweepQuery
+
+// one query of findPointsInConflictWithObstacle: the point itself (the root is taken with <=) and its ghosts in the
+// wrapped dimensions, in getNextGhostPoint's order and under its skip rule (R/ghostPoint.jl:60-111)
+void push_query_with_ghosts(rrtx_ctx *ctx, const double q[4], double range, std::vector<SweepQ> &out) {
+  const double tlt = rrtx::thr_first_ge(range), tgt = rrtx::thr_first_gt(range);
+  SweepQ o = {q[0], q[1], q[2], q[3], tlt, ctx->opt_root_rule ? tgt : tlt};
+  out.push_back(o);
+  const int nw = ctx->n_wraps;
+  for (int k = 1; k < (1 << nw); ++k) {
+    double g[4] = {q[0], q[1], q[2], q[3]}, c[4] = {q[0], q[1], q[2], q[3]};
+    for (int w = 0; w < nw; ++w) {
+      if (!((k >> (nw - 1 - w)) & 1)) continue;
+      const int d = ctx->wrap_dim[w];
+      double dim_val = q[d], dim_closest = 0.0;
+      if (q[d] < ctx->wrap_period[w] / 2.0) { dim_val += ctx->wrap_period[w]; dim_closest += ctx->wrap_period[w]; }
+      else dim_val -= ctx->wrap_period[w];
+      g[d] = dim_val; c[d] = dim_closest;
+    }
+    double s = 0.0;                          // KDdist(closestUnwrappedPoint, ghost)^2, left fold over the d coordinates
+    for (int d = 0; d < ctx->dim; ++d) { const double t = c[d] - g[d]; s = (d == 0) ? t * t : s + t * t; }
+    if (s >= tgt) continue;                  // > bestDist: this ghost is not searched (:104)
+    SweepQ gq = {g[0], g[1], g[2], g[3], tlt, tlt};
+    out.push_back(gq);
+  }
+}
+}  // namespace
+
+int rrtx_obstacle_sweep_polygon(rrtx_ctx *ctx, int obstacle, double robot_radius, double delta, double r_min, int mode,
+                                int32_t *edge_ids, int64_t cap, int64_t *needed) {
+  CHECK_CTX(ctx);
+  const int m = (int)ctx->poly_active.size();
+  if (obstacle < 0 || obstacle >= m) return fail(ctx, RRTX_E_INVALID, "obstacle_sweep_polygon: obstacle %d out of range (%d polygons)", obstacle, m);
+  if (cap < 0 || (cap > 0 && !edge_ids) || (mode != 0 && mode != 1)) return fail(ctx, RRTX_E_INVALID, "obstacle_sweep_polygon: bad arguments");
+  if (ctx->n_nodes <= 0) return fail(ctx, RRTX_E_STATE, "obstacle_sweep_polygon on an empty tree");
+  const bool dubins = ctx->dim == 4, has_time = ctx->opt_space_has_time;
+  const int kind = ctx->poly_kind[obstacle];
+  const double cx = ctx->poly_cr[3 * (size_t)obstacle], cy = ctx->poly_cr[3 * (size_t)obstacle + 1],
+               rad = ctx->poly_cr[3 * (size_t)obstacle + 2];
+  // ---- findPointsInConflictWithObstacle (R/DRRT.jl:3048-3125) ----
+  std::vector<SweepQ> qs;
+  if (kind >= 1 && kind <= 5) {
+    if (has_time) return fail(ctx, RRTX_E_STATE, "this type of obstacle not coded for this type of space (a static obstacle in a "
+                              "space with time, R/DRRT.jl:3067)");
+    // Euclidean space: range robotRadius + delta + radius around ob.position (a dim = 3 tree is the legacy 2-D space
+    // embedded at z = 0); Dubins space: [x y 0.0 pi], range + pi
+    const double q[4] = {cx, cy, 0.0, dubins ? 3.141592653589793 : 0.0};
+    double range = robot_radius + delta + rad;
+    if (dubins) range = range + 3.141592653589793;
+    push_query_with_ghosts(ctx, q, range, qs);
+  } else if (kind == 6 || kind == 7) {
+    const int p0 = ctx->poly_path_off[obstacle], np = ctx->poly_path_off[obstacle + 1] - p0;
+    if (np < 1) return fail(ctx, RRTX_E_STATE, "moving obstacle %d has no path (rrtx_polygon_paths_set)", obstacle);
+    const double base = robot_radius + delta + rad;
+    for (int i = 0; i < np; ++i) {
+      const int j = (np == 1) ? 0 : i + 1;
+      const double *pi = &ctx->poly_path[3 * (size_t)(p0 + i)], *pj = &ctx->poly_path[3 * (size_t)(p0 + j)];
+      const double q[4] = {cx + (pi[0] + pj[0]) / 2.0, cy + (pi[1] + pj[1]) / 2.0, 0.0 + (pi[2] + pj[2]) / 2.0,
+                           dubins ? 3.141592653589793 : 0.0};
+      const double dx = pi[0] - pj[0], dy = pi[1] - pj[1], dt = pi[2] - pj[2];
+      double range = base + std::sqrt((dx * dx + dy * dy) + dt * dt) / 2.0;
+      if (dubins) range += 3.141592653589793;
+      push_query_with_ghosts(ctx, q, range, qs);
+      if (j == np - 1) break;
+    }
+  } else {
+    return fail(ctx, RRTX_E_STATE, "this case not coded yet (obstacle kind %d, R/DRRT.jl:3121)", kind);
+  }
+  if (needed) *needed = 0;
+  const long long ne = ctx->ge_n;
+  if (ne == 0) return RRTX_OK;
+  int rc = sync_polygons(ctx);
+  if (rc) return rc;
+  // the obstacle in the packed (in-use only) table: an unused obstacle collides with nothing (R/DRRT.jl:1525)
+  const std::vector<int32_t> pos = active_positions(ctx->poly_active);
+  int pb, pe;
+  packed_range(pos, obstacle, obstacle + 1, pb, pe);
+  if (pe <= pb) return RRTX_OK;
+  rc = launch_sweep_mark_multi(ctx, qs.data(), (int)qs.size());
+  if (rc) return rc;
+  // ---- the out-edges (and parent edges) of those nodes; removeObstacle looks at blocked ones only ----
+  RRTX_HIP(ctx, ctx->ws_i32a.ensure(sizeof(int32_t) * (size_t)ne));
+  long long *total_dev = nullptr, n_c = 0;
+  span_begin(ctx, KF_EDGES);
+  rc = launch_sweep_select(ctx, mode == 1 ? 1 : 0, ctx->ws_i32a.as<int32_t>(), ne, &total_dev);
+  span_end(ctx);
+  if (rc) return rc;
+  RRTX_HIP(ctx, hipMemcpyAsync(&n_c, total_dev, sizeof(n_c), hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_c == 0) return RRTX_OK;
+  // ---- explicitEdgeCheck(S, edge, ob) of every candidate; removeObstacle: and against every OTHER obstacle in use ----
+  const int n_pass = mode == 1 ? 3 : 1;
+  RRTX_HIP(ctx, ctx->ws_out_u8b.ensure((size_t)n_c * 3));
+  uint8_t *hit = ctx->ws_out_u8b.as<uint8_t>(), *o1 = hit + n_c, *o2 = o1 + n_c;
+  const int32_t *cand = ctx->ws_i32a.as<int32_t>();
+  const int na = (int)pos.size();
+  const int rb[3] = {pb, 0, pe}, re[3] = {pe, pb, na};       // ob | the packed obstacles before it | after it
+  if (dubins) {
+    for (int k = 0; k < n_pass; ++k) {
+      rc = launch_dubins_edges_idx(ctx, cand, n_c, r_min, robot_radius, rb[k], re[k], hit + (size_t)k * n_c);
+      if (rc) return rc;
+    }
+  } else {
+    RRTX_HIP(ctx, ctx->ws_q.ensure(sizeof(double) * 3 * (size_t)n_c));
+    RRTX_HIP(ctx, ctx->ws_q2.ensure(sizeof(double) * 3 * (size_t)n_c));
+    rc = launch_sweep_gather(ctx, cand, n_c, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>());
+    if (rc) return rc;
+    const int lb[3] = {obstacle, 0, obstacle + 1}, le[3] = {obstacle + 1, obstacle, m};   // the same three ranges in list positions
+    for (int k = 0; k < n_pass; ++k) {
+      rc = launch_edges_polygons(ctx, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>(), n_c, robot_radius, -1, lb[k], le[k],
+                                 hit + (size_t)k * n_c, nullptr);
+      if (rc) return rc;
+    }
+  }
+  const int64_t dcap = cap > 0 ? cap : 1;
+  RRTX_HIP(ctx, ctx->ws_out_i32.ensure(sizeof(int32_t) * (size_t)dcap));
+  span_begin(ctx, KF_EDGES);
+  rc = launch_sweep_finish(ctx, cand, n_c, hit, mode == 1 ? o1 : nullptr, mode == 1 ? o2 : nullptr,
+                           ctx->ws_out_i32.as<int32_t>(), cap, &total_dev);
+  span_end(ctx);
+  if (rc) return rc;
+  long long total = 0;
+  RRTX_HIP(ctx, hipMemcpyAsync(&total, total_dev, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (needed) *needed = total;
+  if (total > cap) return fail(ctx, RRTX_E_CAPACITY, "obstacle_sweep_polygon: %lld edges, capacity %lld", total, (long long)cap);
+  if (total > 0) {
+    RRTX_HIP(ctx, hipMemcpyAsync(edge_ids, ctx->ws_out_i32.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return RRTX_OK;
+}
+
+int rrtx_dubins_edges_check_obstacle(rrtx_ctx *ctx, const double *s, const double *g, int64_t ne, double r_min,
+                                     double robot_radius, int obstacle, uint8_t *hit) {
+  CHECK_CTX(ctx);
+  const int m = (int)ctx->poly_active.size();
+  if (ne < 0 || (ne > 0 && (!s || !g || !hit))) return fail(ctx, RRTX_E_INVALID, "dubins_edges_check_obstacle: bad arguments");
+  if (obstacle < 0 || obstacle >= m) return fail(ctx, RRTX_E_INVALID, "dubins_edges_check_obstacle: obstacle %d out of range (%d polygons)", obstacle, m);
+  if (ne == 0) return RRTX_OK;
+  if (ctx->dim != 4) return fail(ctx, RRTX_E_STATE, "Dubins steering needs a dim=4 [x y t theta] context");
+  int pb, pe;
+  packed_range(active_positions(ctx->poly_active), obstacle, obstacle + 1, pb, pe);
+  if (pe <= pb) { std::memset(hit, 0, (size_t)ne); return RRTX_OK; }          // not in use: collides with nothing
+  const size_t pbytes = sizeof(double) * (size_t)ne * 4;
+  int rc = stage_in(ctx, ctx->ws_q, s, pbytes);
+  if (rc) return rc;
+  rc = stage_in(ctx, ctx->ws_q2, g, pbytes);
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_u8b.ensure((size_t)ne));
+  rc = launch_dubins_edges_check(ctx, ctx->ws_q.as<double>(), ctx->ws_q2.as<double>(), ne, r_min, robot_radius, nullptr, nullptr,
+                                 ctx->ws_out_u8b.as<uint8_t>(), nullptr, pb, pe);
+  if (rc) return rc;
+  RRTX_HIP(ctx, hipMemcpyAsync(hit, ctx->ws_out_u8b.p, (size_t)ne, hipMemcpyDeviceToHost, ctx->stream));
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTX_OK;
+}
+
 int rrtx_obstacle_sweep(rrtx_ctx *ctx, int obstacle, double search_range, double robot_radius, int32_t *edge_ids,
                         int64_t cap, int64_t *needed) {
   CHECK_CTX(ctx);

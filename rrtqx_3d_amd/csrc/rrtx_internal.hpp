@@ -307,7 +307,16 @@ int launch_dubins_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev,
                         double *velocity_dev = nullptr, uint8_t *valid_dev = nullptr);
 int launch_dubins_edges_check(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne,
                               double r_min, double robot_radius, double *cost_dev, uint8_t *word_dev,
-                              uint8_t *hit_dev, int32_t *traj_len_dev);
+                              uint8_t *hit_dev, int32_t *traj_len_dev, int pb = -1, int pe = -1);
+int launch_dubins_edges_idx(rrtx_ctx *ctx, const int32_t *ids_dev, int64_t n, double r_min, double robot_radius, int pb,
+                            int pe, uint8_t *hit_dev);
+int launch_sweep_mark_multi(rrtx_ctx *ctx, const void *queries_host, int nqs);
+int launch_sweep_select(rrtx_ctx *ctx, int blocked_only, int32_t *out_dev, long long cap, long long **total_dev);
+int launch_sweep_finish(rrtx_ctx *ctx, const int32_t *ids_dev, long long n, const uint8_t *hit, const uint8_t *o1,
+                        const uint8_t *o2, int32_t *out_dev, long long cap, long long **total_dev);
+int launch_sweep_gather(rrtx_ctx *ctx, const int32_t *ids_dev, long long n, double *p0_dev, double *p1_dev);
+void packed_range(const std::vector<int32_t> &orig, int begin, int end, int &pb, int &pe);
+std::vector<int32_t> active_positions(const std::vector<uint8_t> &active);
 int launch_candidate_dubins(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
                             const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap, double r_min,
                             double robot_radius, double *cost_out, double *cost_in, uint8_t *word_out,

@@ -8,7 +8,7 @@ What it writes
   env_inputs.json   the reference's own environment DATA files parsed to numbers
                     (environments/building2.txt: 31 spheres; rand_Static.txt: 35
                     polygons; rand_StaticTime_7.txt: 13 moving polygons with their
-                    paths).  These are inputs the reference ships, not code.
+                    paths; rand_Disc_3.txt: 89 discoverable polygons).  These are inputs the reference ships, not code.
   hotpath_v2.npz    seeded inputs + expected outputs of the hot path computed by
                     the CPU oracle (oracle/rrtx_oracle.c).  The reference itself
                     is Julia and cannot run here, and it ships no expected
@@ -37,8 +37,10 @@ def main():
     b2 = envio.read_sphere_obstacles(os.path.join(REF_ENV, "building2.txt"))
     rs = envio.read_polygon_obstacles(os.path.join(REF_ENV, "rand_Static.txt"))
     rt = envio.read_time_obstacles(os.path.join(REF_ENV, "rand_StaticTime_7.txt"))
+    rd = envio.read_polygon_obstacles(os.path.join(REF_ENV, "rand_Disc_3.txt"))     # 89 discoverable polygons
     json.dump({
-        "source": "environments/building2.txt, rand_Static.txt and rand_StaticTime_7.txt of jnetter6/RRTQX_3D (data files)",
+        "source": "environments/building2.txt, rand_Static.txt, rand_StaticTime_7.txt and rand_Disc_3.txt of jnetter6/RRTQX_3D (data files)",
+        "rand_Disc_3_polygons": [p.tolist() for p in rd.polygons], "rand_Disc_3_behaviour": rd.behaviour.tolist(),
         "building2_spheres": b2.cxyzr.tolist(), "building2_behaviour": b2.behaviour.tolist(),
         "rand_Static_polygons": [p.tolist() for p in rs.polygons], "rand_Static_behaviour": rs.behaviour.tolist(),
         "rand_StaticTime_7_polygons": [p.tolist() for p in rt.polygons], "rand_StaticTime_7_speed": rt.speed.tolist(),
