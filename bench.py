@@ -9,7 +9,9 @@ Every step takes a FRESH batch (a ring of pre-generated device batches), so chun
 bucket histograms and cache contents differ step to step.
 value = directed edges collision-checked per second (whole job, all ranks).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C4|C3] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C4|C3|C5] [--scaling weak|strong]
+                    [--obstacles spheres|polygons] [--shard edges|obstacles] [--grid ExO] [--batch B]
+    (--config C5: one replanning cycle of BASELINE config 5 per step, see bench_c5)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU: node SoA and obstacle list are replicated (4.8 MB and 8 KB -- trivially small next
@@ -364,6 +366,228 @@ def bench_c3(args, torch, dist, dev, rank, world):
     ctx.close()
 
 
+def cpu_baseline_c5(pts, es, ee, polys, kinds, paths, active, j_new, Q, r, r_min, rr, delta, budget_s=14.0):
+    """BASELINE config 5 on one host core, bounded: the oracle's addNewObstacle edge loop for obstacle j_new
+    (findPointsInConflictWithObstacle over the kd-tree, then explicitEdgeCheck(S, edge, ob) of out-edges of the nodes
+    found) and the per-sample Dubins-with-time preamble of extend() (wrapped range search, both directed edges steered
+    with calculateTrajectory and checked against the whole list), each until its share of the budget is spent."""
+    import math
+    from oracle import oracle as O
+    tree = O.KDTree(4, wraps=[3], wrap_points=[2.0 * math.pi])
+    tree.insert_many(pts)
+    ps = O.PolygonSet(polys, kinds=kinds, paths=paths, active=active)
+    t0 = time.perf_counter()
+    nodes = O.points_in_conflict_polygon(tree, ps, j_new, rr, delta, True, True)
+    t_query = time.perf_counter() - t0
+    mark = np.zeros(len(pts), dtype=bool)
+    mark[nodes] = True
+    cand = np.nonzero(mark[es])[0]
+    n_sw, t1 = 0, time.perf_counter()
+    for e in cand:
+        O.explicit_edge_check_obstacle(ps, j_new, pts[es[e]], pts[ee[e]], rr, True, r_min, has_time=True)
+        n_sw += 1
+        if time.perf_counter() - t1 > 0.3 * budget_s:
+            break
+    t_sw = time.perf_counter() - t1
+    n_ex, n_q, t2 = 0, 0, time.perf_counter()
+    for q in Q:
+        idx, _ = tree.within_range(r, q)
+        for k in idx:
+            for a, b in ((q, pts[k]), (pts[k], q)):
+                d, w, v, wd, tr = O.dubins_steer_time(a, b, r_min)
+                if len(tr):
+                    O.dubins_edge_check_polygons_time(ps, a, b, tr, rr, r_min)
+                n_ex += 1
+            if time.perf_counter() - t2 > 0.7 * budget_s:
+                break
+        n_q += 1
+        if time.perf_counter() - t2 > 0.7 * budget_s:
+            break
+    t_ex = time.perf_counter() - t2
+    return {"value": (n_sw + n_ex) / (t_sw + t_ex), "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"obstacle {j_new} appears: kd-tree conflict query ({len(nodes)} nodes, {t_query * 1e3:.1f} ms), "
+                      f"{n_sw} of {len(cand)} candidate out-edges through the two-stage Dubins check with time "
+                      f"({t_sw:.1f} s); extend(): {n_ex} directed Dubins edges of the first {n_q} sample(s) steered and "
+                      f"checked against {len(polys)} polygons ({t_ex:.1f} s); 1 host core",
+            "sweep_edges_per_s": n_sw / max(t_sw, 1e-9), "extend_edges_per_s": n_ex / max(t_ex, 1e-9),
+            "conflict_query_ms": t_query * 1e3}
+
+
+def bench_c5(args, torch, dist, dev, rank, world):
+    """--config C5: one REPLANNING CYCLE per step of BASELINE config 5 (DubinsEdge in [x y t theta], N = 500 k,
+    256 polygons of which a quarter move in time): an obstacle appears -> rrtx_obstacle_sweep_polygon over the edge
+    mirror -> rrtx_graph_edges_block -> rrtx_graph_cost_update -> the fused Dubins-with-time preamble of extend() on a
+    fresh batch of 16384 samples -> the batch joins the tree.  Every rank runs its own planner (replicas, weak)."""
+    import math
+    from rrtqx_3d_amd import _capi, parallel, synth
+    from rrtqx_3d_amd.context import Context
+    cfg = synth.CONFIGS["C5"]
+    N, M, B = cfg.n_nodes, cfg.n_obstacles, (args.batch or cfg.batch)
+    steps, warm = args.steps, max(args.warmup, 1)
+    r = synth.ball_radius(N, 4, gamma=100.0, delta=10.0)
+    r_min, rr, delta = synth.R_MIN_TIME, ROBOT_RADIUS, 10.0
+    pts = synth.nodes_time(N)
+    polys, kinds, paths, active, hidden = synth.dynamic_polygons(M)
+    moving = [j for j in range(M) if kinds[j] in (6, 7)]
+    if steps + warm > len(moving):
+        raise SystemExit(f"--config C5: {steps} + {warm} cycles need that many discoverable moving obstacles, the list has {len(moving)}")
+    appear = moving[:steps + warm]                     # the dynamic obstacles the robot has not seen yet, one per cycle
+    act = np.array(active, dtype=np.uint8).copy()
+    act[appear] = 0
+    act[hidden] = 1                                    # (static ones are all known: a static obstacle cannot be swept in a
+    #                                                     space with time, R/DRRT.jl:3067)
+    ctx = Context(4, device=dev.index or 0, node_capacity=N + (steps + warm + 1) * B)
+    stream = torch.cuda.current_stream()
+    ctx.set_wrap(3, 2.0 * math.pi)
+    ctx.set_space_has_time(True)
+    ctx.set_dubins_velocity(synth.V_MIN, synth.V_MAX)
+    ctx.polygons_set(polys, kinds=kinds, paths=paths, active=act)
+    ctx.nodes_append(pts)
+    # ---- the planner's edge mirror: both directed edges of every pair of nodes within r_graph (the live graph of
+    #      RRT^X at this size and ball radius would hold ~2 400 out-edges per node, 1.2 x 10^9 edges; the mirror here
+    #      keeps the ~20 nearest, stated in the line) ----
+    r_graph = 2.0
+    es_l, ee_l = [], []
+    for a in range(0, N, 32768):
+        b = min(N, a + 32768)
+        off, idx, _ = ctx.nn_radius(pts[a:b], r_graph, cap=64 * (b - a))
+        own = np.repeat(np.arange(a, b, dtype=np.int32), np.diff(off))
+        keep = own != idx
+        es_l.append(own[keep]); ee_l.append(idx[keep])
+    es, ee = np.concatenate(es_l), np.concatenate(ee_l).astype(np.int32)
+    del es_l, ee_l
+    ctx.graph_edges_append(es, ee)
+    for a in range(0, len(es), 1 << 21):               # edge.dist of a DubinsEdge with time; !validMove edges are blocked
+        b = min(len(es), a + (1 << 21))
+        st = ctx.dubins_steer_full(pts[es[a:b]], pts[ee[a:b]], r_min)
+        d = np.where(st["valid_move"] != 0, st["dist"], np.inf)
+        ctx.graph_edges_set_dist(a, d)
+    lmc0, _, passes0 = ctx.graph_cost_to_root(0)
+    ctx.set_stream(stream.cuda_stream)
+    # ---- fresh batches and output buffers, resident before the clock starts ----
+    Qs = [synth.nodes_time(B, seed=synth.SEED + 1 + 1000 * rank + 17 * j) for j in range(RING)]
+    d_q = [torch.from_numpy(q).to(dev) for q in Qs]
+    cap = 2800 * B
+    f64 = lambda m: torch.empty(m, dtype=torch.float64, device=dev)
+    u8 = lambda m: torch.empty(m, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    d_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_key, d_co, d_ci = f64(cap), f64(cap), f64(cap)
+    d_ho, d_hi, d_un = u8(cap), u8(cap), u8(B)
+    d_need = torch.zeros(steps + warm, dtype=torch.int64, device=dev)
+    d_ni = torch.empty(B, dtype=torch.int32, device=dev)
+    d_nd = f64(B)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    phase = {k: 0.0 for k in ("obstacle_appears", "sweep", "block", "cost_update", "extend_preamble", "append")}
+    counts = {"sweep_candidates": 0, "edges_blocked": 0, "neighbours": 0}
+
+    def cycle(i, timed):
+        j = appear[i]
+        t = [time.perf_counter()]
+        act[j] = 1
+        ctx.polygons_set(polys, kinds=kinds, paths=paths, active=act)            # the obstacle is sensed: the list changes
+        t.append(time.perf_counter())
+        ids = ctx.obstacle_sweep_polygon(j, rr, delta, r_min=r_min, cap=1 << 16)
+        n_c = ctx.stats().last_sweep_candidates
+        t.append(time.perf_counter())
+        if len(ids):
+            ctx.graph_edges_block(ids)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter())
+        ctx.graph_cost_update(0, want_parent=False)
+        t.append(time.perf_counter())
+        n_now = N + i * B
+        ri = synth.ball_radius(n_now, 4, gamma=100.0, delta=10.0)
+        ctx.extend_candidates_dubins_dev(d_q[i % RING].data_ptr(), B, ri, rr, r_min, d_off.data_ptr(), d_idx.data_ptr(),
+                                         d_key.data_ptr(), d_co.data_ptr(), d_ci.data_ptr(), None, None, d_ho.data_ptr(),
+                                         d_hi.data_ptr(), cap, d_need.data_ptr() + 8 * i, d_ni.data_ptr(), d_nd.data_ptr(),
+                                         d_un.data_ptr())
+        torch.cuda.synchronize()
+        t.append(time.perf_counter())
+        ctx.nodes_append_dev(d_q[i % RING].data_ptr(), B)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter())
+        if timed:
+            for k, name in enumerate(phase):
+                phase[name] += t[k + 1] - t[k]
+            counts["sweep_candidates"] += int(n_c)
+            counts["edges_blocked"] += len(ids)
+
+    for i in range(warm):
+        cycle(i, False)
+    fence()
+    k_w = d_need[:warm].tolist()
+    if max(k_w) > cap:
+        raise SystemExit(f"candidate capacity too small: {max(k_w)} > {cap}")
+    t0 = time.perf_counter()
+    for i in range(warm, warm + steps):
+        cycle(i, True)
+    fence()
+    dt = time.perf_counter() - t0
+    ks = [int(v) for v in d_need[warm:warm + steps].tolist()]
+    counts["neighbours"] = sum(ks)
+    units = counts["sweep_candidates"] + 2 * sum(ks)           # directed Dubins edges put through explicitEdgeCheck
+    # per-family device time of the last cycle's preamble
+    ctx.profile(2)
+    ctx.extend_candidates_dubins_dev(d_q[0].data_ptr(), B, r, rr, r_min, d_off.data_ptr(), d_idx.data_ptr(),
+                                     d_key.data_ptr(), d_co.data_ptr(), d_ci.data_ptr(), None, None, d_ho.data_ptr(),
+                                     d_hi.data_ptr(), cap, d_need.data_ptr(), d_ni.data_ptr(), d_nd.data_ptr(), d_un.data_ptr())
+    fence()
+    st = ctx.stats()
+    ctx.profile(0)
+    e_sum, t_max = parallel.reduce_throughput(units, dt, device=dev)
+    if rank == 0:
+        rk = make_run_key(args)
+        d_kernel = "dubins_check_rec_kernel<true>"
+        tj = load_pmc(d_kernel, rk)
+        chk_launches = int(st.launches_dubins)
+        if tj:
+            tj = dict(tj)
+            for kk in ("SQ_INSTS_VALU_per_launch", "SQ_INSTS_SALU_per_launch", "traffic_bytes_per_launch"):
+                if tj.get(kk) is not None:
+                    tj[kk] = tj[kk] * chk_launches
+        out = {
+            "metric": METRIC, "value": e_sum / t_max, "unit": "edges/s", "n_gpus": world, "steps": steps, "warmup": warm,
+            "ms_per_step": 1e3 * t_max / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg.name + " -- one replanning cycle per step", "n_nodes": N, "n_obstacles": M,
+                       "moving_obstacles": len(moving), "batch_per_gpu": B, "radius": r, "edge": "DubinsEdge with time",
+                       "min_turning_radius": r_min, "delta": delta,
+                       "edge_mirror": {"directed_edges": int(len(es)), "r_graph": r_graph,
+                                       "out_edges_per_node": len(es) / N,
+                                       "note": "both directed edges of every pair of nodes within r_graph; the live RRT^X graph "
+                                               "at this ball radius would hold ~2 400 out-edges per node"},
+                       "cycle": "obstacle appears -> rrtx_obstacle_sweep_polygon -> rrtx_graph_edges_block -> "
+                                "rrtx_graph_cost_update -> rrtx_extend_candidates_dubins_dev (fresh batch, r of the current n) "
+                                "-> rrtx_nodes_append_dev",
+                       "sharding": "replicas only: every rank its own planner (tree, obstacle list, edge mirror)"},
+            "phase_ms": {k: 1e3 * v / steps for k, v in phase.items()},
+            "per_cycle": {k: v / steps for k, v in counts.items()},
+            "initial_solve": {"passes": int(passes0), "reachable_nodes": int(np.isfinite(lmc0).sum())},
+            "kernel_ms": {"nn_scan": st.ms_nn_scan / max(st.launches_nn_scan, 1), "nn_finish": st.ms_nn_finish,
+                          "dubins_check": st.ms_dubins, "dubins_steer": st.ms_dubins_steer,
+                          "dubins_check_launches": chk_launches, "points": st.ms_points},
+            "roofline": issue_roofline(d_kernel, tj, st.ms_dubins,
+                                       "; kernel_ms and the instruction counts are the SUM over the check kernel's launches of one "
+                                       "preamble (both directions, every chunk of 2 M edges)"),
+            "run_key": rk, "hip_runtime": _capi.hip_runtime(), "lib_sha16": lib_sha16(), "source_sha16": source_sha16(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            act0 = act.copy()
+            out["cpu_baseline"] = cpu_baseline_c5(pts, es, ee, polys, kinds, paths, act0, appear[warm], Qs[warm % RING], r,
+                                                  r_min, rr, delta)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
 def spawn_ranks(n: int) -> int:
     """One process per GPU through torch.distributed.run on 127.0.0.1 (the launcher the driver itself uses); the
     ranks' output is passed through and their exit code is ours."""
@@ -445,6 +669,8 @@ def main():
 
     if args.config == "C3":
         return bench_c3(args, torch, dist, dev, rank, world)
+    if args.config == "C5":
+        return bench_c5(args, torch, dist, dev, rank, world)
     cfg = synth.CONFIGS[args.config]
     assert cfg.dim == 3, "the bench line is the SimpleEdge path (--config C3 for the Dubins preamble)"
     N, M, B = cfg.n_nodes, cfg.n_obstacles, (args.batch or cfg.batch)
@@ -651,6 +877,8 @@ def main():
         ctx.profile(0)
         extras["kernel_ms_all"] = {"nn_pack_place_finish": st_all.ms_nn_finish / 5,
                                    "nn_scan_separate_pass": st_all.ms_nn_scan / max(st_all.launches_nn_scan, 1)}
+        if use_polys:
+            extras["kernel_ms_all"].update({"edges_polygons": st_all.ms_edges / 5, "points_polygons": st_all.ms_points / 5})
         # the brute-force form of the search (every tile of 64 copies streams every node, north_star's
         # kernel) measured beside the default culled form: a short pass with culling switched off
         if args.nn_filter and args.nn_cull and st.last_scan_units > 0:
@@ -724,29 +952,23 @@ def main():
         kernel = (("nn_tile_kernel<3, false>" if use_polys else "nn_tile_kernel<3, true>") if culled
                   else "nn_scan_f32_kernel<3> + nn_confirm_kernel<3>") if args.nn_filter else "nn_scan_kernel<3>"
         bytes_req = node_visits * 16 + nb * 48 + k_last * (192 + 16 + 8)
+        # the in-loop figure comes from few launches (every 10th step carries events); the separate pass times EVERY launch
+        scan_ms_loop = scan_ms
+        sep = extras.get("kernel_ms_all", {}).get("nn_scan_separate_pass")
+        if sep:
+            scan_ms = sep
         alg_gbs = bytes_alg / (scan_ms * 1e-3) / 1e9
         traffic, traffic_src, frac_traffic, hbm_gbs, issue = None, None, None, None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if args.config == "C4" and args.nn_filter and os.path.exists(tpath) and world == 1:
-            tj = json.load(open(tpath))
-            # counters cannot be read inside this process; the committed PMC passes count only when they were
-            # taken on these kernel sources
-            if tj.get("kernel") == kernel and tj.get("source_sha16") == source_sha16():
-                traffic = tj["traffic_bytes_per_launch"]
-                traffic_src = f"profiles/r02_traffic.json (rocprofv3 PMC passes, sources {tj['source_sha16']})"
-                hbm_gbs = traffic / (scan_ms * 1e-3) / 1e9
-                frac_traffic = hbm_gbs / HBM_PEAK_GBS
-                if tj.get("SQ_INSTS_VALU_per_launch"):
-                    # what bounds this kernel: a SIMD issues about one wave instruction per 4 cycles (MI355X_MICROARCH.md,
-                    # measured in DESIGN.md 4), 1024 SIMDs at 2.4 GHz
-                    insts = tj["SQ_INSTS_VALU_per_launch"] + tj["SQ_INSTS_SALU_per_launch"]
-                    floor_us = insts / 1024.0 * 4.0 / 2.4e3
-                    issue = {"valu_wave_insts_per_launch": tj["SQ_INSTS_VALU_per_launch"],
-                             "salu_wave_insts_per_launch": tj["SQ_INSTS_SALU_per_launch"],
-                             "issue_floor_us": floor_us, "frac_of_kernel_time": floor_us / (scan_ms * 1e3),
-                             "wait_ratio": tj.get("wait_ratio"),
-                             "note": "VALU + SALU wave instructions / 1024 SIMDs x 4 cycles / 2.4 GHz against the kernel's "
-                                     "duration; wait_ratio = SQ_WAIT_ANY / SQ_WAVE_CYCLES (same PMC passes as `traffic`)"}
+        rk = make_run_key(args)
+        # counters cannot be read inside this process; the committed PMC passes count only when they were taken on
+        # these kernel sources AND this run key (configuration, obstacle list, batch, tuning options)
+        tj = load_pmc(kernel, rk) if world == 1 else None
+        if tj and tj.get("traffic_bytes_per_launch"):
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_src = f"{tj['file']} (rocprofv3 PMC passes, sources {tj['source_sha16']}, lib match {tj['lib_match']})"
+            hbm_gbs = traffic / (scan_ms * 1e-3) / 1e9
+            frac_traffic = hbm_gbs / HBM_PEAK_GBS
+        issue = issue_block(tj, scan_ms)
         roof_bf = None
         bf = extras.get("bf")
         if bf:
@@ -794,8 +1016,11 @@ def main():
                 "algorithmic_GBps": alg_gbs, "algorithmic_bytes_per_launch": bytes_alg,
                 "requested_bytes_per_launch": bytes_req, "frac_requested": bytes_req / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "hbm_GBps": hbm_gbs, "frac_traffic": frac_traffic, "issue": issue,
-                "tile_q": tile_q, "kernel_ms": scan_ms, "timed_launches": int(st.launches_nn_scan),
-                "timing": f"HIP events around every {main_r['sample_every']}th launch inside the timed region",
+                "tile_q": tile_q, "kernel_ms": scan_ms, "kernel_ms_in_loop": scan_ms_loop,
+                "timed_launches_in_loop": int(st.launches_nn_scan),
+                "timing": (f"kernel_ms: HIP events around every launch of a separate 5-step pass; kernel_ms_in_loop: around "
+                           f"every {main_r['sample_every']}th launch inside the timed region") if sep else
+                          f"HIP events around every {main_r['sample_every']}th launch inside the timed region",
                 "culled_units": units, "node_visits_per_launch": node_visits,
                 "node_visits_unculled": n_tiles * N,
                 "pairs_per_s": nb * N / (scan_ms * 1e-3),
@@ -814,6 +1039,7 @@ def main():
                         "VALU-issue bound, node arrays are L2-resident; see DESIGN.md",
             },
             "roofline_bruteforce": roof_bf,
+            "run_key": rk,
             "hip_runtime": _capi.hip_runtime(),
             "lib_sha16": lib_sha16(),
             "source_sha16": source_sha16(),
@@ -826,6 +1052,9 @@ def main():
                                              "at B = 16384 a step is four dependent launch-bound kernels, so the per-step "
                                              "floor bounds the speed-up") if modes[1] == "strong" else
                                             "weak: every rank its own B-sample batches"}
+        if use_polys and "edges_polygons" in extras.get("kernel_ms_all", {}):
+            out["roofline_polygon_edges"] = issue_roofline("edges_polygons_kernel", load_pmc("edges_polygons_kernel", rk),
+                                                           extras["kernel_ms_all"]["edges_polygons"])
         if large:
             out["large_batch"] = large
         if steady:
@@ -866,18 +1095,19 @@ def main():
             kt = k_ring[0]
             coll = float((b.hout[:kt].sum() + b.hin[:kt].sum()).item()) / (2 * kt)
             edges_ms = stp.ms_edges / 5
-            # a directed edge against the polygon list = 32 B of edge + M (24 B centre/radius + P x 16 B)
+            # a directed edge against the polygon list = 32 B of edge + M (24 B centre/radius + P x 16 B): the
+            # LOGICAL bytes of the reference's loop.  The kernel never moves them (the table is 22 KB and every wave drops
+            # ~244 of 256 obstacles by their boxes), so they are no roofline; what bounds the kernel is instruction issue.
             pbar = 3.5
             by_poly = 2 * kt * 32 + 2 * kt * M * (24 + pbar * 16)
+            rf_poly = issue_roofline("edges_polygons_kernel", load_pmc("edges_polygons_kernel", make_run_key(args, obstacles="polygons")),
+                                     edges_ms)
+            rf_poly["algorithmic_bytes_logical"] = by_poly
             out["polygon_obstacles"] = {
                 "edges_per_s": 2 * k_mean / dtp, "ms_per_step": dtp * 1e3, "n_polygons": M, "colliding_fraction": coll,
-                "roofline": {"kernel": "edges_polygons_kernel", "bound": "hbm", "unit": "GB/s",
-                             "achieved": by_poly / (edges_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                             "frac": by_poly / (edges_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                             "kernel_ms": edges_ms, "algorithmic_bytes_per_launch": by_poly,
-                             "note": "contract bytes = E (32 + M (24 + Pbar 16)); the obstacle table (22 KB) lives in LDS / L2, "
-                                     "the kernel is VALU-issue bound (fp64 polygon tests of the pairs the box screen leaves), "
-                                     "see DESIGN.md 4.6 and profiles/"},
+                "kernel_ms": {"edges_polygons": edges_ms, "points_polygons": stp.ms_points / 5,
+                              "nn_scan": stp.ms_nn_scan / max(stp.launches_nn_scan, 1), "nn_finish": stp.ms_nn_finish / 5},
+                "roofline": rf_poly,
                 "note": "same samples and tree, candidate edges and samples checked against the polygon list"}
             ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 0)
             ctx.set_stream(None)

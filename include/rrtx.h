@@ -63,6 +63,7 @@ typedef struct {
   /* (round 3, appended) the steering launches of the Dubins edge paths on their own: ms_dubins above then counts
    * the check kernels (and the stand-alone steer / trajectory calls) */
   double ms_dubins_steer; int64_t launches_dubins_steer;
+  int64_t last_sweep_candidates;  /* mirrored edges the last rrtx_obstacle_sweep_polygon put through explicitEdgeCheck */
 } rrtx_stats_t;
 
 /* ---- lifetime ------------------------------------------------------------ */

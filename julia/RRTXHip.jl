@@ -443,6 +443,39 @@ function obstacleSweep(tree::HipTree, S::TS, ob::SphereObstacle) where {TS}
   end
 end
 
+# The same for the POLYGON list (legacy planner, R/DRRT.jl:3048-3290; BASELINE config 5's discoverable / moving
+# obstacles): findPointsInConflictWithObstacle(::Obstacle) -- Euclidean query, the Dubins one ([x y 0.0 pi], range +
+# pi), one query per path segment for kinds 6 / 7 -- and the edge loop of addNewObstacle (remove = false) or
+# removeObstacle (remove = true: blocked edges that collide with ob and with no other obstacle in use) in ONE call;
+# the edge type is the tree's (d = 3 SimpleEdge, d = 4 DubinsEdge with S.minTurningRadius).
+function obstacleSweep(tree::HipTree, S::TS, ob::Obstacle, remove::Bool = false) where {TS}
+  syncPolygonObstacles(tree, S)
+  which = -1
+  ptr = S.obstacles.front
+  for i = 1:S.obstacles.length
+    if ptr.data === ob
+      which = i - 1
+      break
+    end
+    ptr = ptr.child
+  end
+  which >= 0 || error("obstacle is not in CSpace.obstacles")
+  cap = 4096
+  while true
+    ids = Vector{Int32}(undef, cap)
+    needed = Ref{Int64}(0)
+    rc = GC.@preserve ids ccall((:rrtx_obstacle_sweep_polygon, LIBRRTX), Cint,
+        (Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cint, Ptr{Int32}, Int64, Ref{Int64}),
+        tree.ctx, which, S.robotRadius, S.delta, S.minTurningRadius, remove ? 1 : 0, ids, cap, needed)
+    if rc == RRTX_E_CAPACITY
+      cap = Int(needed[])
+      continue
+    end
+    rrtx_check(tree, rc)
+    return ids[1:Int(needed[])]
+  end
+end
+
 # edge.dist of registered edges first_id, first_id+1, ... (ids from registerEdges); registerEdges itself
 # gives every edge the SimpleEdge cost of its two nodes.
 function syncEdgeCosts(tree::HipTree, first_id::Int, edges::Vector{TE}) where {TE}
@@ -551,8 +584,8 @@ function explicitEdgeCheck(S::CSpace{T}, edge::DubinsEdge, verbose::Bool = false
 end
 
 # explicitEdgeCheck(S, edge::DubinsEdge, obstacle) (R/DRRT_DubinsEdge_functions.jl:750-774) against ONE
-# obstacle of the list: the inflated chord test, then every stored piece of edge.trajectory, each through
-# explicitEdgeCheck2D on the device (rrtx_edges_check, kind = 1, obstacle = list position)
+# obstacle of the list: steering, the inflated chord test and every piece of the trajectory in one device call
+# (round 2 composed it from two rrtx_edges_check launches per (edge, obstacle) on the host)
 function explicitEdgeCheck(S::CSpace{T}, edge::DubinsEdge, obstacle::Obstacle) where {T}
   tree = HIP_TREE_OF[S]
   which = -1
@@ -567,27 +600,10 @@ function explicitEdgeCheck(S::CSpace{T}, edge::DubinsEdge, obstacle::Obstacle) w
   which >= 0 || error("obstacle is not in CSpace.obstacles")
   s = vec(convert(Array{Float64}, edge.startNode.position)); g = vec(convert(Array{Float64}, edge.endNode.position))
   hit = Ref{UInt8}(0)
-  GC.@preserve s g rrtx_check(tree, ccall((:rrtx_edges_check, LIBRRTX), Cint,
-      (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cint, Ref{UInt8}, Ptr{Int32}),
-      tree.ctx, 1, s, g, 1, S.robotRadius + 2 * S.minTurningRadius, which, hit, C_NULL))
-  if hit[] == 0x00
-    return false
-  end
-  P = size(edge.trajectory, 1)
-  if P < 2
-    return false
-  end
-  cols = size(edge.trajectory, 2)               # 2, or 3 with time (the moving kinds read it)
-  p0 = zeros(Float64, 4, P - 1); p1 = zeros(Float64, 4, P - 1)
-  for i = 2:P
-    p0[1:cols, i - 1] = edge.trajectory[i - 1, :]
-    p1[1:cols, i - 1] = edge.trajectory[i, :]
-  end
-  hits = Vector{UInt8}(undef, P - 1)
-  GC.@preserve p0 p1 hits rrtx_check(tree, ccall((:rrtx_edges_check, LIBRRTX), Cint,
-      (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cint, Ptr{UInt8}, Ptr{Int32}),
-      tree.ctx, 1, p0, p1, P - 1, S.robotRadius, which, hits, C_NULL))
-  return any(h -> h != 0x00, hits)
+  GC.@preserve s g rrtx_check(tree, ccall((:rrtx_dubins_edges_check_obstacle, LIBRRTX), Cint,
+      (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble, Cint, Ref{UInt8}),
+      tree.ctx, s, g, 1, S.minTurningRadius, S.robotRadius, which, hit))
+  return hit[] != 0x00
 end
 
 # Batched preamble of extend()/findBestParent for Edge = DubinsEdge (BASELINE configs 3 and 5): per sample

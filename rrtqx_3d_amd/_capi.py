@@ -59,6 +59,7 @@ class Stats(C.Structure):
         ("last_pairs", C.c_int64), ("last_neighbors", C.c_int64),
         ("last_tile_q", C.c_int32), ("last_scan_units", C.c_int32),
         ("ms_dubins_steer", C.c_double), ("launches_dubins_steer", C.c_int64),
+        ("last_sweep_candidates", C.c_int64),
     ]
 
 

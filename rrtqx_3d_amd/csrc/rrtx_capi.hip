@@ -535,6 +535,7 @@ int rrtx_stats(rrtx_ctx *ctx, rrtx_stats_t *out) {
   out->ms_points = ctx->fam_ms[KF_POINTS];         out->launches_points = ctx->fam_launches[KF_POINTS];
   out->ms_dubins = ctx->fam_ms[KF_DUBINS];         out->launches_dubins = ctx->fam_launches[KF_DUBINS];
   out->ms_dubins_steer = ctx->fam_ms[KF_DUBINS_STEER]; out->launches_dubins_steer = ctx->fam_launches[KF_DUBINS_STEER];
+  out->last_sweep_candidates = ctx->last_sweep_candidates;
   out->last_pairs = ctx->last_pairs;
   out->last_neighbors = ctx->last_neighbors;
   out->last_tile_q = ctx->last_tile_q;
@@ -1049,6 +1050,7 @@ int rrtx_obstacle_sweep_polygon(rrtx_ctx *ctx, int obstacle, double robot_radius
     return fail(ctx, RRTX_E_STATE, "this case not coded yet (obstacle kind %d, R/DRRT.jl:3121)", kind);
   }
   if (needed) *needed = 0;
+  ctx->last_sweep_candidates = 0;
   const long long ne = ctx->ge_n;
   if (ne == 0) return RRTX_OK;
   int rc = sync_polygons(ctx);
@@ -1069,6 +1071,7 @@ int rrtx_obstacle_sweep_polygon(rrtx_ctx *ctx, int obstacle, double robot_radius
   if (rc) return rc;
   RRTX_HIP(ctx, hipMemcpyAsync(&n_c, total_dev, sizeof(n_c), hipMemcpyDeviceToHost, ctx->stream));
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->last_sweep_candidates = n_c;
   if (n_c == 0) return RRTX_OK;
   // ---- explicitEdgeCheck(S, edge, ob) of every candidate; removeObstacle: and against every OTHER obstacle in use ----
   const int n_pass = mode == 1 ? 3 : 1;

@@ -220,6 +220,7 @@ struct rrtx_ctx {
   int64_t last_pairs = 0, last_neighbors = 0;
   int last_tile_q = 0;
   bool last_culled = false;         // the last range search used the slab-culled scan
+  int64_t last_sweep_candidates = 0;
   int last_visit_slices = 0;        // entries of ws_ev_cnt holding its per-wave chunk counts
 };
 

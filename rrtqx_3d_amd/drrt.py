@@ -631,14 +631,26 @@ def registerEdges(KD: HipTree, edges: Sequence[SimpleEdge]) -> int:
     return KD.ctx.graph_edges_append([e.startNode.index for e in edges], [e.endNode.index for e in edges])
 
 
-def obstacleSweep(S: CSpace, KD: HipTree, ob) -> np.ndarray:
-    """addNewObstacle's edge loop in one call (R/DRRT_Q.jl:3220-3290): ids of the registered edges
-    that start at a node within robotRadius + delta + ob.radius of `ob` and collide with it
-    (explicitEdgeCheck(S, edge, ob)); the caller sets those edges' dist = Inf and updates its queues."""
-    if S.spaceHasTime or S.spaceHasTheta:
-        error("this type of obstacle not coded for this type of space")
+def obstacleSweep(S: CSpace, KD: HipTree, ob, remove: bool = False) -> np.ndarray:
+    """The edge loop of addNewObstacle in one call: ids of the registered edges that start at a node of
+    findPointsInConflictWithObstacle(S, KD, ob) and for which explicitEdgeCheck(S, edge, ob) is true; the caller
+    sets those edges' dist = Inf and updates its queues.
+      SphereObstacle (R/DRRT_Q.jl:3195-3290): range robotRadius + delta + ob.radius, SimpleEdge in 3-D;
+      Obstacle (polygon list, R/DRRT.jl:3048-3200): the Euclidean query or the Dubins one ([x y 0.0 pi], range + pi),
+        one query per path segment for obstacles that move in time; the edge type is the space's (SimpleEdge in a
+        d = 3 tree, DubinsEdge with S.minTurningRadius in a d = 4 one).
+    remove=True (polygon list only) is removeObstacle's loop (R/DRRT.jl:3202-3290): the registered edges that are
+    blocked, collide with ob and with no other obstacle in use -- the caller resets them to distOriginal."""
     S.bind(KD)
     _sync_obstacles(S)
+    if isinstance(ob, Obstacle):
+        return KD.ctx.obstacle_sweep_polygon(_list_position(S, ob), S.robotRadius, S.delta,
+                                             r_min=float(getattr(S, "minTurningRadius", 0.0) or 0.0), remove=remove)
+    if remove:
+        error("removeObstacle frees no edge for sphere obstacles (the reference marks ob unused before its edge loop, "
+              "R/DRRT_Q.jl:3302); use obstacleSweepEdgeChecks for a corrected caller")
+    if S.spaceHasTime or S.spaceHasTheta:
+        error("this type of obstacle not coded for this type of space")
     return KD.ctx.obstacle_sweep(_list_position(S, ob), S.robotRadius + S.delta + ob.radius, S.robotRadius)
 
 
