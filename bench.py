@@ -601,9 +601,28 @@ def spawn_ranks(n: int) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print(f"bench.py: --gpus {n} without a launcher, starting {n} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
-    rc = subprocess.call(cmd, env=env)
+    # stdout carries ONE JSON line: whatever else the ranks' libraries print there (gloo's connection banner ...) goes
+    # to stderr, the bench line is printed last
+    pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in pr.stdout:
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                json.loads(t)
+                line = t
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(ln)
+    rc = pr.wait()
     if rc != 0:
         print(f"bench.py: the {n}-rank run failed with exit code {rc}", file=sys.stderr, flush=True)
+    elif line is None:
+        print(f"bench.py: the {n}-rank run printed no bench line", file=sys.stderr, flush=True)
+        rc = 1
+    else:
+        print(line, flush=True)
     sys.exit(rc)
 
 

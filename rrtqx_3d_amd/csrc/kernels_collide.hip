@@ -386,6 +386,58 @@ __device__ double segment_dist_sqrd(double pax, double pay, double pbx, double p
   return r;
 }
 
+// segmentDistSqrd for the SAME edge taken in both directions -- rF = segmentDistSqrd(pa, pb, qa, qb), rR =
+// segmentDistSqrd(pb, pa, qa, qb) -- as extend() needs them (newNode -> near and near -> newNode are both checked,
+// R/DRRT_Q.jl:1951-1963, 2600-2602).  Each result is the reference's own sequence of operations on its own argument
+// order; what the two sequences have in common is computed once: the "close to vertical" tests (|x - y| = |y - x|),
+// the second line's side test (its two differences swap roles and the test is symmetric in them), the distances of
+// the edge's end points to the other segment (the same two calls in the other order under a commutative min), and
+// len = |u|^2 inside distanceSqrdPointToSegment.  Direction-dependent and therefore computed twice: the edge's slope
+// ((pby - pay) / (pbx - pax) vs (pay - pby) / (pax - pbx): equal except for the sign of a zero), the first side test's
+// differences (anchored at pa resp. pb) and the two distances TO the edge (their det / cross are taken from the other
+// end).  One call replaces two at ~1.3x the cost of one.
+__device__ void segment_dist_sqrd_both(double pax, double pay, double pbx, double pby, double qax, double qay, double qbx,
+                                       double qby, double &rF, double &rR) {
+  bool sepF, sepR;
+  if (fabs(pbx - pax) < .000001) {
+    sepF = (qax >= pax && qbx >= pax) || (qax <= pax && qbx <= pax);
+    sepR = (qax >= pbx && qbx >= pbx) || (qax <= pbx && qbx <= pbx);
+  } else {
+    const double mF = (pby - pay) / (pbx - pax);
+    const double mR = (pay - pby) / (pax - pbx);
+    const double dAF = (mF * (qax - pax) + pay) - qay, dBF = (mF * (qbx - pax) + pay) - qby;
+    const double dAR = (mR * (qax - pbx) + pby) - qay, dBR = (mR * (qbx - pbx) + pby) - qby;
+    sepF = (dAF > 0.0 && dBF > 0.0) || (dAF < 0.0 && dBF < 0.0);
+    sepR = (dAR > 0.0 && dBR > 0.0) || (dAR < 0.0 && dBR < 0.0);
+  }
+  bool sepQ = false;       // (the reference evaluates it only while `possible` holds; its value does not depend on that)
+  if (!(sepF && sepR)) {
+    if (fabs(qbx - qax) < .000001) {
+      sepQ = (pax >= qax && pbx >= qax) || (pax <= qax && pbx <= qax);
+    } else {
+      const double m = (qby - qay) / (qbx - qax);
+      const double diffA = (m * (pax - qax) + qay) - pay;
+      const double diffB = (m * (pbx - qax) + qay) - pby;
+      sepQ = (diffA > 0.0 && diffB > 0.0) || (diffA < 0.0 && diffB < 0.0);
+    }
+  }
+  const bool possF = !sepF && !sepQ, possR = !sepR && !sepQ;
+  rF = 0.0; rR = 0.0;
+  if (possF && possR) return;
+  const double d1 = dist_sqrd_point_to_segment(pax, pay, qax, qay, qbx, qby);
+  const double d2 = dist_sqrd_point_to_segment(pbx, pby, qax, qay, qbx, qby);
+  if (!possF) {
+    double r = jl_min(d1, d2);
+    r = jl_min(r, dist_sqrd_point_to_segment(qax, qay, pax, pay, pbx, pby));
+    rF = jl_min(r, dist_sqrd_point_to_segment(qbx, qby, pax, pay, pbx, pby));
+  }
+  if (!possR) {
+    double r = jl_min(d2, d1);
+    r = jl_min(r, dist_sqrd_point_to_segment(qax, qay, pbx, pby, pax, pay));
+    rR = jl_min(r, dist_sqrd_point_to_segment(qbx, qby, pbx, pby, pax, pay));
+  }
+}
+
 // (explicitEdgeCheck2D for kinds 1 and 3, R/DRRT.jl:1523-1578: its bounding-circle test and its segment tests are
 // stages A and B of edges_polygons_kernel below)
 
@@ -422,6 +474,12 @@ struct PolyCsr {
   int nq, n_nodes;
 };
 
+// PAIRED (the candidate edges of extend(), CSR mode): lanes 2k and 2k + 1 hold the two directions of ONE segment.
+// Only the even lane lists obstacles and hands out pairs; stage A runs the bounding-circle test for both directions
+// in the pair's lane (it differs between them only in rounding: distanceSqrdPointToSegment measures from the other
+// end), and stage B's segment_dist_sqrd_both gives both directions' answers at 1.3x the cost of one.  Every boolean is
+// still the reference's own expression for that directed edge; the rounds of both stages halve.
+template <bool PAIRED>
 __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__restrict__ p0,
                                                              const double *__restrict__ p1, int stride,
                                                              long long ne, PolyCsr csr,
@@ -556,7 +614,12 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     unsigned cand = 0;
-    if (!done) {
+    bool walk = !done;
+    if (PAIRED) {                 // the even lane walks for both directions, as long as either is undecided
+      const int dn = __shfl_down(done ? 1 : 0, 1);
+      walk = !(lane & 1) && !(done && dn != 0);
+    }
+    if (walk) {
       for (int b = 0; b < jn; ++b) {
         const float4 o = w.box[b];
         const bool c = !(exhi < o.x || exlo > o.y || eyhi < o.z || eylo > o.w);
@@ -590,12 +653,18 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
           const int qi = q0 + lane;
           if (qi < nqd) {
             const unsigned ent = w.pq[qi];
-            const int owner = (int)(ent & 63u), sg = (int)(ent >> 11);
+            const int owner = (int)(ent & 63u), sg = (int)((ent >> 11) & 0x7ffffu);
             const int j = w.jidx[(ent >> 6) & 31u];
             const int vb0 = off[j], P = off[j + 1] - vb0;
             const int va = vb0 + (sg == 0 ? P - 1 : sg - 1), vb = vb0 + sg;
-            if (segment_dist_sqrd(w.e[0][owner], w.e[1][owner], w.e[3][owner], w.e[4][owner], vxy[2 * va], vxy[2 * va + 1],
-                                  vxy[2 * vb], vxy[2 * vb + 1]) < rr2)
+            if (PAIRED) {
+              double rF, rR;
+              segment_dist_sqrd_both(w.e[0][owner], w.e[1][owner], w.e[3][owner], w.e[4][owner], vxy[2 * va], vxy[2 * va + 1],
+                                     vxy[2 * vb], vxy[2 * vb + 1], rF, rR);
+              if (((ent >> 30) & 1u) && rF < rr2) atomicMin(&w.first[owner], j);
+              if ((ent >> 31) && rR < rr2) atomicMin(&w.first[owner + 1], j);
+            } else if (segment_dist_sqrd(w.e[0][owner], w.e[1][owner], w.e[3][owner], w.e[4][owner], vxy[2 * va],
+                                         vxy[2 * va + 1], vxy[2 * vb], vxy[2 * vb + 1]) < rr2)
               atomicMin(&w.first[owner], j);
           }
         }
@@ -612,6 +681,8 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
         int owner = 0, slot = 0, vb0 = 0, P = 0;           // P > 0: a polygon past the bounding circle
         double elx = 0.0, ehx = 0.0, ely = 0.0, ehy = 0.0, slack = 0.0;
         double pax = 0.0, pay = 0.0, pbx = 0.0, pby = 0.0, em = 0.0;   // the edge's ends and slope (R/DRRT.jl:1158)
+        double em_r = 0.0;                                 // PAIRED: the slope as the reverse edge divides it
+        bool pass_f = false, pass_r = false;               // which direction(s) got past the bounding circle
         bool evert = false;                                // the edge is "close to vertical" (:1151)
         if (p < npair) {
           const unsigned pe = w.pairq[p];
@@ -625,12 +696,20 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
                                  meta[4 * j + 1], meta[4 * j + 2], path + 3 * (size_t)path_off[j],
                                  path_off[j + 1] - path_off[j]))
               atomicMin(&w.first[owner], j);
+            if (PAIRED && edge_hits_moving(ebx, eby, w.e[5][owner], eax, eay, w.e[2][owner], robot_radius, meta[4 * j + 0],
+                                           meta[4 * j + 1], meta[4 * j + 2], path + 3 * (size_t)path_off[j],
+                                           path_off[j + 1] - path_off[j]))
+              atomicMin(&w.first[owner + 1], j);
           } else {
             const double dsq = dist_sqrd_point_to_segment(meta[4 * j + 0], meta[4 * j + 1], eax, eay, ebx, eby);
             const double rr = robot_radius + meta[4 * j + 2];
-            if (!(dsq > rr * rr)) {
-              if (kind == 1) atomicMin(&w.first[owner], j);
-              else if (kind == 3) {
+            pass_f = !(dsq > rr * rr);
+            if (PAIRED) pass_r = !(dist_sqrd_point_to_segment(meta[4 * j + 0], meta[4 * j + 1], ebx, eby, eax, eay) > rr * rr);
+            if (pass_f || pass_r) {
+              if (kind == 1) {
+                if (pass_f) atomicMin(&w.first[owner], j);
+                if (pass_r) atomicMin(&w.first[owner + 1], j);
+              } else if (kind == 3) {
                 vb0 = off[j];
                 P = off[j + 1] - vb0;
                 if (P < 2) P = 0;                          // (:1551: fewer than two vertices never collide)
@@ -640,7 +719,7 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
                 if (!(eax - eax == 0.0 && eay - eay == 0.0 && ebx - ebx == 0.0 && eby - eby == 0.0)) slack = __builtin_inf();
                 pax = eax; pay = eay; pbx = ebx; pby = eby;
                 evert = fabs(ebx - eax) < .000001;
-                if (!evert) em = w.em[owner];
+                if (!evert) { em = w.em[owner]; if (PAIRED) em_r = w.em[owner + 1]; }
               }
             }
           }
@@ -651,15 +730,17 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
         for (int o = 32; o > 0; o >>= 1) pmax = max(pmax, __shfl_xor(pmax, o));
         // (a side starts where the one before it ends: that vertex, whether it is finite and its difference in the
         // first side test are carried from round to round)
-        double Ax = 0.0, Ay = 0.0, diff_a1 = 0.0;
+        double Ax = 0.0, Ay = 0.0, diff_a1 = 0.0, diff_a1r = 0.0;
         bool fin_a = false;
         if (P > 0) {
           Ax = vxy[2 * (vb0 + P - 1)]; Ay = vxy[2 * (vb0 + P - 1) + 1];
           fin_a = (Ax - Ax == 0.0) && (Ay - Ay == 0.0);
           diff_a1 = (em * (Ax - pax) + pay) - Ay;
+          if (PAIRED) diff_a1r = (em_r * (Ax - pbx) + pby) - Ay;      // the reverse edge's line is anchored at ITS first point
         }
         for (int sg = 0; sg < pmax; ++sg) {
           bool push = false;
+          unsigned dirs = 0u;
           if (sg < P) {
             const int vb = vb0 + sg;
             const double Bx = vxy[2 * vb], By = vxy[2 * vb + 1];
@@ -668,25 +749,37 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
             const bool fin_b = (Bx - Bx == 0.0) && (By - By == 0.0);
             const bool finite = fin_a && fin_b;
             const double diff_b1 = (em * (Bx - pax) + pay) - By;
-            bool one_side;                                 // segmentDistSqrd's side tests, as the reference computes them
-            if (evert) one_side = (Ax >= pax && Bx >= pax) || (Ax <= pax && Bx <= pax);
-            // (both differences strictly positive or both strictly negative <=> their product is positive, except that
-            // the product of two tiny ones can round to zero: the side then just goes to the exact test)
-            else one_side = diff_a1 * diff_b1 > 0.0;
-            if (fabs(Bx - Ax) < .000001) one_side = one_side || (pax >= Ax && pbx >= Ax) || (pax <= Ax && pbx <= Ax);
+            double diff_b1r = 0.0;
+            if (PAIRED) diff_b1r = (em_r * (Bx - pbx) + pby) - By;
+            bool one_side, one_side_r = false;             // segmentDistSqrd's side tests, as the reference computes them
+            if (evert) {
+              one_side = (Ax >= pax && Bx >= pax) || (Ax <= pax && Bx <= pax);
+              if (PAIRED) one_side_r = (Ax >= pbx && Bx >= pbx) || (Ax <= pbx && Bx <= pbx);
+            } else {
+              // (both differences strictly positive or both strictly negative <=> their product is positive, except that
+              // the product of two tiny ones can round to zero: the side then just goes to the exact test)
+              one_side = diff_a1 * diff_b1 > 0.0;
+              if (PAIRED) one_side_r = diff_a1r * diff_b1r > 0.0;
+            }
+            bool sep_q;                                    // the second side test is the same for both directions
+            if (fabs(Bx - Ax) < .000001) sep_q = (pax >= Ax && pbx >= Ax) || (pax <= Ax && pbx <= Ax);
             else {
               const double qm = vslope[vb];                // (By - Ay) / (Bx - Ax), divided once when the list was set
               const double diff_a = (qm * (pax - Ax) + Ay) - pay;
               const double diff_b = (qm * (pbx - Ax) + Ay) - pby;
-              one_side = one_side || diff_a * diff_b > 0.0;
+              sep_q = diff_a * diff_b > 0.0;
             }
-            push = !(apart && one_side) || !finite;        // (slack = +inf or NaN: never apart)
-            Ax = Bx; Ay = By; fin_a = fin_b; diff_a1 = diff_b1;
+            // (slack = +inf or NaN: never apart)
+            const bool need_f = pass_f && (!(apart && (one_side || sep_q)) || !finite);
+            const bool need_r = PAIRED && pass_r && (!(apart && (one_side_r || sep_q)) || !finite);
+            push = need_f || need_r;
+            dirs = (need_f ? 1u : 0u) | (need_r ? 2u : 0u);
+            Ax = Bx; Ay = By; fin_a = fin_b; diff_a1 = diff_b1; diff_a1r = diff_b1r;
           }
           const unsigned long long sv = __ballot(push);
           if (push)
             w.pq[nqd + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sv, 0u))] =
-                (unsigned)owner | ((unsigned)slot << 6) | ((unsigned)sg << 11);
+                (unsigned)owner | ((unsigned)slot << 6) | ((unsigned)sg << 11) | (dirs << 30);
           nqd += __popcll(sv);
           if (nqd > kPolyQueue - 64) stage_b();
         }
@@ -1258,7 +1351,7 @@ int launch_candidate_edges_polygons(rrtx_ctx *ctx, const double *q_dev, int nq, 
   csr.nodes_aos = reinterpret_cast<const double4 *>(ctx->nodes_aos);
   csr.hit_in = hit_in_dev; csr.cap = (long long)cap; csr.nq = nq; csr.n_nodes = (int)ctx->n_nodes;
   span_begin(ctx, KF_EDGES);
-  hipLaunchKernelGGL(edges_polygons_kernel, dim3((unsigned)((2 * cap + 255) / 256)), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(edges_polygons_kernel<true>, dim3((unsigned)((2 * cap + 255) / 256)), dim3(256), 0, ctx->stream,
                      (const double *)nullptr, (const double *)nullptr, ctx->dim, 0ll, csr, ctx->d_poly_meta.as<double>(),
                      ctx->d_poly_off.as<int32_t>(), ctx->d_poly_vxy.as<double>(), ctx->d_poly_slope.as<double>(),
                      ctx->d_poly_path_off.as<int32_t>(),
@@ -1284,7 +1377,7 @@ int launch_edges_polygons(rrtx_ctx *ctx, const double *p0_dev, const double *p1_
   packed_range(active_positions(ctx->poly_active), obs_begin, obs_end, pb, pe);
   if (pe <= pb) return zero_outputs(ctx, ne, hit_dev, first_hit_dev);
   span_begin(ctx, KF_EDGES);
-  hipLaunchKernelGGL(edges_polygons_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
+  hipLaunchKernelGGL(edges_polygons_kernel<false>, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
                      p1_dev, ctx->dim, (long long)ne, PolyCsr{}, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
                      ctx->d_poly_vxy.as<double>(), ctx->d_poly_slope.as<double>(), ctx->d_poly_path_off.as<int32_t>(),
                      ctx->d_poly_path.as<double>(),
