@@ -939,12 +939,104 @@ __global__ __launch_bounds__(256) void points_polygons_kernel(const double *__re
                                                               const double *__restrict__ path, int has_moving,
                                                               int m, double robot_radius,
                                                               uint8_t *__restrict__ unsafe,
-                                                              double *__restrict__ clearance) {
+                                                              double *__restrict__ clearance,
+                                                              const double *__restrict__ bbox,
+                                                              const double *__restrict__ ytab, int n_ytab) {
   const int lane = threadIdx.x & 63;
   const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= np) return;
   const double px = p[i * stride + 0], py = p[i * stride + 1];
   const double pt = has_moving ? p[i * stride + 2] : 0.0;      // point[3] = time (kinds 6 / 7)
+  // ---- flag-only calls (the fused extend preamble asks only whether the sample is in collision) ----
+  // The flag is an OR over the obstacles the reference's loop EVALUATES of "inside or closer than the robot radius".
+  //  * an obstacle whose bound (Wdist - robotRadius) - radius is <= 0 is never skipped (the running certificate is
+  //    >= 0): its own answer counts whatever the list order -- evaluated here exactly as the reference does;
+  //  * an obstacle with bound > 0 lies beyond the robot's reach; evaluated or not, it can only say "in collision"
+  //    through pointInPolygon's strict crossing tests, which miscount when the ray meets a vertex (py equal to a
+  //    vertex's y) or when the point falls in the bounding box of one of its sides (the x-intercept formula of
+  //    R/DRRT.jl:1040-1046 is then evaluated, and it divides by px - 2 max(sx, ex)).  Outside the polygon's bounding
+  //    box and with py different from EVERY vertex y of the list (one look-up in the sorted table) the crossing
+  //    count is decided by comparisons alone and is even: such an obstacle cannot raise the flag, whether or not
+  //    the certificates of the obstacles before it let the reference look at it.
+  // Anything else -- a bound within 1e-9 of zero, a point inside a far obstacle's box, a y that matches a vertex,
+  // non-finite input, obstacles that move in time -- takes the full loop below, which is the reference's sequence.
+  if (clearance == nullptr && !has_moving && n_ytab >= 0 && bbox != nullptr) {
+    bool slow = !((px - px == 0.0) && (py - py == 0.0));
+    if (!slow && n_ytab > 0) {
+      // two-level look-up of py in the sorted table (at most 64 x 64 entries; longer tables: the full loop)
+      const int step = (n_ytab + 63) >> 6;
+      if (step > 64) slow = true;
+      else {
+        const int k0 = lane * step;
+        const double head = ytab[min(k0, n_ytab - 1)];
+        const unsigned long long le = __ballot(k0 < n_ytab && head <= py);
+        const int blk = le ? 63 - __clzll((long long)le) : 0;      // last block whose first entry is <= py
+        const int k = blk * step + lane;
+        const bool eq = lane < step && k < n_ytab && ytab[k] == py;
+        slow = __ballot(eq) != 0ull;
+      }
+    }
+    bool bad = false;
+    // the polygons within reach are collected over the whole list first (typically two or three of 256) and then
+    // evaluated eight at a time, eight lanes each, like the explicit loop below does -- not by the one lane that owns them
+    __shared__ short s_near[4][64];
+    short *near_list = s_near[threadIdx.x >> 6];
+    int n_near = 0;                                              // wave-uniform
+    if (!slow) {
+      for (int j0 = 0; j0 < m; j0 += 64) {
+        const int j = j0 + lane;
+        bool near3 = false;
+        if (j < m) {
+          const double4 mt = reinterpret_cast<const double4 *>(meta)[j];
+          const double4 bb = reinterpret_cast<const double4 *>(bbox)[j];
+          const double cx = mt.x, cy = mt.y, rad = mt.z;
+          const int kind = (int)mt.w;
+          // near / far by squares: reach = robotRadius + radius, the two sure cases leave a band of 1e-9 around it that
+          // goes to the full loop; the reference's own bound (Wdist - robotRadius) - radius is only needed for balls
+          const double s2 = sq2(cx, cy, px, py);
+          const double reach = robot_radius + rad;
+          const double sl = 1e-9 * (1.0 + fabs(cx) + fabs(cy) + fabs(px) + fabs(py) + fabs(reach));
+          const double hi = (reach + sl) * (1.0 + 1e-9), lo = (reach - sl) * (1.0 - 1e-9);
+          if (s2 > hi * hi && hi >= 0.0) {                        // beyond reach for certain: bound > 0
+            const bool outside = px < bb.x || px > bb.y || py < bb.z || py > bb.w;
+            if (kind != 1 && !outside) slow = true;
+          } else if (lo > 0.0 && s2 < lo * lo && robot_radius >= 0.0) {   // within reach for certain: bound < 0, never skipped
+            if (kind == 1) bad = true;                           // (Wdist - robotRadius) - radius < 0
+            else if (kind == 3) near3 = true;
+            else slow = true;
+          } else slow = true;
+        }
+        const unsigned long long nm = __ballot(near3);
+        const int at = n_near + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nm, 0u));
+        if (near3) { if (at < 64) near_list[at] = (short)j; else slow = true; }
+        n_near += __popcll(nm);
+      }
+      if (m > 32767) slow = true;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (__ballot(slow) == 0ull) {
+        for (int r0 = 0; r0 < n_near; r0 += 8) {
+          const int g = r0 + (lane >> 3);
+          int vb = 0, ve = 0;
+          if (g < n_near) { const int j = near_list[g]; vb = off[j]; ve = off[j + 1]; }
+          if (g < n_near && ve - vb < 1) slow = true;
+          int n_rounds = (ve - vb + 7) >> 3;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) n_rounds = max(n_rounds, __shfl_xor(n_rounds, o));
+          bool inside;
+          double dsq;
+          group8_point_vs_polygon(px, py, vxy, vb, ve, false, 0.0, 0.0, n_rounds, inside, dsq);
+          if (g < n_near) bad = bad || inside || (sqrt_rn(dsq) - robot_radius < 0.0);
+        }
+      }
+    }
+    if (__ballot(slow) == 0ull) {
+      const bool any = __ballot(bad) != 0ull;
+      if (lane == 0) unsafe[i] = any ? 1 : 0;
+      return;
+    }
+  }
   // One pass over the list, 64 obstacles at a time: the quickCheck of the group (an OR: "inside any obstacle"),
   // then the group's share of the explicitPointCheck2D loop.  The reference runs the whole quick pass first; both
   // end the call with unsafe = 1 and certificate 0 when they find something and neither influences the other
@@ -1186,7 +1278,7 @@ int sync_polygons(rrtx_ctx *ctx) {
   const int m = (int)ctx->poly_active.size();
   std::vector<double> meta;
   std::vector<int32_t> off(1, 0), orig;
-  std::vector<double> vxy, path, slope;
+  std::vector<double> vxy, path, slope, bbox, ytab;
   std::vector<int32_t> path_off(1, 0);
   bool moving = false;
   for (int i = 0; i < m; ++i) {
@@ -1203,7 +1295,15 @@ int sync_polygons(rrtx_ctx *ctx) {
     meta.push_back(ctx->poly_cr[3 * (size_t)i + 1]);
     meta.push_back(ctx->poly_cr[3 * (size_t)i + 2]);
     meta.push_back((double)ctx->poly_kind[i]);
+    double bx0 = __builtin_inf(), bx1 = -__builtin_inf(), by0 = __builtin_inf(), by1 = -__builtin_inf();
     for (int v = ctx->poly_off[i]; v < ctx->poly_off[i + 1]; ++v) {
+      const double x_v = ctx->poly_vxy[2 * (size_t)v], y_v = ctx->poly_vxy[2 * (size_t)v + 1];
+      // (a NaN vertex makes the box NaN-sided: every "outside the box" comparison is then false)
+      if (!(x_v >= bx0)) bx0 = x_v;
+      if (!(x_v <= bx1)) bx1 = x_v;
+      if (!(y_v >= by0)) by0 = y_v;
+      if (!(y_v <= by1)) by1 = y_v;
+      if (ctx->poly_kind[i] == 3) ytab.push_back(y_v);
       vxy.push_back(ctx->poly_vxy[2 * (size_t)v]);
       vxy.push_back(ctx->poly_vxy[2 * (size_t)v + 1]);
       // slope of the side (previous vertex -> v) as segmentDistSqrd's second side test computes it (R/DRRT.jl:1178;
@@ -1215,7 +1315,13 @@ int sync_polygons(rrtx_ctx *ctx) {
     }
     off.push_back((int32_t)(vxy.size() / 2));
     orig.push_back(i);
+    bbox.push_back(bx0); bbox.push_back(bx1); bbox.push_back(by0); bbox.push_back(by1);
   }
+  // (NaN coordinates sort nowhere: a list with one has no table, and the point kernel takes its full loop)
+  bool y_ok = true;
+  for (double y : ytab) y_ok = y_ok && (y == y);
+  if (y_ok) std::sort(ytab.begin(), ytab.end()); else ytab.clear();
+  ctx->poly_n_ytab = y_ok ? (int)ytab.size() : -1;
   const int na = (int)orig.size();
   ctx->poly_n_active = na;
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1232,6 +1338,11 @@ int sync_polygons(rrtx_ctx *ctx) {
     if (!vxy.empty())
       RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_vxy.p, vxy.data(), sizeof(double) * vxy.size(), hipMemcpyHostToDevice));
     RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_orig.p, orig.data(), sizeof(int32_t) * na, hipMemcpyHostToDevice));
+    RRTX_HIP(ctx, ctx->d_poly_bbox.ensure(sizeof(double) * bbox.size()));
+    RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_bbox.p, bbox.data(), sizeof(double) * bbox.size(), hipMemcpyHostToDevice));
+    RRTX_HIP(ctx, ctx->d_poly_ytab.ensure(sizeof(double) * (ytab.size() + 1)));
+    if (!ytab.empty())
+      RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_ytab.p, ytab.data(), sizeof(double) * ytab.size(), hipMemcpyHostToDevice));
     RRTX_HIP(ctx, ctx->d_poly_path_off.ensure(sizeof(int32_t) * path_off.size()));
     RRTX_HIP(ctx, ctx->d_poly_path.ensure(sizeof(double) * (path.size() + 3)));
     RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_path_off.p, path_off.data(), sizeof(int32_t) * path_off.size(), hipMemcpyHostToDevice));
@@ -1411,7 +1522,8 @@ int launch_points_polygons(rrtx_ctx *ctx, const double *p_dev, int64_t np, doubl
   hipLaunchKernelGGL(points_polygons_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, ctx->stream, p_dev,
                      ctx->dim, (long long)np, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
                      ctx->d_poly_vxy.as<double>(), ctx->d_poly_path_off.as<int32_t>(), ctx->d_poly_path.as<double>(),
-                     ctx->poly_has_moving ? 1 : 0, ctx->poly_n_active, robot_radius, unsafe_dev, clearance_dev);
+                     ctx->poly_has_moving ? 1 : 0, ctx->poly_n_active, robot_radius, unsafe_dev, clearance_dev,
+                     ctx->d_poly_bbox.as<double>(), ctx->d_poly_ytab.as<double>(), ctx->poly_n_ytab);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -161,6 +162,10 @@ struct rrtx_ctx {
   rrtx::DevBuf d_poly_slope;   // per vertex v: slope of the side that ends at v, (y_v - y_prev) / (x_v - x_prev) (R/DRRT.jl:1178)
   rrtx::DevBuf d_poly_off, d_poly_vxy, d_poly_meta; // meta: per active obstacle {cx, cy, radius, kind} doubles
   rrtx::DevBuf d_poly_orig;
+  // flag-only point checks (points_polygons_kernel's fast path): per packed obstacle the exact bounding box of its
+  // vertices (xmin, xmax, ymin, ymax); the sorted y coordinates of every vertex of the packed kind-3 polygons
+  rrtx::DevBuf d_poly_bbox, d_poly_ytab;
+  int poly_n_ytab = 0;
   rrtx::DevBuf ws_knn_off, ws_knn_idx, ws_knn_dist, ws_knn_misc;   // k-nearest via range-search lists
   int opt_knn_lists = 1;
   int opt_extend_polygons = 0;   // rrtx_extend_candidates checks against the polygon list instead of the spheres
