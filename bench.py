@@ -1084,12 +1084,26 @@ def main():
             # H2D of the samples, kernels, D2H of lists/costs/flags.  Reported, never `value`.
             ctx.set_stream(None)
             Q0 = m["host_q"][0]
-            ctx.extend_candidates(Q0, r, ROBOT_RADIUS, cap=cap)
-            t1 = time.perf_counter()
-            for _ in range(5):
-                ctx.extend_candidates(Q0, r, ROBOT_RADIUS, cap=cap)
-            out["host_buffer_path"] = {"edges_per_s": 2 * k_ring[0] * 5 / (time.perf_counter() - t1),
-                                       "note": "PCIe-inclusive: host numpy in/out through rrtx_extend_candidates"}
+            hb = {}
+            for label, reg in (("pageable_arrays", False), ("registered_arrays", True)):
+                ob = ctx.extend_out_buffers(nb, cap, register=reg)          # allocated once, as a Julia host would
+                for a in ob.values():
+                    a.fill(0)                                                # (touch the pages before the clock starts)
+                ctx.extend_candidates(Q0, r, ROBOT_RADIUS, out=ob)
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    ctx.extend_candidates(Q0, r, ROBOT_RADIUS, out=ob)
+                dth = (time.perf_counter() - t1) / 10
+                hb[label] = {"ms_per_step": dth * 1e3, "edges_per_s": 2 * k_ring[0] / dth}
+                if reg:
+                    for a in ob.values():
+                        ctx.host_unregister(a)
+            out["host_buffer_path"] = {**hb["pageable_arrays"], "registered_arrays": hb["registered_arrays"],
+                                       "bytes_out_per_step": int(k_ring[0] * 14 + nb * 21 + 8),
+                                       "note": "PCIe-inclusive: rrtx_extend_candidates with host numpy arrays in and out that the "
+                                               "caller keeps across calls; results travel through the context's pinned staging "
+                                               "arena + one memcpy per array (ms_per_step), or by direct DMA into arrays the "
+                                               "caller registered with rrtx_host_register (registered_arrays)"}
             # BASELINE.json's config text says "polygon obstacles": the reference's 3-D planner checks
             # spheres (explicitEdgeCheck3D) and `value` above is that; this is the same step against 256
             # random polygons in the (x, y) projection (explicitEdgeCheck2D), device-resident, reported only.

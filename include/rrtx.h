@@ -25,6 +25,7 @@
 #ifndef RRTX_H
 #define RRTX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -139,6 +140,13 @@ int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value);
 /* The value an option currently has (as rrtx_set_option normalised it): callers that size buffers by an
  * option -- the row width of rrtx_dubins_trajectory -- read it here instead of keeping a shadow copy. */
 int rrtx_get_option(rrtx_ctx *ctx, int option, int64_t *value);
+/* Host-pointer entry points move their results through a pinned staging arena owned by the context (DMA at PCIe rate,
+ * then one memcpy per output array).  A caller that keeps its output arrays alive across calls -- the Julia host
+ * preallocates them -- can have them page-locked instead: after rrtx_host_register(ptr, bytes) every output pointer
+ * inside [ptr, ptr + bytes) receives its DMA directly (hipHostRegister; unregister before freeing the array).
+ * Results are identical either way. */
+int rrtx_host_register(rrtx_ctx *ctx, void *ptr, size_t bytes);
+int rrtx_host_unregister(rrtx_ctx *ctx, void *ptr);
 
 /* Host-only helper (no GPU needed): the exact thresholds on SQUARED distances the kernels
  * compare against, so that no device sqrt sits on a decision path:

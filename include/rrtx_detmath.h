@@ -105,15 +105,11 @@ RRTX_DM_FN double rrtx_dm_cos(double x) {
 /* atan(a / b) for a >= 0, b >= 0 finite, not both zero, with ONE division: the classical five ranges of
  * t = a / b (breakpoints 7/16, 11/16, 19/16, 39/16), the reduced argument formed from a and b directly.
  * Result in [0, pi/2]. */
-RRTX_DM_FN double rrtx_dm_atan_ratio(double a, double b) {
+RRTX_DM_FN double rrtx_dm_atan_ratio_core(double a, double b) {
   const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 = 1.42857142725034663711e-01,
                aT3 = -1.11111104054623557880e-01, aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
                aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 = 4.97687799461593236017e-02,
                aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
-  /* keep 2 b + a, a + 1.5 b ... away from overflow and the quotient's operands away from the subnormals */
-  const double big = (a > b) ? a : b;
-  if (big > 1e150) { a = a * 0x1p-600; b = b * 0x1p-600; }
-  else if (big < 1e-150) { a = a * 0x1p600; b = b * 0x1p600; }
   double num, den, hi, lo;
   int direct = 0;
   if (a < 0.4375 * b) { num = a; den = b; hi = 0.0; lo = 0.0; direct = 1; }
@@ -129,9 +125,28 @@ RRTX_DM_FN double rrtx_dm_atan_ratio(double a, double b) {
   if (direct) return x - x * (s1 + s2);
   return hi - ((x * (s1 + s2) - lo) - x);
 }
+RRTX_DM_FN double rrtx_dm_atan_ratio(double a, double b) {
+  /* keep 2 b + a, a + 1.5 b ... away from overflow and the quotient's operands away from the subnormals */
+  const double big = (a > b) ? a : b;
+  if (big > 1e150) { a = a * 0x1p-600; b = b * 0x1p-600; }
+  else if (big < 1e-150) { a = a * 0x1p600; b = b * 0x1p600; }
+  return rrtx_dm_atan_ratio_core(a, b);
+}
 
 /* atan2(y, x) with the IEEE / C99 special cases (signed zeros, infinities, NaN) */
 RRTX_DM_FN double rrtx_dm_atan2(double y, double x) {
+  {
+    /* the ordinary case first -- both operands non-zero, the larger magnitude between 1e-150 and 1e150 -- behind ONE
+     * test (NaN fails it): exactly what the general sequence below computes for such operands (no special case
+     * applies, no rescaling happens), without walking through its tests.  22 calls per steered Dubins edge. */
+    const double fx = fabs(x), fy = fabs(y);
+    const double mx = (fx > fy) ? fx : fy, mn = (fx > fy) ? fy : fx;
+    if (mn > 0.0 && mx > 1e-150 && mx < 1e150) {
+      double zf = rrtx_dm_atan_ratio_core(fy, fx);
+      if (x < 0.0) zf = RRTX_DM_PI - (zf - RRTX_DM_PI_LO);
+      return (y < 0.0) ? -zf : zf;
+    }
+  }
   if (x != x || y != y) return x + y;
   const int sy = __builtin_signbit(y) ? 1 : 0, sx = __builtin_signbit(x) ? 1 : 0;
   const double ax = fabs(x), ay = fabs(y);

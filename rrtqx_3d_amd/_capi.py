@@ -78,6 +78,8 @@ SYMBOLS = [
     ("rrtx_stats", C.c_int, [_VP, C.POINTER(Stats)]),
     ("rrtx_set_option", C.c_int, [_VP, C.c_int, C.c_int64]),
     ("rrtx_get_option", C.c_int, [_VP, C.c_int, c_int64_p]),
+    ("rrtx_host_register", C.c_int, [_VP, _VP, C.c_size_t]),
+    ("rrtx_host_unregister", C.c_int, [_VP, _VP]),
     ("rrtx_nodes_append", C.c_int, [_VP, _VP, C.c_int64, c_int64_p]),
     ("rrtx_nodes_count", C.c_int64, [_VP]),
     ("rrtx_nodes_append_dev", C.c_int, [_VP, _VP, C.c_int64]),

@@ -293,9 +293,41 @@ class Context:
         return out
 
     # ---- fused extend() preamble --------------------------------------------------------------
-    def extend_candidates(self, q, r: float, robot_radius: float, cap: Optional[int] = None):
+    def host_register(self, arr: np.ndarray):
+        """Page-lock a caller array that outlives many calls (rrtx_host_register): output pointers inside it receive
+        their results by direct DMA instead of through the context's staging arena."""
+        assert arr.flags["C_CONTIGUOUS"]
+        self._check(self._lib.rrtx_host_register(self._h, arr.ctypes.data, arr.nbytes))
+
+    def host_unregister(self, arr: np.ndarray):
+        self._check(self._lib.rrtx_host_unregister(self._h, arr.ctypes.data))
+
+    def extend_out_buffers(self, nq: int, cap: int, register: bool = False) -> dict:
+        """Output arrays for extend_candidates(..., out=...) that a caller keeps across calls, as a Julia host does
+        (one allocation; register=True page-locks them)."""
+        out = dict(offsets=np.empty(nq + 1, dtype=np.int64), idx=np.empty(cap, dtype=np.int32),
+                   cost=np.empty(cap, dtype=np.float64), hit_out=np.empty(cap, dtype=np.uint8),
+                   hit_in=np.empty(cap, dtype=np.uint8), nearest_idx=np.empty(nq, dtype=np.int32),
+                   nearest_dist=np.empty(nq, dtype=np.float64), sample_unsafe=np.empty(nq, dtype=np.uint8))
+        if register:
+            for a in out.values():
+                self.host_register(a)
+        return out
+
+    def extend_candidates(self, q, r: float, robot_radius: float, cap: Optional[int] = None, out: Optional[dict] = None):
         q = f64(q, (-1, self.dim))
         nq = q.shape[0]
+        if out is not None:                      # caller-owned arrays (extend_out_buffers): no allocation, no growth
+            cap = out["idx"].shape[0]
+            needed = C.c_int64()
+            self._check(self._lib.rrtx_extend_candidates(
+                self._h, _capi._ptr(q), nq, r, robot_radius, _capi._ptr(out["offsets"]), _capi._ptr(out["idx"]),
+                _capi._ptr(out["cost"]), _capi._ptr(out["hit_out"]), _capi._ptr(out["hit_in"]), cap, C.byref(needed),
+                _capi._ptr(out["nearest_idx"]), _capi._ptr(out["nearest_dist"]), _capi._ptr(out["sample_unsafe"])))
+            n = int(needed.value)
+            return dict(offsets=out["offsets"], idx=out["idx"][:n], cost=out["cost"][:n], hit_out=out["hit_out"][:n],
+                        hit_in=out["hit_in"][:n], nearest_idx=out["nearest_idx"], nearest_dist=out["nearest_dist"],
+                        sample_unsafe=out["sample_unsafe"])
         if cap is None:
             cap = max(64 * nq, 1024)
         offsets = np.empty(nq + 1, dtype=np.int64)

@@ -110,25 +110,31 @@ __device__ __forceinline__ Piece make_line(double x1, double y1, double x2, doub
   return p;
 }
 
-template <bool WANT_TRAJ>
-__device__ void dubins_steer(const double *__restrict__ s, const double *__restrict__ g, double r_min,
-                             Steer &out) {
-  const double ilx = s[0], ily = s[1], it = s[3];
-  const double glx = g[0], gly = g[1], gt = g[3];
-  // circle centres (:348-357)
+// What calculateTrajectory derives from ONE pose alone: the centres of its right / left turning circles (:348-357) and
+// the pose's angle on each of them (see right_turn_from).  An edge and its reverse use the same two poses with the
+// roles of start and goal swapped -- the expressions are the same, so the values are shared.
+struct PoseCircles { double rcx, rcy, lcx, lcy, a_r, a_l; };
+__device__ __forceinline__ PoseCircles pose_circles(double x, double y, double th, double r_min) {
+  PoseCircles p;
   double sn, cs;
-  rrtx_dm_sincos(it - kPi / 2.0, &sn, &cs);
-  const double ircx = ilx + r_min * cs, ircy = ily + r_min * sn;
-  rrtx_dm_sincos(it + kPi / 2.0, &sn, &cs);
-  const double ilcx = ilx + r_min * cs, ilcy = ily + r_min * sn;
-  rrtx_dm_sincos(gt - kPi / 2.0, &sn, &cs);
-  const double grcx = glx + r_min * cs, grcy = gly + r_min * sn;
-  rrtx_dm_sincos(gt + kPi / 2.0, &sn, &cs);
-  const double glcx = glx + r_min * cs, glcy = gly + r_min * sn;
+  rrtx_dm_sincos(th - kPi / 2.0, &sn, &cs);
+  p.rcx = x + r_min * cs; p.rcy = y + r_min * sn;
+  rrtx_dm_sincos(th + kPi / 2.0, &sn, &cs);
+  p.lcx = x + r_min * cs; p.lcy = y + r_min * sn;
+  p.a_r = rrtx_dm_atan2(y - p.rcy, x - p.rcx);
+  p.a_l = rrtx_dm_atan2(y - p.lcy, x - p.lcx);
+  return p;
+}
 
-  // the poses' angles on their circles (see right_turn_from)
-  const double a_ir = rrtx_dm_atan2(ily - ircy, ilx - ircx), a_il = rrtx_dm_atan2(ily - ilcy, ilx - ilcx);
-  const double a_gr = rrtx_dm_atan2(gly - grcy, glx - grcx), a_gl = rrtx_dm_atan2(gly - glcy, glx - glcx);
+template <bool WANT_TRAJ>
+__device__ __forceinline__ void dubins_steer_poses(const double *__restrict__ s, const double *__restrict__ g, const PoseCircles &ps,
+                                   const PoseCircles &pg, double r_min, Steer &out) {
+  const double ilx = s[0], ily = s[1];
+  const double glx = g[0], gly = g[1];
+  const double ircx = ps.rcx, ircy = ps.rcy, ilcx = ps.lcx, ilcy = ps.lcy;
+  const double grcx = pg.rcx, grcy = pg.rcy, glcx = pg.lcx, glcy = pg.lcy;
+  const double a_ir = ps.a_r, a_il = ps.a_l, a_gr = pg.a_r, a_gl = pg.a_l;
+  double sn, cs;
 
   double best = __builtin_inf();
   int word = 6;
@@ -287,6 +293,12 @@ __device__ void dubins_steer(const double *__restrict__ s, const double *__restr
     if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi;
     out.pc[2] = make_arc(glcx, glcy, phi_start, phi_end, dphi);
   }
+}
+
+template <bool WANT_TRAJ>
+__device__ void dubins_steer(const double *__restrict__ s, const double *__restrict__ g, double r_min, Steer &out) {
+  const PoseCircles ps = pose_circles(s[0], s[1], s[3], r_min), pg = pose_circles(g[0], g[1], g[3], r_min);
+  dubins_steer_poses<WANT_TRAJ>(s, g, ps, pg, r_min, out);
 }
 
 __device__ __forceinline__ void piece_point(const Piece &p, int k, double r_min, double &x, double &y) {
@@ -1063,23 +1075,42 @@ __device__ __forceinline__ void load_rec(const double *__restrict__ rec, Steer &
 
 // calculateTrajectory of the edges [base, base + count) of the source: the record of edge base + k at rec[k],
 // cost = edge.dist (sqrt(Wdist^2 + dt^2) in a space with time), the word, the number of polyline rows.
+// rec2 / cost2 / word2 (candidate edges of extend() only): the REVERSE edge g -> s in the same thread, its record at
+// rec2[k] -- the two poses' circle centres and angles (4 sincos + 4 atan2 of the ~30 transcendentals of a steer) are
+// computed once for both directions.
 __global__ __launch_bounds__(256) void dubins_steer_rec_kernel(const EdgeSrc src, long long base, long long count, long long n,
                                                                double r_min, int has_time, double *__restrict__ rec,
                                                                double *__restrict__ cost, uint8_t *__restrict__ word,
-                                                               int32_t *__restrict__ traj_len) {
+                                                               int32_t *__restrict__ traj_len, double *__restrict__ rec2,
+                                                               double *__restrict__ cost2, uint8_t *__restrict__ word2) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= count) return;
   const long long i = base + k;
   double s[4] = {0, 0, 0, 0}, g[4] = {1, 0, 0, 0};
   const bool valid = load_edge(src, i, n, s, g);
   if (__ballot(valid) == 0ull) return;          // (mode 1: the grid covers the caller's capacity)
-  Steer st;
-  dubins_steer<true>(s, g, r_min, st);
-  store_rec(rec + kRecDoubles * k, st);
-  if (!valid) return;
-  if (cost) cost[i] = has_time ? dist_with_time(st.cost, s[2], g[2]) : st.cost;
-  if (word) write_word(word, i, st.word);
-  if (traj_len) traj_len[i] = st.pc[0].len + st.pc[1].len + st.pc[2].len;
+  PoseCircles pa = pose_circles(s[0], s[1], s[3], r_min), pb = pose_circles(g[0], g[1], g[3], r_min);
+  double a0 = s[0], a1 = s[1], a2 = s[2], b0 = g[0], b1 = g[1], b2 = g[2];
+  // ONE copy of the six-word evaluation in the code, run once or twice (the second time with the poses swapped)
+#pragma unroll 1
+  for (int d = 0; d < (rec2 ? 2 : 1); ++d) {
+    const double sa[4] = {a0, a1, a2, 0.0}, ga[4] = {b0, b1, b2, 0.0};
+    Steer st;
+    dubins_steer_poses<true>(sa, ga, pa, pb, r_min, st);
+    store_rec((d ? rec2 : rec) + kRecDoubles * k, st);
+    if (valid) {
+      double *co = d ? cost2 : cost;
+      uint8_t *wo = d ? word2 : word;
+      if (co) co[i] = has_time ? dist_with_time(st.cost, a2, b2) : st.cost;
+      if (wo) write_word(wo, i, st.word);
+      if (!d && traj_len) traj_len[i] = st.pc[0].len + st.pc[1].len + st.pc[2].len;
+    }
+    const PoseCircles t = pa; pa = pb; pb = t;
+    double x;
+    x = a0; a0 = b0; b0 = x;
+    x = a1; a1 = b1; b1 = x;
+    x = a2; a2 = b2; b2 = x;
+  }
 }
 
 // explicitEdgeCheck(S, ::DubinsEdge, ob) over the polygon list (:750-774) for the steered edges of a chunk:
@@ -1182,28 +1213,39 @@ extern "C" int rrtx_debug_dubins_clocks(unsigned long long *out, int reset) {
 #endif
 
 // steer + check of the edges [0, n) of a source, chunk by chunk
+// cost2 / word2 / hit2 (candidate edges, src.mode == 1 with dir == 0): the reverse edges too, steered in the same launch
 static int run_dubins_edges(rrtx_ctx *ctx, const EdgeSrc &src, long long n, int spread, double r_min, double robot_radius,
-                            const PolyTab &tab, bool check, double *cost, uint8_t *word, uint8_t *hit, int32_t *traj_len) {
+                            const PolyTab &tab, bool check, double *cost, uint8_t *word, uint8_t *hit, int32_t *traj_len,
+                            double *cost2 = nullptr, uint8_t *word2 = nullptr, uint8_t *hit2 = nullptr) {
+  const bool both = hit2 != nullptr;
   const long long chunk = n < kDubChunk ? n : kDubChunk;
-  RRTX_HIP(ctx, ctx->ws_dub_rec.ensure(sizeof(double) * kRecDoubles * (size_t)chunk));
+  RRTX_HIP(ctx, ctx->ws_dub_rec.ensure(sizeof(double) * kRecDoubles * (size_t)chunk * (both ? 2 : 1)));
   double *rec = ctx->ws_dub_rec.as<double>();
+  double *rec2 = both ? rec + kRecDoubles * (size_t)chunk : nullptr;
   const int has_time = ctx->opt_space_has_time ? 1 : 0;
+  EdgeSrc rsrc = src;
+  rsrc.dir = 1;
   for (long long base = 0; base < n; base += chunk) {
     const long long count = (n - base < chunk) ? n - base : chunk;
     const dim3 grid((unsigned)((count + 255) / 256)), block(256);
     span_begin(ctx, KF_DUBINS_STEER);
     hipLaunchKernelGGL(dubins_steer_rec_kernel, grid, block, 0, ctx->stream, src, base, count, n, r_min, has_time, rec, cost,
-                       word, traj_len);
+                       word, traj_len, rec2, cost2, word2);
     span_end(ctx);
     if (!check) continue;
-    span_begin(ctx, KF_DUBINS);
-    if (has_time)
-      hipLaunchKernelGGL(dubins_check_rec_kernel<true>, grid, block, 0, ctx->stream, src, base, count, n, spread, r_min,
-                         robot_radius, ctx->dubins_vmin, ctx->dubins_vmax, tab, rec, hit);
-    else
-      hipLaunchKernelGGL(dubins_check_rec_kernel<false>, grid, block, 0, ctx->stream, src, base, count, n, spread, r_min,
-                         robot_radius, ctx->dubins_vmin, ctx->dubins_vmax, tab, rec, hit);
-    span_end(ctx);
+    for (int d = 0; d < (both ? 2 : 1); ++d) {
+      const EdgeSrc &cs = d ? rsrc : src;
+      const double *rc_ = d ? rec2 : rec;
+      uint8_t *h = d ? hit2 : hit;
+      span_begin(ctx, KF_DUBINS);
+      if (has_time)
+        hipLaunchKernelGGL(dubins_check_rec_kernel<true>, grid, block, 0, ctx->stream, cs, base, count, n, spread, r_min,
+                           robot_radius, ctx->dubins_vmin, ctx->dubins_vmax, tab, rc_, h);
+      else
+        hipLaunchKernelGGL(dubins_check_rec_kernel<false>, grid, block, 0, ctx->stream, cs, base, count, n, spread, r_min,
+                           robot_radius, ctx->dubins_vmin, ctx->dubins_vmax, tab, rc_, h);
+      span_end(ctx);
+    }
   }
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
@@ -1229,12 +1271,8 @@ int launch_candidate_dubins(rrtx_ctx *ctx, const double *q_dev, int nq, const in
   src.n_nodes = (int)ctx->n_nodes;
   src.cap = (long long)cap;
   src.dir = 0;
-  rc = run_dubins_edges(ctx, src, (long long)cap, 0, r_min, robot_radius, tab, true, cost_out, word_out, hit_out, nullptr);
-  if (!rc) {
-    src.dir = 1;
-    rc = run_dubins_edges(ctx, src, (long long)cap, 0, r_min, robot_radius, tab, true, cost_in, word_in, hit_in, nullptr);
-  }
-  return rc;
+  return run_dubins_edges(ctx, src, (long long)cap, 0, r_min, robot_radius, tab, true, cost_out, word_out, hit_out, nullptr,
+                          cost_in, word_in, hit_in);
 }
 
 int launch_detmath_eval(rrtx_ctx *ctx, int op, const double *x_dev, const double *y_dev, int64_t n, double *out_dev) {

@@ -328,10 +328,72 @@ int grow_nodes(rrtx_ctx *ctx, int64_t need) {
   return RRTX_OK;
 }
 
+// ---- host <-> device transfers of the host-pointer entry points ----
+static bool host_registered(const rrtx_ctx *ctx, const void *p, size_t bytes) {
+  const char *c = static_cast<const char *>(p);
+  for (const auto &r : ctx->h_registered)
+    if (c >= r.first && c + bytes <= r.first + r.second) return true;
+  return false;
+}
+// room for `bytes` more in the pinned arena; a call reserves its whole need up front (arena_begin), so the arena never
+// moves while copies into it are in flight
+static int arena_begin(rrtx_ctx *ctx, size_t need) {
+  ctx->h_arena_used = 0;
+  ctx->h_pending.clear();
+  if (need <= ctx->h_arena_bytes) return RRTX_OK;
+  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->h_arena) (void)hipHostFree(ctx->h_arena);
+  ctx->h_arena = nullptr; ctx->h_arena_bytes = 0;
+  size_t nb = 1 << 20;
+  while (nb < need) nb *= 2;
+  RRTX_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_arena), nb, hipHostMallocDefault));
+  ctx->h_arena_bytes = nb;
+  return RRTX_OK;
+}
+static char *arena_take(rrtx_ctx *ctx, size_t bytes) {
+  const size_t at = (ctx->h_arena_used + 63) & ~(size_t)63;
+  if (at + bytes > ctx->h_arena_bytes) return nullptr;
+  ctx->h_arena_used = at + bytes;
+  return ctx->h_arena + at;
+}
+// device -> caller array: straight DMA when the array is registered, else through the arena (copied out by
+// arena_flush after the stream has been synchronised)
+// Only SMALL results are staged (a 16 KB pageable destination costs a driver-side bounce of its own, ~35 us against
+// ~20 us pinned): measured on the MI355X box (tools/pcie_probe.py), a pageable destination of a megabyte or more
+// receives its DMA at the same ~50 GB/s as a pinned one, while a staged copy has to be read back from DRAM by one host
+// thread at a third of that.
+static int d2h(rrtx_ctx *ctx, void *dst, const void *src_dev, size_t bytes) {
+  if (!bytes) return RRTX_OK;
+  void *to = dst;
+  if (bytes <= (256u << 10) && !host_registered(ctx, dst, bytes)) {
+    char *a = arena_take(ctx, bytes);
+    if (a) { to = a; ctx->h_pending.push_back({dst, a, bytes}); }
+  }
+  RRTX_HIP(ctx, hipMemcpyAsync(to, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return RRTX_OK;
+}
+static void arena_flush(rrtx_ctx *ctx) {
+  for (const auto &c : ctx->h_pending) std::memcpy(c.dst, c.src, c.bytes);
+  ctx->h_pending.clear();
+}
+
 // stage a host array on the device workspace `buf`
 int stage_in(rrtx_ctx *ctx, DevBuf &buf, const void *host, size_t bytes) {
   RRTX_HIP(ctx, buf.ensure(bytes ? bytes : 8));
   if (bytes) RRTX_HIP(ctx, hipMemcpyAsync(buf.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return RRTX_OK;
+}
+// the samples of a batched call: through the pinned arena when they are small (one host memcpy of cache-resident data,
+// then a pinned H2D), so the driver does not bounce them itself.  Call after arena_begin.
+static int stage_in_small(rrtx_ctx *ctx, DevBuf &buf, const void *host, size_t bytes) {
+  RRTX_HIP(ctx, buf.ensure(bytes ? bytes : 8));
+  if (!bytes) return RRTX_OK;
+  const void *from = host;
+  if (bytes <= (1u << 20) && !host_registered(ctx, host, bytes)) {
+    char *a = arena_take(ctx, bytes);
+    if (a) { std::memcpy(a, host, bytes); from = a; }
+  }
+  RRTX_HIP(ctx, hipMemcpyAsync(buf.p, from, bytes, hipMemcpyHostToDevice, ctx->stream));
   return RRTX_OK;
 }
 
@@ -439,6 +501,8 @@ int rrtx_destroy(rrtx_ctx *ctx) {
   if (ctx->ge_dist) (void)hipFree(ctx->ge_dist);
   if (ctx->ge_dirty) (void)hipFree(ctx->ge_dirty);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+  if (ctx->h_arena) (void)hipHostFree(ctx->h_arena);
+  for (const auto &r : ctx->h_registered) (void)hipHostUnregister(const_cast<char *>(r.first));
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return RRTX_OK;
@@ -496,6 +560,27 @@ int rrtx_set_option(rrtx_ctx *ctx, int option, int64_t value) {
     }
     default: return fail(ctx, RRTX_E_INVALID, "set_option: unknown option %d", option);
   }
+}
+
+int rrtx_host_register(rrtx_ctx *ctx, void *ptr, size_t bytes) {
+  CHECK_CTX(ctx);
+  if (!ptr || bytes == 0) return fail(ctx, RRTX_E_INVALID, "host_register: bad arguments");
+  if (host_registered(ctx, ptr, bytes)) return RRTX_OK;
+  RRTX_HIP(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  ctx->h_registered.push_back({static_cast<const char *>(ptr), bytes});
+  return RRTX_OK;
+}
+
+int rrtx_host_unregister(rrtx_ctx *ctx, void *ptr) {
+  CHECK_CTX(ctx);
+  for (size_t k = 0; k < ctx->h_registered.size(); ++k)
+    if (ctx->h_registered[k].first == static_cast<const char *>(ptr)) {
+      RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      RRTX_HIP(ctx, hipHostUnregister(ptr));
+      ctx->h_registered.erase(ctx->h_registered.begin() + (long)k);
+      return RRTX_OK;
+    }
+  return fail(ctx, RRTX_E_INVALID, "host_unregister: %p was not registered with this context", ptr);
 }
 
 int rrtx_get_option(rrtx_ctx *ctx, int option, int64_t *value) {
@@ -1412,45 +1497,60 @@ int rrtx_extend_candidates(rrtx_ctx *ctx, const double *q, int nq, double r, dou
   if (nq < 0 || cap < 0 || (nq > 0 && (!q || !offsets)) || (cap > 0 && (!idx || !cost || !hit_out || !hit_in)))
     return fail(ctx, RRTX_E_INVALID, "extend_candidates: bad arguments");
   if (nq == 0) { if (needed) *needed = 0; if (offsets) offsets[0] = 0; return RRTX_OK; }
-  int rc = stage_in(ctx, ctx->ws_q, q, sizeof(double) * (size_t)nq * ctx->dim);
-  if (rc) return rc;
+  // ONE small device block for everything that is per sample -- [offsets (nq + 1) | count | nearest_dist (nq) |
+  // nearest_idx (nq) | sample_unsafe (nq)] -- so that it leaves in one transfer; the per-entry arrays follow once the
+  // count is known.  Small transfers go through the context's pinned arena, large ones straight to the caller.
   const int64_t dcap = cap > 0 ? cap : 1;
-  RRTX_HIP(ctx, ctx->ws_out_off.ensure(sizeof(int64_t) * ((size_t)nq + 2)));
+  const size_t o_cnt = sizeof(int64_t) * ((size_t)nq + 1), o_nd = o_cnt + sizeof(int64_t), o_ni = o_nd + sizeof(double) * (size_t)nq,
+               o_un = o_ni + sizeof(int32_t) * (size_t)nq, small_bytes = o_un + (size_t)nq;
+  int rc = arena_begin(ctx, small_bytes + sizeof(double) * (size_t)nq * ctx->dim + 256);
+  if (rc) return rc;
+  rc = stage_in_small(ctx, ctx->ws_q, q, sizeof(double) * (size_t)nq * ctx->dim);
+  if (rc) return rc;
+  RRTX_HIP(ctx, ctx->ws_out_off.ensure(small_bytes + 64));
   RRTX_HIP(ctx, ctx->ws_out_idx.ensure(sizeof(int32_t) * (size_t)dcap));
   RRTX_HIP(ctx, ctx->ws_out_dist.ensure(sizeof(double) * (size_t)dcap));
   RRTX_HIP(ctx, ctx->ws_out_u8a.ensure((size_t)dcap));
-  RRTX_HIP(ctx, ctx->ws_out_u8b.ensure((size_t)dcap + (size_t)nq));
-  RRTX_HIP(ctx, ctx->ws_out_i32.ensure(sizeof(int32_t) * (size_t)nq));
-  RRTX_HIP(ctx, ctx->ws_out_f64.ensure(sizeof(double) * (size_t)nq));
-  int64_t *off_dev = ctx->ws_out_off.as<int64_t>();
+  RRTX_HIP(ctx, ctx->ws_out_u8b.ensure((size_t)dcap));
+  char *blk = ctx->ws_out_off.as<char>();
+  int64_t *off_dev = reinterpret_cast<int64_t *>(blk);
   int64_t *needed_dev = off_dev + nq + 1;
-  uint8_t *unsafe_dev = ctx->ws_out_u8b.as<uint8_t>() + dcap;
+  double *nd_dev = reinterpret_cast<double *>(blk + o_nd);
+  int32_t *ni_dev = reinterpret_cast<int32_t *>(blk + o_ni);
+  uint8_t *unsafe_dev = reinterpret_cast<uint8_t *>(blk + o_un);
+  const bool want_nearest = nearest_idx && nearest_dist;
   rc = rrtx_extend_candidates_dev(ctx, ctx->ws_q.as<double>(), nq, r, robot_radius, off_dev,
                                   ctx->ws_out_idx.as<int32_t>(), ctx->ws_out_dist.as<double>(),
                                   ctx->ws_out_u8a.as<uint8_t>(), ctx->ws_out_u8b.as<uint8_t>(), cap, needed_dev,
-                                  ctx->ws_out_i32.as<int32_t>(), ctx->ws_out_f64.as<double>(),
+                                  want_nearest ? ni_dev : nullptr, want_nearest ? nd_dev : nullptr,
                                   sample_unsafe ? unsafe_dev : nullptr);
   if (rc) return rc;
-  int64_t total = 0;
-  RRTX_HIP(ctx, hipMemcpyAsync(offsets, off_dev, sizeof(int64_t) * ((size_t)nq + 1), hipMemcpyDeviceToHost, ctx->stream));
-  RRTX_HIP(ctx, hipMemcpyAsync(&total, needed_dev, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  char *host_blk = arena_take(ctx, small_bytes);
+  if (!host_blk) return fail(ctx, RRTX_E_NOMEM, "extend_candidates: staging arena");
+  RRTX_HIP(ctx, hipMemcpyAsync(host_blk, blk, small_bytes, hipMemcpyDeviceToHost, ctx->stream));
   RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int64_t total = 0;
+  std::memcpy(offsets, host_blk, o_cnt);
+  std::memcpy(&total, host_blk + o_cnt, sizeof(int64_t));
   if (needed) *needed = total;
   ctx->last_neighbors = total;
   if (total > cap) return fail(ctx, RRTX_E_CAPACITY, "extend_candidates: %lld neighbours, capacity %lld", (long long)total, (long long)cap);
   if (total > 0) {
-    RRTX_HIP(ctx, hipMemcpyAsync(idx, ctx->ws_out_idx.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
-    RRTX_HIP(ctx, hipMemcpyAsync(cost, ctx->ws_out_dist.p, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
-    RRTX_HIP(ctx, hipMemcpyAsync(hit_out, ctx->ws_out_u8a.p, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
-    RRTX_HIP(ctx, hipMemcpyAsync(hit_in, ctx->ws_out_u8b.p, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = d2h(ctx, cost, ctx->ws_out_dist.p, sizeof(double) * (size_t)total))) return rc;
+    if ((rc = d2h(ctx, idx, ctx->ws_out_idx.p, sizeof(int32_t) * (size_t)total))) return rc;
+    if ((rc = d2h(ctx, hit_out, ctx->ws_out_u8a.p, (size_t)total))) return rc;
+    if ((rc = d2h(ctx, hit_in, ctx->ws_out_u8b.p, (size_t)total))) return rc;
   }
-  if (sample_unsafe)
-    RRTX_HIP(ctx, hipMemcpyAsync(sample_unsafe, unsafe_dev, (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
-  if (nearest_idx && nearest_dist) {
-    RRTX_HIP(ctx, hipMemcpyAsync(nearest_idx, ctx->ws_out_i32.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
-    RRTX_HIP(ctx, hipMemcpyAsync(nearest_dist, ctx->ws_out_f64.p, sizeof(double) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+  // (the per-sample results are copied out of the arena while the per-entry transfers are in flight)
+  if (sample_unsafe) std::memcpy(sample_unsafe, host_blk + o_un, (size_t)nq);
+  if (want_nearest) {
+    std::memcpy(nearest_dist, host_blk + o_nd, sizeof(double) * (size_t)nq);
+    std::memcpy(nearest_idx, host_blk + o_ni, sizeof(int32_t) * (size_t)nq);
   }
-  RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (total > 0) {
+    RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    arena_flush(ctx);
+  }
   if (nearest_idx && nearest_dist) {
     // samples with an empty ball: resolve with the full nearest scan
     std::vector<int> miss;

@@ -81,6 +81,14 @@ struct rrtx_ctx {
   int dim = 3;
   int device = 0;
   hipStream_t own_stream = nullptr;
+  // host-pointer entry points: results leave the device through ONE pinned staging arena (hipHostMalloc; DMA at PCIe
+  // rate, no driver-side staging of pageable memory) and are copied into the caller's arrays after the final sync --
+  // unless the caller registered its arrays (rrtx_host_register), in which case the DMA goes straight to them
+  char *h_arena = nullptr;
+  size_t h_arena_bytes = 0, h_arena_used = 0;
+  struct HostCopy { void *dst; const void *src; size_t bytes; };
+  std::vector<HostCopy> h_pending;                       // arena -> caller copies to run after the next sync
+  std::vector<std::pair<const char *, size_t>> h_registered;
   hipStream_t stream = nullptr;
   std::string err;
 

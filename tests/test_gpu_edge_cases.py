@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from rrtqx_3d_amd import _capi
+from rrtqx_3d_amd._capi import RrtxError
 from rrtqx_3d_amd.context import Context
 
 pytestmark = pytest.mark.gpu
@@ -129,3 +130,33 @@ def test_results_are_deterministic_across_runs():
                 assert np.array_equal(out[k], ref[k]), k
             n = ctx.nn_nearest(Q)
             assert np.array_equal(n[0], refn[0]) and np.array_equal(n[1], refn[1])
+
+
+def test_host_path_registered_and_pageable_outputs_agree():
+    """rrtx_extend_candidates moves results through the context's pinned arena, or by direct DMA into arrays the caller
+    registered (rrtx_host_register): same bytes either way, also when the arrays are reused across calls of different
+    sizes and when capacity runs out (two-call pattern)."""
+    from rrtqx_3d_amd import synth
+    pts, sph = synth.nodes(20_000, 3), synth.spheres(24)
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        ctx.spheres_set(sph)
+        ref = ctx.extend_candidates(synth.queries(700, 3), 5.0, 0.5)
+        plain = ctx.extend_out_buffers(700, 40_000)
+        pinned = ctx.extend_out_buffers(700, 40_000, register=True)
+        for ob in (plain, pinned, plain, pinned):
+            got = ctx.extend_candidates(synth.queries(700, 3), 5.0, 0.5, out=ob)
+            for k in ref:
+                assert np.array_equal(got[k], ref[k]), k
+        small = ctx.extend_candidates(synth.queries(300, 3, seed=5), 5.0, 0.5)          # fewer samples through the same arrays
+        sub = {k: (v[:301] if k == "offsets" else (v[:300] if v.shape[0] == 700 else v)) for k, v in pinned.items()}
+        got = ctx.extend_candidates(synth.queries(300, 3, seed=5), 5.0, 0.5, out=sub)
+        for k in small:
+            assert np.array_equal(got[k], small[k]), k
+        tiny = ctx.extend_out_buffers(700, 100)
+        with pytest.raises(RrtxError):
+            ctx.extend_candidates(synth.queries(700, 3), 5.0, 0.5, out=tiny)
+        for a in pinned.values():
+            ctx.host_unregister(a)
+        with pytest.raises(RrtxError):
+            ctx.host_unregister(pinned["idx"])

@@ -387,3 +387,79 @@ def test_T3_dubins_time_moving_obstacle(oracle):
     # a static polygon sitting on the route is hit whatever the times are
     static = oracle.PolygonSet([sq + [0.0, 5.0]])
     assert oracle.dubins_edge_check_polygons_time(static, s, g, traj, 0.5, 1.0) == (True, 0)
+
+
+def test_T4_time_column_piecewise_vs_running_sum(oracle):
+    """The time column of edge.trajectory: the reference adds the straight pieces between stored rows up one by one
+    (R/DRRT_DubinsEdge_functions.jl:691-695; oracle default); the HIP kernels take (distance at the first row of the
+    piece) + k x (the piece's first chord) (oracle piecewise=True, what the device is compared with bit for bit).
+    Same x / y rows, time stamps equal to 1e-12 relative, first and last rows exact in both."""
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for _ in range(400):
+        s = np.r_[rng.uniform(-20, 20, 2), rng.uniform(10, 30), rng.uniform(0, 2 * math.pi)]
+        g = np.r_[s[:2] + rng.normal(0, 8, 2), s[2] - rng.uniform(0.1, 5.0), rng.uniform(0, 2 * math.pi)]
+        a = oracle.dubins_steer_time(s, g, 2.0)
+        b = oracle.dubins_steer_time(s, g, 2.0, piecewise=True)
+        assert a[:4] == b[:4] and a[4].shape == b[4].shape
+        assert np.array_equal(a[4][:, :2], b[4][:, :2])
+        assert np.array_equal(a[4][0], b[4][0]) and np.array_equal(a[4][-1], b[4][-1]) and np.array_equal(b[4][-1], g[:3])
+        worst = max(worst, float(np.abs(a[4][:, 2] - b[4][:, 2]).max() / max(1.0, abs(s[2]))))
+    assert 0.0 < worst < 1e-12
+
+
+def test_K13_conflict_nodes_dubins_query(oracle):
+    """findPointsInConflictWithObstacle(::Obstacle) in the Dubins space (R/DRRT.jl:3061-3065): query [x y 0.0 pi],
+    range robotRadius + delta + ob.radius + pi, KDdist over all four coordinates, the root taken with <=.
+    Unit square at the origin: centre (.5, .5), radius sqrt(.5); robotRadius .5, delta 1 => range = 2.2071 + pi."""
+    rng_ = 0.5 + 1.0 + math.sqrt(0.5) + math.pi
+    sq = [[0, 0], [1, 0], [1, 1], [0, 1]]
+    ps = oracle.PolygonSet([sq])
+    tree = oracle.KDTree(4, wraps=[3], wrap_points=[2 * math.pi])
+    nodes = [
+        [0.5 + rng_, 0.5, 0.0, math.pi],       # 0, the root, exactly at the range: in (<=)
+        [0.5, 0.5, 0.0, 0.0],                   # 1: only the heading differs, by pi: in (pi < range)
+        [0.5 + 4.0, 0.5, 0.0, math.pi],         # 2: 4.0 < range: in
+        [0.5 + 5.4, 0.5, 0.0, math.pi],         # 3: 5.4 > range: out
+        [0.5 + rng_, 0.5, 0.0, math.pi],        # 4: the root's twin, not the root: exactly at the range is OUT (<)
+        [0.5 + 4.5, 0.5, 0.0, 6.2],             # 5: sqrt(4.5^2 + (6.2 - pi)^2) = 5.44 > range: out (the ghost at -pi is farther)
+        [0.5, 0.5 - 3.0, 0.0, 1.0],             # 6: sqrt(9 + (pi - 1)^2) = 3.69: in
+    ]
+    for p in nodes:
+        tree.insert(np.array(p))
+    d0 = math.sqrt((((rng_ * rng_) + 0.0) + 0.0) + 0.0)
+    assert d0 == rng_                                        # the construction really puts nodes 0 and 4 AT the range
+    got = sorted(oracle.points_in_conflict_polygon(tree, ps, 0, 0.5, 1.0, False, True).tolist())
+    assert got == [0, 1, 2, 6]
+    with pytest.raises(RuntimeError):                        # a static obstacle in a space with time: the reference raises (:3067)
+        oracle.points_in_conflict_polygon(tree, ps, 0, 0.5, 1.0, True, True)
+
+
+def test_K14_conflict_nodes_moving_obstacle_path_queries(oracle):
+    """kinds 6 / 7 (R/DRRT.jl:3070-3118): one query per path segment i -> i + 1 at [ob.position 0.0] + (path[i] +
+    path[i+1]) / 2 (x, y and time) with range base + |path[i] - path[i+1]| / 2, accumulated; a one-row path gives one
+    query at [ob.position 0.0] + path[1] with range base.  Euclidean space with time (d = 3: [x y t])."""
+    sq = np.array([[-0.5, -0.5], [0.5, -0.5], [0.5, 0.5], [-0.5, 0.5]])          # centre (0, 0), radius sqrt(.5)
+    base = 0.5 + 1.0 + math.sqrt(0.5)                                            # 2.2071
+    path = np.array([[0.0, 0.0, 0.0], [2.0, 0.0, 10.0], [2.0, 4.0, 20.0]])
+    # query 1 at (1, 0, 5), range base + sqrt(104) / 2 = 7.306; query 2 at (2, 2, 15), range base + sqrt(116) / 2 = 7.592
+    ps = oracle.PolygonSet([sq], kinds=[6], paths=[path])
+    tree = oracle.KDTree(3)
+    nodes = [
+        [50.0, 50.0, 50.0],     # 0 root, far: out
+        [1.0, 0.0, 5.0],        # 1 at query 1: in
+        [1.0, 7.0, 5.0],        # 2: 7.0 from query 1: in
+        [1.0, 7.4, 5.0],        # 3: 7.4 > 7.306 from query 1; from query 2: sqrt(1 + 5.4^2 + 100) = 11.4: out
+        [2.0, 2.0, 22.5],       # 4: 7.5 from query 2 only: in
+        [2.0, 2.0, 22.7],       # 5: 7.7 > 7.592: out
+        [1.5, 1.0, 10.0],       # 6: within both (5.1 and 5.1): in once
+    ]
+    for p in nodes:
+        tree.insert(np.array(p))
+    got = oracle.points_in_conflict_polygon(tree, ps, 0, 0.5, 1.0, True, False).tolist()
+    assert sorted(got) == [1, 2, 4, 6] and len(got) == 4          # node 6 is in the list once (inHeap)
+    one = oracle.PolygonSet([sq], kinds=[7], paths=[np.array([[3.0, 0.0, 7.0]])])
+    tree2 = oracle.KDTree(3)
+    for p in ([40.0, 0.0, 0.0], [3.0, 0.0, 7.0], [3.0, 2.2, 7.0], [3.0, 2.21, 7.0]):
+        tree2.insert(np.array(p))
+    assert sorted(oracle.points_in_conflict_polygon(tree2, one, 0, 0.5, 1.0, True, False).tolist()) == [1, 2]
