@@ -286,8 +286,12 @@ int rrtx_obstacle_sweep_polygon(rrtx_ctx *ctx, int obstacle, double robot_radius
  * with rrtx_graph_edges_block for the ids rrtx_obstacle_sweep returned (addNewObstacle: `dist = Inf`,
  * R/DRRT_Q.jl:3249).  parent_edge[v] (may be NULL) = the id of the mirrored edge v -> rrtParent(v): the lowest id
  * among the edges that attain the minimum (-1: the root, or an orphan).  passes (may be NULL) = relaxation
- * passes run.  A positive changeThresh makes the reference's result depend on its pop order; that variant is
- * not offered.
+ * passes run.  CONTRACT: changeThresh = 0 run to exhaustion only -- a positive changeThresh (the value the one
+ * runnable script passes, R/experimentsForRRTQX.jl:30,132) and the goal-bounded loop of reduceInconsistency
+ * (R/DRRT_Q.jl:2706) make the reference's result depend on its pop order; that epsilon-consistent variant is not
+ * offered and stays on the host.  A solve that cannot reach a fixed point (a pass limit, a parent structure that is
+ * no forest, a HIP error part-way) returns RRTX_E_STATE / RRTX_E_DEVICE and FORGETS the previous solve: the next
+ * rrtx_graph_cost_update then solves in full.
  * rrtx_graph_cost_update gives the same answer starting from the state the previous call (either function, same
  * root) left on the device: nodes and edges appended since then, costs changed with set_dist / block.  This is
  * the replanning step: edges whose cost was touched and that were parent edges orphan their subtrees

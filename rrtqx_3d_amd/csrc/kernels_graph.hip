@@ -435,7 +435,21 @@ int launch_graph_touch(rrtx_ctx *ctx, long long first, long long n) {
 
 // lmc_dev: n_nodes doubles, parent_dev: n_nodes int32 (may be null).  update = continue from the previous solve when
 // there is one for this root.
+static int graph_cost_impl(rrtx_ctx *ctx, int root, bool update, double *lmc_dev, int32_t *parent_dev, int *passes_out);
+
+// A solve that fails part-way (a HIP error, a round or pass limit reached) has already rewritten the node state: the
+// record of the last solve is dropped, so the next call -- update or not -- starts from scratch instead of resuming from
+// a state no fixed point stands behind.
 int launch_graph_cost(rrtx_ctx *ctx, int root, bool update, double *lmc_dev, int32_t *parent_dev, int *passes_out) {
+  const int rc = graph_cost_impl(ctx, root, update, lmc_dev, parent_dev, passes_out);
+  if (rc != RRTX_OK) {
+    if (ctx->span_open) span_end(ctx);
+    graph_cost_forget(ctx);
+  }
+  return rc;
+}
+
+static int graph_cost_impl(rrtx_ctx *ctx, int root, bool update, double *lmc_dev, int32_t *parent_dev, int *passes_out) {
   GraphCost &gc = ctx->gc;
   const int n = (int)ctx->n_nodes;
   const long long ne = ctx->ge_n;
@@ -486,6 +500,7 @@ int launch_graph_cost(rrtx_ctx *ctx, int root, bool update, double *lmc_dev, int
       if (host_flags[kFlagOrphans]) {
         // pointer jumping doubles the reach every round; 40 rounds bound the work whatever the forest looks like
         int cur = 0;
+        bool settled = false;
         for (int round = 0; round < 40;) {
           RRTX_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(int) * 4, st));
           for (int k = 0; k < 4; ++k, ++round) {
@@ -495,8 +510,11 @@ int launch_graph_cost(rrtx_ctx *ctx, int root, bool update, double *lmc_dev, int
           }
           rc = read_flags(ctx, host_flags);
           if (rc) return rc;
-          if (!host_flags[3]) break;
+          if (!host_flags[3]) { settled = true; break; }
         }
+        if (!settled)
+          return fail(ctx, RRTX_E_STATE, "graph_cost_update: the orphan marking did not settle in 40 rounds of pointer jumping "
+                                         "(a parent forest deeper than 2^40 cannot exist: the parent edges do not form a forest)");
         orph += (size_t)cur * n;
         hipLaunchKernelGGL(graph_orphan_reset_kernel, grid_for(n), dim3(256), 0, st, s, orph, n);
       } else {
@@ -515,7 +533,8 @@ int launch_graph_cost(rrtx_ctx *ctx, int root, bool update, double *lmc_dev, int
   const dim3 pgrid((unsigned)(node_blocks + (tail_now + 255) / 256));
   int pass = resume ? 2 : 1;
   int group = 8;                                 // 8, 16, 32, 32, ...: a pass over an empty frontier costs little
-  while (ne > 0 && pgrid.x > 0 && total < (1 << 22)) {
+  bool fixed_point = !(ne > 0 && pgrid.x > 0);
+  while (!fixed_point && total < (1 << 22)) {
     RRTX_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(int) * kGroupMax, st));
     for (int k = 0; k < group; ++k)
       hipLaunchKernelGGL(graph_pass_kernel, pgrid, dim3(256), 0, st, gc.in_start.as<int>(), gc.in_src.as<int32_t>(), gc.in_w.as<double>(),
@@ -524,9 +543,11 @@ int launch_graph_cost(rrtx_ctx *ctx, int root, bool update, double *lmc_dev, int
     if (rc) return rc;
     pass += group;
     total += group;
-    if (!host_flags[group - 1]) break;            // the last pass of the group changed nothing: fixed point
+    if (!host_flags[group - 1]) { fixed_point = true; break; }   // the last pass of the group changed nothing
     if (group < kGroupMax) group *= 2;
   }
+  if (!fixed_point)
+    return fail(ctx, RRTX_E_STATE, "graph_cost: no fixed point after %d relaxation passes (negative or NaN edge costs?)", total);
   // parent edges, from scratch (so that an update and a full solve agree on ties too)
   RRTX_HIP(ctx, hipMemsetAsync(flags + kFlagZeroCost, 0, sizeof(int), st));
   hipLaunchKernelGGL(graph_parent_clear_kernel, grid_for(n), dim3(256), 0, st, s.parent, n);

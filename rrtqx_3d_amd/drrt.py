@@ -483,8 +483,8 @@ def explicitEdgeChecks(S: CSpace, edges: Sequence[SimpleEdge], obstacle=None) ->
     s = np.concatenate([e.startNode.position for e in edges], axis=0)
     g = np.concatenate([e.endNode.position for e in edges], axis=0)
     if isinstance(edges[0], DubinsEdge):
-        if which >= 0:
-            error("single-obstacle Dubins checks are not batched yet")
+        if which >= 0:      # explicitEdgeCheck(S, edge::DubinsEdge, ob), R/DRRT_DubinsEdge_functions.jl:750-774
+            return ctx.dubins_edges_check_obstacle(s, g, S.minTurningRadius, S.robotRadius, which).astype(bool)
         _, _, hit, _ = ctx.dubins_edges_check(s, g, S.minTurningRadius, S.robotRadius)
         return hit.astype(bool)
     hit, _ = ctx.edges_check(s, g, S.robotRadius, kind=kind, obstacle=which, want_first=False)

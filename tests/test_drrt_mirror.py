@@ -160,3 +160,50 @@ def test_obstacle_sweeps(oracle):
     ko, mk = oracle.make_spheres(np.array([[*o.position, o.radius] for o in keep]))
     for e, h in zip(edges, others):
         assert bool(h) == oracle.edge_check_spheres(ko, mk, e.startNode.position, e.endNode.position, 0.5)[0]
+
+
+@pytest.mark.gpu
+def test_obstacle_sweep_polygon_through_the_mirror(oracle):
+    """drrt.obstacleSweep with an Obstacle (polygon list): addNewObstacle's and removeObstacle's edge loops of the
+    legacy planner (R/DRRT.jl:3127-3290) in one call each, against the oracle's restatement over the same edges."""
+    import math
+    from rrtqx_3d_amd import drrt
+    rng = np.random.default_rng(17)
+    S = drrt.CSpace(4, -1.0, [-15, -15, 0, 0], [15, 15, 0, 2 * math.pi], [0, 0, 0, 0], [1, 1, 0, 0])
+    S.robotRadius, S.delta, S.minTurningRadius, S.spaceHasTheta = 0.5, 6.0, 1.0, True
+    KD = drrt.KDTree(4, None, [4], [2.0 * math.pi])
+    pts = np.c_[rng.uniform(-15, 15, (600, 2)), np.zeros(600), rng.uniform(0, 2 * math.pi, 600)]
+    nodes = [drrt.RRTNode(p) for p in pts]
+    for nd in nodes:
+        drrt.kdInsert(KD, nd)
+    squares = [np.array([[x, y], [x + 3, y], [x + 3, y + 2], [x, y + 2]], dtype=float) for x, y in ((-6, -4), (2, 1), (2.5, 1.5))]
+    obs = [drrt.Obstacle(3, sq) for sq in squares]
+    for ob in obs:
+        ob.obstacleUnused = False
+        drrt.listPush(S.obstacles, ob)
+    edges = []
+    for i in range(600):
+        for j in rng.choice(600, 5, replace=False):
+            if i != j:
+                edges.append(drrt.newEdge(nodes[i], nodes[int(j)], drrt.DubinsEdge))
+    assert drrt.registerEdges(KD, edges) == 0
+    es = np.array([e.startNode.index for e in edges], dtype=np.int32)
+    ee = np.array([e.endNode.index for e in edges], dtype=np.int32)
+    tree = oracle.KDTree(4, wraps=[3], wrap_points=[2.0 * math.pi])
+    tree.insert_many(pts)
+    order = list(S.obstacles)                                   # list order: front = most recently pushed
+    ps = oracle.PolygonSet([o.polygon for o in order])
+    blocked = np.zeros(len(edges), dtype=bool)
+    for ob in obs:
+        j = order.index(ob)
+        ids = drrt.obstacleSweep(S, KD, ob)
+        want = oracle.add_new_obstacle_edges(tree, pts, es, ee, ps, j, 0.5, 6.0, dubins=True, r_min=1.0)
+        assert np.array_equal(ids, want)
+        blocked[ids] = True
+    assert blocked.sum() > 20
+    drrt.blockEdges(KD, np.nonzero(blocked)[0].astype(np.int32))
+    dist = np.where(blocked, np.inf, 1.0)
+    ob = obs[1]                                                 # overlaps obs[2]: shared edges stay blocked
+    ids = drrt.obstacleSweep(S, KD, ob, remove=True)
+    want = oracle.remove_obstacle_edges(tree, pts, es, ee, dist, ps, order.index(ob), 0.5, 6.0, dubins=True, r_min=1.0)
+    assert np.array_equal(ids, want) and 0 < len(ids) < blocked.sum()
