@@ -1278,7 +1278,7 @@ int sync_polygons(rrtx_ctx *ctx) {
   const int m = (int)ctx->poly_active.size();
   std::vector<double> meta;
   std::vector<int32_t> off(1, 0), orig;
-  std::vector<double> vxy, path, slope, bbox, ytab;
+  std::vector<double> vxy, path, slope, bbox, ytab, pbox;
   std::vector<int32_t> path_off(1, 0);
   bool moving = false;
   for (int i = 0; i < m; ++i) {
@@ -1290,6 +1290,22 @@ int sync_polygons(rrtx_ctx *ctx) {
       moving = true;
     }
     path.insert(path.end(), ctx->poly_path.begin() + 3 * (size_t)pr0, ctx->poly_path.begin() + 3 * (size_t)pr1);
+    {
+      // where the obstacle's centre can be while it moves: the box of position + path[k, 1:2] over all rows, the very
+      // sums the moving-obstacle edge test forms (R/DRRT.jl:1607-1608); a NaN makes that side NaN (nothing is disjoint
+      // from such a box)
+      const double pcx = ctx->poly_cr[3 * (size_t)i + 0], pcy = ctx->poly_cr[3 * (size_t)i + 1];
+      double x0 = pcx, x1 = pcx, y0 = pcy, y1 = pcy;
+      if (pr1 > pr0) { x0 = y0 = __builtin_inf(); x1 = y1 = -__builtin_inf(); }
+      for (int k = pr0; k < pr1; ++k) {
+        const double x = ctx->poly_path[3 * (size_t)k] + pcx, y = ctx->poly_path[3 * (size_t)k + 1] + pcy;
+        if (!(x >= x0)) x0 = x;
+        if (!(x <= x1)) x1 = x;
+        if (!(y >= y0)) y0 = y;
+        if (!(y <= y1)) y1 = y;
+      }
+      pbox.push_back(x0); pbox.push_back(x1); pbox.push_back(y0); pbox.push_back(y1);
+    }
     path_off.push_back((int32_t)(path.size() / 3));
     meta.push_back(ctx->poly_cr[3 * (size_t)i + 0]);
     meta.push_back(ctx->poly_cr[3 * (size_t)i + 1]);
@@ -1340,6 +1356,8 @@ int sync_polygons(rrtx_ctx *ctx) {
     RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_orig.p, orig.data(), sizeof(int32_t) * na, hipMemcpyHostToDevice));
     RRTX_HIP(ctx, ctx->d_poly_bbox.ensure(sizeof(double) * bbox.size()));
     RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_bbox.p, bbox.data(), sizeof(double) * bbox.size(), hipMemcpyHostToDevice));
+    RRTX_HIP(ctx, ctx->d_poly_pbox.ensure(sizeof(double) * pbox.size()));
+    RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_pbox.p, pbox.data(), sizeof(double) * pbox.size(), hipMemcpyHostToDevice));
     RRTX_HIP(ctx, ctx->d_poly_ytab.ensure(sizeof(double) * (ytab.size() + 1)));
     if (!ytab.empty())
       RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_ytab.p, ytab.data(), sizeof(double) * ytab.size(), hipMemcpyHostToDevice));

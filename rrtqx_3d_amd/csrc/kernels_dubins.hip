@@ -390,6 +390,7 @@ struct PolyTab {
   const double *vslope;      // per vertex: slope of the side that ends there (sync_polygons)
   const int32_t *poff;       // path CSR (kinds 6 / 7)
   const double *path;        // rows (dx, dy, t)
+  const double *pbox;        // per obstacle: box (xlo, xhi, ylo, yhi) of its centre over its whole path
   int m;
 };
 
@@ -593,11 +594,24 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
       const int j = j0 + lane;
       const float inf = __builtin_inff();
       float4 o = {-inf, inf, -inf, inf};
-      if (!(TIME && meta[4 * j + 3] >= 6.0)) {                 // (a moving obstacle is not where its record says)
+      if (!(TIME && meta[4 * j + 3] >= 6.0)) {
         const double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
         const double R = fabs((robot_radius + 2 * r_min) + meta[4 * j + 2]) * (1.0 + 1e-9) + 1e-9 * (1.0 + fabs(cx) + fabs(cy));
         o.x = __double2float_rd(cx - R); o.y = __double2float_ru(cx + R);
         o.z = __double2float_rd(cy - R); o.w = __double2float_ru(cy + R);
+      } else {
+        // An obstacle that moves is not where its record says -- but wherever the closest-approach test places it (a point
+        // of one of its path segments, R/DRRT.jl:1607-1640: the time of closest approach is clamped into the segment's
+        // window) its centre lies in the box of position + path rows, and the robot's centre on the chord.  Boxes farther
+        // apart than the test radius + the obstacle's radius: the squared distance the test compares is at least that
+        // gap squared -- no hit for any segment.  (NaN sides, NaN comparisons: the obstacle is kept.)
+        const double4 pb = reinterpret_cast<const double4 *>(tab.pbox)[j];
+        const double R = fabs((robot_radius + 2 * r_min) + meta[4 * j + 2]) * (1.0 + 1e-9) +
+                         1e-9 * (1.0 + fabs(pb.x) + fabs(pb.y) + fabs(pb.z) + fabs(pb.w));
+        if (R == R && pb.x == pb.x && pb.y == pb.y && pb.z == pb.z && pb.w == pb.w) {
+          o.x = __double2float_rd(pb.x - R); o.y = __double2float_ru(pb.y + R);
+          o.z = __double2float_rd(pb.z - R); o.w = __double2float_ru(pb.w + R);
+        }
       }
       obox[lane] = o;
     }
@@ -914,7 +928,17 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
               const int b = __ffsll((long long)mm) - 1;
               mm &= mm - 1ull;
               const bool moving = TIME && meta[4 * (j0 + b) + 3] >= 6.0;   // no bounding-circle step for those (:1579)
-              if (moving || !seg_outside_circle(px, py, x, y, robot_radius, meta, j0 + b)) pending |= 1ull << b;
+              bool keep;
+              if (moving) {
+                // ... but the same box argument as in stage 1a: the obstacle's centre stays in the box of its path, the
+                // robot's on this piece; farther apart than robotRadius + radius in x or in y: no hit at any instant
+                const double4 pb = reinterpret_cast<const double4 *>(tab.pbox)[j0 + b];
+                const double R = fabs(robot_radius + meta[4 * (j0 + b) + 2]) * (1.0 + 1e-9) +
+                                 1e-9 * (1.0 + fabs(pb.x) + fabs(pb.y) + fabs(pb.z) + fabs(pb.w) + fabs(px) + fabs(py));
+                keep = !((fmin(px, x) - pb.y > R) || (pb.x - fmax(px, x) > R) || (fmin(py, y) - pb.w > R) || (pb.z - fmax(py, y) > R));
+                if (!(px - px == 0.0 && py - py == 0.0 && x - x == 0.0 && y - y == 0.0)) keep = true;   // (fmin / fmax drop a NaN)
+              } else keep = !seg_outside_circle(px, py, x, y, robot_radius, meta, j0 + b);
+              if (keep) pending |= 1ull << b;
             }
           }
         }
@@ -1187,6 +1211,7 @@ PolyTab poly_tab(rrtx_ctx *ctx) {
   t.vslope = ctx->d_poly_slope.as<double>();
   t.poff = ctx->d_poly_path_off.as<int32_t>();
   t.path = ctx->d_poly_path.as<double>();
+  t.pbox = ctx->d_poly_pbox.as<double>();
   t.m = ctx->poly_n_active;
   return t;
 }
@@ -1321,6 +1346,7 @@ static PolyTab tab_range(const PolyTab &t, int pb, int pe) {
   r.meta = t.meta + 4 * (size_t)pb;
   r.off = t.off + pb;
   r.poff = t.poff + pb;
+  r.pbox = t.pbox + 4 * (size_t)pb;
   r.m = pe - pb;
   return r;
 }

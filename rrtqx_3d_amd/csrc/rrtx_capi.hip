@@ -482,7 +482,7 @@ int rrtx_destroy(rrtx_ctx *ctx) {
   ctx->d_absmax.release();
   ctx->d_xrange.release();
   DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_reach, &ctx->d_sph_reach_f, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_slope, &ctx->d_poly_meta,
-                    &ctx->d_poly_orig, &ctx->d_poly_bbox, &ctx->d_poly_ytab, &ctx->d_poly_path_off, &ctx->d_poly_path, &ctx->ws_knn_off, &ctx->ws_knn_idx,
+                    &ctx->d_poly_orig, &ctx->d_poly_bbox, &ctx->d_poly_ytab, &ctx->d_poly_pbox, &ctx->d_poly_path_off, &ctx->d_poly_path, &ctx->ws_knn_off, &ctx->ws_knn_idx,
                     &ctx->ws_knn_dist, &ctx->ws_knn_misc, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
                     &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_bsum, &ctx->ws_scalars, &ctx->ws_scalars_nn, &ctx->ws_tmp,
                     &ctx->ws_owner, &ctx->ws_dub_rec, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,

@@ -173,6 +173,7 @@ struct rrtx_ctx {
   // flag-only point checks (points_polygons_kernel's fast path): per packed obstacle the exact bounding box of its
   // vertices (xmin, xmax, ymin, ymax); the sorted y coordinates of every vertex of the packed kind-3 polygons
   rrtx::DevBuf d_poly_bbox, d_poly_ytab;
+  rrtx::DevBuf d_poly_pbox;    // per packed obstacle: box of its centre over its whole path (kinds 6 / 7; a point otherwise)
   int poly_n_ytab = 0;
   rrtx::DevBuf ws_knn_off, ws_knn_idx, ws_knn_dist, ws_knn_misc;   // k-nearest via range-search lists
   int opt_knn_lists = 1;
