@@ -123,28 +123,36 @@ def issue_roofline(kernel, tj, kernel_ms, extra_note=""):
 
 
 # --------------------------------------------------------------------- CPU baselines ----
-def cpu_baseline(cfg, pts, Q, sph, r, budget_s=10.0):
-    """Oracle (C restatement of the reference's per-sample loop) on one host core."""
+def cpu_baseline(cfg, pts, Q, sph, r, budget_s=10.0, polys=None):
+    """Oracle (C restatement of the reference's per-sample loop) on one host core; polys: against the polygon list."""
     from oracle import oracle as O
     tree = O.KDTree(cfg.dim)
     tree.insert_many(pts)
-    osph, m = O.make_spheres(sph)
+    if polys is not None:
+        ps = O.PolygonSet(polys)
+        m, what = ps.m, "polygons"
+        run = lambda qs: O.extend_batch_polygons(tree, ps, qs, r, ROBOT_RADIUS)
+    else:
+        osph, m = O.make_spheres(sph)
+        what = "spheres"
+        run = lambda qs: O.extend_batch_spheres(tree, osph, m, qs, r, ROBOT_RADIUS)
     nq = Q.shape[0]
     # calibrate on a slice, then run a bounded sample
     t0 = time.perf_counter()
-    O.extend_batch_spheres(tree, osph, m, Q[:256], r, ROBOT_RADIUS)
+    run(Q[:256])
     per_q = (time.perf_counter() - t0) / 256
     n_sample = int(min(nq, max(256, budget_s / max(per_q, 1e-9))))
     t0 = time.perf_counter()
-    edges, neigh, hits, _ = O.extend_batch_spheres(tree, osph, m, Q[:n_sample], r, ROBOT_RADIUS)
+    edges, neigh, hits, _ = run(Q[:n_sample])
     dt = time.perf_counter() - t0
     out = {
         "value": edges / dt, "unit": "edges/s", "cores": 1, "kind": "port",
         "sample": f"first {n_sample} of {nq} samples of the same workload (kd-tree nearest + range + "
-                  f"{edges} directed edges x {m} spheres with first-hit early-out), {dt:.1f} s on 1 host core",
+                  f"{edges} directed edges x {m} {what} with first-hit early-out), {dt:.1f} s on 1 host core",
         "nn_queries_per_s": n_sample / dt,
     }
-    out["all_cores"] = cpu_baseline_all_cores(cfg, pts, Q, sph, r, per_q)
+    if polys is None:
+        out["all_cores"] = cpu_baseline_all_cores(cfg, pts, Q, sph, r, per_q)
     return out
 
 
@@ -1147,7 +1155,7 @@ def main():
         if world == 1 and args.agents > 1:
             out["concurrent_agents"] = concurrent_agents(args.agents, torch, dev, pts, sph, r, B, cap, N)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, pts, m["host_q"][0], sph, r)
+            out["cpu_baseline"] = cpu_baseline(cfg, pts, m["host_q"][0], sph, r, polys=polys_all if use_polys else None)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -156,6 +156,9 @@ def lib() -> C.CDLL:
     L.orc_extend_batch_spheres.restype = C.c_int64
     L.orc_extend_batch_spheres.argtypes = [C.c_void_p, C.POINTER(Sphere), C.c_int, c_double_p, C.c_int64,
                                            C.c_double, C.c_double, c_int64_p, c_int64_p, c_int64_p]
+    L.orc_extend_batch_polygons.restype = C.c_int64
+    L.orc_extend_batch_polygons.argtypes = [C.c_void_p, C.POINTER(Polygon), C.c_int, c_double_p, C.c_int64,
+                                            C.c_double, C.c_double, c_int64_p, c_int64_p, c_int64_p]
     _lib = L
     return L
 
@@ -628,6 +631,17 @@ class Graph:
 
 def julia_range_len(start, step, stop) -> int:
     return lib().orc_julia_range_len(start, step, stop)
+
+
+def extend_batch_polygons(tree: KDTree, ps: "PolygonSet", queries: np.ndarray, r: float, robot_radius: float):
+    """CPU-baseline loop against a polygon list. Returns (edges_checked, neighbours, hits, nearest_idx)."""
+    q = np.ascontiguousarray(queries, dtype=np.float64)
+    nq = q.shape[0]
+    nearest = np.empty(nq, dtype=np.int64)
+    nn, nh = C.c_int64(), C.c_int64()
+    e = lib().orc_extend_batch_polygons(tree.handle, ps.arr, ps.m, _dp(q), nq, r, robot_radius,
+                                        nearest.ctypes.data_as(c_int64_p), C.byref(nn), C.byref(nh))
+    return e, nn.value, nh.value, nearest
 
 
 def extend_batch_spheres(tree: KDTree, spheres, m, queries: np.ndarray, r: float, robot_radius: float):

@@ -1432,3 +1432,35 @@ int64_t orc_extend_batch_spheres(orc_kd *t, const orc_sphere *obs, int m, const 
   if (n_hits_total) *n_hits_total = hits;
   return edges;
 }
+
+/* the same loop with CSpace.obstacles a list of polygon Obstacles: explicitEdgeCheck over the list with the first
+ * hit's early return (R/DRRT.jl:1660-1678), explicitPointCheck of the sample (R/DRRT.jl:1434-1470) */
+int64_t orc_extend_batch_polygons(orc_kd *t, const orc_polygon *obs, int m, const double *queries, int64_t nq, double r,
+                                  double robot_radius, int64_t *nearest_idx, int64_t *n_neighbors_total,
+                                  int64_t *n_hits_total) {
+  int64_t edges = 0, neigh = 0, hits = 0;
+  volatile double sink = 0.0;
+  for (int64_t i = 0; i < nq; ++i) {
+    const double *q = queries + i * t->d;
+    int64_t ni; double nd, cl;
+    orc_kd_nearest(t, q, &ni, &nd);
+    if (nearest_idx) nearest_idx[i] = ni;
+    hits += orc_point_check_polygons(obs, m, q, robot_radius, &cl);
+    orc_list *l = orc_kd_find_within_range(t, r, q);
+    for (int64_t k = l->n - 1; k >= 0; --k) {
+      const double *pn = KPOS(t, l->idx[k]);
+      double c_out = orc_euclid(q, pn, t->d);
+      hits += orc_edge_check_polygons(obs, m, q, pn, robot_radius, NULL);
+      double c_in = orc_euclid(pn, q, t->d);
+      hits += orc_edge_check_polygons(obs, m, pn, q, robot_radius, NULL);
+      sink += c_out + c_in;
+      edges += 2;
+    }
+    neigh += l->n;
+    orc_kd_empty_range_list(t, l);
+  }
+  (void)sink;
+  if (n_neighbors_total) *n_neighbors_total = neigh;
+  if (n_hits_total) *n_hits_total = hits;
+  return edges;
+}

@@ -167,6 +167,10 @@ int64_t orc_extend_batch_spheres(orc_kd *t, const orc_sphere *obs, int m, const 
                                  int64_t *nearest_idx, int64_t *n_neighbors_total,
                                  int64_t *n_hits_total);
 
+int64_t orc_extend_batch_polygons(orc_kd *t, const orc_polygon *obs, int m, const double *queries, int64_t nq, double r,
+                                  double robot_radius, int64_t *nearest_idx, int64_t *n_neighbors_total,
+                                  int64_t *n_hits_total);
+
 /* ---- N4: cost propagation (rrtx_oracle_graph.c): rewire / reduceInconsistency / propogateDescendants with the
  * reference's BinaryHeap and list orders, R/DRRT_Q.jl:2052-2077, 2364-2541, 2647-2817, 3244-3268, R/heap.jl:138-273 */
 typedef struct orc_graph orc_graph;
