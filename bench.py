@@ -465,24 +465,30 @@ def bench_c5(args, torch, dist, dev, rank, world):
     es, ee = np.concatenate(es_l), np.concatenate(ee_l).astype(np.int32)
     del es_l, ee_l
     ctx.graph_edges_append(es, ee)
-    for a in range(0, len(es), 1 << 21):               # edge.dist of a DubinsEdge with time; !validMove edges are blocked
+    # edge.dist of a DubinsEdge with time.  Planning runs in reverse time: an edge leads from a later state to an earlier
+    # one (validMove's first condition, R/DRRT_DubinsEdge_functions.jl:120); the velocity bounds are not applied to the
+    # mirror, so that 24 out-edges per node still make a connected graph.  The root is the earliest node.
+    n_valid = 0
+    for a in range(0, len(es), 1 << 21):
         b = min(len(es), a + (1 << 21))
         st = ctx.dubins_steer_full(pts[es[a:b]], pts[ee[a:b]], r_min)
-        d = np.where(st["valid_move"] != 0, st["dist"], np.inf)
-        ctx.graph_edges_set_dist(a, d)
-    lmc0, _, passes0 = ctx.graph_cost_to_root(0)
+        ok = pts[es[a:b], 2] > pts[ee[a:b], 2]
+        n_valid += int(ok.sum())
+        ctx.graph_edges_set_dist(a, np.where(ok, st["dist"], np.inf))
+    root = int(np.argmin(pts[:, 2]))
+    lmc0, _, passes0 = ctx.graph_cost_to_root(root)
     ctx.set_stream(stream.cuda_stream)
     # ---- fresh batches and output buffers, resident before the clock starts ----
     Qs = [synth.nodes_time(B, seed=synth.SEED + 1 + 1000 * rank + 17 * j) for j in range(RING)]
     d_q = [torch.from_numpy(q).to(dev) for q in Qs]
-    cap = 2800 * B
+    cap = 3400 * B
     f64 = lambda m: torch.empty(m, dtype=torch.float64, device=dev)
     u8 = lambda m: torch.empty(m, dtype=torch.uint8, device=dev)
     d_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
     d_idx = torch.empty(cap, dtype=torch.int32, device=dev)
     d_key, d_co, d_ci = f64(cap), f64(cap), f64(cap)
     d_ho, d_hi, d_un = u8(cap), u8(cap), u8(B)
-    d_need = torch.zeros(steps + warm, dtype=torch.int64, device=dev)
+    d_need = torch.zeros(steps + warm + 1, dtype=torch.int64, device=dev)
     d_ni = torch.empty(B, dtype=torch.int32, device=dev)
     d_nd = f64(B)
 
@@ -507,7 +513,7 @@ def bench_c5(args, torch, dist, dev, rank, world):
             ctx.graph_edges_block(ids)
         torch.cuda.synchronize()
         t.append(time.perf_counter())
-        ctx.graph_cost_update(0, want_parent=False)
+        ctx.graph_cost_update(root, want_parent=False)
         t.append(time.perf_counter())
         n_now = N + i * B
         ri = synth.ball_radius(n_now, 4, gamma=100.0, delta=10.0)
@@ -538,16 +544,22 @@ def bench_c5(args, torch, dist, dev, rank, world):
     fence()
     dt = time.perf_counter() - t0
     ks = [int(v) for v in d_need[warm:warm + steps].tolist()]
+    if max(ks) > cap:
+        raise SystemExit(f"candidate capacity too small in a timed cycle: {max(ks)} > {cap}")
     counts["neighbours"] = sum(ks)
     units = counts["sweep_candidates"] + 2 * sum(ks)           # directed Dubins edges put through explicitEdgeCheck
     # per-family device time of the last cycle's preamble
     ctx.profile(2)
-    ctx.extend_candidates_dubins_dev(d_q[0].data_ptr(), B, r, rr, r_min, d_off.data_ptr(), d_idx.data_ptr(),
+    r_last = synth.ball_radius(N + (warm + steps) * B, 4, gamma=100.0, delta=10.0)
+    ctx.extend_candidates_dubins_dev(d_q[0].data_ptr(), B, r_last, rr, r_min, d_off.data_ptr(), d_idx.data_ptr(),
                                      d_key.data_ptr(), d_co.data_ptr(), d_ci.data_ptr(), None, None, d_ho.data_ptr(),
-                                     d_hi.data_ptr(), cap, d_need.data_ptr(), d_ni.data_ptr(), d_nd.data_ptr(), d_un.data_ptr())
+                                     d_hi.data_ptr(), cap, d_need.data_ptr() + 8 * (steps + warm), d_ni.data_ptr(), d_nd.data_ptr(),
+                                     d_un.data_ptr())
     fence()
     st = ctx.stats()
     ctx.profile(0)
+    if int(d_need[steps + warm].item()) > cap:
+        raise SystemExit("candidate capacity too small in the profiled pass")
     e_sum, t_max = parallel.reduce_throughput(units, dt, device=dev)
     if rank == 0:
         rk = make_run_key(args)
@@ -576,7 +588,8 @@ def bench_c5(args, torch, dist, dev, rank, world):
                        "sharding": "replicas only: every rank its own planner (tree, obstacle list, edge mirror)"},
             "phase_ms": {k: 1e3 * v / steps for k, v in phase.items()},
             "per_cycle": {k: v / steps for k, v in counts.items()},
-            "initial_solve": {"passes": int(passes0), "reachable_nodes": int(np.isfinite(lmc0).sum())},
+            "initial_solve": {"root": root, "passes": int(passes0), "reachable_nodes": int(np.isfinite(lmc0).sum()),
+                              "edges_forward_in_reverse_time": n_valid},
             "kernel_ms": {"nn_scan": st.ms_nn_scan / max(st.launches_nn_scan, 1), "nn_finish": st.ms_nn_finish,
                           "dubins_check": st.ms_dubins, "dubins_steer": st.ms_dubins_steer,
                           "dubins_check_launches": chk_launches, "points": st.ms_points},
