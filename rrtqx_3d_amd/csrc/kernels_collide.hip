@@ -786,23 +786,36 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
        }
        npair = 0;
       };
-      // the wave's (edge, obstacle) pairs: every edge hands out one set bit of its mask per round
-      for (unsigned rem = cand; __ballot(rem != 0u) != 0ull;) {
-        const bool has = rem != 0u;
-        const int slot = has ? __ffs((int)rem) - 1 : 0;
-        rem &= rem - 1u;
-        const unsigned long long pv = __ballot(has);
-        if (has)
-          w.pairq[npair + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pv, 0u))] =
-              (unsigned short)(lane | (slot << 6));
-        npair += __popcll(pv);
-        if (npair > kPolyPairs - 64) stage_a();
+      // the wave's (edge, obstacle) pairs: every edge hands out one set bit of its mask per round, in list order.  After
+      // every second round the queued pairs are decided, and an edge that has its hit hands out nothing more: a later
+      // obstacle of the list can neither change the boolean nor lower the first-hit position (55 % of C4's candidate edges
+      // collide, typically with one of the first obstacles they come near).
+      int rounds = 0;
+      for (unsigned rem = cand;;) {
+        const bool any = __ballot(rem != 0u) != 0ull;
+        if (any) {
+          const bool has = rem != 0u;
+          const int slot = has ? __ffs((int)rem) - 1 : 0;
+          rem &= rem - 1u;
+          const unsigned long long pv = __ballot(has);
+          if (has)
+            w.pairq[npair + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pv, 0u))] =
+                (unsigned short)(lane | (slot << 6));
+          npair += __popcll(pv);
+          ++rounds;
+        }
+        if (!any || npair > kPolyPairs - 64 || rounds == 2) {
+          stage_a();
+          stage_b();
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          bool fin = w.first[lane] != 0x7fffffff;
+          if (PAIRED) fin = fin && w.first[lane | 1] != 0x7fffffff;      // (the even lane walks for both directions)
+          if (fin) rem = 0u;
+        }
+        if (!any) break;
       }
-      stage_a();
-      stage_b();
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int f = w.first[lane];
       if (!done && f != 0x7fffffff) { done = true; first = orig[f]; }
     }

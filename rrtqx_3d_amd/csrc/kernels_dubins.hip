@@ -550,6 +550,7 @@ struct WaveDubinsT {
   unsigned long long pm[3][64];   // per piece of the edge: the marked obstacles that piece can touch at all (arc screen)
   unsigned char piece_edge[64];
   unsigned char lc[2][64];        // rows to walk in piece 0 / piece 1 of the edge (0: that piece touches nothing)
+  unsigned short nseg[64], rot[64];   // pieces the edge walks in all; where its walk starts (the order is free, see stage 2)
   int pstart[65];
   int pqn;
   unsigned char done[64];
@@ -831,6 +832,24 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
       w.lc[1][lane] = (unsigned char)c1;
       if (mask != 0ull && rows > 1) segs = c0 + c1 + c2;
     }
+    // The answer is an OR over the pieces, so the ORDER in which an edge's pieces are walked is free -- and most candidate
+    // edges near an obstacle do collide somewhere (60 % at C3, 88 % at C5), after which the edge leaves the walk.  The walk
+    // therefore starts where a hit is most likely: at the piece whose share of the chord lies nearest the first marked
+    // obstacle's centre (a guess: any value gives the same result), and wraps around.
+    {
+      int rot = 0;
+      if (segs > 8 && segs < 65536) {
+        const int j = j0 + (__ffsll((long long)mask) - 1);
+        const double ux = gx - sx, uy = gy - sy;
+        double t = ((meta[4 * j + 0] - sx) * ux + (meta[4 * j + 1] - sy) * uy) / (ux * ux + uy * uy);
+        if (!(t > 0.0)) t = 0.0;               // (NaN too)
+        if (t > 1.0) t = 1.0;
+        rot = (int)(t * (double)segs) - 3;
+        rot = rot < 0 ? 0 : (rot >= segs ? segs - 1 : rot);
+      }
+      w.rot[lane] = (unsigned short)rot;
+      w.nseg[lane] = (unsigned short)(segs < 65536 ? segs : 0);
+    }
     // ---- stage 2 (lane = one polyline piece of one edge), a window of rows of every live edge at a
     // time: an edge that has collided leaves the numbering at the next window, so its remaining pieces
     // stop taking up lanes (most candidate edges do collide somewhere along the polyline).  The window is
@@ -908,7 +927,8 @@ __device__ bool wave_dubins_collides(WaveDubinsT<TIME> &w, bool valid, const Ste
           e = lo;
           if (!w.done[e]) {
             // live piece number -> row and the piece it belongs to
-            int tt = base + (i - w.pstart[e]);
+            int tt = base + (i - w.pstart[e]) + (int)w.rot[e];
+            if (tt >= (int)w.nseg[e] && w.nseg[e] != 0) tt -= (int)w.nseg[e];
             const int la = w.pc[e][0].len, lb = w.pc[e][1].len;
             const bool line1 = w.pc[e][1].kind == 1;
             const int c0 = w.lc[0][e], c1 = w.lc[1][e];
