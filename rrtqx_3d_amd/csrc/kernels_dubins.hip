@@ -246,53 +246,49 @@ __device__ __forceinline__ void dubins_steer_poses(const double *__restrict__ s,
   if (word == 6 || best == __builtin_inf()) return;   // no trajectory is built (:661-662)
 
   const double dphi = .1;
+  // The three pieces (:511-655).  Which circle, which tangent point and which sense of rotation a piece has depends on the
+  // word; the operands are SELECTED first and every expression is then written once, so that a wave whose lanes hold
+  // different words evaluates one atan2 / sincos per piece instead of one per branch (the values are the reference's:
+  // the same expressions on the same operands).
   const bool fr = (word <= 2);                        // first letter 'r'
-  double px, py, phi_start, phi_end;
+  double px, py, cx, cy, phi_start, phi_end;
   // first piece (:511-555)
-  if (fr) {
-    if (word == 0) { px = rsl1x; py = rsl1y; } else if (word == 1) { px = rsr1x; py = rsr1y; } else { px = rlr_rlx; py = rlr_rly; }
-    phi_start = a_ir;
-    phi_end = rrtx_dm_atan2(py - ircy, px - ircx);
-    if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi;
-    out.pc[0] = make_arc(ircx, ircy, phi_start, phi_end, -dphi);
-  } else {
-    if (word == 4) { px = lsl1x; py = lsl1y; } else if (word == 3) { px = lsr1x; py = lsr1y; } else { px = lrl_lrx; py = lrl_lry; }
-    phi_start = a_il;
-    phi_end = rrtx_dm_atan2(py - ilcy, px - ilcx);
-    if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi;
-    out.pc[0] = make_arc(ilcx, ilcy, phi_start, phi_end, dphi);
-  }
+  cx = fr ? ircx : ilcx; cy = fr ? ircy : ilcy;
+  if (fr) { px = word == 0 ? rsl1x : (word == 1 ? rsr1x : rlr_rlx); py = word == 0 ? rsl1y : (word == 1 ? rsr1y : rlr_rly); }
+  else { px = word == 4 ? lsl1x : (word == 3 ? lsr1x : lrl_lrx); py = word == 4 ? lsl1y : (word == 3 ? lsr1y : lrl_lry); }
+  phi_start = fr ? a_ir : a_il;
+  phi_end = rrtx_dm_atan2(py - cy, px - cx);
+  if (fr) { if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi; }
+  else { if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi; }
+  out.pc[0] = make_arc(cx, cy, phi_start, phi_end, fr ? -dphi : dphi);
   // second piece (:559-608)
-  if (word == 0) out.pc[1] = make_line(rsl1x, rsl1y, rsl2x, rsl2y);
-  else if (word == 1) out.pc[1] = make_line(rsr1x, rsr1y, rsr2x, rsr2y);
-  else if (word == 3) out.pc[1] = make_line(lsr1x, lsr1y, lsr2x, lsr2y);
-  else if (word == 4) out.pc[1] = make_line(lsl1x, lsl1y, lsl2x, lsl2y);
-  else if (word == 5) {   // lrl: middle is a right turn
-    phi_start = rrtx_dm_atan2(lrl_lry - lrl_cy, lrl_lrx - lrl_cx);
-    phi_end = rrtx_dm_atan2(lrl_rly - lrl_cy, lrl_rlx - lrl_cx);
-    if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi;
-    out.pc[1] = make_arc(lrl_cx, lrl_cy, phi_start, phi_end, -dphi);
-  } else {                // rlr: middle is a left turn
-    phi_start = rrtx_dm_atan2(rlr_rly - rlr_cy, rlr_rlx - rlr_cx);
-    phi_end = rrtx_dm_atan2(rlr_lry - rlr_cy, rlr_lrx - rlr_cx);
-    if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi;
-    out.pc[1] = make_arc(rlr_cx, rlr_cy, phi_start, phi_end, dphi);
+  if (word == 2 || word == 5) {
+    const bool mr = word == 5;                        // lrl: the middle turn is a right turn; rlr: a left turn
+    cx = mr ? lrl_cx : rlr_cx; cy = mr ? lrl_cy : rlr_cy;
+    const double ax = mr ? lrl_lrx : rlr_rlx, ay = mr ? lrl_lry : rlr_rly;
+    const double bx = mr ? lrl_rlx : rlr_lrx, by = mr ? lrl_rly : rlr_lry;
+    phi_start = rrtx_dm_atan2(ay - cy, ax - cx);
+    phi_end = rrtx_dm_atan2(by - cy, bx - cx);
+    if (mr) { if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi; }
+    else { if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi; }
+    out.pc[1] = make_arc(cx, cy, phi_start, phi_end, mr ? -dphi : dphi);
+  } else {
+    const double x1 = word == 0 ? rsl1x : (word == 1 ? rsr1x : (word == 3 ? lsr1x : lsl1x));
+    const double y1 = word == 0 ? rsl1y : (word == 1 ? rsr1y : (word == 3 ? lsr1y : lsl1y));
+    const double x2 = word == 0 ? rsl2x : (word == 1 ? rsr2x : (word == 3 ? lsr2x : lsl2x));
+    const double y2 = word == 0 ? rsl2y : (word == 1 ? rsr2y : (word == 3 ? lsr2y : lsl2y));
+    out.pc[1] = make_line(x1, y1, x2, y2);
   }
   // third piece (:611-655)
   const bool tr = (word == 1 || word == 3 || word == 2);   // last letter 'r'
-  if (tr) {
-    if (word == 1) { px = rsr2x; py = rsr2y; } else if (word == 3) { px = lsr2x; py = lsr2y; } else { px = rlr_lrx; py = rlr_lry; }
-    phi_start = rrtx_dm_atan2(py - grcy, px - grcx);
-    phi_end = a_gr;
-    if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi;
-    out.pc[2] = make_arc(grcx, grcy, phi_start, phi_end, -dphi);
-  } else {
-    if (word == 4) { px = lsl2x; py = lsl2y; } else if (word == 0) { px = rsl2x; py = rsl2y; } else { px = lrl_rlx; py = lrl_rly; }
-    phi_start = rrtx_dm_atan2(py - glcy, px - glcx);
-    phi_end = a_gl;
-    if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi;
-    out.pc[2] = make_arc(glcx, glcy, phi_start, phi_end, dphi);
-  }
+  cx = tr ? grcx : glcx; cy = tr ? grcy : glcy;
+  if (tr) { px = word == 1 ? rsr2x : (word == 3 ? lsr2x : rlr_lrx); py = word == 1 ? rsr2y : (word == 3 ? lsr2y : rlr_lry); }
+  else { px = word == 4 ? lsl2x : (word == 0 ? rsl2x : lrl_rlx); py = word == 4 ? lsl2y : (word == 0 ? rsl2y : lrl_rly); }
+  phi_start = rrtx_dm_atan2(py - cy, px - cx);
+  phi_end = tr ? a_gr : a_gl;
+  if (tr) { if (phi_end > phi_start) phi_end = phi_end - 2.0 * kPi; }
+  else { if (phi_end < phi_start) phi_end = phi_end + 2.0 * kPi; }
+  out.pc[2] = make_arc(cx, cy, phi_start, phi_end, tr ? -dphi : dphi);
 }
 
 template <bool WANT_TRAJ>

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export PYTHONPATH="$GRAFT_REPO_ROOT"
 out=gpurun_out/r3l
 mkdir -p $out
-timeout -k 10 900 python3 -m pytest tests -m gpu -x -q -k "dubins or golden or c3_ or c5_ or lattice or sweep" > $out/pytest.log 2>&1
+timeout -k 10 900 python3 -m pytest tests -m gpu -x -q -k "dubins or golden or c3_ or c5_ or lattice or sweep or shards" > $out/pytest.log 2>&1
 echo "pytest rc=$?"; tail -4 $out/pytest.log
 timeout -k 10 300 python3 tools/soak_dubins.py 60 > $out/soak_dubins.log 2>&1; echo "soak rc=$?"; tail -1 $out/soak_dubins.log
 timeout -k 10 300 python3 bench.py --config C3 --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_c3.json 2> $out/bench_c3.err
