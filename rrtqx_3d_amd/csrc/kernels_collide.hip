@@ -447,6 +447,8 @@ constexpr int kPolyPairs = 256;        // (edge, obstacle) pairs a wave queues f
 constexpr int kPolyQueue = 512;        // (edge, polygon segment) tests a wave queues
 constexpr int kPolyWaveCand = 256;     // candidate obstacles a wave lists (more: the whole list is walked)
 constexpr int kPolyWaveSamples = 16;   // ... for at most this many samples per wave
+constexpr int kPolyListCap = 64;       // obstacles the sample pass lists per sample (more: the wave lists for itself)
+constexpr int kPolyBitWords = 16;      // ... merged per wave through a bit set of this many 64-bit words
 // per-wave scratch of edges_polygons_kernel: the wave's 64 edges, the boxes of the current group of 32 obstacles,
 // each edge's first hit (list position), the queues of the two test stages, the wave's candidate obstacles
 struct PolyWave {
@@ -458,6 +460,8 @@ struct PolyWave {
   unsigned short pairq[kPolyPairs];   // (edge lane | obstacle slot << 6) of the pairs the box test leaves
   unsigned pq[kPolyQueue];         // (edge lane | obstacle slot << 6 | segment << 11) of the segment tests to run
   short wc[kPolyWaveCand];   // CSR mode: the obstacles any edge of the wave can reach (list positions, ascending)
+  unsigned long long bits[kPolyBitWords];   // CSR mode: union of the lists of the wave's samples
+  unsigned head[64];         // stage A: (pair lane | chunk number << 6) where a pair's run of polygon sides starts in the chunk
 };
 
 // Second edge source of edges_polygons_kernel: the candidate edges of extend() straight from the CSR
@@ -474,28 +478,42 @@ struct PolyCsr {
   int nq, n_nodes;
 };
 
+#ifdef RRTX_TILE_CLOCKS
+// (one row per wave, plain stores: atomics on eight shared words slowed the measured kernels tenfold)
+constexpr int kClkRows = 65536;
+__device__ unsigned long long g_pe_clk[kClkRows * 8];
+__device__ unsigned long long g_pp_clk[kClkRows * 8];
+#define RRTX_PE_T(var) const unsigned long long var = clock64()
+#define RRTX_PE_ACC(acc, a, b) acc += (b) - (a)
+#else
+#define RRTX_PE_T(var) do { } while (0)
+#define RRTX_PE_ACC(acc, a, b) do { } while (0)
+#endif
+
 // PAIRED (the candidate edges of extend(), CSR mode): lanes 2k and 2k + 1 hold the two directions of ONE segment.
 // Only the even lane lists obstacles and hands out pairs; stage A runs the bounding-circle test for both directions
 // in the pair's lane (it differs between them only in rounding: distanceSqrdPointToSegment measures from the other
 // end), and stage B's segment_dist_sqrd_both gives both directions' answers at 1.3x the cost of one.  Every boolean is
 // still the reference's own expression for that directed edge; the rounds of both stages halve.
 template <bool PAIRED>
-__global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__restrict__ p0,
-                                                             const double *__restrict__ p1, int stride,
-                                                             long long ne, PolyCsr csr,
-                                                             const double *__restrict__ meta,
-                                                             const int32_t *__restrict__ off,
-                                                             const double *__restrict__ vxy,
-                                                             const double *__restrict__ vslope,
-                                                             const int32_t *__restrict__ path_off,
-                                                             const double *__restrict__ path, int has_moving,
-                                                             const int32_t *__restrict__ orig, int m_begin,
-                                                             int m_end, double robot_radius,
-                                                             uint8_t *__restrict__ hit,
-                                                             int32_t *__restrict__ first_hit) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave &w, const double *__restrict__ p0,
+                                                    const double *__restrict__ p1, int stride, long long ne,
+                                                    const PolyCsr &csr, const double *__restrict__ meta,
+                                                    const int32_t *__restrict__ off, const double *__restrict__ vxy,
+                                                    const double *__restrict__ vslope,
+                                                    const int32_t *__restrict__ path_off,
+                                                    const double *__restrict__ path, int has_moving,
+                                                    const int32_t *__restrict__ orig, int m_begin, int m_end,
+                                                    double robot_radius, uint8_t *__restrict__ hit,
+                                                    int32_t *__restrict__ first_hit,
+                                                    const unsigned short *__restrict__ near_lists,
+                                                    const unsigned short *__restrict__ near_cnt, double list_r) {
   bool act;
   double ax = 0, ay = 0, at = 0, bx = 0, by = 0, bt = 0;
+#ifdef RRTX_TILE_CLOCKS
+  unsigned long long acc_box = 0ull, acc_hand = 0ull, acc_a1 = 0ull, acc_a2 = 0ull, acc_b = 0ull;
+#endif
+  RRTX_PE_T(t_start);
   if (csr.q) {
     const long long total = csr.offsets[csr.nq];
     if (total > csr.cap) return;          // capacity overflow: the CSR arrays are only partly written
@@ -527,8 +545,6 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
   // that lie near several obstacles.  An edge's first
   // hit is the smallest list position among its hits; an edge that has hit takes no part in later
   // groups.  The set of tests that can decide a result and the arithmetic of each are unchanged.
-  __shared__ PolyWave s_w[4];
-  PolyWave &w = s_w[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
   // CSR mode: the 64 edges of a wave belong to a few consecutive samples (the CSR is ordered by sample), and every
   // point of a candidate edge lies within the edge's length of its sample.  An obstacle whose bounding circle
@@ -551,6 +567,40 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
     if (__ballot(!fin) != 0ull) lmax = __builtin_inf();          // a non-finite edge: keep everything
     if (s1 >= s0 && s1 - s0 < kPolyWaveSamples) {
       int nc = 0;                                                  // wave-uniform
+      // The sample pass (points_polygons_flag_kernel) has listed, per sample, the obstacles within the same bound taken
+      // with the radius of the search ball in place of the wave's longest edge -- a superset, since no candidate edge is
+      // longer than that radius (checked here: lmax <= list_r).  The wave's list is the union of its samples' lists.
+      bool from_lists = false;
+      const int mm = m_end - m_begin;
+      if (near_cnt != nullptr && m_begin == 0 && mm <= 64 * kPolyBitWords && lmax <= list_r) {
+        if (lane < kPolyBitWords) w.bits[lane] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bool ok = true;
+        for (int sidx = s0; sidx <= s1; ++sidx) {
+          const int c = near_cnt[sidx];                            // wave-uniform
+          if (c > kPolyListCap) { ok = false; break; }
+          if (lane < c) {
+            const int j = near_lists[(size_t)sidx * kPolyListCap + lane];
+            if (j < mm) atomicOr(&w.bits[j >> 6], 1ull << (j & 63));
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (ok) {
+          from_lists = true;
+          for (int wd = 0; wd * 64 < mm; ++wd) {
+            const unsigned long long km = w.bits[wd];
+            const bool keep = ((km >> lane) & 1ull) != 0ull;
+            const int at = nc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+            if (keep && at < kPolyWaveCand) w.wc[at] = (short)(wd * 64 + lane);
+            nc += __popcll(km);
+          }
+        }
+      }
+      if (!from_lists)
       for (int j0 = m_begin; j0 < m_end; j0 += 64) {
         const int j = j0 + lane;
         bool keep = false;
@@ -576,10 +626,12 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
       if (nc <= kPolyWaveCand && m_end - m_begin < 32768) { listed = true; n_walk = nc; }
     }
   }
+  RRTX_PE_T(t_listed);
   w.e[0][lane] = ax; w.e[1][lane] = ay; w.e[2][lane] = at;
   w.e[3][lane] = bx; w.e[4][lane] = by; w.e[5][lane] = bt;
   w.em[lane] = (by - ay) / (bx - ax);          // (read only where the edge is not "close to vertical")
   w.first[lane] = 0x7fffffff;
+  w.head[lane] = 0u;                               // (chunk numbers start at 1)
   // The edge's own box, widened by far more than any rounding of the exact test (1e-9 relative against
   // ~1e-15) and rounded outward to fp32.  NaN-propagating min / max: an edge with a NaN coordinate keeps
   // every obstacle (all comparisons below are false); inf / overflow give an unbounded box.
@@ -591,8 +643,10 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
   }
   bool done = !act;
   int first = -1;
+  unsigned chunk_no = 0u;                          // stage A's chunks of polygon sides, numbered through the whole kernel
   for (int g0 = 0; g0 < n_walk; g0 += 32) {
     const int jn = min(32, n_walk - g0);
+    RRTX_PE_T(t_g0);
     // boxes of the group's bounding circles (lane b = b-th obstacle of the group), widened the same way and
     // rounded outward to fp32: a pair whose boxes are disjoint fails the reference's first test for
     // certain.  Kinds 6 / 7 have no bounding test (:1532): unbounded box.
@@ -626,6 +680,8 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
         cand |= (c ? 1u : 0u) << b;
       }
     }
+    RRTX_PE_T(t_g1);
+    RRTX_PE_ACC(acc_box, t_g0, t_g1);
     if (__ballot(cand != 0u) != 0ull) {
       // The pairs are decided in two stages so that the lanes stay together.  Stage A, lane = pair: the reference's
       // first test (bounding circle, explicitEdgeCheck2D :1536-1539), which settles balls and the obstacles that
@@ -646,6 +702,7 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
       const double gap_min = fabs(robot_radius) * (1.0 + 1e-9);
       int nqd = 0;                                          // wave-uniform: tests in the queue
       auto stage_b = [&]() {
+        RRTX_PE_T(t_b0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -669,6 +726,8 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
           }
         }
         nqd = 0;
+        RRTX_PE_T(t_b1);
+        RRTX_PE_ACC(acc_b, t_b0, t_b1);
       };
       // stage A over the first `np` entries of the pair queue
       int npair = 0;                                        // wave-uniform: pairs queued
@@ -677,13 +736,10 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
        __builtin_amdgcn_wave_barrier();
        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
        for (int p0 = 0; p0 < npair; p0 += 64) {
+        RRTX_PE_T(t_a0);
         const int p = p0 + lane;
         int owner = 0, slot = 0, vb0 = 0, P = 0;           // P > 0: a polygon past the bounding circle
-        double elx = 0.0, ehx = 0.0, ely = 0.0, ehy = 0.0, slack = 0.0;
-        double pax = 0.0, pay = 0.0, pbx = 0.0, pby = 0.0, em = 0.0;   // the edge's ends and slope (R/DRRT.jl:1158)
-        double em_r = 0.0;                                 // PAIRED: the slope as the reverse edge divides it
         bool pass_f = false, pass_r = false;               // which direction(s) got past the bounding circle
-        bool evert = false;                                // the edge is "close to vertical" (:1151)
         if (p < npair) {
           const unsigned pe = w.pairq[p];
           owner = (int)(pe & 63u);
@@ -704,7 +760,14 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
             const double dsq = dist_sqrd_point_to_segment(meta[4 * j + 0], meta[4 * j + 1], eax, eay, ebx, eby);
             const double rr = robot_radius + meta[4 * j + 2];
             pass_f = !(dsq > rr * rr);
-            if (PAIRED) pass_r = !(dist_sqrd_point_to_segment(meta[4 * j + 0], meta[4 * j + 1], ebx, eby, eax, eay) > rr * rr);
+            if (PAIRED) {
+              // The reverse edge measures the same distance from the other end: the two results differ by rounding only
+              // (below 1e-14 of the squared lengths involved), so the reverse test is evaluated only where the forward
+              // distance lies within 1e-7 of those lengths of the threshold -- or is not finite.
+              const double scale = sq2(meta[4 * j + 0], meta[4 * j + 1], eax, eay) + sq2(ebx, eby, eax, eay) + rr * rr;
+              if (fabs(dsq - rr * rr) > 1e-7 * scale) pass_r = pass_f;
+              else pass_r = !(dist_sqrd_point_to_segment(meta[4 * j + 0], meta[4 * j + 1], ebx, eby, eax, eay) > rr * rr);
+            }
             if (pass_f || pass_r) {
               if (kind == 1) {
                 if (pass_f) atomicMin(&w.first[owner], j);
@@ -713,44 +776,55 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
                 vb0 = off[j];
                 P = off[j + 1] - vb0;
                 if (P < 2) P = 0;                          // (:1551: fewer than two vertices never collide)
-                elx = fmin(eax, ebx); ehx = fmax(eax, ebx); ely = fmin(eay, eby); ehy = fmax(eay, eby);
-                slack = gap_min + 1e-9 * (fabs(elx) + fabs(ehx) + fabs(ely) + fabs(ehy));
-                // (fmin / fmax drop a NaN operand: an edge with a non-finite coordinate keeps every segment)
-                if (!(eax - eax == 0.0 && eay - eay == 0.0 && ebx - ebx == 0.0 && eby - eby == 0.0)) slack = __builtin_inf();
-                pax = eax; pay = eay; pbx = ebx; pby = eby;
-                evert = fabs(ebx - eax) < .000001;
-                if (!evert) { em = w.em[owner]; if (PAIRED) em_r = w.em[owner + 1]; }
               }
             }
           }
         }
-        // the polygon's segments, one per round: sg = 0 is (last vertex, first vertex)
-        int pmax = P;
+        // The sides of the polygons that got past the bounding circle, one (pair, side) per lane (side 0 is (last vertex,
+        // first vertex)): the pairs' side counts are summed along the wave, every pair marks where its run of sides
+        // starts in the current chunk of 64, and lane t finds the last mark at or before it.  (Lane = pair with a loop
+        // over the sides kept a third of the lanes busy: half the pairs stop at the bounding circle, the others have
+        // three to six sides.)
+        RRTX_PE_T(t_a1);
+        RRTX_PE_ACC(acc_a1, t_a0, t_a1);
+#ifdef RRTX_TILE_CLOCKS
+        const unsigned long long b_before = acc_b;
+#endif
+        int pstart = P;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) pmax = max(pmax, __shfl_xor(pmax, o));
-        // (a side starts where the one before it ends: that vertex, whether it is finite and its difference in the
-        // first side test are carried from round to round)
-        double Ax = 0.0, Ay = 0.0, diff_a1 = 0.0, diff_a1r = 0.0;
-        bool fin_a = false;
-        if (P > 0) {
-          Ax = vxy[2 * (vb0 + P - 1)]; Ay = vxy[2 * (vb0 + P - 1) + 1];
-          fin_a = (Ax - Ax == 0.0) && (Ay - Ay == 0.0);
-          diff_a1 = (em * (Ax - pax) + pay) - Ay;
-          if (PAIRED) diff_a1r = (em_r * (Ax - pbx) + pby) - Ay;      // the reverse edge's line is anchored at ITS first point
-        }
-        for (int sg = 0; sg < pmax; ++sg) {
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pstart, o); if (lane >= o) pstart += v; }
+        const int total_sides = __builtin_amdgcn_readlane(pstart, 63);
+        pstart -= P;                                       // the pair's first side is number pstart of the wave
+        const int pk = owner | (slot << 6) | (pass_f ? 1 << 11 : 0) | (pass_r ? 1 << 12 : 0);
+        for (int t0 = 0; t0 < total_sides; t0 += 64) {
+          ++chunk_no;
+          if (P > 0 && pstart < t0 + 64 && pstart + P > t0) w.head[max(pstart, t0) - t0] = (unsigned)lane | (chunk_no << 6);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const unsigned hv = w.head[lane];
+          const unsigned long long heads = __ballot((hv >> 6) == chunk_no);       // (bit 0 is always set: some pair covers t0)
+          const unsigned long long below = heads & ((2ull << lane) - 1ull);
+          const int k = __shfl((int)hv, below ? 63 - __clzll((long long)below) : 0) & 63;
+          const int pk_e = __shfl(pk, k), vb0_e = __shfl(vb0, k), P_e = __shfl(P, k), sg = t0 + lane - __shfl(pstart, k);
           bool push = false;
-          unsigned dirs = 0u;
-          if (sg < P) {
-            const int vb = vb0 + sg;
-            const double Bx = vxy[2 * vb], By = vxy[2 * vb + 1];
+          unsigned ent = 0u;
+          if (t0 + lane < total_sides) {
+            const int owner_e = pk_e & 63;
+            const bool pf = (pk_e >> 11) & 1, pr = (pk_e >> 12) & 1;
+            const double pax = w.e[0][owner_e], pay = w.e[1][owner_e], pbx = w.e[3][owner_e], pby = w.e[4][owner_e];
+            const double elx = fmin(pax, pbx), ehx = fmax(pax, pbx), ely = fmin(pay, pby), ehy = fmax(pay, pby);
+            double slack = gap_min + 1e-9 * (fabs(elx) + fabs(ehx) + fabs(ely) + fabs(ehy));
+            // (fmin / fmax drop a NaN operand: an edge with a non-finite coordinate keeps every segment)
+            if (!(pax - pax == 0.0 && pay - pay == 0.0 && pbx - pbx == 0.0 && pby - pby == 0.0)) slack = __builtin_inf();
+            const bool evert = fabs(pbx - pax) < .000001;  // the edge is "close to vertical" (:1151)
+            double em = 0.0, em_r = 0.0;                   // the edge's slope (R/DRRT.jl:1158), and as the reverse edge divides it
+            if (!evert) { em = w.em[owner_e]; if (PAIRED) em_r = w.em[owner_e + 1]; }
+            const int va = vb0_e + (sg == 0 ? P_e - 1 : sg - 1), vb = vb0_e + sg;
+            const double Ax = vxy[2 * va], Ay = vxy[2 * va + 1], Bx = vxy[2 * vb], By = vxy[2 * vb + 1];
             const bool apart = (fmin(Ax, Bx) - ehx > slack) || (elx - fmax(Ax, Bx) > slack) ||
                                (fmin(Ay, By) - ehy > slack) || (ely - fmax(Ay, By) > slack);
-            const bool fin_b = (Bx - Bx == 0.0) && (By - By == 0.0);
-            const bool finite = fin_a && fin_b;
-            const double diff_b1 = (em * (Bx - pax) + pay) - By;
-            double diff_b1r = 0.0;
-            if (PAIRED) diff_b1r = (em_r * (Bx - pbx) + pby) - By;
+            const bool finite = (Ax - Ax == 0.0) && (Ay - Ay == 0.0) && (Bx - Bx == 0.0) && (By - By == 0.0);
             bool one_side, one_side_r = false;             // segmentDistSqrd's side tests, as the reference computes them
             if (evert) {
               one_side = (Ax >= pax && Bx >= pax) || (Ax <= pax && Bx <= pax);
@@ -758,8 +832,12 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
             } else {
               // (both differences strictly positive or both strictly negative <=> their product is positive, except that
               // the product of two tiny ones can round to zero: the side then just goes to the exact test)
+              const double diff_a1 = (em * (Ax - pax) + pay) - Ay, diff_b1 = (em * (Bx - pax) + pay) - By;
               one_side = diff_a1 * diff_b1 > 0.0;
-              if (PAIRED) one_side_r = diff_a1r * diff_b1r > 0.0;
+              if (PAIRED) {                                // the reverse edge's line is anchored at ITS first point
+                const double diff_a1r = (em_r * (Ax - pbx) + pby) - Ay, diff_b1r = (em_r * (Bx - pbx) + pby) - By;
+                one_side_r = diff_a1r * diff_b1r > 0.0;
+              }
             }
             bool sep_q;                                    // the second side test is the same for both directions
             if (fabs(Bx - Ax) < .000001) sep_q = (pax >= Ax && pbx >= Ax) || (pax <= Ax && pbx <= Ax);
@@ -770,19 +848,21 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
               sep_q = diff_a * diff_b > 0.0;
             }
             // (slack = +inf or NaN: never apart)
-            const bool need_f = pass_f && (!(apart && (one_side || sep_q)) || !finite);
-            const bool need_r = PAIRED && pass_r && (!(apart && (one_side_r || sep_q)) || !finite);
+            const bool need_f = pf && (!(apart && (one_side || sep_q)) || !finite);
+            const bool need_r = PAIRED && pr && (!(apart && (one_side_r || sep_q)) || !finite);
             push = need_f || need_r;
-            dirs = (need_f ? 1u : 0u) | (need_r ? 2u : 0u);
-            Ax = Bx; Ay = By; fin_a = fin_b; diff_a1 = diff_b1; diff_a1r = diff_b1r;
+            ent = (unsigned)(pk_e & 0x7ff) | ((unsigned)sg << 11) | (need_f ? 1u << 30 : 0u) | (need_r ? 1u << 31 : 0u);
           }
           const unsigned long long sv = __ballot(push);
           if (push)
-            w.pq[nqd + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sv, 0u))] =
-                (unsigned)owner | ((unsigned)slot << 6) | ((unsigned)sg << 11) | (dirs << 30);
+            w.pq[nqd + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sv, 0u))] = ent;
           nqd += __popcll(sv);
           if (nqd > kPolyQueue - 64) stage_b();
         }
+        RRTX_PE_T(t_a2);
+#ifdef RRTX_TILE_CLOCKS
+        acc_a2 += (t_a2 - t_a1) - (acc_b - b_before);
+#endif
        }
        npair = 0;
       };
@@ -791,6 +871,10 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
       // obstacle of the list can neither change the boolean nor lower the first-hit position (55 % of C4's candidate edges
       // collide, typically with one of the first obstacles they come near).
       int rounds = 0;
+      RRTX_PE_T(t_h0);
+#ifdef RRTX_TILE_CLOCKS
+      const unsigned long long in_before = acc_a1 + acc_a2 + acc_b;
+#endif
       for (unsigned rem = cand;;) {
         const bool any = __ballot(rem != 0u) != 0ull;
         if (any) {
@@ -816,6 +900,10 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
         }
         if (!any) break;
       }
+      RRTX_PE_T(t_h1);
+#ifdef RRTX_TILE_CLOCKS
+      acc_hand += (t_h1 - t_h0) - (acc_a1 + acc_a2 + acc_b - in_before);
+#endif
       const int f = w.first[lane];
       if (!done && f != 0x7fffffff) { done = true; first = orig[f]; }
     }
@@ -829,6 +917,45 @@ __global__ __launch_bounds__(256) void edges_polygons_kernel(const double *__res
       if (first_hit) first_hit[i] = first;
     }
   }
+#ifdef RRTX_TILE_CLOCKS
+  {
+    const unsigned long long t_end = clock64();
+    if (lane == 0) {
+      unsigned long long *row = g_pe_clk + (size_t)((i >> 6) & (kClkRows - 1)) * 8;
+      row[0] = t_listed - t_start; row[1] = acc_box; row[2] = acc_hand; row[3] = acc_a1; row[4] = acc_a2; row[5] = acc_b;
+      row[6] = t_end - t_start; row[7] = 1ull;
+    }
+  }
+#endif
+}
+
+// WAVES waves per workgroup, each with its own 64 edges and its own scratch (no workgroup barrier anywhere).  The fused
+// extend preamble runs one wave per workgroup: the waves' running times differ by a factor of several, and a workgroup's
+// registers are only handed on when its last wave is through (measured: 0.166 -> 0.161 ms per step; a resident grid
+// striding over the edges instead costs registers and was slower).  OCC: waves per SIMD the register budget is cut for
+// (5 = 96 registers with two spilled, 0.160 ms).
+template <bool PAIRED, int WAVES, int OCC>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC))) void edges_polygons_kernel(const double *__restrict__ p0,
+                                                                    const double *__restrict__ p1, int stride,
+                                                                    long long ne, PolyCsr csr,
+                                                                    const double *__restrict__ meta,
+                                                                    const int32_t *__restrict__ off,
+                                                                    const double *__restrict__ vxy,
+                                                                    const double *__restrict__ vslope,
+                                                                    const int32_t *__restrict__ path_off,
+                                                                    const double *__restrict__ path, int has_moving,
+                                                                    const int32_t *__restrict__ orig, int m_begin,
+                                                                    int m_end, double robot_radius,
+                                                                    uint8_t *__restrict__ hit,
+                                                                    int32_t *__restrict__ first_hit,
+                                                                    const unsigned short *__restrict__ near_lists,
+                                                                    const unsigned short *__restrict__ near_cnt,
+                                                                    double list_r) {
+  __shared__ PolyWave s_w[WAVES];
+  PolyWave &w = s_w[threadIdx.x >> 6];
+  edges_polygons_wave<PAIRED>((long long)blockIdx.x * (64 * WAVES) + threadIdx.x, w, p0, p1, stride, ne, csr, meta, off, vxy,
+                              vslope, path_off, path, has_moving, orig, m_begin, m_end, robot_radius, hit, first_hit,
+                              near_lists, near_cnt, list_r);
 }
 
 // pointInPolygon (MacMartin crossings), R/DRRT.jl:1009-1056
@@ -944,112 +1071,15 @@ __device__ void group8_point_vs_polygon(double px, double py, const double *__re
 //   cannot be left out of a flag-only call, since pointInPolygon answers "inside" for points far outside a polygon
 //   when the ray meets a vertex whose two sides lie on opposite sides of it (the crossing tests are strict), and
 //   whether the reference looks at such an obstacle is decided by the certificates of everything before it.
-__global__ __launch_bounds__(256) void points_polygons_kernel(const double *__restrict__ p, int stride,
-                                                              long long np, const double *__restrict__ meta,
-                                                              const int32_t *__restrict__ off,
-                                                              const double *__restrict__ vxy,
-                                                              const int32_t *__restrict__ path_off,
-                                                              const double *__restrict__ path, int has_moving,
-                                                              int m, double robot_radius,
-                                                              uint8_t *__restrict__ unsafe,
-                                                              double *__restrict__ clearance,
-                                                              const double *__restrict__ bbox,
-                                                              const double *__restrict__ ytab, int n_ytab) {
+__device__ __forceinline__ void point_full_loop(const double *__restrict__ p, int stride, long long i,
+                                                const double *__restrict__ meta, const int32_t *__restrict__ off,
+                                                const double *__restrict__ vxy, const int32_t *__restrict__ path_off,
+                                                const double *__restrict__ path, int has_moving, int m,
+                                                double robot_radius, uint8_t *__restrict__ unsafe,
+                                                double *__restrict__ clearance) {
   const int lane = threadIdx.x & 63;
-  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= np) return;
   const double px = p[i * stride + 0], py = p[i * stride + 1];
   const double pt = has_moving ? p[i * stride + 2] : 0.0;      // point[3] = time (kinds 6 / 7)
-  // ---- flag-only calls (the fused extend preamble asks only whether the sample is in collision) ----
-  // The flag is an OR over the obstacles the reference's loop EVALUATES of "inside or closer than the robot radius".
-  //  * an obstacle whose bound (Wdist - robotRadius) - radius is <= 0 is never skipped (the running certificate is
-  //    >= 0): its own answer counts whatever the list order -- evaluated here exactly as the reference does;
-  //  * an obstacle with bound > 0 lies beyond the robot's reach; evaluated or not, it can only say "in collision"
-  //    through pointInPolygon's strict crossing tests, which miscount when the ray meets a vertex (py equal to a
-  //    vertex's y) or when the point falls in the bounding box of one of its sides (the x-intercept formula of
-  //    R/DRRT.jl:1040-1046 is then evaluated, and it divides by px - 2 max(sx, ex)).  Outside the polygon's bounding
-  //    box and with py different from EVERY vertex y of the list (one look-up in the sorted table) the crossing
-  //    count is decided by comparisons alone and is even: such an obstacle cannot raise the flag, whether or not
-  //    the certificates of the obstacles before it let the reference look at it.
-  // Anything else -- a bound within 1e-9 of zero, a point inside a far obstacle's box, a y that matches a vertex,
-  // non-finite input, obstacles that move in time -- takes the full loop below, which is the reference's sequence.
-  if (clearance == nullptr && !has_moving && n_ytab >= 0 && bbox != nullptr) {
-    bool slow = !((px - px == 0.0) && (py - py == 0.0));
-    if (!slow && n_ytab > 0) {
-      // two-level look-up of py in the sorted table (at most 64 x 64 entries; longer tables: the full loop)
-      const int step = (n_ytab + 63) >> 6;
-      if (step > 64) slow = true;
-      else {
-        const int k0 = lane * step;
-        const double head = ytab[min(k0, n_ytab - 1)];
-        const unsigned long long le = __ballot(k0 < n_ytab && head <= py);
-        const int blk = le ? 63 - __clzll((long long)le) : 0;      // last block whose first entry is <= py
-        const int k = blk * step + lane;
-        const bool eq = lane < step && k < n_ytab && ytab[k] == py;
-        slow = __ballot(eq) != 0ull;
-      }
-    }
-    bool bad = false;
-    // the polygons within reach are collected over the whole list first (typically two or three of 256) and then
-    // evaluated eight at a time, eight lanes each, like the explicit loop below does -- not by the one lane that owns them
-    __shared__ short s_near[4][64];
-    short *near_list = s_near[threadIdx.x >> 6];
-    int n_near = 0;                                              // wave-uniform
-    if (!slow) {
-      for (int j0 = 0; j0 < m; j0 += 64) {
-        const int j = j0 + lane;
-        bool near3 = false;
-        if (j < m) {
-          const double4 mt = reinterpret_cast<const double4 *>(meta)[j];
-          const double4 bb = reinterpret_cast<const double4 *>(bbox)[j];
-          const double cx = mt.x, cy = mt.y, rad = mt.z;
-          const int kind = (int)mt.w;
-          // near / far by squares: reach = robotRadius + radius, the two sure cases leave a band of 1e-9 around it that
-          // goes to the full loop; the reference's own bound (Wdist - robotRadius) - radius is only needed for balls
-          const double s2 = sq2(cx, cy, px, py);
-          const double reach = robot_radius + rad;
-          const double sl = 1e-9 * (1.0 + fabs(cx) + fabs(cy) + fabs(px) + fabs(py) + fabs(reach));
-          const double hi = (reach + sl) * (1.0 + 1e-9), lo = (reach - sl) * (1.0 - 1e-9);
-          if (s2 > hi * hi && hi >= 0.0) {                        // beyond reach for certain: bound > 0
-            const bool outside = px < bb.x || px > bb.y || py < bb.z || py > bb.w;
-            if (kind != 1 && !outside) slow = true;
-          } else if (lo > 0.0 && s2 < lo * lo && robot_radius >= 0.0) {   // within reach for certain: bound < 0, never skipped
-            if (kind == 1) bad = true;                           // (Wdist - robotRadius) - radius < 0
-            else if (kind == 3) near3 = true;
-            else slow = true;
-          } else slow = true;
-        }
-        const unsigned long long nm = __ballot(near3);
-        const int at = n_near + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nm, 0u));
-        if (near3) { if (at < 64) near_list[at] = (short)j; else slow = true; }
-        n_near += __popcll(nm);
-      }
-      if (m > 32767) slow = true;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (__ballot(slow) == 0ull) {
-        for (int r0 = 0; r0 < n_near; r0 += 8) {
-          const int g = r0 + (lane >> 3);
-          int vb = 0, ve = 0;
-          if (g < n_near) { const int j = near_list[g]; vb = off[j]; ve = off[j + 1]; }
-          if (g < n_near && ve - vb < 1) slow = true;
-          int n_rounds = (ve - vb + 7) >> 3;
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) n_rounds = max(n_rounds, __shfl_xor(n_rounds, o));
-          bool inside;
-          double dsq;
-          group8_point_vs_polygon(px, py, vxy, vb, ve, false, 0.0, 0.0, n_rounds, inside, dsq);
-          if (g < n_near) bad = bad || inside || (sqrt_rn(dsq) - robot_radius < 0.0);
-        }
-      }
-    }
-    if (__ballot(slow) == 0ull) {
-      const bool any = __ballot(bad) != 0ull;
-      if (lane == 0) unsafe[i] = any ? 1 : 0;
-      return;
-    }
-  }
   // One pass over the list, 64 obstacles at a time: the quickCheck of the group (an OR: "inside any obstacle"),
   // then the group's share of the explicitPointCheck2D loop.  The reference runs the whole quick pass first; both
   // end the call with unsafe = 1 and certificate 0 when they find something and neither influences the other
@@ -1140,6 +1170,222 @@ __global__ __launch_bounds__(256) void points_polygons_kernel(const double *__re
   if (lane == 0) { unsafe[i] = 0; if (clearance) clearance[i] = ret_cert; }
 }
 
+__global__ __launch_bounds__(256) void points_polygons_kernel(const double *__restrict__ p, int stride,
+                                                              long long np, const double *__restrict__ meta,
+                                                              const int32_t *__restrict__ off,
+                                                              const double *__restrict__ vxy,
+                                                              const int32_t *__restrict__ path_off,
+                                                              const double *__restrict__ path, int has_moving,
+                                                              int m, double robot_radius,
+                                                              uint8_t *__restrict__ unsafe,
+                                                              double *__restrict__ clearance) {
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= np) return;
+  point_full_loop(p, stride, i, meta, off, vxy, path_off, path, has_moving, m, robot_radius, unsafe, clearance);
+}
+
+  // ---- flag-only calls (the fused extend preamble asks only whether the sample is in collision) ----
+struct PolyGrid {        // sync_polygon_grid; g == 0: none
+  double x0, y0, inv_wx, inv_wy;
+  int g;
+  const int32_t *start;
+  const uint16_t *items;
+};
+
+// points_polygons_flag_kernel: explicitPointCheck when only the flag is wanted (the fused extend preamble).
+// The flag is an OR over the obstacles the reference's loop EVALUATES of "inside or closer than the robot radius".
+//  * an obstacle whose bound (Wdist - robotRadius) - radius is <= 0 is never skipped (the running certificate is
+//    >= 0): its own answer counts whatever the list order -- evaluated here exactly as the reference does;
+//  * an obstacle with bound > 0 lies beyond the robot's reach; evaluated or not, it can only say "in collision"
+//    through pointInPolygon's strict crossing tests, which miscount when the ray meets a vertex (py equal to a
+//    vertex's y) or when the point falls in the bounding box of one of its sides (the x-intercept formula of
+//    R/DRRT.jl:1040-1046 is then evaluated, and it divides by px - 2 max(sx, ex)).  Outside the polygon's bounding
+//    box and with py different from EVERY vertex y of the list (one look-up in the sorted table) the crossing
+//    count is decided by comparisons alone and is even: such an obstacle cannot raise the flag, whether or not
+//    the certificates of the obstacles before it let the reference look at it.  Inside the box the reference's crossing
+//    count is taken: "outside" cannot raise the flag either; "inside" would, if the reference gets to look.
+// Anything else -- a bound within 1e-9 of zero, a far polygon whose crossing count says "inside", a y that matches a
+// vertex, non-finite input, obstacles that move in time -- takes the full loop above, which is the reference's sequence.
+// Two points per wave, 32 lanes each (the list is gone through 32 obstacles at a time per point, the near polygons four
+// at a time, eight lanes each): half the waves of the one-point form for the same instructions per wave.
+__global__ __launch_bounds__(256) void points_polygons_flag_kernel(const double *__restrict__ p, int stride,
+                                                                   long long np, const double *__restrict__ meta,
+                                                                   const int32_t *__restrict__ off,
+                                                                   const double *__restrict__ vxy, int m,
+                                                                   double robot_radius, uint8_t *__restrict__ unsafe,
+                                                                   const double *__restrict__ bbox,
+                                                                   const double *__restrict__ ytab, int n_ytab,
+                                                                   double list_r, unsigned short *__restrict__ lists,
+                                                                   unsigned short *__restrict__ list_cnt, PolyGrid grid) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+  const long long i0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+  RRTX_PE_T(t_0);
+  // (np >= 1; a wave or half past the last point repeats it and writes nothing: the workgroup stays whole for the barriers)
+  const long long i = min(i0 + half, np - 1);
+  const double px = p[i * stride + 0], py = p[i * stride + 1];
+  bool slow = !((px - px == 0.0) && (py - py == 0.0)) || m > 32767;
+  if (n_ytab > 0) {
+    // two-level look-up of py in the sorted table (at most 64 x 64 entries; longer tables: the full loop), all 64 lanes
+    // for one point, then for the other
+    const int step = (n_ytab + 63) >> 6;
+    if (step > 64) slow = true;
+    else {
+      const int k0 = lane * step;
+      const double head = ytab[min(k0, n_ytab - 1)];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double qy = lane_f64(py, 32 * h);
+        const unsigned long long le = __ballot(k0 < n_ytab && head <= qy);
+        const int blk = le ? 63 - __clzll((long long)le) : 0;    // last block whose first entry is <= qy
+        const int k = blk * step + lane;
+        const bool eq = lane < step && k < n_ytab && ytab[k] == qy;
+        if (__ballot(eq) != 0ull && half == h) slow = true;
+      }
+    }
+  }
+  bool bad = false;
+  RRTX_PE_T(t_1);
+  // the polygons within reach are collected over the whole list first (typically two or three of 256) and then
+  // evaluated by eight lanes each -- not by the one lane that owns them
+  __shared__ short s_near[4][2][32];
+  short *near_list = s_near[threadIdx.x >> 6][half];
+  int n_near = 0;                                                // uniform over the half
+  int n_list = 0;
+  const bool mine = i0 + half < np;
+  // one group of (up to) 32 obstacles per half: lane hl of each half looks at obstacle j of ITS point's list
+  auto visit = [&](bool valid, int j, const double4 &mt, const double4 &bb) {
+    bool near3 = false, far3 = false, within = false;
+    if (valid) {
+      const double cx = mt.x, cy = mt.y, rad = mt.z;
+      const int kind = (int)mt.w;
+      // near / far by squares: reach = robotRadius + radius, the two sure cases leave a band of 1e-9 around it that
+      // goes to the full loop; the reference's own bound (Wdist - robotRadius) - radius is only needed for balls
+      const double s2 = sq2(cx, cy, px, py);
+      const double reach = robot_radius + rad;
+      if (lists) {
+        // for edges_polygons_kernel: the obstacles a candidate edge of this sample (no longer than list_r) can reach --
+        // its own bound (see there) with list_r for the wave's longest edge
+        const double R = fabs(reach) * (1.0 + 1e-9) + 1e-9 * (1.0 + fabs(cx) + fabs(cy));
+        const double bnd = (R + list_r) * (1.0 + 1e-9) + 1e-9 * (fabs(px) + fabs(py));
+        within = !(s2 > bnd * bnd);                             // NaN anywhere: kept
+      }
+      const double sl = 1e-9 * (1.0 + fabs(cx) + fabs(cy) + fabs(px) + fabs(py) + fabs(reach));
+      const double hi = (reach + sl) * (1.0 + 1e-9), lo = (reach - sl) * (1.0 - 1e-9);
+      if (s2 > hi * hi && hi >= 0.0) {                          // beyond reach for certain: bound > 0
+        // inside the polygon's box (its corners reach past the bounding circle: one point in twelve at C4's density) the
+        // crossing count is taken below; only if it says "inside" does the reference's order of skipping matter
+        const bool outside = px < bb.x || px > bb.y || py < bb.z || py > bb.w;
+        if (kind == 3 && !outside) { near3 = true; far3 = true; }
+        else if (kind != 1 && !outside) slow = true;
+      } else if (lo > 0.0 && s2 < lo * lo && robot_radius >= 0.0) {   // within reach for certain: bound < 0, never skipped
+        if (kind == 1) bad = true;                             // (Wdist - robotRadius) - radius < 0
+        else if (kind == 3) near3 = true;
+        else slow = true;
+      } else slow = true;
+    }
+    const unsigned hm = (unsigned)(__ballot(near3) >> (32 * half));
+    const int at = n_near + __popc(hm & ((1u << hl) - 1u));
+    if (near3) { if (at < 32) near_list[at] = (short)(j | (far3 ? 0x8000 : 0)); else slow = true; }
+    n_near += __popc(hm);
+    if (lists) {
+      const unsigned wm = (unsigned)(__ballot(within) >> (32 * half));
+      const int wat = n_list + __popc(wm & ((1u << hl) - 1u));
+      if (within && wat < kPolyListCap && mine) lists[(size_t)i * kPolyListCap + wat] = (unsigned short)j;
+      n_list += __popc(wm);
+    }
+  };
+  // With a grid over the obstacles (sync_polygon_grid) a point looks at the obstacles listed for its cell only: every
+  // other one is beyond reach for certain, has the point outside its box and is outside the bound of the per-sample
+  // lists.  A point outside the grid (or not finite), a negative robot radius, a list too short for a grid: the whole
+  // list, as before.
+  const double fx = (px - grid.x0) * grid.inv_wx, fy = (py - grid.y0) * grid.inv_wy;
+  const bool in_grid = grid.g > 0 && robot_radius >= 0.0 && fx >= 0.0 && fx < (double)grid.g && fy >= 0.0 && fy < (double)grid.g;
+  const bool wave_grid = __ballot(!in_grid) == 0ull;
+  const int wg_walk = __syncthreads_or(wave_grid ? 0 : 1);
+  if (wave_grid) {
+    const int cellid = (int)fy * grid.g + (int)fx;
+    const int cs = grid.start[cellid], cnt = grid.start[cellid + 1] - cs;
+    const int cnt_max = max(cnt, __shfl_xor(cnt, 32));
+    for (int t0 = 0; t0 < cnt_max; t0 += 32) {
+      const int t = t0 + hl;
+      const bool valid = t < cnt;
+      int j = 0;
+      double4 mt = {0.0, 0.0, 0.0, 0.0}, bb = {0.0, 0.0, 0.0, 0.0};
+      if (valid) {
+        j = grid.items[cs + t];
+        mt = reinterpret_cast<const double4 *>(meta)[j];
+        bb = reinterpret_cast<const double4 *>(bbox)[j];
+      }
+      visit(valid, j, mt, bb);
+    }
+  }
+  if (wg_walk) {
+    // the records (centre, radius, kind; box) of 256 obstacles at a time go through LDS: one trip to memory per 256 for
+    // the workgroup instead of one per 32 for every wave
+    __shared__ double4 s_tab[2][256];
+    for (int c0 = 0; c0 < m; c0 += 256) {
+      if (c0 > 0) __syncthreads();
+      if (c0 + (int)threadIdx.x < m) {
+        s_tab[0][threadIdx.x] = reinterpret_cast<const double4 *>(meta)[c0 + threadIdx.x];
+        s_tab[1][threadIdx.x] = reinterpret_cast<const double4 *>(bbox)[c0 + threadIdx.x];
+      }
+      __syncthreads();
+      const int c1 = min(m, c0 + 256);
+      if (!wave_grid)
+        for (int j0 = c0; j0 < c1; j0 += 32) {
+          const int j = j0 + hl;
+          const bool valid = j < c1;
+          visit(valid, j, s_tab[0][valid ? j - c0 : 0], s_tab[1][valid ? j - c0 : 0]);
+        }
+    }
+  }
+  if (lists && mine && hl == 0) list_cnt[i] = (unsigned short)min(n_list, 0xffff);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  RRTX_PE_T(t_2);
+  const int n_eval = min(n_near, 32);
+  const int n_max = max(n_eval, __shfl_xor(n_eval, 32));
+  for (int r0 = 0; r0 < n_max; r0 += 4) {
+    const int g = r0 + (hl >> 3);
+    int vb = 0, ve = 0;
+    bool far = false;
+    if (g < n_eval) { const int e = near_list[g]; far = (e & 0x8000) != 0; const int j = e & 0x7fff; vb = off[j]; ve = off[j + 1]; }
+    if (g < n_eval && ve - vb < 1) slow = true;
+    int n_rounds = (ve - vb + 7) >> 3;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_rounds = max(n_rounds, __shfl_xor(n_rounds, o));
+    bool inside;
+    double dsq;
+    group8_point_vs_polygon(px, py, vxy, vb, ve, false, 0.0, 0.0, n_rounds, inside, dsq);
+    if (g < n_eval) {
+      if (far) slow = slow || inside;          // (farther than the robot radius from every side for certain)
+      else bad = bad || inside || (sqrt_rn(dsq) - robot_radius < 0.0);
+    }
+  }
+  const unsigned long long sb = __ballot(slow), bm = __ballot(bad);
+  RRTX_PE_T(t_3);
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if (i0 + h >= np) break;
+    const unsigned long long hmask = 0xffffffffull << (32 * h);
+    if (unsafe == nullptr) break;                              // (a call for the lists alone)
+    if (sb & hmask)
+      point_full_loop(p, stride, i0 + h, meta, off, vxy, nullptr, nullptr, 0, m, robot_radius, unsafe, nullptr);
+    else if (lane == 0) unsafe[i0 + h] = (bm & hmask) ? 1 : 0;
+  }
+#ifdef RRTX_TILE_CLOCKS
+  {
+    const unsigned long long t_end = clock64();
+    if (lane == 0 && i0 < np) {
+      unsigned long long *row = g_pp_clk + (size_t)((i0 >> 1) & (kClkRows - 1)) * 8;
+      row[0] = t_1 - t_0; row[1] = t_2 - t_1; row[2] = t_3 - t_2; row[3] = t_end - t_3; row[4] = t_end - t_0; row[5] = 1ull;
+      row[6] = t_0; row[7] = t_end;
+    }
+  }
+#endif
+}
+
 // calculateTrajectory(S, ::SimpleEdge), R/DRRT_SimpleEdge_functions.jl:177-181
 __global__ void simple_steer_kernel(const double *__restrict__ s, const double *__restrict__ g, int dim,
                                     long long ne, double *__restrict__ dist, double *__restrict__ wdist) {
@@ -1172,6 +1418,20 @@ __global__ __launch_bounds__(256) void pack_hits_kernel(const uint8_t *__restric
 }
 
 }  // namespace
+
+#ifdef RRTX_TILE_CLOCKS
+// out: kClkRows x 8 words, one row per wave (rows of waves that did not run are zero after a reset)
+extern "C" int rrtx_debug_polygon_point_clocks(unsigned long long *out, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_clk), sizeof(unsigned long long) * kClkRows * 8);
+  if (reset) { void *p = nullptr; rc |= (int)hipGetSymbolAddress(&p, HIP_SYMBOL(g_pp_clk)); rc |= (int)hipMemset(p, 0, sizeof(unsigned long long) * kClkRows * 8); }
+  return rc;
+}
+extern "C" int rrtx_debug_polygon_edge_clocks(unsigned long long *out, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pe_clk), sizeof(unsigned long long) * kClkRows * 8);
+  if (reset) { void *p = nullptr; rc |= (int)hipGetSymbolAddress(&p, HIP_SYMBOL(g_pe_clk)); rc |= (int)hipMemset(p, 0, sizeof(unsigned long long) * kClkRows * 8); }
+  return rc;
+}
+#endif
 
 // map a list-position range [begin, end) onto the packed active table
 void packed_range(const std::vector<int32_t> &orig, int begin, int end, int &pb, int &pe) {
@@ -1382,6 +1642,76 @@ int sync_polygons(rrtx_ctx *ctx) {
   }
   ctx->poly_has_moving = moving;
   ctx->poly_dirty = false;
+  ctx->poly_h_meta.swap(meta);
+  ctx->poly_h_bbox.swap(bbox);
+  ctx->poly_grid_pad = -1.0;
+  return RRTX_OK;
+}
+
+// Grid for points_polygons_flag_kernel.  A point in cell (ix, iy) -- ix = (int)((px - x0) * inv_wx), the expression the
+// kernel evaluates, monotone in px -- can only be concerned with the obstacles listed for the cell: an obstacle is listed in
+// every cell of ix(lo) .. ix(hi) x iy(lo) .. iy(hi), where [lo, hi] is its bounding circle's box padded by more than
+// |robot radius| + list_r (by 1e-6 relative, against the kernel's 1e-9 slacks) joined with its vertex box.  For any other
+// obstacle the point lies outside that box in x or in y: beyond reach for certain, outside the vertex box, and outside
+// the bound of the per-sample lists -- the three things the kernel's walk over the whole list would find out one by one.
+int sync_polygon_grid(rrtx_ctx *ctx, double pad_needed) {
+  const int na = ctx->poly_n_active;
+  // (a wider pad than needed only lengthens the cell lists; calls with and without the per-sample lists share one grid)
+  if (ctx->poly_grid_pad >= pad_needed && ctx->poly_grid_pad <= 4.0 * pad_needed + 8.0) return RRTX_OK;
+  ctx->poly_grid_pad = -1.0;
+  if (na < 64 || na > 65535 || !(pad_needed >= 0.0) || !(pad_needed < 1e300)) return RRTX_OK;   // short lists: walked whole
+  const double pad = pad_needed * 1.25;
+  const std::vector<double> &meta = ctx->poly_h_meta, &bbox = ctx->poly_h_bbox;
+  std::vector<double> box(4 * (size_t)na);
+  double cmax = 0.0, gx0 = __builtin_inf(), gx1 = -__builtin_inf(), gy0 = __builtin_inf(), gy1 = -__builtin_inf();
+  for (int j = 0; j < na; ++j)
+    for (int k = 0; k < 3; ++k) cmax = std::max(cmax, std::fabs(meta[4 * (size_t)j + k]));
+  for (int j = 0; j < na; ++j) {
+    const double cx = meta[4 * (size_t)j], cy = meta[4 * (size_t)j + 1], rad = std::fabs(meta[4 * (size_t)j + 2]);
+    const double h = (rad + pad) * (1.0 + 1e-6) + 1e-6 * (1.0 + 4.0 * cmax + pad);
+    double lox = std::min(cx - h, bbox[4 * (size_t)j]), hix = std::max(cx + h, bbox[4 * (size_t)j + 1]);
+    double loy = std::min(cy - h, bbox[4 * (size_t)j + 2]), hiy = std::max(cy + h, bbox[4 * (size_t)j + 3]);
+    if (!(lox - lox == 0.0 && hix - hix == 0.0 && loy - loy == 0.0 && hiy - hiy == 0.0)) return RRTX_OK;   // not finite: no grid
+    box[4 * (size_t)j] = lox; box[4 * (size_t)j + 1] = hix; box[4 * (size_t)j + 2] = loy; box[4 * (size_t)j + 3] = hiy;
+    gx0 = std::min(gx0, lox); gx1 = std::max(gx1, hix); gy0 = std::min(gy0, loy); gy1 = std::max(gy1, hiy);
+  }
+  const int G = 64;
+  if (!(gx1 > gx0) || !(gy1 > gy0)) return RRTX_OK;
+  const double inv_wx = (double)G / (gx1 - gx0), inv_wy = (double)G / (gy1 - gy0);
+  if (!(inv_wx - inv_wx == 0.0) || !(inv_wy - inv_wy == 0.0)) return RRTX_OK;
+  auto cell = [G](double v, double v0, double inv_w) {     // the kernel's expression, clamped
+    const double f = (v - v0) * inv_w;
+    return f < 0.0 ? 0 : (f >= (double)G ? G - 1 : (int)f);
+  };
+  std::vector<int32_t> start((size_t)G * G + 1, 0);
+  for (int pass = 0; pass < 2; ++pass) {
+    std::vector<int32_t> cursor;
+    std::vector<uint16_t> items;
+    if (pass == 1) {
+      for (size_t c = 0; c < (size_t)G * G; ++c) start[c + 1] += start[c];
+      cursor.assign(start.begin(), start.end() - 1);
+      items.resize((size_t)start[(size_t)G * G] + 1);
+    }
+    for (int j = 0; j < na; ++j) {        // ascending j within every cell
+      const int ix0 = cell(box[4 * (size_t)j], gx0, inv_wx), ix1 = cell(box[4 * (size_t)j + 1], gx0, inv_wx);
+      const int iy0 = cell(box[4 * (size_t)j + 2], gy0, inv_wy), iy1 = cell(box[4 * (size_t)j + 3], gy0, inv_wy);
+      for (int iy = iy0; iy <= iy1; ++iy)
+        for (int ix = ix0; ix <= ix1; ++ix) {
+          if (pass == 0) ++start[(size_t)iy * G + ix + 1];
+          else items[(size_t)cursor[(size_t)iy * G + ix]++] = (uint16_t)j;
+        }
+    }
+    if (pass == 1) {
+      RRTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      RRTX_HIP(ctx, ctx->d_poly_grid_start.ensure(sizeof(int32_t) * start.size()));
+      RRTX_HIP(ctx, ctx->d_poly_grid_items.ensure(sizeof(uint16_t) * items.size()));
+      RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_grid_start.p, start.data(), sizeof(int32_t) * start.size(), hipMemcpyHostToDevice));
+      RRTX_HIP(ctx, hipMemcpy(ctx->d_poly_grid_items.p, items.data(), sizeof(uint16_t) * items.size(), hipMemcpyHostToDevice));
+    }
+  }
+  ctx->poly_grid_x0 = gx0; ctx->poly_grid_y0 = gy0; ctx->poly_grid_inv_wx = inv_wx; ctx->poly_grid_inv_wy = inv_wy;
+  ctx->poly_grid_g = G;
+  ctx->poly_grid_pad = pad;
   return RRTX_OK;
 }
 
@@ -1470,15 +1800,18 @@ int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int
 int launch_candidate_edges_polygons(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
                                     const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap,
                                     double robot_radius, uint8_t *hit_out_dev, uint8_t *hit_in_dev,
-                                    uint8_t *sample_unsafe_dev) {
+                                    uint8_t *sample_unsafe_dev, double r) {
+  // r >= 0: radius of the ball the lists were built with -> per-sample obstacle lists from the sample pass
   if (nq <= 0) return RRTX_OK;
   int rc = sync_polygons(ctx);
   if (rc) return rc;
-  if (sample_unsafe_dev) {
+  const double list_r = (r >= 0.0 && r - r == 0.0) ? r * (1.0 + 1e-8) : -1.0;
+  const unsigned short *near_lists = nullptr, *near_cnt = nullptr;
+  if (sample_unsafe_dev || (list_r >= 0.0 && cap > 0)) {
     if (ctx->poly_n_active > 0) {
-      rc = launch_points_polygons(ctx, q_dev, nq, robot_radius, sample_unsafe_dev, nullptr);
+      rc = launch_points_polygons(ctx, q_dev, nq, robot_radius, sample_unsafe_dev, nullptr, list_r, &near_lists, &near_cnt);
       if (rc) return rc;
-    } else {
+    } else if (sample_unsafe_dev) {
       RRTX_HIP(ctx, hipMemsetAsync(sample_unsafe_dev, 0, (size_t)nq, ctx->stream));
     }
   }
@@ -1493,12 +1826,13 @@ int launch_candidate_edges_polygons(rrtx_ctx *ctx, const double *q_dev, int nq, 
   csr.nodes_aos = reinterpret_cast<const double4 *>(ctx->nodes_aos);
   csr.hit_in = hit_in_dev; csr.cap = (long long)cap; csr.nq = nq; csr.n_nodes = (int)ctx->n_nodes;
   span_begin(ctx, KF_EDGES);
-  hipLaunchKernelGGL(edges_polygons_kernel<true>, dim3((unsigned)((2 * cap + 255) / 256)), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL((edges_polygons_kernel<true, 1, 5>),
+                     dim3((unsigned)((2 * cap + 63) / 64)), dim3(64), 0, ctx->stream,
                      (const double *)nullptr, (const double *)nullptr, ctx->dim, 0ll, csr, ctx->d_poly_meta.as<double>(),
                      ctx->d_poly_off.as<int32_t>(), ctx->d_poly_vxy.as<double>(), ctx->d_poly_slope.as<double>(),
                      ctx->d_poly_path_off.as<int32_t>(),
                      ctx->d_poly_path.as<double>(), ctx->poly_has_moving ? 1 : 0, ctx->d_poly_orig.as<int32_t>(), 0,
-                     ctx->poly_n_active, robot_radius, hit_out_dev, (int32_t *)nullptr);
+                     ctx->poly_n_active, robot_radius, hit_out_dev, (int32_t *)nullptr, near_lists, near_cnt, list_r);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
@@ -1519,12 +1853,12 @@ int launch_edges_polygons(rrtx_ctx *ctx, const double *p0_dev, const double *p1_
   packed_range(active_positions(ctx->poly_active), obs_begin, obs_end, pb, pe);
   if (pe <= pb) return zero_outputs(ctx, ne, hit_dev, first_hit_dev);
   span_begin(ctx, KF_EDGES);
-  hipLaunchKernelGGL(edges_polygons_kernel<false>, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
+  hipLaunchKernelGGL((edges_polygons_kernel<false, 4, 4>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
                      p1_dev, ctx->dim, (long long)ne, PolyCsr{}, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
                      ctx->d_poly_vxy.as<double>(), ctx->d_poly_slope.as<double>(), ctx->d_poly_path_off.as<int32_t>(),
                      ctx->d_poly_path.as<double>(),
                      ctx->poly_has_moving ? 1 : 0, ctx->d_poly_orig.as<int32_t>(), pb, pe, robot_radius, hit_dev,
-                     first_hit_dev);
+                     first_hit_dev, (const unsigned short *)nullptr, (const unsigned short *)nullptr, 0.0);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
@@ -1545,16 +1879,46 @@ int launch_points_spheres(rrtx_ctx *ctx, const double *p_dev, int64_t np, double
 }
 
 int launch_points_polygons(rrtx_ctx *ctx, const double *p_dev, int64_t np, double robot_radius,
-                           uint8_t *unsafe_dev, double *clearance_dev) {
+                           uint8_t *unsafe_dev, double *clearance_dev, double list_r,
+                           const unsigned short **lists_out, const unsigned short **list_cnt_out) {
+  if (lists_out) *lists_out = nullptr;
+  if (list_cnt_out) *list_cnt_out = nullptr;
   if (np <= 0) return RRTX_OK;
   int rc = sync_polygons(ctx);
   if (rc) return rc;
+  unsigned short *lists = nullptr, *list_cnt = nullptr;
   span_begin(ctx, KF_POINTS);
-  hipLaunchKernelGGL(points_polygons_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, ctx->stream, p_dev,
-                     ctx->dim, (long long)np, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
-                     ctx->d_poly_vxy.as<double>(), ctx->d_poly_path_off.as<int32_t>(), ctx->d_poly_path.as<double>(),
-                     ctx->poly_has_moving ? 1 : 0, ctx->poly_n_active, robot_radius, unsafe_dev, clearance_dev,
-                     ctx->d_poly_bbox.as<double>(), ctx->d_poly_ytab.as<double>(), ctx->poly_n_ytab);
+  // flag-only calls over obstacles that stand still: two points per wave with the reference's loop as the fall-back
+  // inside the kernel; a wanted certificate or obstacles that move in time: the reference's loop, one point per wave
+  const bool flag_only = clearance_dev == nullptr && !ctx->poly_has_moving && ctx->poly_n_ytab >= 0 &&
+                         ctx->d_poly_bbox.as<double>() != nullptr;
+  if (flag_only) {
+    // list_r >= 0: also list, per point, the obstacles an edge of at most that length from the point can reach (the
+    // fused extend preamble hands them to edges_polygons_kernel)
+    if (lists_out && list_cnt_out && list_r >= 0.0 && ctx->poly_n_active <= 65535) {
+      RRTX_HIP(ctx, ctx->ws_poly_lists.ensure(sizeof(unsigned short) * (size_t)np * (kPolyListCap + 1)));
+      lists = ctx->ws_poly_lists.as<unsigned short>();
+      list_cnt = lists + (size_t)np * kPolyListCap;
+    }
+    PolyGrid grid = {0.0, 0.0, 0.0, 0.0, 0, nullptr, nullptr};
+    if (np >= 256) {                            // (a handful of points: not worth a grid build)
+      rc = sync_polygon_grid(ctx, std::fabs(robot_radius) + (lists ? list_r : 0.0));
+      if (rc) { span_end(ctx); return rc; }
+      if (ctx->poly_grid_pad >= 0.0)
+        grid = PolyGrid{ctx->poly_grid_x0, ctx->poly_grid_y0, ctx->poly_grid_inv_wx, ctx->poly_grid_inv_wy, ctx->poly_grid_g,
+                        ctx->d_poly_grid_start.as<int32_t>(), ctx->d_poly_grid_items.as<uint16_t>()};
+    }
+    hipLaunchKernelGGL(points_polygons_flag_kernel, dim3((unsigned)((np + 7) / 8)), dim3(256), 0, ctx->stream, p_dev,
+                       ctx->dim, (long long)np, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
+                       ctx->d_poly_vxy.as<double>(), ctx->poly_n_active, robot_radius, unsafe_dev,
+                       ctx->d_poly_bbox.as<double>(), ctx->d_poly_ytab.as<double>(), ctx->poly_n_ytab, list_r, lists,
+                       list_cnt, grid);
+    if (lists) { *lists_out = lists; *list_cnt_out = list_cnt; }
+  } else
+    hipLaunchKernelGGL(points_polygons_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, ctx->stream, p_dev,
+                       ctx->dim, (long long)np, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
+                       ctx->d_poly_vxy.as<double>(), ctx->d_poly_path_off.as<int32_t>(), ctx->d_poly_path.as<double>(),
+                       ctx->poly_has_moving ? 1 : 0, ctx->poly_n_active, robot_radius, unsafe_dev, clearance_dev);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;

@@ -482,7 +482,7 @@ int rrtx_destroy(rrtx_ctx *ctx) {
   ctx->d_absmax.release();
   ctx->d_xrange.release();
   DevBuf *bufs[] = {&ctx->d_sph, &ctx->d_sph_reach, &ctx->d_sph_reach_f, &ctx->d_sph_aux, &ctx->d_poly_off, &ctx->d_poly_vxy, &ctx->d_poly_slope, &ctx->d_poly_meta,
-                    &ctx->d_poly_orig, &ctx->d_poly_bbox, &ctx->d_poly_ytab, &ctx->d_poly_pbox, &ctx->d_poly_path_off, &ctx->d_poly_path, &ctx->ws_knn_off, &ctx->ws_knn_idx,
+                    &ctx->d_poly_orig, &ctx->d_poly_bbox, &ctx->d_poly_ytab, &ctx->d_poly_pbox, &ctx->d_poly_grid_start, &ctx->d_poly_grid_items, &ctx->d_poly_path_off, &ctx->d_poly_path, &ctx->ws_knn_off, &ctx->ws_knn_idx,
                     &ctx->ws_knn_dist, &ctx->ws_knn_misc, &ctx->ws_q, &ctx->ws_q2, &ctx->ws_slots, &ctx->ws_copies,
                     &ctx->ws_copy_meta, &ctx->ws_copies_f, &ctx->ws_recs, &ctx->ws_counts, &ctx->ws_bsum, &ctx->ws_scalars, &ctx->ws_scalars_nn, &ctx->ws_tmp,
                     &ctx->ws_owner, &ctx->ws_dub_rec, &ctx->ws_out_off, &ctx->ws_out_idx, &ctx->ws_out_dist, &ctx->ws_out_u8a,
@@ -490,7 +490,7 @@ int rrtx_destroy(rrtx_ctx *ctx) {
                     &ctx->ws_slab_hist, &ctx->ws_slab_start, &ctx->ws_slab_sr, &ctx->ws_slab_params, &ctx->ws_run_hist, &ctx->ws_run_sr,
                     &ctx->ws_copies_s,
                     &ctx->ws_meta_s, &ctx->ws_cb, &ctx->ws_qhist, &ctx->ws_bkt,
-                    &ctx->ws_ev_a, &ctx->ws_ev_cnt, &ctx->ws_confirm_args, &ctx->ws_sph_lists, &ctx->d_sph_sample,
+                    &ctx->ws_ev_a, &ctx->ws_ev_cnt, &ctx->ws_confirm_args, &ctx->ws_sph_lists, &ctx->ws_poly_lists, &ctx->d_sph_sample,
                     &ctx->ws_sweep_mark, &ctx->ws_sweep_flag, &ctx->ws_sweep_cnt, &ctx->ws_sweep_start,
                     &ctx->gc.lmc, &ctx->gc.parent, &ctx->gc.stamp, &ctx->gc.flags, &ctx->gc.orph, &ctx->gc.anc, &ctx->gc.ids,
                     &ctx->gc.in_cnt, &ctx->gc.in_start, &ctx->gc.in_cursor, &ctx->gc.in_tiles, &ctx->gc.in_src, &ctx->gc.in_w,
@@ -1471,7 +1471,7 @@ int rrtx_extend_candidates_dev(rrtx_ctx *ctx, const double *q, int nq, double r,
                               want_nearest ? nearest_dist : nullptr);
     if (rc) return rc;
     return launch_candidate_edges_polygons(ctx, q, nq, offsets, idx, ctx->ws_owner.as<int32_t>(), cap, robot_radius,
-                                           hit_out, hit_in, sample_unsafe);
+                                           hit_out, hit_in, sample_unsafe, (r >= 0.0) ? r : -1.0);
   }
   // sphere list: in the culled search the sample pass and both directed edges of every neighbour are
   // decided where the neighbour is found (kernels_nn.hip, TileEmit) and the finish kernel hands out

@@ -175,6 +175,13 @@ struct rrtx_ctx {
   rrtx::DevBuf d_poly_bbox, d_poly_ytab;
   rrtx::DevBuf d_poly_pbox;    // per packed obstacle: box of its centre over its whole path (kinds 6 / 7; a point otherwise)
   int poly_n_ytab = 0;
+  // uniform grid over the packed obstacles for the flag-only point check (kernels_collide.hip, sync_polygon_grid): per cell
+  // the obstacles whose bounding circle or box, padded by poly_grid_pad, reaches the cell
+  rrtx::DevBuf d_poly_grid_start, d_poly_grid_items;
+  std::vector<double> poly_h_meta, poly_h_bbox;      // host copies of the packed records the grid is built from
+  double poly_grid_pad = -1.0;                        // < 0: no grid
+  double poly_grid_x0 = 0.0, poly_grid_y0 = 0.0, poly_grid_inv_wx = 0.0, poly_grid_inv_wy = 0.0;
+  int poly_grid_g = 0;
   rrtx::DevBuf ws_knn_off, ws_knn_idx, ws_knn_dist, ws_knn_misc;   // k-nearest via range-search lists
   int opt_knn_lists = 1;
   int opt_extend_polygons = 0;   // rrtx_extend_candidates checks against the polygon list instead of the spheres
@@ -212,6 +219,7 @@ struct rrtx_ctx {
   rrtx::DevBuf ws_mask;     // per-call obstacle mask (packed order)
   rrtx::DevBuf ws_i32a, ws_i32b;  // staged index arrays
   rrtx::DevBuf ws_sph_lists;      // per sample: spheres its candidate edges can touch (+ counts)
+  rrtx::DevBuf ws_poly_lists;     // per sample: polygons its candidate edges can reach (+ counts), uint16
 
   // device mirror of the planner's directed edges (obstacle sweeps, kernels_sweep.hip)
   int32_t *ge_start = nullptr, *ge_end = nullptr;
@@ -314,7 +322,8 @@ int launch_edges_polygons(rrtx_ctx *ctx, const double *p0_dev, const double *p1_
 int launch_points_spheres(rrtx_ctx *ctx, const double *p_dev, int64_t np, double robot_radius, int quick,
                           uint8_t *unsafe_dev, double *clearance_dev);
 int launch_points_polygons(rrtx_ctx *ctx, const double *p_dev, int64_t np, double robot_radius,
-                           uint8_t *unsafe_dev, double *clearance_dev);
+                           uint8_t *unsafe_dev, double *clearance_dev, double list_r = -1.0,
+                           const unsigned short **lists_out = nullptr, const unsigned short **list_cnt_out = nullptr);
 int launch_simple_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne,
                         double *dist_dev, double *wdist_dev);
 int launch_dubins_steer(rrtx_ctx *ctx, const double *s_dev, const double *g_dev, int64_t ne, double r_min,
@@ -348,7 +357,7 @@ int launch_candidate_edges(rrtx_ctx *ctx, const double *q_dev, int nq, const int
 int launch_candidate_edges_polygons(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
                                     const int32_t *idx_dev, const int32_t *owner_dev, int64_t cap,
                                     double robot_radius, uint8_t *hit_out_dev, uint8_t *hit_in_dev,
-                                    uint8_t *sample_unsafe_dev);
+                                    uint8_t *sample_unsafe_dev, double r = -1.0);
 int launch_nearest_from_lists(rrtx_ctx *ctx, const double *q_dev, int nq, const int64_t *offsets_dev,
                               const int32_t *idx_dev, const double *dist_dev, int32_t *nearest_idx_dev,
                               double *nearest_dist_dev);
@@ -368,5 +377,6 @@ int launch_pack_hits(rrtx_ctx *ctx, const uint8_t *hit_out, const uint8_t *hit_i
 // make sure the packed obstacle tables on the device match the host truth
 int sync_spheres(rrtx_ctx *ctx, double robot_radius);
 int sync_polygons(rrtx_ctx *ctx);
+int sync_polygon_grid(rrtx_ctx *ctx, double pad_needed);
 
 }  // namespace rrtx

@@ -470,23 +470,26 @@ def test_polygons_edges_and_points(oracle):
         assert np.array_equal(clr, rc)
 
 
-def test_polygon_point_flag_without_certificate_matches_full_check(oracle):
+@pytest.mark.parametrize("moving", [True, False])
+def test_polygon_point_flag_without_certificate_matches_full_check(oracle, moving):
     """explicitPointCheck with no certificate wanted (clearance == NULL) must return the flag of the call that
     wants it -- random points, points at the robot radius from a polygon edge or a ball to within ulps, points on
     bounding circles, moving obstacles, non-finite points.  (Until the end of round 2 the flag-only call walked the
-    near obstacles only; the lattice scenes showed that wrong, tests/test_gpu_lattice.py, K12.)"""
+    near obstacles only; the lattice scenes showed that wrong, tests/test_gpu_lattice.py, K12.)  Without moving
+    obstacles the flag-only call is a kernel of its own (two points per wave, the reference's loop as its fall-back:
+    an odd number of points, points at the height of a vertex and points inside far bounding boxes go through it)."""
     rng = np.random.default_rng(78)
     polys, kinds, paths = [], [], []
     for i in range(200):
         c = rng.uniform(-40, 40, 2)
         ang = np.sort(rng.uniform(0, 2 * np.pi, rng.integers(3, 7)))
         polys.append(c + np.c_[np.cos(ang), np.sin(ang)] * rng.uniform(0.5, 6))
-        k = 1 if i % 5 == 0 else (6 if i % 11 == 3 else 3)
+        k = 1 if i % 5 == 0 else (6 if i % 11 == 3 and moving else 3)
         kinds.append(k)
         paths.append(np.c_[rng.uniform(-10, 10, (4, 2)), np.sort(rng.uniform(0, 30, 4))] if k == 6 else None)
     ps = oracle.PolygonSet(polys, kinds=kinds, paths=paths)
     cr = ps.centre_radius()
-    n = 30_000
+    n = 30_000 if moving else 30_001
     P = np.zeros((n, 3))
     P[:, :2] = rng.uniform(-45, 45, (n, 2))
     P[:, 2] = rng.uniform(0, 30, n)
@@ -506,15 +509,19 @@ def test_polygon_point_flag_without_certificate_matches_full_check(oracle):
         t = rng.uniform(0, 2 * np.pi)
         P[i, :2] = cr[j, :2] + np.array([np.cos(t), np.sin(t)]) * (cr[j, 2] + rr) * (1.0 + (i % 7 - 3) * 2.0 ** -52)
     P[9000] = [np.nan, 0, 0]; P[9001] = [np.inf, 1, 2]; P[9002] = [1e300, -1e300, 5]
+    for i in range(9003, 11000):                # at the height of a vertex of some polygon, anywhere along x
+        P[i, 1] = polys[i % 200][i % len(polys[i % 200]), 1]
+    P[12000:12040, :2] *= 3.0                   # outside the grid over the obstacles (the whole list is walked), ...
+    P[12100:12108, 0] += 200.0                  # ... whole workgroups of them and single ones among points inside
     with Context(3) as ctx:
         ctx.nodes_append(synth.nodes(16, 3))
-        ctx.polygons_set(polys, kinds=kinds, paths=paths)
+        ctx.polygons_set(polys, kinds=kinds, paths=paths if moving else None)
         full, clr = ctx.points_check(P, rr, kind=1)
         flag, none = ctx.points_check(P, rr, kind=1, want_clearance=False)
         assert none is None
         assert np.array_equal(full, flag)
         assert 0 < full.sum() < n
-        for i in list(range(0, 9003, 37)) + [9000, 9001, 9002]:       # and the full check is the oracle's
+        for i in list(range(0, 11000, 37)) + [9000, 9001, 9002, n - 1] + list(range(12000, 12040, 3)) + [12100, 12107]:       # and the full check is the oracle's
             u, c = oracle.point_check_polygons(ps, P[i], rr)
             assert full[i] == u and (clr[i] == c or (np.isnan(clr[i]) and np.isnan(c)))
 
