@@ -444,7 +444,7 @@ __device__ void segment_dist_sqrd_both(double pax, double pay, double pbx, doubl
 // (index_before_time, transform_obs_to_time, edge_hits_moving: collide_device.hpp, shared with kernels_dubins.hip)
 
 constexpr int kPolyPairs = 256;        // (edge, obstacle) pairs a wave queues for the bounding-circle test
-constexpr int kPolyQueue = 512;        // (edge, polygon segment) tests a wave queues
+constexpr int kPolyQueue = 384;        // (edge, polygon segment) tests a wave queues
 constexpr int kPolyWaveCand = 256;     // candidate obstacles a wave lists (more: the whole list is walked)
 constexpr int kPolyWaveSamples = 16;   // ... for at most this many samples per wave
 constexpr int kPolyListCap = 64;       // obstacles the sample pass lists per sample (more: the wave lists for itself)
@@ -457,6 +457,8 @@ struct PolyWave {
   float4 box[32];      // current group: bounding boxes (xlo, xhi, ylo, yhi) rounded outward to fp32
   int first[64];
   int jidx[32];        // current group: list position of each of its obstacles
+  double4 gmeta[32];   // current group: (cx, cy, radius, kind) of each of its obstacles
+  int goff[32], gcnt[32];   // current group: first vertex and number of vertices
   unsigned short pairq[kPolyPairs];   // (edge lane | obstacle slot << 6) of the pairs the box test leaves
   unsigned pq[kPolyQueue];         // (edge lane | obstacle slot << 6 | segment << 11) of the segment tests to run
   short wc[kPolyWaveCand];   // CSR mode: the obstacles any edge of the wave can reach (list positions, ascending)
@@ -514,20 +516,21 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
   unsigned long long acc_box = 0ull, acc_hand = 0ull, acc_a1 = 0ull, acc_a2 = 0ull, acc_b = 0ull;
 #endif
   RRTX_PE_T(t_start);
+  int qi_mine = 0;
   if (csr.q) {
+    // (the entry's owner and node are asked for before the list length is known: the arrays hold `cap` entries, and what
+    // lies past the last written one is never looked at)
+    int n = 0;
+    if ((i >> 1) < csr.cap) { qi_mine = csr.owner[i >> 1]; n = csr.idx[i >> 1]; }
     const long long total = csr.offsets[csr.nq];
     if (total > csr.cap) return;          // capacity overflow: the CSR arrays are only partly written
-    act = i < 2 * total;
+    act = i < 2 * total && (unsigned)qi_mine < (unsigned)csr.nq && (unsigned)n < (unsigned)csr.n_nodes;   // defensive
     if (act) {
-      const int qi = csr.owner[i >> 1], n = csr.idx[i >> 1];
-      act = (unsigned)qi < (unsigned)csr.nq && (unsigned)n < (unsigned)csr.n_nodes;   // defensive
-      if (act) {
-        const double *s = csr.q + (size_t)qi * stride;
-        const double4 g = csr.nodes_aos[n];
-        if (i & 1) { ax = g.x; ay = g.y; at = g.z; bx = s[0]; by = s[1]; bt = s[2]; }
-        else { ax = s[0]; ay = s[1]; at = s[2]; bx = g.x; by = g.y; bt = g.z; }
-      }
-    }
+      const double *s = csr.q + (size_t)qi_mine * stride;
+      const double4 g = csr.nodes_aos[n];
+      if (i & 1) { ax = g.x; ay = g.y; at = g.z; bx = s[0]; by = s[1]; bt = s[2]; }
+      else { ax = s[0]; ay = s[1]; at = s[2]; bx = g.x; by = g.y; bt = g.z; }
+    } else qi_mine = 0;
     if (__ballot(act) == 0ull) return;    // the grid covers the caller's capacity
   } else {
     act = i < ne;
@@ -556,8 +559,39 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
   if (csr.q) {
     const unsigned long long amask = __ballot(act);
     const int lf = __ffsll((long long)amask) - 1, ll = 63 - __clzll((long long)amask);
-    const int qmine = act ? csr.owner[i >> 1] : 0;
-    const int s0 = __builtin_amdgcn_readlane(qmine, lf), s1 = __builtin_amdgcn_readlane(qmine, ll);
+    const int s0 = __builtin_amdgcn_readlane(qi_mine, lf), s1 = __builtin_amdgcn_readlane(qi_mine, ll);
+    const bool span_ok = s1 >= s0 && s1 - s0 < kPolyWaveSamples;
+    // The sample pass (points_polygons_flag_kernel) has listed, per sample, the obstacles within the same bound taken
+    // with the radius of the search ball in place of the wave's longest edge -- a superset, since no candidate edge is
+    // longer than that radius (checked below: lmax <= list_r).  The wave's list is the union of its samples' lists;
+    // it is put together here, while the edges' coordinates are still on their way.
+    const int mm = m_end - m_begin;
+    bool merged = false;
+    if (span_ok && near_cnt != nullptr && m_begin == 0 && mm <= 64 * kPolyBitWords) {
+      if (lane < kPolyBitWords) w.bits[lane] = 0ull;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // (the counts in one load, the lists four samples at a time without waiting for the counts: a row of the list array
+      // is kPolyListCap entries whatever its count, what lies past the count is dropped below)
+      const int span = s1 - s0 + 1;
+      const int c_mine = lane < span ? (int)near_cnt[s0 + lane] : 0;
+      int jv[4];
+      for (int k0 = 0; k0 < span; k0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) jv[u] = (k0 + u < span) ? (int)near_lists[(size_t)(s0 + k0 + u) * kPolyListCap + lane] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (k0 + u >= span) break;
+          const int c = __shfl(c_mine, k0 + u);                 // wave-uniform
+          if (lane < c && jv[u] < mm) atomicOr(&w.bits[jv[u] >> 6], 1ull << (jv[u] & 63));
+        }
+      }
+      merged = __ballot(c_mine > kPolyListCap) == 0ull;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     double l2 = 0.0;
     if (act) { const double ex = bx - ax, ey = by - ay; l2 = ex * ex + ey * ey; }
     const bool fin = (l2 - l2 == 0.0);               // false for NaN / inf lengths
@@ -565,39 +599,16 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
     for (int off = 32; off > 0; off >>= 1) l2 = fmax(l2, __shfl_xor(l2, off));
     double lmax = sqrt_rn(l2) * (1.0 + 1e-9);
     if (__ballot(!fin) != 0ull) lmax = __builtin_inf();          // a non-finite edge: keep everything
-    if (s1 >= s0 && s1 - s0 < kPolyWaveSamples) {
+    if (span_ok) {
       int nc = 0;                                                  // wave-uniform
-      // The sample pass (points_polygons_flag_kernel) has listed, per sample, the obstacles within the same bound taken
-      // with the radius of the search ball in place of the wave's longest edge -- a superset, since no candidate edge is
-      // longer than that radius (checked here: lmax <= list_r).  The wave's list is the union of its samples' lists.
-      bool from_lists = false;
-      const int mm = m_end - m_begin;
-      if (near_cnt != nullptr && m_begin == 0 && mm <= 64 * kPolyBitWords && lmax <= list_r) {
-        if (lane < kPolyBitWords) w.bits[lane] = 0ull;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        bool ok = true;
-        for (int sidx = s0; sidx <= s1; ++sidx) {
-          const int c = near_cnt[sidx];                            // wave-uniform
-          if (c > kPolyListCap) { ok = false; break; }
-          if (lane < c) {
-            const int j = near_lists[(size_t)sidx * kPolyListCap + lane];
-            if (j < mm) atomicOr(&w.bits[j >> 6], 1ull << (j & 63));
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (ok) {
-          from_lists = true;
-          for (int wd = 0; wd * 64 < mm; ++wd) {
-            const unsigned long long km = w.bits[wd];
-            const bool keep = ((km >> lane) & 1ull) != 0ull;
-            const int at = nc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-            if (keep && at < kPolyWaveCand) w.wc[at] = (short)(wd * 64 + lane);
-            nc += __popcll(km);
-          }
+      const bool from_lists = merged && lmax <= list_r;
+      if (from_lists) {
+        for (int wd = 0; wd * 64 < mm; ++wd) {
+          const unsigned long long km = w.bits[wd];
+          const bool keep = ((km >> lane) & 1ull) != 0ull;
+          const int at = nc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+          if (keep && at < kPolyWaveCand) w.wc[at] = (short)(wd * 64 + lane);
+          nc += __popcll(km);
         }
       }
       if (!from_lists)
@@ -653,12 +664,18 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
     if (lane < jn) {
       const int j = m_begin + (listed ? (int)w.wc[g0 + lane] : g0 + lane);
       w.jidx[lane] = j;
-      const int kind = (int)meta[4 * j + 3];
+      // (the group's records stay in LDS for stages A and B: neither goes back to memory for them)
+      const double4 mt = reinterpret_cast<const double4 *>(meta)[j];
+      const int v0 = off[j];
+      w.gmeta[lane] = mt;
+      w.goff[lane] = v0;
+      w.gcnt[lane] = off[j + 1] - v0;
+      const int kind = (int)mt.w;
       const float inf = __builtin_inff();
       float4 o = {-inf, inf, -inf, inf};
       if (kind != 6 && kind != 7) {
-        const double cx = meta[4 * j + 0], cy = meta[4 * j + 1];
-        const double R = fabs(robot_radius + meta[4 * j + 2]) * (1.0 + 1e-9) + 1e-9 * (1.0 + fabs(cx) + fabs(cy));
+        const double cx = mt.x, cy = mt.y;
+        const double R = fabs(robot_radius + mt.z) * (1.0 + 1e-9) + 1e-9 * (1.0 + fabs(cx) + fabs(cy));
         o.x = __double2float_rd(cx - R); o.y = __double2float_ru(cx + R);
         o.z = __double2float_rd(cy - R); o.w = __double2float_ru(cy + R);
       }
@@ -711,8 +728,9 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
           if (qi < nqd) {
             const unsigned ent = w.pq[qi];
             const int owner = (int)(ent & 63u), sg = (int)((ent >> 11) & 0x7ffffu);
-            const int j = w.jidx[(ent >> 6) & 31u];
-            const int vb0 = off[j], P = off[j + 1] - vb0;
+            const int slot = (int)((ent >> 6) & 31u);
+            const int j = w.jidx[slot];
+            const int vb0 = w.goff[slot], P = w.gcnt[slot];
             const int va = vb0 + (sg == 0 ? P - 1 : sg - 1), vb = vb0 + sg;
             if (PAIRED) {
               double rF, rR;
@@ -746,35 +764,36 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
           slot = (int)(pe >> 6);
           const int j = w.jidx[slot];
           const double eax = w.e[0][owner], eay = w.e[1][owner], ebx = w.e[3][owner], eby = w.e[4][owner];
-          const int kind = (int)meta[4 * j + 3];
+          const double4 mt = w.gmeta[slot];
+          const int kind = (int)mt.w;
           if (kind == 6 || kind == 7) {
-            if (edge_hits_moving(eax, eay, w.e[2][owner], ebx, eby, w.e[5][owner], robot_radius, meta[4 * j + 0],
-                                 meta[4 * j + 1], meta[4 * j + 2], path + 3 * (size_t)path_off[j],
+            if (edge_hits_moving(eax, eay, w.e[2][owner], ebx, eby, w.e[5][owner], robot_radius, mt.x,
+                                 mt.y, mt.z, path + 3 * (size_t)path_off[j],
                                  path_off[j + 1] - path_off[j]))
               atomicMin(&w.first[owner], j);
-            if (PAIRED && edge_hits_moving(ebx, eby, w.e[5][owner], eax, eay, w.e[2][owner], robot_radius, meta[4 * j + 0],
-                                           meta[4 * j + 1], meta[4 * j + 2], path + 3 * (size_t)path_off[j],
+            if (PAIRED && edge_hits_moving(ebx, eby, w.e[5][owner], eax, eay, w.e[2][owner], robot_radius, mt.x,
+                                           mt.y, mt.z, path + 3 * (size_t)path_off[j],
                                            path_off[j + 1] - path_off[j]))
               atomicMin(&w.first[owner + 1], j);
           } else {
-            const double dsq = dist_sqrd_point_to_segment(meta[4 * j + 0], meta[4 * j + 1], eax, eay, ebx, eby);
-            const double rr = robot_radius + meta[4 * j + 2];
+            const double dsq = dist_sqrd_point_to_segment(mt.x, mt.y, eax, eay, ebx, eby);
+            const double rr = robot_radius + mt.z;
             pass_f = !(dsq > rr * rr);
             if (PAIRED) {
               // The reverse edge measures the same distance from the other end: the two results differ by rounding only
               // (below 1e-14 of the squared lengths involved), so the reverse test is evaluated only where the forward
               // distance lies within 1e-7 of those lengths of the threshold -- or is not finite.
-              const double scale = sq2(meta[4 * j + 0], meta[4 * j + 1], eax, eay) + sq2(ebx, eby, eax, eay) + rr * rr;
+              const double scale = sq2(mt.x, mt.y, eax, eay) + sq2(ebx, eby, eax, eay) + rr * rr;
               if (fabs(dsq - rr * rr) > 1e-7 * scale) pass_r = pass_f;
-              else pass_r = !(dist_sqrd_point_to_segment(meta[4 * j + 0], meta[4 * j + 1], ebx, eby, eax, eay) > rr * rr);
+              else pass_r = !(dist_sqrd_point_to_segment(mt.x, mt.y, ebx, eby, eax, eay) > rr * rr);
             }
             if (pass_f || pass_r) {
               if (kind == 1) {
                 if (pass_f) atomicMin(&w.first[owner], j);
                 if (pass_r) atomicMin(&w.first[owner + 1], j);
               } else if (kind == 3) {
-                vb0 = off[j];
-                P = off[j + 1] - vb0;
+                vb0 = w.goff[slot];
+                P = w.gcnt[slot];
                 if (P < 2) P = 0;                          // (:1551: fewer than two vertices never collide)
               }
             }
