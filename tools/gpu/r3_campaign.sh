@@ -30,7 +30,7 @@ fi
 if has pmc; then
   bash tools/gpu/pmc_bench.sh $tag/pmc_c4 "nn_tile_kernel<3, true>" --steps 5 --warmup 2 > $out/pmc_c4.log 2>&1; echo "pmc c4 rc=$?"
   bash tools/gpu/pmc_bench.sh $tag/pmc_poly "edges_polygons_kernel" --obstacles polygons --steps 5 --warmup 2 > $out/pmc_poly.log 2>&1; echo "pmc poly rc=$?"
-  python3 tools/pmc_traffic.py $out/pmc_poly "points_polygons_kernel" $out/pmc_poly/p1.json > $out/pmc_poly/traffic_points.json
+  python3 tools/pmc_traffic.py $out/pmc_poly "points_polygons_flag_kernel" $out/pmc_poly/p1.json > $out/pmc_poly/traffic_points.json
   python3 tools/pmc_traffic.py $out/pmc_poly "nn_tile_kernel<3, false>" $out/pmc_poly/p1.json > $out/pmc_poly/traffic_tile.json
   bash tools/gpu/pmc_bench.sh $tag/pmc_c3 "dubins_check_rec_kernel<false>" --config C3 --steps 2 --warmup 1 > $out/pmc_c3.log 2>&1; echo "pmc c3 rc=$?"
   python3 tools/pmc_traffic.py $out/pmc_c3 "dubins_steer_rec_kernel" $out/pmc_c3/p1.json > $out/pmc_c3/traffic_steer.json
