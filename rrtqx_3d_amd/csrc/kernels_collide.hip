@@ -454,8 +454,9 @@ constexpr int kPolyBitWords = 16;      // ... merged per wave through a bit set 
 struct PolyWave {
   double e[6][64];     // ax, ay, at, bx, by, bt per lane
   double em[64];       // the edge's slope (by - ay) / (bx - ax) as segmentDistSqrd divides it (R/DRRT.jl:1158)
+  double emr[64];      // PAIRED: the slope as the reverse edge divides it, (ay - by) / (ax - bx)
   float4 box[32];      // current group: bounding boxes (xlo, xhi, ylo, yhi) rounded outward to fp32
-  int first[64];
+  int first[128];      // first hit (list position) per edge; PAIRED: [2 lane] forward, [2 lane + 1] reverse
   int jidx[32];        // current group: list position of each of its obstacles
   double4 gmeta[32];   // current group: (cx, cy, radius, kind) of each of its obstacles
   int goff[32], gcnt[32];   // current group: first vertex and number of vertices
@@ -467,7 +468,7 @@ struct PolyWave {
 };
 
 // Second edge source of edges_polygons_kernel: the candidate edges of extend() straight from the CSR
-// neighbour lists -- thread 2e is sample -> neighbour of entry e, thread 2e + 1 the reverse edge
+// neighbour lists -- thread e holds sample -> neighbour of entry e and the reverse edge
 // (R/DRRT_Q.jl:1951-1963, 2600-2602).  q == nullptr selects the p0 / p1 arrays.
 struct PolyCsr {
   const double *q;
@@ -492,11 +493,13 @@ __device__ unsigned long long g_pp_clk[kClkRows * 8];
 #define RRTX_PE_ACC(acc, a, b) do { } while (0)
 #endif
 
-// PAIRED (the candidate edges of extend(), CSR mode): lanes 2k and 2k + 1 hold the two directions of ONE segment.
-// Only the even lane lists obstacles and hands out pairs; stage A runs the bounding-circle test for both directions
-// in the pair's lane (it differs between them only in rounding: distanceSqrdPointToSegment measures from the other
-// end), and stage B's segment_dist_sqrd_both gives both directions' answers at 1.3x the cost of one.  Every boolean is
-// still the reference's own expression for that directed edge; the rounds of both stages halve.
+// PAIRED (the candidate edges of extend(), CSR mode): a lane holds BOTH directions of one CSR entry -- sample -> neighbour
+// and the reverse edge (R/DRRT_Q.jl:1951-1963, 2600-2602).  The lane lists obstacles and hands out pairs once for the two;
+// stage A runs the bounding-circle test for both directions in the pair's lane (it differs between them only in
+// rounding: distanceSqrdPointToSegment measures from the other end), and stage B's segment_dist_sqrd_both gives both
+// directions' answers at 1.3x the cost of one.  Every boolean is still the reference's own expression for that directed
+// edge.  (Until late in round 3 the two directions sat in neighbouring lanes and the odd one idled through the listing, the
+// boxes and the hand-out: 64 entries per wave instead of 32 halve those per-wave costs and fill the rounds of both stages.)
 template <bool PAIRED>
 __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave &w, const double *__restrict__ p0,
                                                     const double *__restrict__ p1, int stride, long long ne,
@@ -521,15 +524,14 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
     // (the entry's owner and node are asked for before the list length is known: the arrays hold `cap` entries, and what
     // lies past the last written one is never looked at)
     int n = 0;
-    if ((i >> 1) < csr.cap) { qi_mine = csr.owner[i >> 1]; n = csr.idx[i >> 1]; }
+    if (i < csr.cap) { qi_mine = csr.owner[i]; n = csr.idx[i]; }        // (CSR mode: i = entry, both directions)
     const long long total = csr.offsets[csr.nq];
     if (total > csr.cap) return;          // capacity overflow: the CSR arrays are only partly written
-    act = i < 2 * total && (unsigned)qi_mine < (unsigned)csr.nq && (unsigned)n < (unsigned)csr.n_nodes;   // defensive
+    act = i < total && (unsigned)qi_mine < (unsigned)csr.nq && (unsigned)n < (unsigned)csr.n_nodes;   // defensive
     if (act) {
       const double *s = csr.q + (size_t)qi_mine * stride;
       const double4 g = csr.nodes_aos[n];
-      if (i & 1) { ax = g.x; ay = g.y; at = g.z; bx = s[0]; by = s[1]; bt = s[2]; }
-      else { ax = s[0]; ay = s[1]; at = s[2]; bx = g.x; by = g.y; bt = g.z; }
+      ax = s[0]; ay = s[1]; at = s[2]; bx = g.x; by = g.y; bt = g.z;      // forward: sample -> neighbour
     } else qi_mine = 0;
     if (__ballot(act) == 0ull) return;    // the grid covers the caller's capacity
   } else {
@@ -641,7 +643,9 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
   w.e[0][lane] = ax; w.e[1][lane] = ay; w.e[2][lane] = at;
   w.e[3][lane] = bx; w.e[4][lane] = by; w.e[5][lane] = bt;
   w.em[lane] = (by - ay) / (bx - ax);          // (read only where the edge is not "close to vertical")
+  if (PAIRED) w.emr[lane] = (ay - by) / (ax - bx);
   w.first[lane] = 0x7fffffff;
+  w.first[lane + 64] = 0x7fffffff;
   w.head[lane] = 0u;                               // (chunk numbers start at 1)
   // The edge's own box, widened by far more than any rounding of the exact test (1e-9 relative against
   // ~1e-15) and rounded outward to fp32.  NaN-propagating min / max: an edge with a NaN coordinate keeps
@@ -652,8 +656,8 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
     exlo = __double2float_rd(jl_min(ax, bx) - eslack); exhi = __double2float_ru(jl_max(ax, bx) + eslack);
     eylo = __double2float_rd(jl_min(ay, by) - eslack); eyhi = __double2float_ru(jl_max(ay, by) + eslack);
   }
-  bool done = !act;
-  int first = -1;
+  bool done = !act, done_r = PAIRED ? !act : true;
+  int first = -1, first_r = -1;
   unsigned chunk_no = 0u;                          // stage A's chunks of polygon sides, numbered through the whole kernel
   for (int g0 = 0; g0 < n_walk; g0 += 32) {
     const int jn = min(32, n_walk - g0);
@@ -685,12 +689,7 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     unsigned cand = 0;
-    bool walk = !done;
-    if (PAIRED) {                 // the even lane walks for both directions, as long as either is undecided
-      const int dn = __shfl_down(done ? 1 : 0, 1);
-      walk = !(lane & 1) && !(done && dn != 0);
-    }
-    if (walk) {
+    if (!(done && done_r)) {         // (PAIRED: as long as either direction is undecided)
       for (int b = 0; b < jn; ++b) {
         const float4 o = w.box[b];
         const bool c = !(exhi < o.x || exlo > o.y || eyhi < o.z || eylo > o.w);
@@ -736,8 +735,8 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
               double rF, rR;
               segment_dist_sqrd_both(w.e[0][owner], w.e[1][owner], w.e[3][owner], w.e[4][owner], vxy[2 * va], vxy[2 * va + 1],
                                      vxy[2 * vb], vxy[2 * vb + 1], rF, rR);
-              if (((ent >> 30) & 1u) && rF < rr2) atomicMin(&w.first[owner], j);
-              if ((ent >> 31) && rR < rr2) atomicMin(&w.first[owner + 1], j);
+              if (((ent >> 30) & 1u) && rF < rr2) atomicMin(&w.first[2 * owner], j);
+              if ((ent >> 31) && rR < rr2) atomicMin(&w.first[2 * owner + 1], j);
             } else if (segment_dist_sqrd(w.e[0][owner], w.e[1][owner], w.e[3][owner], w.e[4][owner], vxy[2 * va],
                                          vxy[2 * va + 1], vxy[2 * vb], vxy[2 * vb + 1]) < rr2)
               atomicMin(&w.first[owner], j);
@@ -770,11 +769,11 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
             if (edge_hits_moving(eax, eay, w.e[2][owner], ebx, eby, w.e[5][owner], robot_radius, mt.x,
                                  mt.y, mt.z, path + 3 * (size_t)path_off[j],
                                  path_off[j + 1] - path_off[j]))
-              atomicMin(&w.first[owner], j);
+              atomicMin(&w.first[PAIRED ? 2 * owner : owner], j);
             if (PAIRED && edge_hits_moving(ebx, eby, w.e[5][owner], eax, eay, w.e[2][owner], robot_radius, mt.x,
                                            mt.y, mt.z, path + 3 * (size_t)path_off[j],
                                            path_off[j + 1] - path_off[j]))
-              atomicMin(&w.first[owner + 1], j);
+              atomicMin(&w.first[2 * owner + 1], j);
           } else {
             const double dsq = dist_sqrd_point_to_segment(mt.x, mt.y, eax, eay, ebx, eby);
             const double rr = robot_radius + mt.z;
@@ -789,8 +788,8 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
             }
             if (pass_f || pass_r) {
               if (kind == 1) {
-                if (pass_f) atomicMin(&w.first[owner], j);
-                if (pass_r) atomicMin(&w.first[owner + 1], j);
+                if (pass_f) atomicMin(&w.first[PAIRED ? 2 * owner : owner], j);
+                if (pass_r) atomicMin(&w.first[2 * owner + 1], j);
               } else if (kind == 3) {
                 vb0 = w.goff[slot];
                 P = w.gcnt[slot];
@@ -838,7 +837,7 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
             if (!(pax - pax == 0.0 && pay - pay == 0.0 && pbx - pbx == 0.0 && pby - pby == 0.0)) slack = __builtin_inf();
             const bool evert = fabs(pbx - pax) < .000001;  // the edge is "close to vertical" (:1151)
             double em = 0.0, em_r = 0.0;                   // the edge's slope (R/DRRT.jl:1158), and as the reverse edge divides it
-            if (!evert) { em = w.em[owner_e]; if (PAIRED) em_r = w.em[owner_e + 1]; }
+            if (!evert) { em = w.em[owner_e]; if (PAIRED) em_r = w.emr[owner_e]; }
             const int va = vb0_e + (sg == 0 ? P_e - 1 : sg - 1), vb = vb0_e + sg;
             const double Ax = vxy[2 * va], Ay = vxy[2 * va + 1], Bx = vxy[2 * vb], By = vxy[2 * vb + 1];
             const bool apart = (fmin(Ax, Bx) - ehx > slack) || (elx - fmax(Ax, Bx) > slack) ||
@@ -913,8 +912,8 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          bool fin = w.first[lane] != 0x7fffffff;
-          if (PAIRED) fin = fin && w.first[lane | 1] != 0x7fffffff;      // (the even lane walks for both directions)
+          bool fin = w.first[PAIRED ? 2 * lane : lane] != 0x7fffffff;
+          if (PAIRED) fin = fin && w.first[2 * lane + 1] != 0x7fffffff;   // (the lane hands out for both directions)
           if (fin) rem = 0u;
         }
         if (!any) break;
@@ -923,14 +922,19 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
 #ifdef RRTX_TILE_CLOCKS
       acc_hand += (t_h1 - t_h0) - (acc_a1 + acc_a2 + acc_b - in_before);
 #endif
-      const int f = w.first[lane];
+      const int f = w.first[PAIRED ? 2 * lane : lane];
       if (!done && f != 0x7fffffff) { done = true; first = orig[f]; }
+      if (PAIRED) {
+        const int fr = w.first[2 * lane + 1];
+        if (!done_r && fr != 0x7fffffff) { done_r = true; first_r = orig[fr]; }
+      }
     }
-    if (__ballot(!done) == 0ull) break;
+    if (__ballot(!(done && done_r)) == 0ull) break;
   }
   if (act) {
     if (csr.q) {
-      ((i & 1) ? csr.hit_in : hit)[i >> 1] = first >= 0 ? 1 : 0;
+      hit[i] = first >= 0 ? 1 : 0;
+      csr.hit_in[i] = first_r >= 0 ? 1 : 0;
     } else {
       hit[i] = first >= 0 ? 1 : 0;
       if (first_hit) first_hit[i] = first;
@@ -942,7 +946,7 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
     if (lane == 0) {
       unsigned long long *row = g_pe_clk + (size_t)((i >> 6) & (kClkRows - 1)) * 8;
       row[0] = t_listed - t_start; row[1] = acc_box; row[2] = acc_hand; row[3] = acc_a1; row[4] = acc_a2; row[5] = acc_b;
-      row[6] = t_end - t_start; row[7] = 1ull;
+      row[6] = t_end - t_start; row[7] = 1ull | (wall_clock64() << 8);          // (bits 8..: 100 MHz time the wave ended at)
     }
   }
 #endif
@@ -952,7 +956,7 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
 // extend preamble runs one wave per workgroup: the waves' running times differ by a factor of several, and a workgroup's
 // registers are only handed on when its last wave is through (measured: 0.166 -> 0.161 ms per step; a resident grid
 // striding over the edges instead costs registers and was slower).  OCC: waves per SIMD the register budget is cut for
-// (5 = 96 registers with two spilled, 0.160 ms).
+// (the wave's 9.3 KB of LDS allow 16 waves per CU = 4 per SIMD, so nothing is gained by spilling down to 96 registers).
 template <bool PAIRED, int WAVES, int OCC>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC))) void edges_polygons_kernel(const double *__restrict__ p0,
                                                                     const double *__restrict__ p1, int stride,
@@ -1698,7 +1702,7 @@ int sync_polygon_grid(rrtx_ctx *ctx, double pad_needed) {
   if (!(gx1 > gx0) || !(gy1 > gy0)) return RRTX_OK;
   const double inv_wx = (double)G / (gx1 - gx0), inv_wy = (double)G / (gy1 - gy0);
   if (!(inv_wx - inv_wx == 0.0) || !(inv_wy - inv_wy == 0.0)) return RRTX_OK;
-  auto cell = [G](double v, double v0, double inv_w) {     // the kernel's expression, clamped
+  auto cell = [](double v, double v0, double inv_w) {     // the kernel's expression, clamped
     const double f = (v - v0) * inv_w;
     return f < 0.0 ? 0 : (f >= (double)G ? G - 1 : (int)f);
   };
@@ -1845,8 +1849,8 @@ int launch_candidate_edges_polygons(rrtx_ctx *ctx, const double *q_dev, int nq, 
   csr.nodes_aos = reinterpret_cast<const double4 *>(ctx->nodes_aos);
   csr.hit_in = hit_in_dev; csr.cap = (long long)cap; csr.nq = nq; csr.n_nodes = (int)ctx->n_nodes;
   span_begin(ctx, KF_EDGES);
-  hipLaunchKernelGGL((edges_polygons_kernel<true, 1, 5>),
-                     dim3((unsigned)((2 * cap + 63) / 64)), dim3(64), 0, ctx->stream,
+  hipLaunchKernelGGL((edges_polygons_kernel<true, 1, 4>),
+                     dim3((unsigned)((cap + 63) / 64)), dim3(64), 0, ctx->stream,
                      (const double *)nullptr, (const double *)nullptr, ctx->dim, 0ll, csr, ctx->d_poly_meta.as<double>(),
                      ctx->d_poly_off.as<int32_t>(), ctx->d_poly_vxy.as<double>(), ctx->d_poly_slope.as<double>(),
                      ctx->d_poly_path_off.as<int32_t>(),
@@ -1906,11 +1910,12 @@ int launch_points_polygons(rrtx_ctx *ctx, const double *p_dev, int64_t np, doubl
   int rc = sync_polygons(ctx);
   if (rc) return rc;
   unsigned short *lists = nullptr, *list_cnt = nullptr;
-  span_begin(ctx, KF_POINTS);
   // flag-only calls over obstacles that stand still: two points per wave with the reference's loop as the fall-back
   // inside the kernel; a wanted certificate or obstacles that move in time: the reference's loop, one point per wave
   const bool flag_only = clearance_dev == nullptr && !ctx->poly_has_moving && ctx->poly_n_ytab >= 0 &&
                          ctx->d_poly_bbox.as<double>() != nullptr;
+  if (!flag_only && unsafe_dev == nullptr && clearance_dev == nullptr) return RRTX_OK;   // (a call for the lists alone)
+  span_begin(ctx, KF_POINTS);
   if (flag_only) {
     // list_r >= 0: also list, per point, the obstacles an edge of at most that length from the point can reach (the
     // fused extend preamble hands them to edges_polygons_kernel)

@@ -307,3 +307,46 @@ def test_radius_lists_that_outgrow_their_buckets(oracle):
             hh, _ = ctx.edges_check(p0, p1, RR)
             n = len(ridx)
             assert np.array_equal(out["hit_out"], hh[:n]) and np.array_equal(out["hit_in"], hh[n:])
+
+
+@pytest.mark.parametrize("moving", [False, True])
+def test_extend_dev_polygons_without_the_sample_flags(moving):
+    """rrtx_extend_candidates_dev against the polygon list with sample_unsafe == NULL: the sample pass then runs for the
+    per-sample obstacle lists alone (obstacles that stand still) or not at all (obstacles that move in time: the edge
+    kernel lists for itself) -- the edge flags are those of the call that asks for the sample flags too."""
+    torch = pytest.importorskip("torch")
+    from rrtqx_3d_amd import _capi
+    dev = torch.device("cuda", 0)
+    n, nq = 40_000, 1500
+    pts, Q = synth.nodes(n, 3), synth.queries(nq, 3)
+    if moving:
+        polys, kinds, paths, active, _ = synth.dynamic_polygons(128)
+    else:
+        polys, kinds, paths, active = synth.polygons(128), None, None, None
+    r = synth.ball_radius(n, 3)
+    with Context(3) as ctx:
+        ctx.nodes_append(pts)
+        ctx.polygons_set(polys, kinds=kinds, paths=paths, active=active)
+        ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 1)
+        d_q = torch.from_numpy(Q).to(dev)
+        cap = 96 * nq
+        res = []
+        for want_flags in (True, False):
+            d_off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+            d_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+            d_cost = torch.empty(cap, dtype=torch.float64, device=dev)
+            d_ho = torch.zeros(cap, dtype=torch.uint8, device=dev)
+            d_hi = torch.zeros(cap, dtype=torch.uint8, device=dev)
+            d_un = torch.zeros(nq, dtype=torch.uint8, device=dev)
+            d_need = torch.zeros(1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            ctx.extend_candidates_dev(d_q.data_ptr(), nq, r, RR, d_off.data_ptr(), d_idx.data_ptr(), d_cost.data_ptr(),
+                                      d_ho.data_ptr(), d_hi.data_ptr(), cap, d_need.data_ptr(), None, None,
+                                      d_un.data_ptr() if want_flags else None)
+            ctx.sync()
+            total = int(d_off.cpu().numpy()[-1])
+            assert 0 < total <= cap
+            res.append((d_off.cpu().numpy(), d_idx.cpu().numpy()[:total], d_ho.cpu().numpy()[:total], d_hi.cpu().numpy()[:total]))
+        for a, b in zip(res[0], res[1]):
+            assert np.array_equal(a, b)
+        assert 0 < res[0][2].sum() < len(res[0][2])

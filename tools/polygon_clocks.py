@@ -38,7 +38,15 @@ with Context(3, node_capacity=cfg.n_nodes) as ctx:
     assert L.rrtx_debug_polygon_edge_clocks(buf.ctypes.data_as(C.c_void_p), C.c_int(1)) == 0
     st1 = ctx.stats()
     print("this build: edges kernel %.4f ms, points kernel %.4f ms" % (st1.ms_edges - st0.ms_edges, st1.ms_points - st0.ms_points))
-    rows = buf[buf[:, 7] > 0].astype(np.float64)
+    live = buf[buf[:, 7] > 0]
+    t_end = (live[:, 7] >> np.uint64(8)).astype(np.float64) / 100.0                 # us
+    dur = live[:, 6].astype(np.float64) / 2400.0                                    # us at 2.4 GHz (shader clock: an estimate)
+    t0 = (t_end - dur).min()
+    edges = np.arange(0.0, t_end.max() - t0 + 5.0, 5.0)
+    resident = [int(((t_end - dur - t0 < b + 2.5) & (t_end - t0 > b + 2.5)).sum()) for b in edges]
+    print("waves resident (whole GPU) every 5 us from the first start:", resident)
+    live = live.copy(); live[:, 7] = 1
+    rows = live.astype(np.float64)
     wt = rows[:, 6]
     print("wave time (shader clock ticks): median %.0f, 90 %% %.0f, max %.0f" % (np.median(wt), np.percentile(wt, 90), wt.max()))
     buf = rows.sum(axis=0)
