@@ -942,3 +942,40 @@ def test_pack_hits_layout():
     flags[:n_valid] = ho[:n_valid]
     flags[cap:cap + n_valid] = hi[:n_valid]
     assert np.array_equal(words.cpu().numpy(), np.packbits(flags, bitorder="little").view(np.int64))
+
+
+def test_polygon_point_flag_grid_follows_radius_and_list_changes(oracle):
+    """The flag-only point check looks at the obstacles of its grid cell only; the grid is padded for the robot radius
+    (and the ball radius of a fused extend call) it was built for, and is rebuilt when a call needs more, when the pad
+    is far too wide, and when the obstacle list changes.  A sequence of calls that forces all three, each against the
+    call that also asks for the certificate (which walks the whole list in the reference's order)."""
+    from rrtqx_3d_amd import _capi
+    rng = np.random.default_rng(79)
+    polys = synth.polygons(200)
+    n = 4001
+    P = np.zeros((n, 3))
+    P[:, :2] = rng.uniform(-60, 60, (n, 2))
+    with Context(3) as ctx:
+        ctx.nodes_append(synth.nodes(20_000, 3))
+        ctx.polygons_set(polys)
+        ctx.set_option(_capi.RRTX_OPT_EXTEND_OBSTACLES, 1)
+
+        def check(rr):
+            full, _ = ctx.points_check(P, rr, kind=1)
+            flag, _ = ctx.points_check(P, rr, kind=1, want_clearance=False)
+            assert np.array_equal(full, flag), rr
+            return int(full.sum())
+
+        counts = [check(rr) for rr in (0.1, 3.0, 0.2, 25.0, 0.0, -0.5, 0.3)]
+        assert counts[1] > counts[0] and counts[3] > counts[1]
+        Q = synth.queries(512, 3)
+        a = ctx.extend_candidates(Q, 6.0, 0.5)             # per-sample lists: the pad now covers the ball radius too
+        check(0.5)
+        ctx.polygons_set(polys[:90])                       # the list changes: records, grid and lists are rebuilt
+        b = ctx.extend_candidates(Q, 6.0, 0.5)
+        assert np.array_equal(a["idx"], b["idx"]) and not np.array_equal(a["hit_out"], b["hit_out"])
+        ps = oracle.PolygonSet(polys[:90])
+        for i in range(0, n, 97):
+            u, _ = oracle.point_check_polygons(ps, P[i], 0.5)
+            assert ctx.points_check(P[i:i + 300], 0.5, kind=1, want_clearance=False)[0][0] == u
+        check(0.5)
