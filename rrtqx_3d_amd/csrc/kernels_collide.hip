@@ -444,15 +444,16 @@ __device__ void segment_dist_sqrd_both(double pax, double pay, double pbx, doubl
 // (index_before_time, transform_obs_to_time, edge_hits_moving: collide_device.hpp, shared with kernels_dubins.hip)
 
 constexpr int kPolyPairs = 256;        // (edge, obstacle) pairs a wave queues for the bounding-circle test
-constexpr int kPolyQueue = 384;        // (edge, polygon segment) tests a wave queues
+constexpr int kPolyQueue = 384;        // (edge, polygon segment) tests a wave queues (320 in the build without a time column)
 constexpr int kPolyWaveCand = 256;     // candidate obstacles a wave lists (more: the whole list is walked)
 constexpr int kPolyWaveSamples = 16;   // ... for at most this many samples per wave
 constexpr int kPolyListCap = 64;       // obstacles the sample pass lists per sample (more: the wave lists for itself)
 constexpr int kPolyBitWords = 16;      // ... merged per wave through a bit set of this many 64-bit words
 // per-wave scratch of edges_polygons_kernel: the wave's 64 edges, the boxes of the current group of 32 obstacles,
 // each edge's first hit (list position), the queues of the two test stages, the wave's candidate obstacles
-struct PolyWave {
-  double e[6][64];     // ax, ay, at, bx, by, bt per lane
+template <bool MOVING, int QUEUE>
+struct PolyWaveT {
+  double e[MOVING ? 6 : 4][64];   // ax, ay, bx, by per lane; with obstacles that move in time also at, bt (startPoint[3])
   double em[64];       // the edge's slope (by - ay) / (bx - ax) as segmentDistSqrd divides it (R/DRRT.jl:1158)
   double emr[64];      // PAIRED: the slope as the reverse edge divides it, (ay - by) / (ax - bx)
   float4 box[32];      // current group: bounding boxes (xlo, xhi, ylo, yhi) rounded outward to fp32
@@ -461,7 +462,7 @@ struct PolyWave {
   double4 gmeta[32];   // current group: (cx, cy, radius, kind) of each of its obstacles
   int goff[32], gcnt[32];   // current group: first vertex and number of vertices
   unsigned short pairq[kPolyPairs];   // (edge lane | obstacle slot << 6) of the pairs the box test leaves
-  unsigned pq[kPolyQueue];         // (edge lane | obstacle slot << 6 | segment << 11) of the segment tests to run
+  unsigned pq[QUEUE];              // (edge lane | obstacle slot << 6 | segment << 11) of the segment tests to run
   short wc[kPolyWaveCand];   // CSR mode: the obstacles any edge of the wave can reach (list positions, ascending)
   unsigned long long bits[kPolyBitWords];   // CSR mode: union of the lists of the wave's samples
   unsigned head[64];         // stage A: (pair lane | chunk number << 6) where a pair's run of polygon sides starts in the chunk
@@ -500,8 +501,9 @@ __device__ unsigned long long g_pp_clk[kClkRows * 8];
 // directions' answers at 1.3x the cost of one.  Every boolean is still the reference's own expression for that directed
 // edge.  (Until late in round 3 the two directions sat in neighbouring lanes and the odd one idled through the listing, the
 // boxes and the hand-out: 64 entries per wave instead of 32 halve those per-wave costs and fill the rounds of both stages.)
-template <bool PAIRED>
-__device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave &w, const double *__restrict__ p0,
+template <bool PAIRED, bool MOVING, int QUEUE>
+__device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWaveT<MOVING, QUEUE> &w,
+                                                    const double *__restrict__ p0,
                                                     const double *__restrict__ p1, int stride, long long ne,
                                                     const PolyCsr &csr, const double *__restrict__ meta,
                                                     const int32_t *__restrict__ off, const double *__restrict__ vxy,
@@ -640,8 +642,8 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
     }
   }
   RRTX_PE_T(t_listed);
-  w.e[0][lane] = ax; w.e[1][lane] = ay; w.e[2][lane] = at;
-  w.e[3][lane] = bx; w.e[4][lane] = by; w.e[5][lane] = bt;
+  w.e[0][lane] = ax; w.e[1][lane] = ay; w.e[2][lane] = bx; w.e[3][lane] = by;
+  if constexpr (MOVING) { w.e[4][lane] = at; w.e[5][lane] = bt; }
   w.em[lane] = (by - ay) / (bx - ax);          // (read only where the edge is not "close to vertical")
   if (PAIRED) w.emr[lane] = (ay - by) / (ax - bx);
   w.first[lane] = 0x7fffffff;
@@ -733,11 +735,11 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
             const int va = vb0 + (sg == 0 ? P - 1 : sg - 1), vb = vb0 + sg;
             if (PAIRED) {
               double rF, rR;
-              segment_dist_sqrd_both(w.e[0][owner], w.e[1][owner], w.e[3][owner], w.e[4][owner], vxy[2 * va], vxy[2 * va + 1],
+              segment_dist_sqrd_both(w.e[0][owner], w.e[1][owner], w.e[2][owner], w.e[3][owner], vxy[2 * va], vxy[2 * va + 1],
                                      vxy[2 * vb], vxy[2 * vb + 1], rF, rR);
               if (((ent >> 30) & 1u) && rF < rr2) atomicMin(&w.first[2 * owner], j);
               if ((ent >> 31) && rR < rr2) atomicMin(&w.first[2 * owner + 1], j);
-            } else if (segment_dist_sqrd(w.e[0][owner], w.e[1][owner], w.e[3][owner], w.e[4][owner], vxy[2 * va],
+            } else if (segment_dist_sqrd(w.e[0][owner], w.e[1][owner], w.e[2][owner], w.e[3][owner], vxy[2 * va],
                                          vxy[2 * va + 1], vxy[2 * vb], vxy[2 * vb + 1]) < rr2)
               atomicMin(&w.first[owner], j);
           }
@@ -762,15 +764,17 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
           owner = (int)(pe & 63u);
           slot = (int)(pe >> 6);
           const int j = w.jidx[slot];
-          const double eax = w.e[0][owner], eay = w.e[1][owner], ebx = w.e[3][owner], eby = w.e[4][owner];
+          const double eax = w.e[0][owner], eay = w.e[1][owner], ebx = w.e[2][owner], eby = w.e[3][owner];
+          double eat = 0.0, ebt = 0.0;
+          if constexpr (MOVING) { eat = w.e[4][owner]; ebt = w.e[5][owner]; }
           const double4 mt = w.gmeta[slot];
           const int kind = (int)mt.w;
           if (kind == 6 || kind == 7) {
-            if (edge_hits_moving(eax, eay, w.e[2][owner], ebx, eby, w.e[5][owner], robot_radius, mt.x,
+            if (edge_hits_moving(eax, eay, eat, ebx, eby, ebt, robot_radius, mt.x,
                                  mt.y, mt.z, path + 3 * (size_t)path_off[j],
                                  path_off[j + 1] - path_off[j]))
               atomicMin(&w.first[PAIRED ? 2 * owner : owner], j);
-            if (PAIRED && edge_hits_moving(ebx, eby, w.e[5][owner], eax, eay, w.e[2][owner], robot_radius, mt.x,
+            if (PAIRED && edge_hits_moving(ebx, eby, ebt, eax, eay, eat, robot_radius, mt.x,
                                            mt.y, mt.z, path + 3 * (size_t)path_off[j],
                                            path_off[j + 1] - path_off[j]))
               atomicMin(&w.first[2 * owner + 1], j);
@@ -830,7 +834,7 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
           if (t0 + lane < total_sides) {
             const int owner_e = pk_e & 63;
             const bool pf = (pk_e >> 11) & 1, pr = (pk_e >> 12) & 1;
-            const double pax = w.e[0][owner_e], pay = w.e[1][owner_e], pbx = w.e[3][owner_e], pby = w.e[4][owner_e];
+            const double pax = w.e[0][owner_e], pay = w.e[1][owner_e], pbx = w.e[2][owner_e], pby = w.e[3][owner_e];
             const double elx = fmin(pax, pbx), ehx = fmax(pax, pbx), ely = fmin(pay, pby), ehy = fmax(pay, pby);
             double slack = gap_min + 1e-9 * (fabs(elx) + fabs(ehx) + fabs(ely) + fabs(ehy));
             // (fmin / fmax drop a NaN operand: an edge with a non-finite coordinate keeps every segment)
@@ -875,7 +879,7 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
           if (push)
             w.pq[nqd + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sv, 0u))] = ent;
           nqd += __popcll(sv);
-          if (nqd > kPolyQueue - 64) stage_b();
+          if (nqd > QUEUE - 64) stage_b();
         }
         RRTX_PE_T(t_a2);
 #ifdef RRTX_TILE_CLOCKS
@@ -957,7 +961,7 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWave 
 // registers are only handed on when its last wave is through (measured: 0.166 -> 0.161 ms per step; a resident grid
 // striding over the edges instead costs registers and was slower).  OCC: waves per SIMD the register budget is cut for
 // (the wave's 9.3 KB of LDS allow 16 waves per CU = 4 per SIMD, so nothing is gained by spilling down to 96 registers).
-template <bool PAIRED, int WAVES, int OCC>
+template <bool PAIRED, int WAVES, int OCC, bool MOVING>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC))) void edges_polygons_kernel(const double *__restrict__ p0,
                                                                     const double *__restrict__ p1, int stride,
                                                                     long long ne, PolyCsr csr,
@@ -974,9 +978,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC)
                                                                     const unsigned short *__restrict__ near_lists,
                                                                     const unsigned short *__restrict__ near_cnt,
                                                                     double list_r) {
-  __shared__ PolyWave s_w[WAVES];
-  PolyWave &w = s_w[threadIdx.x >> 6];
-  edges_polygons_wave<PAIRED>((long long)blockIdx.x * (64 * WAVES) + threadIdx.x, w, p0, p1, stride, ne, csr, meta, off, vxy,
+  constexpr int QUEUE = MOVING ? kPolyQueue : kPolyQueue - 64;
+  __shared__ PolyWaveT<MOVING, QUEUE> s_w[WAVES];
+  PolyWaveT<MOVING, QUEUE> &w = s_w[threadIdx.x >> 6];
+  edges_polygons_wave<PAIRED, MOVING, QUEUE>((long long)blockIdx.x * (64 * WAVES) + threadIdx.x, w, p0, p1, stride, ne, csr, meta, off, vxy,
                               vslope, path_off, path, has_moving, orig, m_begin, m_end, robot_radius, hit, first_hit,
                               near_lists, near_cnt, list_r);
 }
@@ -1849,7 +1854,8 @@ int launch_candidate_edges_polygons(rrtx_ctx *ctx, const double *q_dev, int nq, 
   csr.nodes_aos = reinterpret_cast<const double4 *>(ctx->nodes_aos);
   csr.hit_in = hit_in_dev; csr.cap = (long long)cap; csr.nq = nq; csr.n_nodes = (int)ctx->n_nodes;
   span_begin(ctx, KF_EDGES);
-  hipLaunchKernelGGL((edges_polygons_kernel<true, 1, 4>),
+  // (without a time column a wave's scratch is 8 KB: five waves per SIMD, with the register budget cut to match)
+  hipLaunchKernelGGL((ctx->poly_has_moving ? edges_polygons_kernel<true, 1, 4, true> : edges_polygons_kernel<true, 1, 5, false>),
                      dim3((unsigned)((cap + 63) / 64)), dim3(64), 0, ctx->stream,
                      (const double *)nullptr, (const double *)nullptr, ctx->dim, 0ll, csr, ctx->d_poly_meta.as<double>(),
                      ctx->d_poly_off.as<int32_t>(), ctx->d_poly_vxy.as<double>(), ctx->d_poly_slope.as<double>(),
@@ -1876,7 +1882,7 @@ int launch_edges_polygons(rrtx_ctx *ctx, const double *p0_dev, const double *p1_
   packed_range(active_positions(ctx->poly_active), obs_begin, obs_end, pb, pe);
   if (pe <= pb) return zero_outputs(ctx, ne, hit_dev, first_hit_dev);
   span_begin(ctx, KF_EDGES);
-  hipLaunchKernelGGL((edges_polygons_kernel<false, 4, 4>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
+  hipLaunchKernelGGL((edges_polygons_kernel<false, 4, 4, true>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, p0_dev,
                      p1_dev, ctx->dim, (long long)ne, PolyCsr{}, ctx->d_poly_meta.as<double>(), ctx->d_poly_off.as<int32_t>(),
                      ctx->d_poly_vxy.as<double>(), ctx->d_poly_slope.as<double>(), ctx->d_poly_path_off.as<int32_t>(),
                      ctx->d_poly_path.as<double>(),
