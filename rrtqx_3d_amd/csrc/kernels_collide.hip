@@ -502,7 +502,7 @@ __device__ unsigned long long g_pp_clk[kClkRows * 8];
 // edge.  (Until late in round 3 the two directions sat in neighbouring lanes and the odd one idled through the listing, the
 // boxes and the hand-out: 64 entries per wave instead of 32 halve those per-wave costs and fill the rounds of both stages.)
 template <bool PAIRED, bool MOVING, int QUEUE>
-__device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWaveT<MOVING, QUEUE> &w,
+__device__ __forceinline__ void edges_polygons_wave(long long i, PolyWaveT<MOVING, QUEUE> &w,
                                                     const double *__restrict__ p0,
                                                     const double *__restrict__ p1, int stride, long long ne,
                                                     const PolyCsr &csr, const double *__restrict__ meta,
@@ -514,7 +514,8 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWaveT
                                                     double robot_radius, uint8_t *__restrict__ hit,
                                                     int32_t *__restrict__ first_hit,
                                                     const unsigned short *__restrict__ near_lists,
-                                                    const unsigned short *__restrict__ near_cnt, double list_r) {
+                                                    const unsigned short *__restrict__ near_cnt, double list_r,
+                                                    int tail_eighths) {
   bool act;
   double ax = 0, ay = 0, at = 0, bx = 0, by = 0, bt = 0;
 #ifdef RRTX_TILE_CLOCKS
@@ -526,10 +527,27 @@ __device__ __forceinline__ void edges_polygons_wave(const long long i, PolyWaveT
     // (the entry's owner and node are asked for before the list length is known: the arrays hold `cap` entries, and what
     // lies past the last written one is never looked at)
     int n = 0;
-    if (i < csr.cap) { qi_mine = csr.owner[i]; n = csr.idx[i]; }        // (CSR mode: i = entry, both directions)
-    const long long total = csr.offsets[csr.nq];
-    if (total > csr.cap) return;          // capacity overflow: the CSR arrays are only partly written
-    act = i < total && (unsigned)qi_mine < (unsigned)csr.nq && (unsigned)n < (unsigned)csr.n_nodes;   // defensive
+    bool lane_on = true;
+    long long total;
+    if (tail_eighths > 0) {
+      // The last eighths of the entries go through in waves of 32: the kernel ends with the GPU draining (6 466 waves of
+      // ~28 us for 5 120 slots), and what runs then should be short rather than full.  (The entry a lane holds then
+      // depends on the list length, so these loads wait for it.)
+      total = csr.offsets[csr.nq];
+      if (total > csr.cap) return;
+      const long long t1 = (total / 8 * (8 - tail_eighths)) & ~63ll;
+      const long long wv = i >> 6;
+      if (wv >= (t1 >> 6)) {
+        i = t1 + 32 * (wv - (t1 >> 6)) + (threadIdx.x & 31);
+        lane_on = (threadIdx.x & 63) < 32;
+      }
+      if (lane_on && i < csr.cap) { qi_mine = csr.owner[i]; n = csr.idx[i]; }
+    } else {
+      if (i < csr.cap) { qi_mine = csr.owner[i]; n = csr.idx[i]; }        // (CSR mode: i = entry, both directions)
+      total = csr.offsets[csr.nq];
+      if (total > csr.cap) return;          // capacity overflow: the CSR arrays are only partly written
+    }
+    act = lane_on && i < total && (unsigned)qi_mine < (unsigned)csr.nq && (unsigned)n < (unsigned)csr.n_nodes;   // defensive
     if (act) {
       const double *s = csr.q + (size_t)qi_mine * stride;
       const double4 g = csr.nodes_aos[n];
@@ -977,13 +995,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC)
                                                                     int32_t *__restrict__ first_hit,
                                                                     const unsigned short *__restrict__ near_lists,
                                                                     const unsigned short *__restrict__ near_cnt,
-                                                                    double list_r) {
+                                                                    double list_r, int tail_eighths) {
   constexpr int QUEUE = MOVING ? kPolyQueue : kPolyQueue - 64;
   __shared__ PolyWaveT<MOVING, QUEUE> s_w[WAVES];
   PolyWaveT<MOVING, QUEUE> &w = s_w[threadIdx.x >> 6];
   edges_polygons_wave<PAIRED, MOVING, QUEUE>((long long)blockIdx.x * (64 * WAVES) + threadIdx.x, w, p0, p1, stride, ne, csr, meta, off, vxy,
                               vslope, path_off, path, has_moving, orig, m_begin, m_end, robot_radius, hit, first_hit,
-                              near_lists, near_cnt, list_r);
+                              near_lists, near_cnt, list_r, tail_eighths);
 }
 
 // pointInPolygon (MacMartin crossings), R/DRRT.jl:1009-1056
@@ -1855,13 +1873,15 @@ int launch_candidate_edges_polygons(rrtx_ctx *ctx, const double *q_dev, int nq, 
   csr.hit_in = hit_in_dev; csr.cap = (long long)cap; csr.nq = nq; csr.n_nodes = (int)ctx->n_nodes;
   span_begin(ctx, KF_EDGES);
   // (without a time column a wave's scratch is 8 KB: five waves per SIMD, with the register budget cut to match)
+  // the last eighth of the entries in waves of 32 (measured: 1/8 0.1314, 2/8 0.1319, 3/8 0.1326, 4/8 0.1347, none 0.1345 ms)
+  const int tail_eighths = 1;
   hipLaunchKernelGGL((ctx->poly_has_moving ? edges_polygons_kernel<true, 1, 4, true> : edges_polygons_kernel<true, 1, 5, false>),
-                     dim3((unsigned)((cap + 63) / 64)), dim3(64), 0, ctx->stream,
+                     dim3((unsigned)((cap + 63) / 64 + (tail_eighths ? (cap + 31) / 32 * tail_eighths / 8 + 2 : 0))), dim3(64), 0, ctx->stream,
                      (const double *)nullptr, (const double *)nullptr, ctx->dim, 0ll, csr, ctx->d_poly_meta.as<double>(),
                      ctx->d_poly_off.as<int32_t>(), ctx->d_poly_vxy.as<double>(), ctx->d_poly_slope.as<double>(),
                      ctx->d_poly_path_off.as<int32_t>(),
                      ctx->d_poly_path.as<double>(), ctx->poly_has_moving ? 1 : 0, ctx->d_poly_orig.as<int32_t>(), 0,
-                     ctx->poly_n_active, robot_radius, hit_out_dev, (int32_t *)nullptr, near_lists, near_cnt, list_r);
+                     ctx->poly_n_active, robot_radius, hit_out_dev, (int32_t *)nullptr, near_lists, near_cnt, list_r, tail_eighths);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
@@ -1887,7 +1907,7 @@ int launch_edges_polygons(rrtx_ctx *ctx, const double *p0_dev, const double *p1_
                      ctx->d_poly_vxy.as<double>(), ctx->d_poly_slope.as<double>(), ctx->d_poly_path_off.as<int32_t>(),
                      ctx->d_poly_path.as<double>(),
                      ctx->poly_has_moving ? 1 : 0, ctx->d_poly_orig.as<int32_t>(), pb, pe, robot_radius, hit_dev,
-                     first_hit_dev, (const unsigned short *)nullptr, (const unsigned short *)nullptr, 0.0);
+                     first_hit_dev, (const unsigned short *)nullptr, (const unsigned short *)nullptr, 0.0, 0);
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   return RRTX_OK;
