@@ -17,8 +17,9 @@ value = directed edges collision-checked per second (whole job, all ranks).
 Multi-GPU: node SoA and obstacle list are replicated (4.8 MB and 8 KB -- trivially small next
 to 288 GB of HBM).  --scaling weak (default): every rank owns its own batches of B samples.
 --scaling strong: ONE global batch of B samples per step, rank r takes samples
-parallel.shard_range(B, r, world).  Either way the per-edge collision bitmask is exchanged with
-one RCCL all-reduce so every rank (the planner host of every agent) sees all results.  With
+parallel.shard_range(B, r, world).  Either way the per-edge collision bitmasks of four steps are exchanged with
+one RCCL all-gather (an all-reduce over disjoint slices in an E x O grid, where one rank per obstacle group publishes)
+so every rank (the planner host of every agent) sees all results.  With
 N > 1 the line carries both modes (`value` is the one --scaling names, `other_scaling` the other).
 """
 from __future__ import annotations
@@ -806,7 +807,10 @@ def main():
         bit_cap = (k_max + 4095) // 4096 * 4096
         wpr = parallel.words_for(bit_cap)
         K = max(1, args.exchange_every)
-        d_bits = [torch.zeros((K, E, wpr), dtype=torch.int64, device=dev) for _ in range(2)]
+        # edge shards only: every rank publishes -> one all-gather, buffer [ranks, steps, words] (half the ring traffic of
+        # the all-reduce over disjoint slices, which stays for E x O grids where one rank per obstacle group publishes)
+        gathered = O == 1
+        d_bits = [torch.zeros((E, K, wpr) if gathered else (K, E, wpr), dtype=torch.int64, device=dev) for _ in range(2)]
         pending = [None, None]
         if O > 1:
             # obstacle shards: the flag arrays are re-allocated at exactly the exchanged size, so that hit_out | hit_in |
@@ -836,9 +840,14 @@ def main():
                     pending[s] = None
                 if own is not None:
                     ctx.pack_hits_dev(b.hout.data_ptr(), b.hin.data_ptr(), b.off.data_ptr() + 8 * m["nb"], bit_cap,
-                                      d_bits[s].data_ptr() + 8 * (slot * E + e_idx) * wpr)
+                                      d_bits[s].data_ptr() + 8 * ((e_idx * K + slot) if gathered else (slot * E + e_idx)) * wpr)
                 if slot == K - 1 or last:
-                    pending[s] = parallel.exchange_hit_bitmasks_grouped(d_bits[s], own, async_op=True)
+                    pending[s] = exchange(d_bits[s], async_op=True)
+
+        def exchange(bits, async_op=False):
+            if gathered:
+                return parallel.exchange_hit_bitmasks_gathered(bits, e_idx, async_op=async_op)
+            return parallel.exchange_hit_bitmasks_grouped(bits, own, async_op=async_op)
 
         def drain():
             for s in range(2):
@@ -853,7 +862,7 @@ def main():
             # both exchange buffers have been through the collective once before the clock starts (first use of a
             # buffer pays registration / staging set-up in the backend)
             for s in range(2):
-                parallel.exchange_hit_bitmasks_grouped(d_bits[s], own)
+                exchange(d_bits[s])
         fence()
         # (every 10th step of a default run: an instrumented step costs ~10 us more, every 4th step was 2.5 us of a
         #  54 us step -- tools/graph_probe.py times the same calls without events at 0.0516 ms)
@@ -1044,7 +1053,8 @@ def main():
                        "collective": (None if world == 1 else
                                       (("all_reduce(MAX) of the uint8 edge / sample flags inside every obstacle group each step "
                                         "(OR over obstacle shards), then " if O > 1 else "") +
-                                       "one RCCL all-reduce of the per-edge collision bitmasks of %d steps, asynchronous, double-buffered"
+                                       ("one RCCL all-gather" if O == 1 else "one RCCL all-reduce (disjoint slices)") +
+                                       " of the per-edge collision bitmasks of %d steps, asynchronous, double-buffered"
                                        % max(1, args.exchange_every)))},
             "nn_queries_per_s": (nb * E if modes[0] == "weak" else B) * args.steps / t_max,
             "launches_per_step": 4,

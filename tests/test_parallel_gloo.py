@@ -67,6 +67,15 @@ def _worker(rank, world, port, cap, q):
         for k in range(steps):
             for r in range(world):
                 ok &= torch.equal(grp[k, r], parallel.rank_slice(bits, r, wpr) ^ k)
+        # ... and as one all-gather (every rank publishes: [ranks, steps, words])
+        gat = torch.full((world, steps, wpr), 0x5555, dtype=torch.int64)
+        for k in range(steps):
+            gat[rank, k].copy_(mine ^ k)
+        w4 = parallel.exchange_hit_bitmasks_gathered(gat, rank, async_op=True)
+        w4.wait()
+        for k in range(steps):
+            for r in range(world):
+                ok &= torch.equal(gat[r, k], parallel.rank_slice(bits, r, wpr) ^ k)
         units, tmax = parallel.reduce_throughput(1000 + rank, 0.5 + rank)
         ok &= (units == sum(1000 + r for r in range(world))) and (tmax == 0.5 + world - 1)
         q.put((rank, bool(ok)))
