@@ -43,68 +43,90 @@ __global__ void slab_rank_kernel(const double *__restrict__ nx, const double *__
 }
 
 // exclusive scan of n ints by one workgroup of 1024; out[n] = total
+// exclusive prefix sum of n counters by ONE workgroup, 4096 at a time: every thread takes four neighbouring counters (one
+// 16-byte load, the wave reads 1 KB in a row), the waves' sums meet in LDS, the running total carries over.  (Round 2 gave
+// every thread a contiguous stretch of n / 1024 counters: 64 cache lines per load instruction and two dependent loads per
+// counter -- 22 us for the 15 000 counters of a 500 k-node index, a quarter of a rebuild.)
 __global__ __launch_bounds__(1024) void excl_scan_kernel(const int *__restrict__ in, int *__restrict__ out, int n) {
-  __shared__ int wsum[16];
+  __shared__ int wsum[2][16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int per = (n + 1023) / 1024;
-  const int b = min(t * per, n), e = min(b + per, n);
-  int local = 0;
-  for (int i = b; i < e; ++i) local += in[i];
-  int v = local;
+  int carry = 0, flip = 0;
+  for (int base = 0; base < n; base += 4096, flip ^= 1) {
+    const int i = base + 4 * t;
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (i + 3 < n) {
+      const int4 v4 = *reinterpret_cast<const int4 *>(in + i);       // (in is 256-byte aligned, i a multiple of four)
+      c0 = v4.x; c1 = v4.y; c2 = v4.z; c3 = v4.w;
+    } else {
+      if (i < n) c0 = in[i];
+      if (i + 1 < n) c1 = in[i + 1];
+      if (i + 2 < n) c2 = in[i + 2];
+    }
+    const int local = c0 + c1 + c2 + c3;
+    int v = local;
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(v, off);
-    if (lane >= off) v += o;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(v, off);
+      if (lane >= off) v += o;
+    }
+    if (lane == 63) wsum[flip][wave] = v;
+    __syncthreads();                      // (two sets of sums: the next round's writes cannot overtake this round's reads)
+    int prefix = carry + v - local, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int x = wsum[flip][w];
+      if (w < wave) prefix += x;
+      total += x;
+    }
+    if (i + 3 < n) {
+      *reinterpret_cast<int4 *>(out + i) = make_int4(prefix, prefix + c0, prefix + c0 + c1, prefix + c0 + c1 + c2);
+    } else {
+      if (i < n) out[i] = prefix;
+      if (i + 1 < n) out[i + 1] = prefix + c0;
+      if (i + 2 < n) out[i + 2] = prefix + c0 + c1;
+    }
+    carry += total;
   }
-  if (lane == 63) wsum[wave] = v;
-  __syncthreads();
-  int prefix = v - local;
-  for (int w = 0; w < wave; ++w) prefix += wsum[w];
-  for (int i = b; i < e; ++i) {
-    const int c = in[i];
-    out[i] = prefix;
-    prefix += c;
-  }
-  if (t == 1023) out[n] = prefix;
+  if (t == 0) out[n] = carry;
 }
 
-__global__ void slab_scatter_kernel(int n, const int2 *__restrict__ sr, const int *__restrict__ start,
-                                    const float *__restrict__ fx, const float *__restrict__ fy,
-                                    const float *__restrict__ fz, const float *__restrict__ fw,
-                                    const float *__restrict__ fpp, int dim, float *__restrict__ sx,
-                                    float *__restrict__ sy, float *__restrict__ sz, float *__restrict__ sw,
-                                    float *__restrict__ spp, int32_t *__restrict__ sid,
-                                    const double *__restrict__ nx, const double *__restrict__ ny,
-                                    const double *__restrict__ nz, const double *__restrict__ nw,
-                                    double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ dz,
-                                    double *__restrict__ dw) {
+// Rebuild, last two steps.  (Round 2 scattered every node's ten values to its place -- ten partial-line writes to
+// random addresses per node, 33 us for 400 k nodes -- and read them back in a separate launch for the chunks' extents, 11
+// us.)  Now only the node's index goes to its place (4 bytes), and a second kernel walks the places in order, fetches
+// the values of the node that sits there (random READS of arrays that fit the L2) and writes rows; a workgroup is one
+// chunk, so the chunk's exact fp64 extent is a reduction over the workgroup on the way.
+__global__ void slab_sid_kernel(int n, const int2 *__restrict__ sr, const int *__restrict__ start,
+                                int32_t *__restrict__ sid) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int2 r = sr[i];
-  const int p = start[r.x] + r.y;
-  sx[p] = fx[i]; sy[p] = fy[i]; sz[p] = fz[i];
-  dx[p] = nx[i]; dy[p] = ny[i]; dz[p] = nz[i];
-  if (dim == 4) { sw[p] = fw[i]; dw[p] = nw[i]; }
-  spp[p] = fpp[i];
-  sid[p] = i;
+  sid[start[r.x] + r.y] = i;
 }
 
-// exact fp64 x and y extent of every chunk of kSlabChunk positions (one wave per chunk)
-__global__ __launch_bounds__(256) void chunk_range_kernel(const double *__restrict__ nx, const double *__restrict__ ny,
-                                                          const int32_t *__restrict__ sid, int n, int n_chunks,
-                                                          ChunkExt *__restrict__ chunk_ext) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (c >= n_chunks) return;
+__global__ __launch_bounds__(kSlabChunk) void slab_gather_kernel(
+    int n, const int32_t *__restrict__ sid, const double4 *__restrict__ aos, double ox, double oy, double oz, double ow,
+    int dim, float *__restrict__ sx, float *__restrict__ sy, float *__restrict__ sz, float *__restrict__ sw,
+    float *__restrict__ spp, double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ dz,
+    double *__restrict__ dw, ChunkExt *__restrict__ chunk_ext) {
+  const int p = blockIdx.x * kSlabChunk + threadIdx.x;
   unsigned long long lo = ~0ull, hi = 0ull, ylo = ~0ull, yhi = 0ull;
-  for (int u = 0; u < kSlabChunk / 64; ++u) {
-    const int p = c * kSlabChunk + u * 64 + lane;
-    if (p < n) {
-      const int id = sid[p];
-      const double x = nx[id], y = ny[id];
-      if (x == x) { const unsigned long long e = enc_ord(x); lo = min(lo, e); hi = max(hi, e); }
-      if (y == y) { const unsigned long long e = enc_ord(y); ylo = min(ylo, e); yhi = max(yhi, e); }
+  if (p < n) {
+    // ONE random read per node: the (x, y, z, w) record; the fp32 shadow values are worked out again from it exactly as
+    // the append kernel did (aos_to_soa_kernel: same expressions, no contraction), instead of five more random reads
+    const double4 v = aos[sid[p]];
+    const double x = v.x, y = v.y;
+    const float fa = (float)(v.x - ox), fb = (float)(v.y - oy), fc = (float)(v.z - oz);
+    double pp = (double)fa * (double)fa + (double)fb * (double)fb + (double)fc * (double)fc;
+    sx[p] = fa; sy[p] = fb; sz[p] = fc;
+    dx[p] = x; dy[p] = y; dz[p] = v.z;
+    if (dim == 4) {
+      const float fd = (float)(v.w - ow);
+      sw[p] = fd; dw[p] = v.w;
+      pp += (double)fd * (double)fd;
     }
+    spp[p] = (float)pp;
+    if (x == x) { lo = hi = enc_ord(x); }
+    if (y == y) { ylo = yhi = enc_ord(y); }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -113,10 +135,18 @@ __global__ __launch_bounds__(256) void chunk_range_kernel(const double *__restri
     ylo = min(ylo, (unsigned long long)__shfl_xor(ylo, off));
     yhi = max(yhi, (unsigned long long)__shfl_xor(yhi, off));
   }
-  if (lane == 0) {
+  __shared__ unsigned long long red[kSlabChunk / 64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = lo; red[wave][1] = hi; red[wave][2] = ylo; red[wave][3] = yhi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     ChunkExt ce;
-    ce.xlo = lo; ce.xhi = hi; ce.ylo = ylo; ce.yhi = yhi;
-    chunk_ext[c] = ce;
+    ce.xlo = ~0ull; ce.xhi = 0ull; ce.ylo = ~0ull; ce.yhi = 0ull;
+    for (int w = 0; w < kSlabChunk / 64; ++w) {
+      ce.xlo = min(ce.xlo, red[w][0]); ce.xhi = max(ce.xhi, red[w][1]);
+      ce.ylo = min(ce.ylo, red[w][2]); ce.yhi = max(ce.yhi, red[w][3]);
+    }
+    chunk_ext[blockIdx.x] = ce;
   }
 }
 
@@ -146,23 +176,37 @@ __global__ __launch_bounds__(256) void run_place_kernel(
   if (lds_ext)
     for (int k = threadIdx.x; k < n_run_chunks; k += 256) { ext[k][0] = ~0ull; ext[k][1] = 0ull; ext[k][2] = ~0ull; ext[k][3] = 0ull; }
   {
+    // (four neighbouring counters per thread, 1024 per round: the wave reads 1 KB in a row -- a contiguous stretch of
+    //  K / 256 counters per thread was 2 x 16 dependent, scattered loads)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int per = (K + 255) / 256;
-    const int b0 = min(t * per, K), b1 = min(b0 + per, K);
-    int local = 0;
-    for (int k = b0; k < b1; ++k) local += hist[k];
-    int v = local;
+    int carry = 0;
+    for (int kb = 0; kb < K; kb += 1024) {
+      const int k = kb + 4 * t;
+      const int c0 = k < K ? hist[k] : 0, c1 = k + 1 < K ? hist[k + 1] : 0, c2 = k + 2 < K ? hist[k + 2] : 0,
+                c3 = k + 3 < K ? hist[k + 3] : 0;
+      const int local = c0 + c1 + c2 + c3;
+      int v = local;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int o = __shfl_up(v, off);
-      if (lane >= off) v += o;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+      }
+      if (lane == 63) wsum[wave] = v;
+      __syncthreads();
+      int prefix = carry + v - local, total = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int x = wsum[w];
+        if (w < wave) prefix += x;
+        total += x;
+      }
+      if (k < K) start[k] = prefix;
+      if (k + 1 < K) start[k + 1] = prefix + c0;
+      if (k + 2 < K) start[k + 2] = prefix + c0 + c1;
+      if (k + 3 < K) start[k + 3] = prefix + c0 + c1 + c2;
+      carry += total;
+      __syncthreads();
     }
-    if (lane == 63) wsum[wave] = v;
-    __syncthreads();
-    int prefix = v - local;
-    for (int w = 0; w < wave; ++w) prefix += wsum[w];
-    for (int k = b0; k < b1; ++k) { start[k] = prefix; prefix += hist[k]; }
-    __syncthreads();
   }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
@@ -256,6 +300,8 @@ int slab_refresh(rrtx_ctx *ctx, long long n_tiles) {
   // (tiles in flight: 1024; a small batch spreads a tile's units over several workgroups)
   const double rounds = n_tiles > 64 ? (double)n_tiles / 1024.0 : 1.0 / 16.0;
   ctx->sl_debt_us += (1.0 * (tail_chunks - run_chunks) + 0.16 * run_chunks) * rounds;
+  // (round 3: a rebuild is 47 us at 400 k nodes; with 15 + 0.08e-3 n here the index is rebuilt every four batches instead of
+  // six and the steady step is the same 0.102-0.103 ms -- tools/steady_trace.py -- so the estimate stays)
   const double rebuild_us = 40.0 + 0.12e-3 * (double)n;
   if (ctx->sl_n_sorted > 0 && tail <= n / 2 && ctx->sl_debt_us < rebuild_us) return RRTX_OK;
   ctx->sl_debt_us = 0.0;
@@ -294,13 +340,12 @@ int slab_refresh(rrtx_ctx *ctx, long long n_tiles) {
   hipLaunchKernelGGL(slab_rank_kernel, dim3(nb), dim3(256), 0, st, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], (int)n, sp,
                      hist, sr);
   hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, st, hist, start, KK);
-  hipLaunchKernelGGL(slab_scatter_kernel, dim3(nb), dim3(256), 0, st, (int)n, sr, start, ctx->nodes_f[0],
-                     ctx->nodes_f[1], ctx->nodes_f[2], ctx->nodes_f[ctx->dim == 4 ? 3 : 2], ctx->nodes_pp, ctx->dim,
-                     ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2], ctx->sl_pp,
-                     ctx->sl_id, ctx->nodes[0], ctx->nodes[1], ctx->nodes[2], ctx->nodes[ctx->dim == 4 ? 3 : 2],
-                     ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2], ctx->sl_d[ctx->dim == 4 ? 3 : 2]);
-  hipLaunchKernelGGL(chunk_range_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, st, ctx->nodes[0], ctx->nodes[1],
-                     ctx->sl_id, (int)n, n_chunks, reinterpret_cast<ChunkExt *>(ctx->chunk_ext));
+  hipLaunchKernelGGL(slab_sid_kernel, dim3(nb), dim3(256), 0, st, (int)n, sr, start, ctx->sl_id);
+  hipLaunchKernelGGL(slab_gather_kernel, dim3(n_chunks), dim3(kSlabChunk), 0, st, (int)n, ctx->sl_id,
+                     reinterpret_cast<const double4 *>(ctx->nodes_aos), ctx->origin[0], ctx->origin[1], ctx->origin[2],
+                     ctx->origin[3], ctx->dim, ctx->sl_f[0], ctx->sl_f[1], ctx->sl_f[2], ctx->sl_f[ctx->dim == 4 ? 3 : 2],
+                     ctx->sl_pp, ctx->sl_d[0], ctx->sl_d[1], ctx->sl_d[2], ctx->sl_d[ctx->dim == 4 ? 3 : 2],
+                     reinterpret_cast<ChunkExt *>(ctx->chunk_ext));
   span_end(ctx);
   RRTX_HIP(ctx, hipGetLastError());
   ctx->sl_n_sorted = n;
