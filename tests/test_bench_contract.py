@@ -64,7 +64,7 @@ def _check_common(line, baseline):
 
 def test_committed_driver_line():
     baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    line = _line("r03_v8_bench.json")
+    line = _line("r03_v9_bench.json")
     _check_common(line, baseline)
     assert line["config"]["workload"].startswith("C4") and line["config"]["obstacle_list"] == "spheres"
     rf = line["roofline"]
@@ -90,16 +90,16 @@ def test_committed_driver_line():
 
 def test_committed_polygon_c3_c5_lines():
     baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    poly = _line("r03_v8_bench_poly.json")
+    poly = _line("r03_v9_bench_poly.json")
     _check_common(poly, baseline)
     assert poly["config"]["obstacle_list"] == "polygons" and "polygons" in poly["cpu_baseline"]["sample"]
     _check_roofline(poly["roofline_polygon_edges"])
     assert poly["roofline_polygon_edges"]["frac"] is not None
-    c3 = _line("r03_v8_bench_c3.json")
+    c3 = _line("r03_v9_bench_c3.json")
     _check_common(c3, baseline)
     assert c3["config"]["edge"] == "DubinsEdge" and c3["roofline"]["bound"] == "valu_issue" and c3["roofline"]["frac"] is not None
     assert c3["kernel_ms"]["dubins_check"] > c3["kernel_ms"]["dubins_steer"] > 0
-    c5 = _line("r03_v8_bench_c5.json")
+    c5 = _line("r03_v9_bench_c5.json")
     _check_common(c5, baseline)
     assert c5["config"]["workload"].startswith("C5") and c5["config"]["n_nodes"] == 500_000
     assert set(c5["phase_ms"]) == {"obstacle_appears", "sweep", "block", "cost_update", "extend_preamble", "append"}
