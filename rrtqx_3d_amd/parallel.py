@@ -149,16 +149,14 @@ def exchange_hit_bitmasks_gathered(bits: torch.Tensor, rank: int, group=None, as
     (its slices of all the steps, contiguous).  Every rank publishes, so nothing has to be zeroed or summed: a ring
     all-gather moves (n - 1)/n of the buffer over every xGMI link, the all-reduce of exchange_hit_bitmasks_grouped twice
     that -- the choice when every rank owns a slice (edge shards only; in an E x O grid only one rank per obstacle group
-    publishes, and the all-reduce over disjoint slices stays).  In place with RCCL (input = the rank's own part of the
-    output, the in-place form of ncclAllGather); gloo gets a copy of the slice.
+    publishes, and the all-reduce over disjoint slices stays).  The input is a copy of the rank's slice (one small
+    device copy; no backend has to accept an input that aliases its output).
     Returns bits, or with async_op=True the work handle (None without a process group)."""
     assert bits.dim() == 3 and bits.dtype == torch.int64 and bits.is_contiguous()
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return None if async_op else bits
     assert bits.shape[0] == dist.get_world_size(group) and 0 <= rank < bits.shape[0]
-    own = bits[rank].reshape(-1)
-    if dist.get_backend(group) != "nccl":
-        own = own.clone()
+    own = bits[rank].reshape(-1).clone()
     work = dist.all_gather_into_tensor(bits.view(-1), own, group=group, async_op=async_op)
     return work if async_op else bits
 
